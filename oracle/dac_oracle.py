@@ -1,0 +1,163 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (torch fp32) of DAC ``decode`` (codes → waveform).
+
+Reference call sites: parler_tts/dac_wrapper/modeling_dac.py:138 (``quantizer.from_codes``) and :139
+(``model.decode``). The arithmetic lives in the third-party package ``descript-audio-codec``
+(setup.py:24, UNPINNED, not vendored under /root/reference, not installed, no network), so this file
+restates its published 44 kHz architecture: RVQ ``from_codes`` = Σ_i out_proj_i(codebook_i[codes_i])
+(codebook_dim 8, 1×1 conv to 1024), decoder = Conv1d(1024→1536,k7) → 4 × [Snake, ConvTranspose1d(k=2s,
+stride s, pad ⌈s/2⌉), 3 × ResidualUnit(dil 1,3,9: Snake, Conv k7 dilated, Snake, Conv k1, +skip)] with
+strides (8,8,4,2) → Snake → Conv1d(96→1,k7) → tanh; Snake(x) = x + (α+1e-9)⁻¹·sin²(αx); every conv is
+weight-normalised (w = g·v/‖v‖ per output channel; modeling_dac.py:148-164 re-applies it), folded here
+once at load.
+
+Pinning status: "parity unpinned" against descript-audio-codec itself (absent). The restatement is
+cross-checked against the only other on-disk statement of the same model — the independent
+transformers-5.15 ``DacModel`` port (tests/test_oracle_dac.py) — and frozen into tests/golden/dac_*.npz.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class DacSpec:
+    """dac.model.DAC(...) as constructed at dac_wrapper/modeling_dac.py:24-28 (+ descript 44 kHz defaults)."""
+
+    num_codebooks: int = 9
+    codebook_size: int = 1024
+    codebook_dim: int = 8
+    latent_dim: int = 1024
+    decoder_dim: int = 1536
+    decoder_rates: Tuple[int, ...] = (8, 8, 4, 2)
+    sampling_rate: int = 44100
+    frame_rate: int = 86
+
+    @property
+    def hop_length(self) -> int:
+        return int(math.prod(self.decoder_rates))
+
+
+DAC_44KHZ = DacSpec()
+DAC_TINY = DacSpec(num_codebooks=9, latent_dim=64, decoder_dim=96, decoder_rates=(4, 2, 2, 2))
+
+
+def make_dac_weights(spec: DacSpec, seed: int = 4321, weight_norm_format: str = "folded") -> Dict[str, torch.Tensor]:
+    """Seeded synthetic DAC weights under descript's module names (``quantizer.quantizers.i.*``,
+    ``decoder.model.N.*``). Variance-preserving init (std = 1/sqrt(fan_in)) instead of N(0,0.02): with 0.02
+    the 30-conv stack underflows to ~1e-12 and a waveform RMS tolerance would be vacuous.
+
+    weight_norm_format: "folded" → ``.weight``; "legacy" → ``.weight_g/.weight_v``;
+    "parametrized" → ``.parametrizations.weight.original0/original1`` (modeling_dac.py:148-157).
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, cin, k, transpose=False, gain=1.0):
+        shape = (cin, cout, k) if transpose else (cout, cin, k)
+        fan_in = cin * k / (1 if not transpose else 1)
+        v = torch.randn(*shape, generator=g) / math.sqrt(fan_in) * gain
+        bias = 0.01 * torch.randn(cout, generator=g)
+        if weight_norm_format == "folded":
+            sd[name + ".weight"] = v
+        else:
+            # weight_norm dim=0: one g per index of dim 0 (for ConvTranspose1d that is the INPUT channel)
+            norm = v.flatten(1).norm(dim=1).view(-1, 1, 1)
+            gg = norm * (1.0 + 0.1 * torch.randn(norm.shape, generator=g))
+            if weight_norm_format == "legacy":
+                sd[name + ".weight_g"], sd[name + ".weight_v"] = gg, v
+            else:
+                sd[name + ".parametrizations.weight.original0"] = gg
+                sd[name + ".parametrizations.weight.original1"] = v
+        sd[name + ".bias"] = bias
+
+    def snake(name, c):
+        sd[name + ".alpha"] = (0.5 + torch.rand(1, c, 1, generator=g))
+
+    for i in range(spec.num_codebooks):
+        q = f"quantizer.quantizers.{i}."
+        sd[q + "codebook.weight"] = torch.randn(spec.codebook_size, spec.codebook_dim, generator=g)
+        conv(q + "out_proj", spec.latent_dim, spec.codebook_dim, 1, gain=1.0 / math.sqrt(spec.num_codebooks))
+    d = "decoder.model."
+    ch = spec.decoder_dim
+    conv(d + "0", ch, spec.latent_dim, 7)
+    for bi, s in enumerate(spec.decoder_rates):
+        cin, cout = ch // 2 ** bi, ch // 2 ** (bi + 1)
+        b = f"{d}{bi + 1}.block."
+        snake(b + "0", cin)
+        conv(b + "1", cout, cin, 2 * s, transpose=True, gain=math.sqrt(s))  # each output sees k/s = 2 taps
+        for ri in range(3):
+            r = f"{b}{ri + 2}.block."
+            snake(r + "0", cout)
+            conv(r + "1", cout, cout, 7, gain=0.5)
+            snake(r + "2", cout)
+            conv(r + "3", cout, cout, 1, gain=0.5)
+    cl = ch // 2 ** len(spec.decoder_rates)
+    snake(f"{d}{len(spec.decoder_rates) + 1}", cl)
+    conv(f"{d}{len(spec.decoder_rates) + 2}", 1, cl, 7)
+    return sd
+
+
+def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """w = g · v / ‖v‖ over all dims but 0 (torch weight_norm default dim=0), for either key format."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_g") or k.endswith(".parametrizations.weight.original0"):
+            base = k[: -len(".weight_g")] if k.endswith(".weight_g") else k[: -len(".parametrizations.weight.original0")]
+            vv = sd.get(base + ".weight_v", sd.get(base + ".parametrizations.weight.original1"))
+            norm = vv.flatten(1).norm(dim=1).view(-1, *([1] * (vv.dim() - 1)))
+            out[base + ".weight"] = v * vv / norm
+        elif k.endswith(".weight_v") or k.endswith(".parametrizations.weight.original1"):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+def snake1d(x: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
+
+
+class DacOracle:
+    def __init__(self, spec: DacSpec, sd: Dict[str, torch.Tensor], prefix: str = ""):
+        self.spec = spec
+        sd = {k[len(prefix):]: v.detach().to(torch.float32) for k, v in sd.items() if k.startswith(prefix)}
+        self.w = fold_weight_norm(sd)
+
+    def from_codes(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes [B, K, T] int64 → z [B, latent, T] (ResidualVectorQuantize.from_codes)."""
+        z = 0.0
+        for i in range(codes.shape[1]):
+            q = f"quantizer.quantizers.{i}."
+            zp = F.embedding(codes[:, i, :], self.w[q + "codebook.weight"]).transpose(1, 2)
+            z = z + F.conv1d(zp, self.w[q + "out_proj.weight"], self.w[q + "out_proj.bias"])
+        return z
+
+    def decode_latents(self, z: torch.Tensor) -> torch.Tensor:
+        w, d = self.w, "decoder.model."
+        x = F.conv1d(z, w[d + "0.weight"], w[d + "0.bias"], padding=3)
+        for bi, s in enumerate(self.spec.decoder_rates):
+            b = f"{d}{bi + 1}.block."
+            x = snake1d(x, w[b + "0.alpha"])
+            x = F.conv_transpose1d(x, w[b + "1.weight"], w[b + "1.bias"], stride=s, padding=math.ceil(s / 2))
+            for ri, dil in enumerate((1, 3, 9)):
+                r = f"{b}{ri + 2}.block."
+                y = snake1d(x, w[r + "0.alpha"])
+                y = F.conv1d(y, w[r + "1.weight"], w[r + "1.bias"], dilation=dil, padding=3 * dil)
+                y = snake1d(y, w[r + "2.alpha"])
+                y = F.conv1d(y, w[r + "3.weight"], w[r + "3.bias"])
+                x = x + y
+        n = len(self.spec.decoder_rates)
+        x = snake1d(x, w[f"{d}{n + 1}.alpha"])
+        x = F.conv1d(x, w[f"{d}{n + 2}.weight"], w[f"{d}{n + 2}.bias"], padding=3)
+        return torch.tanh(x)
+
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes [B, K, T] → waveform [B, 1, hop·T]  (DACModel.decode, modeling_dac.py:138-139)."""
+        return self.decode_latents(self.from_codes(codes))

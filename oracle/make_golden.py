@@ -1,0 +1,306 @@
+"""TEST INFRASTRUCTURE ONLY — generates tests/golden/*.npz by running the REFERENCE's own classes
+(imported from /root/reference under oracle/reference_shims.py) and checks the oracle restatements
+against them. Run in the build container (no GPU needed):
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+What is frozen (all inputs are seeded; weights are regenerated from seeds by the tests):
+  decoder_<variant>.npz  reference ParlerTTSForCausalLM logits: prefill (prompt prepended, padded prompt
+                         and description masks) + 6 teacher-forced cached steps, sinusoidal and RoPE.
+  greedy_<variant>.npz   greedy token ids of a free run driven by the reference forward, the reference
+                         ParlerTTSLogitsProcessor and the reference delay-pattern helpers inside the
+                         restated transformers-4.46.1 ``_sample`` loop (EOS reachable: small min_new_tokens).
+  delay_kat.npz          build_delay_pattern_mask / apply_delay_pattern_mask known answers.
+  eosgate_kat.npz        ParlerTTSLogitsProcessor known answers over a scripted id history.
+  dac_tiny.npz           DAC decode restatement outputs (cross-checked against the transformers DacModel port).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import decoder_oracle as DO  # noqa: E402
+from oracle import dac_oracle as DA  # noqa: E402
+from oracle.reference_shims import import_reference  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def synth_inputs(spec: DO.DecoderSpec, bsz: int, N: int, P: int, seed: int, padded: bool):
+    g = torch.Generator().manual_seed(seed)
+    enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
+    prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
+    enc_mask = torch.ones(bsz, N, dtype=torch.long)
+    prompt_mask = torch.ones(bsz, P, dtype=torch.long)
+    if padded:  # left-padded prompt / right-padded description for the LAST batch row
+        enc_mask[-1, N - 3:] = 0
+        prompt_mask[-1, :2] = 0
+        enc = enc * enc_mask[..., None]  # :3092-3093
+    return enc, enc_mask, prompt, prompt_mask
+
+
+def build_reference_lm(ref, spec: DO.DecoderSpec, sd, attn="sdpa"):
+    cfg = ref.ParlerTTSDecoderConfig(
+        vocab_size=spec.vocab_size, max_position_embeddings=spec.max_position_embeddings,
+        num_hidden_layers=spec.num_hidden_layers, ffn_dim=spec.ffn_dim,
+        num_attention_heads=spec.num_attention_heads, hidden_size=spec.hidden_size,
+        num_codebooks=spec.num_codebooks, pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id,
+        bos_token_id=spec.bos_token_id, rope_embeddings=spec.rope_embeddings, rope_theta=spec.rope_theta,
+        use_fused_lm_heads=spec.use_fused_lm_heads)
+    cfg._attn_implementation = attn
+    m = ref.ParlerTTSForCausalLM(cfg).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary_emb" in k for k in missing), missing
+    return m
+
+
+@torch.no_grad()
+def reference_forward(m, cache, ids, enc, enc_mask, prompt, prompt_mask, past_len):
+    """Drives ParlerTTSForCausalLM.forward the way ForConditionalGeneration.forward does (:2846-2864),
+    with the decoder_attention_mask synthesised as prepare_inputs_for_generation does (:2944-2969)."""
+    T = ids.shape[-1] + (prompt.shape[1] if (prompt is not None and past_len == 0) else 0)
+    cache_position = torch.arange(past_len, past_len + T)
+    bsz = enc.shape[0]
+    dec_mask = None
+    if prompt_mask is not None:
+        gen_len = 1 if past_len == 0 else past_len - prompt_mask.shape[1] + 1
+        dec_mask = torch.ones(bsz, gen_len, dtype=prompt_mask.dtype)
+    out = m(input_ids=ids, attention_mask=dec_mask, encoder_hidden_states=enc, encoder_attention_mask=enc_mask,
+            prompt_hidden_states=prompt if past_len == 0 else None, prompt_attention_mask=prompt_mask,
+            past_key_values=cache, use_cache=True, cache_position=cache_position, return_dict=True)
+    return out.logits
+
+
+def gen_decoder(ref, variant: str):
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+
+    rope = variant == "rope"
+    spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "rope_embeddings": rope})
+    sd = DO.make_decoder_weights(spec, seed=1234)
+    bsz, N, P, steps = 2, 11, 5, 6
+    enc, enc_mask, prompt, prompt_mask = synth_inputs(spec, bsz, N, P, seed=7, padded=True)
+    g = torch.Generator().manual_seed(99)
+    K = spec.num_codebooks
+    ids0 = torch.full((bsz * K, 1), spec.bos_token_id, dtype=torch.long)
+    step_ids = torch.randint(0, 1024, (steps, bsz * K, 1), generator=g)
+
+    m = build_reference_lm(ref, spec, sd)
+    cache = EncoderDecoderCache(DynamicCache(), DynamicCache())
+    ref_logits = [reference_forward(m, cache, ids0, enc, enc_mask, prompt, prompt_mask, 0)]
+    past = P + 1
+    for s in range(steps):
+        ref_logits.append(reference_forward(m, cache, step_ids[s], enc, enc_mask, prompt, prompt_mask, past))
+        past += 1
+
+    worst = 0.0
+    for prec_attn in ("sdpa", "eager"):
+        orc = DO.DecoderOracle(spec, sd, precision="fp32", attn_impl=prec_attn)
+        o = [orc.forward(ids0, enc, enc_mask, prompt, prompt_mask)]
+        for s in range(steps):
+            o.append(orc.forward(step_ids[s]))
+        # prefill: only the last position is consumed by generation (_sample reads logits[:, -1]); padded-prompt
+        # QUERY rows are garbage in the reference too (finfo.min fill → uniform attention) and are not compared
+        for a, b in zip(ref_logits, o):
+            worst = max(worst, float((a[:, -1] - b[:, -1]).abs().max()))
+    print(f"[decoder/{variant}] oracle vs reference ParlerTTSForCausalLM: max|Δlogit| = {worst:.3e}")
+    assert worst < 2e-6, worst
+    np.savez_compressed(
+        os.path.join(GOLD, f"decoder_{variant}.npz"),
+        spec=np.array([spec.hidden_size, spec.num_hidden_layers, spec.num_attention_heads, spec.ffn_dim,
+                       spec.max_position_embeddings, int(rope)]),
+        weight_seed=1234, enc=enc.numpy(), enc_mask=enc_mask.numpy(), prompt=prompt.numpy(),
+        prompt_mask=prompt_mask.numpy(), step_ids=step_ids.numpy(),
+        prefill_logits=ref_logits[0][:, -1].numpy(), step_logits=np.stack([l[:, -1].numpy() for l in ref_logits[1:]]))
+
+
+@torch.no_grad()
+def gen_greedy(ref, variant: str):
+    """Free-running greedy ids: reference forward + reference processor + reference delay helpers, inside the
+    restated ``_sample`` loop. Compared with oracle.sample_loop (same loop, restated pieces)."""
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+
+    rope = variant == "rope"
+    spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "rope_embeddings": rope})
+    K = spec.num_codebooks
+    bsz, N, P = 2, 9, 4
+    gp = DO.GenParams(max_length=40, min_new_tokens=3)
+    seed = 1234
+    # EOS must be reachable with random weights: bias the EOS row of every LM head so codebooks finish
+    for seed in range(1234, 1400):
+        sd = DO.make_decoder_weights(spec, seed=seed)
+        for k in range(K):
+            sd[f"lm_heads.{k}.weight"][spec.eos_token_id] *= 6.0
+        enc, enc_mask, prompt, prompt_mask = synth_inputs(spec, bsz, N, P, seed=11, padded=True)
+        orc = DO.DecoderOracle(spec, sd, precision="fp32")
+        tr = DO.sample_loop(orc, enc, enc_mask, prompt, prompt_mask, gp)
+        n_eos = int((tr.sequences[:, 1:] == spec.eos_token_id).any(dim=1).sum())
+        # top-2 margins of a 128-wide model with N(0,0.02) heads are ~1e-4; fp32 summation-order noise on its logits is
+        # ~2e-7, so 2e-4 leaves a 1000x tie-safety factor (recorded in the fixture; tests assert against it)
+        if tr.min_margin >= 2e-4 and 2 <= n_eos < bsz * K and tr.sequences.shape[1] >= 20:
+            break
+    else:
+        raise RuntimeError("no margin-safe seed with EOS events found")
+    print(f"[greedy/{variant}] seed {seed}: Lout={tr.sequences.shape[1]} rows-with-EOS={n_eos} min margin={tr.min_margin:.2e}")
+
+    m = build_reference_lm(ref, spec, sd)
+    cache = EncoderDecoderCache(DynamicCache(), DynamicCache())
+    seq = torch.full((bsz * K, 1), spec.bos_token_id, dtype=torch.long)
+    _, pattern = ref.build_delay_pattern_mask(seq, spec.bos_token_id, spec.pad_token_id, gp.max_length, K)
+    proc = ref.modeling_parler_tts.ParlerTTSLogitsProcessor(spec.eos_token_id, K, bsz, "cpu")
+    unfinished = torch.ones(bsz * K, dtype=torch.long)
+    past = 0
+    while True:
+        fed = ref.apply_delay_pattern_mask(seq, pattern)
+        if past == 0:
+            logits = reference_forward(m, cache, fed, enc, enc_mask, prompt, prompt_mask, 0)
+            past = P + 1
+        else:
+            logits = reference_forward(m, cache, fed[:, -1:], enc, enc_mask, prompt, prompt_mask, past)
+            past += 1
+        scores = logits[:, -1, :].clone().float()
+        if (seq.shape[-1] - 1) < gp.min_new_tokens:
+            scores[:, spec.eos_token_id] = -math.inf
+        scores = proc(seq, scores)
+        nxt = torch.argmax(scores, dim=-1)
+        nxt = nxt * unfinished + spec.pad_token_id * (1 - unfinished)
+        seq = torch.cat([seq, nxt[:, None]], dim=-1)
+        unfinished = unfinished & ~((nxt == spec.eos_token_id) | (seq.shape[-1] >= gp.max_length)).long()
+        if unfinished.max() == 0:
+            break
+    assert torch.equal(seq, tr.sequences), "oracle sample_loop diverged from the reference-driven loop"
+    codes = DO.undelay(seq, spec, gp.max_length)
+    np.savez_compressed(
+        os.path.join(GOLD, f"greedy_{variant}.npz"),
+        spec=np.array([spec.hidden_size, spec.num_hidden_layers, spec.num_attention_heads, spec.ffn_dim,
+                       spec.max_position_embeddings, int(rope)]),
+        weight_seed=seed, eos_row_gain=6.0, enc=enc.numpy(), enc_mask=enc_mask.numpy(), prompt=prompt.numpy(),
+        prompt_mask=prompt_mask.numpy(), max_length=gp.max_length, min_new_tokens=gp.min_new_tokens,
+        sequences=seq.numpy(), codes=codes.numpy(), min_margin=tr.min_margin)
+
+
+def gen_delay_kat(ref):
+    out = {}
+    cases = [(9, 1, 30, 2), (4, 1, 8, 1), (4, 3, 8, 1), (9, 1, 12, 1), (9, 1, 17, 3), (2, 1, 3, 2)]
+    for ci, (K, seq_len, max_len, bsz) in enumerate(cases):
+        g = torch.Generator().manual_seed(ci)
+        ids = torch.randint(0, 1024, (bsz * K, seq_len), generator=g)
+        ids[:, 0] = 1025
+        r_ids, r_mask = ref.build_delay_pattern_mask(ids, 1025, 1024, max_len, K)
+        o_ids, o_mask = DO.build_delay_pattern_mask(ids, 1025, 1024, max_len, K)
+        assert torch.equal(r_ids, o_ids) and torch.equal(r_mask, o_mask), (K, seq_len, max_len)
+        full = torch.randint(0, 1024, (bsz * K, max_len), generator=g)
+        assert torch.equal(ref.apply_delay_pattern_mask(full, r_mask), DO.apply_delay_pattern_mask(full, o_mask))
+        out[f"c{ci}_args"] = np.array([K, seq_len, max_len, bsz])
+        out[f"c{ci}_in"] = ids.numpy()
+        out[f"c{ci}_ids"] = r_ids.numpy()
+        out[f"c{ci}_mask"] = r_mask.numpy()
+    np.savez_compressed(os.path.join(GOLD, "delay_kat.npz"), n=len(cases), **out)
+    print(f"[delay] {len(cases)} known-answer cases match the reference bit-exactly")
+
+
+def gen_eosgate_kat(ref):
+    K, bsz, V, steps = 9, 3, 1088, 24
+    g = torch.Generator().manual_seed(5)
+    proc = ref.modeling_parler_tts.ParlerTTSLogitsProcessor(1024, K, bsz, "cpu")
+    gate = DO.EosGate(1024, K, bsz)
+    seq = torch.full((bsz * K, 1), 1025, dtype=torch.long)
+    gated = []
+    for s in range(steps):
+        col = torch.randint(0, 1024, (bsz * K,), generator=g)
+        # scripted EOS events: sample 0 finishes codebooks one per step from step 3; sample 1 finishes cb0 at 10
+        if s >= 3 and s - 3 < K:
+            col[0 * K + (s - 3)] = 1024
+        if s == 10:
+            col[1 * K + 0] = 1024
+        if s == 12:
+            col[1 * K + 1] = 1024
+        seq = torch.cat([seq, col[:, None]], dim=1)
+        a = proc(seq, torch.zeros(bsz * K, V))
+        b = gate(seq, torch.zeros(bsz * K, V))
+        assert torch.equal(a, b)
+        gated.append(torch.isinf(a[:, 1024]).numpy())
+    np.savez_compressed(os.path.join(GOLD, "eosgate_kat.npz"), K=K, bsz=bsz, history=seq.numpy(), gated=np.stack(gated))
+    print("[eosgate] scripted history matches the reference processor bit-exactly")
+
+
+def hf_dac_port(spec: DA.DacSpec, sd):
+    """The transformers-5.15 DacModel port (third-party, independent of descript's code) loaded with the
+    same folded weights — used only as a cross-check of the restatement."""
+    from transformers import DacConfig, DacModel
+
+    cfg = DacConfig(encoder_hidden_size=16, downsampling_ratios=list(reversed(spec.decoder_rates)),
+                    decoder_hidden_size=spec.decoder_dim, n_codebooks=spec.num_codebooks,
+                    codebook_size=spec.codebook_size, codebook_dim=spec.codebook_dim,
+                    upsampling_ratios=list(spec.decoder_rates), hidden_size=spec.latent_dim, sampling_rate=spec.sampling_rate)
+    m = DacModel(cfg).eval()
+    w = DA.fold_weight_norm(sd)
+    tgt = m.state_dict()
+    mp = {}
+    for i in range(spec.num_codebooks):
+        mp[f"quantizer.quantizers.{i}.codebook.weight"] = w[f"quantizer.quantizers.{i}.codebook.weight"]
+        mp[f"quantizer.quantizers.{i}.out_proj.weight"] = w[f"quantizer.quantizers.{i}.out_proj.weight"]
+        mp[f"quantizer.quantizers.{i}.out_proj.bias"] = w[f"quantizer.quantizers.{i}.out_proj.bias"]
+    mp["decoder.conv1.weight"], mp["decoder.conv1.bias"] = w["decoder.model.0.weight"], w["decoder.model.0.bias"]
+    for bi in range(len(spec.decoder_rates)):
+        b, t = f"decoder.model.{bi + 1}.block.", f"decoder.block.{bi}."
+        mp[t + "snake1.alpha"] = w[b + "0.alpha"]
+        mp[t + "conv_t1.weight"], mp[t + "conv_t1.bias"] = w[b + "1.weight"], w[b + "1.bias"]
+        for ri in range(3):
+            r, u = f"{b}{ri + 2}.block.", f"{t}res_unit{ri + 1}."
+            mp[u + "snake1.alpha"] = w[r + "0.alpha"]
+            mp[u + "conv1.weight"], mp[u + "conv1.bias"] = w[r + "1.weight"], w[r + "1.bias"]
+            mp[u + "snake2.alpha"] = w[r + "2.alpha"]
+            mp[u + "conv2.weight"], mp[u + "conv2.bias"] = w[r + "3.weight"], w[r + "3.bias"]
+    n = len(spec.decoder_rates)
+    mp["decoder.snake1.alpha"] = w[f"decoder.model.{n + 1}.alpha"]
+    mp["decoder.conv2.weight"], mp["decoder.conv2.bias"] = w[f"decoder.model.{n + 2}.weight"], w[f"decoder.model.{n + 2}.bias"]
+    for k, v in mp.items():
+        assert tgt[k].shape == v.shape, (k, tgt[k].shape, v.shape)
+    m.load_state_dict({**tgt, **mp})
+    return m
+
+
+@torch.no_grad()
+def gen_dac():
+    spec = DA.DAC_TINY
+    sd = DA.make_dac_weights(spec, seed=4321, weight_norm_format="parametrized")
+    g = torch.Generator().manual_seed(3)
+    codes = torch.randint(0, spec.codebook_size, (2, spec.num_codebooks, 13), generator=g)
+    orc = DA.DacOracle(spec, sd)
+    wav = orc.decode(codes)
+    port = hf_dac_port(spec, sd)
+    wav2 = port.decode(audio_codes=codes).audio_values
+    wav2 = wav2.reshape(wav.shape)
+    err = float((wav - wav2).abs().max())
+    rms = float(wav.pow(2).mean().sqrt())
+    print(f"[dac] restatement vs transformers DacModel port: max|Δ| = {err:.3e} (waveform rms {rms:.3f})")
+    assert err < 1e-5 and rms > 0.05
+    np.savez_compressed(os.path.join(GOLD, "dac_tiny.npz"), weight_seed=4321, codes=codes.numpy(), wav=wav.numpy(),
+                        latents=orc.from_codes(codes).numpy())
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    gen_delay_kat(ref)
+    gen_eosgate_kat(ref)
+    for v in ("sin", "rope"):
+        gen_decoder(ref, v)
+        gen_greedy(ref, v)
+    gen_dac()
+    print("golden vectors written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()
