@@ -1,0 +1,160 @@
+/*
+ * ptts.h — C ABI of libptts_hip.so: the MI355X-native Parler-TTS generation hot path.
+ *
+ * The reference (huggingface/parler-tts) has NO native FFI: its boundary is Python-level
+ * (SURVEY.md §8(b)). Each entry point below therefore cites the reference *Python* interface it
+ * replaces (file:line under /root/reference/parler_tts/); INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add. Plain C: pointers + sizes only, no torch / C++ types.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = error class (PTTS_E_*); ptts_last_error() returns the
+ *     message of the last failing call on the calling thread. No C++ exception crosses this boundary.
+ *   - all `*_dev` pointers are DEVICE pointers (HIP). Borrowed for the duration of the call only, unless
+ *     stated otherwise; the engine copies / re-packs what it keeps.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the engine's own stream). Work is enqueued
+ *     asynchronously unless the function is documented as synchronising.
+ *   - one engine per stream; an engine is not re-entrant (same as the reference model object,
+ *     modeling_parler_tts.py:3297 per-call `_cache`), but may be driven from any host thread.
+ */
+#ifndef PTTS_H_
+#define PTTS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTTS_ABI_VERSION 1
+
+enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
+
+enum {
+  PTTS_OK = 0,
+  PTTS_E_INVALID = -1,   /* bad argument / shape / state (Python wrapper raises ValueError) */
+  PTTS_E_HIP = -2,       /* HIP runtime error */
+  PTTS_E_MISSING = -3,   /* weights not fully loaded */
+  PTTS_E_CAPACITY = -4,  /* batch / context / encoder length exceeds what the engine was created for */
+  PTTS_E_UNSUPPORTED = -5
+};
+
+typedef struct ptts_engine ptts_engine; /* decoder LM engine: packed weights, KV arena, sampler state, hipGraph */
+typedef struct ptts_dac ptts_dac;       /* DAC codes -> waveform engine */
+
+/* ParlerTTSDecoderConfig integers (configuration_parler_tts.py:111-172) + engine capacities. */
+typedef struct {
+  int32_t hidden_size;
+  int32_t num_layers;
+  int32_t num_heads;     /* MHA only (num_key_value_heads == num_attention_heads; Mini/Large v1) */
+  int32_t ffn_dim;
+  int32_t num_codebooks;
+  int32_t vocab_size;    /* LM-head rows per codebook; embedding tables have vocab_size+1 rows (:1353) */
+  int32_t max_positions; /* max_position_embeddings */
+  int32_t rope;          /* rope_embeddings */
+  float rope_theta;
+  int32_t pad_token_id, eos_token_id, bos_token_id;
+  int32_t dtype;         /* PTTS_F32 (parity mode, BASELINE configs[0] numerics) | PTTS_BF16 (bf16 weights + KV, fp32 accumulate) */
+  int32_t max_batch;     /* utterances per call */
+  int32_t max_ctx;       /* self-attention KV capacity in positions: P + max_length (cf. _get_cache :3254-3309) */
+  int32_t max_enc;       /* cross-attention capacity: description (+ prompt if prompt_cross_attention) tokens */
+  int32_t max_prompt;    /* prefill capacity in positions per utterance: P + 1 (prompt tokens + the BOS column) */
+  int32_t device;        /* HIP device ordinal */
+} ptts_config;
+
+/* Generation parameters: the subset of GenerationConfig that generate() consumes (:3395-3552). */
+typedef struct {
+  int32_t max_length;      /* total columns incl. the BOS column = 1 + max_new_tokens (:3458-3469) */
+  int32_t min_new_tokens;  /* MinNewTokensLengthLogitsProcessor */
+  int32_t do_sample;       /* 0 greedy (argmax), 1 multinomial */
+  float temperature;       /* TemperatureLogitsWarper (1.0 = off) */
+  int32_t top_k;           /* TopKLogitsWarper (0 = off) */
+  float top_p;             /* TopPLogitsWarper (1.0 = off) */
+  int32_t use_eos_gate;    /* default LogitsProcessorList([ParlerTTSLogitsProcessor]) (:3418, logits_processors.py:6-53) */
+  uint64_t seed;           /* Philox key for multinomial sampling */
+} ptts_gen_params;
+
+const char* ptts_last_error(void);
+int ptts_abi_version(void);
+
+/* ---- decoder LM engine -------------------------------------------------------------------------
+ * replaces ParlerTTSForCausalLM (+ the _sample loop around it): modeling_parler_tts.py:1824-1974,
+ * :1338-1736, :940-1074, :818-930, logits_processors.py:6-53, :205-276, transformers _sample (:3564). */
+int ptts_engine_create(const ptts_config* cfg, ptts_engine** out);
+void ptts_engine_destroy(ptts_engine* e);
+
+/* Load one tensor by its reference state-dict name relative to the decoder, e.g.
+ * "model.decoder.layers.3.self_attn.q_proj.weight", "model.decoder.embed_tokens.0.weight",
+ * "model.decoder.embed_positions.weights", "model.decoder.layer_norm.bias", "lm_heads.4.weight"
+ * (or fused "lm_heads.weight" [K*V,H], :1834-1840). `src_dtype` is the dtype of `dev_ptr` (PTTS_F32|PTTS_BF16);
+ * the engine converts to its own dtype and re-packs into MFMA fragment order. Replaces
+ * load_state_dict via from_pretrained (:2469-2488). */
+int ptts_load_weight(ptts_engine* e, const char* name, const void* dev_ptr, int32_t src_dtype,
+                     const int64_t* shape, int32_t ndim, void* stream);
+/* 0 when every tensor the config requires has been loaded, PTTS_E_MISSING (message lists names) otherwise. */
+int ptts_weights_ready(ptts_engine* e);
+
+int ptts_set_gen_params(ptts_engine* e, const ptts_gen_params* gp);
+
+/* Prefill = the first _sample iteration (:3564; forward :1392-1655 with prompt_hidden_states prepended
+ * :1437-1439): computes cross K/V from the (already projected + masked, :3086-3093) encoder states, runs
+ * P+1 positions (prompt embeddings + the BOS column) through the stack, fills the self KV cache, leaves
+ * the step-0 logits in the engine. If `sample` != 0 it also runs the device-side tail (processors +
+ * select + append), i.e. the first token is materialised when this call's work completes (TTFT).
+ *   enc_dev        [B, N, H] float32   encoder_hidden_states
+ *   enc_mask_dev   [B, N] int32 or NULL (attention_mask; 1 = keep)
+ *   prompt_dev     [B, P, H] float32 or NULL (embed_prompts(prompt_input_ids), :3100)
+ *   prompt_mask_dev[B, P] int32 or NULL (prompt_attention_mask) */
+int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_dev, const float* prompt_dev,
+                 const int32_t* prompt_mask_dev, int32_t B, int32_t N, int32_t P, int32_t sample, void* stream);
+
+/* n_steps iterations of {embed(delay-masked last column) -> layers -> LM heads -> tail}; replayed from a
+ * captured hipGraph. Steps after every row has finished are no-ops (device-side check), so callers may
+ * over-run and poll ptts_state() every few dozen steps instead of syncing per token (:_sample's
+ * `unfinished_sequences.max() == 0` host sync). */
+int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream);
+
+/* Host-visible loop state (SYNCHRONISES the stream): number of columns written so far (incl. BOS),
+ * and whether every row has finished (EOS or max_length). */
+int ptts_state(ptts_engine* e, int32_t* cur_len, int32_t* all_finished, void* stream);
+
+/* Raw (un-masked) token ids as _sample stores them: int64 [B*K, row_stride] device buffer owned by the
+ * engine, column 0 = BOS. Valid columns: [0, cur_len). */
+int ptts_ids(ptts_engine* e, int64_t** ids_dev, int32_t* row_stride);
+
+/* ---- hooks for user LogitsProcessorList / StoppingCriteria (the `logits_processor=` argument, :3418) ----
+ * ptts_step_forward: forward only (no tail) for the next position; logits fp32 [B*K, V] at *logits_dev.
+ * ptts_push_tokens : append caller-chosen raw tokens [B*K] int64 (already pad-substituted) and per-row
+ *                    finished flags [B*K] int32 (1 = this row is now finished). */
+int ptts_step_forward(ptts_engine* e, void* stream);
+int ptts_logits(ptts_engine* e, float** logits_dev);
+int ptts_push_tokens(ptts_engine* e, const int64_t* tokens_dev, const int32_t* finished_dev, void* stream);
+
+/* Debug / parity probes: residual stream after the last forward, fp32 [rows, H]. */
+int ptts_debug_hidden(ptts_engine* e, float** hidden_dev, int32_t* rows);
+
+/* ---- DAC decode engine ----------------------------------------------------------------------------
+ * replaces DACModel.decode (dac_wrapper/modeling_dac.py:106-142): quantizer.from_codes (:138) + the
+ * descript-audio-codec decoder stack (:139). */
+typedef struct {
+  int32_t num_codebooks, codebook_size, codebook_dim, latent_dim, decoder_dim;
+  int32_t num_rates;
+  int32_t rates[8];
+  int32_t compute_dtype; /* PTTS_F32: exact-f32 MFMA (parity, RMS <= 1e-4); PTTS_BF16: bf16 MFMA operands, fp32 accumulate */
+  int32_t max_batch, max_frames;
+  int32_t device;
+} ptts_dac_config;
+
+int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out);
+void ptts_dac_destroy(ptts_dac* d);
+/* names relative to dac.model.DAC, weight-norm ALREADY folded by the caller (w = g*v/||v||,
+ * modeling_dac.py:148-164): "quantizer.quantizers.i.codebook.weight", "quantizer.quantizers.i.out_proj.{weight,bias}",
+ * "decoder.model.N...{weight,bias,alpha}". float32 device tensors. */
+int ptts_dac_load_weight(ptts_dac* d, const char* name, const float* dev_ptr, const int64_t* shape, int32_t ndim, void* stream);
+int ptts_dac_weights_ready(ptts_dac* d);
+/* codes_dev int64 [B, K, T] -> wave_dev float32 [B, hop*T]  (hop = prod(rates)). */
+int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTTS_H_ */

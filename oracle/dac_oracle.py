@@ -45,7 +45,7 @@ class DacSpec:
 
 
 DAC_44KHZ = DacSpec()
-DAC_TINY = DacSpec(num_codebooks=9, latent_dim=64, decoder_dim=96, decoder_rates=(4, 2, 2, 2))
+DAC_TINY = DacSpec(num_codebooks=9, latent_dim=64, decoder_dim=256, decoder_rates=(4, 2, 2, 2))
 
 
 def make_dac_weights(spec: DacSpec, seed: int = 4321, weight_norm_format: str = "folded") -> Dict[str, torch.Tensor]:

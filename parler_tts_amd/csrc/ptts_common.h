@@ -1,0 +1,98 @@
+// Shared host/device helpers for libptts_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string>
+
+#include "../../include/ptts.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+// ---- error plumbing: no exception crosses the C ABI ------------------------------------------------
+extern thread_local std::string g_ptts_err;
+int ptts_fail(int code, const char* fmt, ...);
+#define PTTS_HIP(call)                                                                       \
+  do {                                                                                       \
+    hipError_t _e = (call);                                                                  \
+    if (_e != hipSuccess) return ptts_fail(PTTS_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define PTTS_CHECK(cond, code, ...) \
+  do {                              \
+    if (!(cond)) return ptts_fail(code, __VA_ARGS__); \
+  } while (0)
+#define PTTS_TRY(expr)       \
+  do {                       \
+    int _r = (expr);         \
+    if (_r != PTTS_OK) return _r; \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, identical to torch's .to(bfloat16)) -------------------------
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  u = __float_as_uint(f);
+#else
+  memcpy(&u, &f, 4);
+#endif
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// element traits of the engine dtype
+template <typename WT> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int KT = 16;   // k per packed weight fragment (4 x mfma_f32_16x16x4f32)
+  static constexpr int EPL = 4;   // elements per 16-byte lane load
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }  // value as stored in this dtype
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int KT = 32;   // 1 x mfma_f32_16x16x32_bf16
+  static constexpr int EPL = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ float rnd(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// unpack a 16-byte lane load into EPL floats
+__device__ __forceinline__ void unpack16(const uint4& v, float (&o)[4], float) {
+  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+}
+__device__ __forceinline__ void unpack16(const uint4& v, float (&o)[8], bf16_t) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack16(const float (&o)[4], float) {
+  return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+}
+__device__ __forceinline__ uint4 pack16(const float (&o)[8], bf16_t) {
+  return make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+}
+
+// 16-byte non-temporal (streamed-once) global load: weights are read exactly once per decode step
+__device__ __forceinline__ uint4 ld_nt16(const uint4* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,470 @@
+// DAC decode engine (codes -> waveform) behind include/ptts.h. Replaces DACModel.decode
+// (dac_wrapper/modeling_dac.py:106-142): quantizer.from_codes (:138) + the descript-audio-codec decoder (:139).
+//
+// Design:
+//   * activations are channels-last fp32 [b][t][c]: a B-operand fragment (16 consecutive channels of one frame and
+//     tap) is 4 x 16 B per lane group, an output fragment (4 consecutive channels of one frame) is one float4 store;
+//   * every Conv1d / ConvTranspose1d is an implicit GEMM  out[co][t] = sum_{tap,ci} W[co][tap][ci] * x[t + off(tap)][ci]
+//     on v_mfma_f32_16x16x4_f32 (exact f32 = an fmaf chain, so the fp32 parity bar RMS <= 1e-4 holds by construction);
+//     a stride-s transposed conv is s interleaved 2-tap phase convolutions;
+//   * Snake is evaluated ONCE per element in the producer's epilogue (x + sin^2(ax)/(a+1e-9)), never in a consumer
+//     prologue (7 taps x Cout/16 strips would recompute each sin dozens of times); bias, residual skip and the
+//     next layer's Snake are fused into the same epilogue; weight-norm is folded by the caller at load;
+//   * RVQ from_codes is a gather-sum over K precomputed [codebook_size][latent] tables (out_proj(codebook_i)+bias_i).
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+#include <string.h>
+
+#include "ptts_common.h"
+
+namespace {
+
+constexpr int MAXTAPS = 8;
+
+struct ConvArgs {
+  const float* x;      // activated input, channels-last [B][Tin][Cin]
+  const float* Wp;     // packed [phase][Cout/16][ntaps*Cin/16][64][4]
+  const float* bias;   // [Cout]
+  const float* skip;   // optional residual [B][Tout][Cout] (may alias out_raw)
+  float* out_raw;      // optional
+  float* out_act;      // optional: snake(alpha) of the result
+  const float* alpha;  // [Cout] for out_act
+  int toff[MAXTAPS * 8];  // [phase][tap] input-frame offset relative to j
+  int B, Tin, Cin, Cout, ntaps, nphase;
+};
+
+__device__ __forceinline__ float snake_f(float x, float al) {
+  const float s = sinf(al * x);
+  return x + (1.0f / (al + 1e-9f)) * (s * s);
+}
+
+// workgroup: 4 waves; wave w owns CS consecutive 16-channel output strips; all waves share one tile of 32 frames.
+template <int CS>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int ntile = (a.Tin + 31) / 32;
+  const int tile = blockIdx.x % ntile, ph = (blockIdx.x / ntile) % a.nphase, b = blockIdx.x / (ntile * a.nphase);
+  const int strip0 = (blockIdx.y * 4 + wave) * CS;
+  const int nstrips = a.Cout / 16;
+  if (strip0 >= nstrips) return;
+  const int cpt = a.Cin / 16;           // k-steps per tap
+  const int nk = a.ntaps * cpt;
+  const float* xb = a.x + (size_t)b * a.Tin * a.Cin;
+  const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)ph * nstrips * nk) * 64 + lane;
+  const int j0 = tile * 32;
+
+  f32x4 acc[CS][2];
+#pragma unroll
+  for (int s = 0; s < CS; ++s) { acc[s][0] = f32x4{0, 0, 0, 0}; acc[s][1] = f32x4{0, 0, 0, 0}; }
+
+  for (int tap = 0; tap < a.ntaps; ++tap) {
+    const int off = a.toff[ph * MAXTAPS + tap];
+    const int ti0 = j0 + j + off, ti1 = ti0 + 16;
+    const bool ok0 = ti0 >= 0 && ti0 < a.Tin, ok1 = ti1 >= 0 && ti1 < a.Tin;
+    const float* x0 = xb + (size_t)ti0 * a.Cin + q * 4;
+    const float* x1 = xb + (size_t)ti1 * a.Cin + q * 4;
+    for (int cc = 0; cc < cpt; ++cc) {
+      float4 b0 = make_float4(0, 0, 0, 0), b1 = make_float4(0, 0, 0, 0);
+      if (ok0) b0 = *reinterpret_cast<const float4*>(x0 + cc * 16);
+      if (ok1) b1 = *reinterpret_cast<const float4*>(x1 + cc * 16);
+      const int ks = tap * cpt + cc;
+#pragma unroll
+      for (int s = 0; s < CS; ++s) {
+        if (strip0 + s < nstrips) {
+          const float4 w = Wp[((size_t)(strip0 + s) * nk + ks) * 64];
+          acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b0.x, acc[s][0], 0, 0, 0);
+          acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b1.x, acc[s][1], 0, 0, 0);
+          acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b0.y, acc[s][0], 0, 0, 0);
+          acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b1.y, acc[s][1], 0, 0, 0);
+          acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b0.z, acc[s][0], 0, 0, 0);
+          acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b1.z, acc[s][1], 0, 0, 0);
+          acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b0.w, acc[s][0], 0, 0, 0);
+          acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b1.w, acc[s][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // epilogue: D[row = co_local = q*4 + r][col = frame j]
+  const int Tout = a.Tin * a.nphase;
+#pragma unroll
+  for (int s = 0; s < CS; ++s) {
+    if (strip0 + s >= nstrips) continue;
+    const int co = (strip0 + s) * 16 + q * 4;
+    const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int jj = j0 + half * 16 + j;
+      if (jj >= a.Tin) continue;
+      const size_t o = ((size_t)b * Tout + (size_t)jj * a.nphase + ph) * a.Cout + co;
+      float4 v = make_float4(acc[s][half][0] + bs.x, acc[s][half][1] + bs.y, acc[s][half][2] + bs.z, acc[s][half][3] + bs.w);
+      if (a.skip) {
+        const float4 sk = *reinterpret_cast<const float4*>(a.skip + o);
+        v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
+      }
+      if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
+      if (a.out_act) {
+        const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
+        *reinterpret_cast<float4*>(a.out_act + o) = make_float4(snake_f(v.x, al.x), snake_f(v.y, al.y), snake_f(v.z, al.z), snake_f(v.w, al.w));
+      }
+    }
+  }
+}
+
+// final Conv1d(C -> 1, k7, pad 3) + tanh; one thread per output sample, weights [7][C] in LDS.
+__global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                     float* __restrict__ out, int B, int T, int C, int ktaps) {
+  extern __shared__ float sw[];
+  for (int i = threadIdx.x; i < ktaps * C; i += blockDim.x) sw[i] = w[i];
+  __syncthreads();
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * T) return;
+  const int b = (int)(idx / T), t = (int)(idx % T);
+  float acc = bias[0];
+  for (int tap = 0; tap < ktaps; ++tap) {
+    const int ti = t + tap - ktaps / 2;
+    if (ti < 0 || ti >= T) continue;
+    const float4* xr = reinterpret_cast<const float4*>(x + ((size_t)b * T + ti) * C);
+    const float4* wr = reinterpret_cast<const float4*>(sw + tap * C);
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+      const float4 xv = xr[c4], wv = wr[c4];
+      acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+    }
+  }
+  out[idx] = tanhf(acc);
+}
+
+// RVQ table: table[i][code][c] = bias_i[c] + sum_d W_i[c][d] * codebook_i[code][d]
+__global__ void rvq_table_kernel(const float* __restrict__ cb, const float* __restrict__ w, const float* __restrict__ bias,
+                                 float* __restrict__ table, int ncodes, int cdim, int latent) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)ncodes * latent) return;
+  const int code = (int)(idx / latent), c = (int)(idx % latent);
+  float acc = 0.f;
+  for (int d = 0; d < cdim; ++d) acc = fmaf(w[(size_t)c * cdim + d], cb[(size_t)code * cdim + d], acc);
+  table[idx] = acc + bias[c];
+}
+
+// z[b][t][c] = sum_i table[i][codes[b][i][t]][c]   (sequential over i, like from_codes)
+__global__ void rvq_gather_kernel(const long long* __restrict__ codes, const float* __restrict__ table, float* __restrict__ z,
+                                  int K, int T, int ncodes, int latent) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  __shared__ int s_code[32];
+  if (threadIdx.x < K) {
+    long long cde = codes[((size_t)b * K + threadIdx.x) * T + t];
+    if (cde < 0) cde = 0;
+    if (cde >= ncodes) cde = ncodes - 1;
+    s_code[threadIdx.x] = (int)cde;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < latent; c += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < K; ++i) acc += table[((size_t)i * ncodes + s_code[i]) * latent + c];
+    z[((size_t)b * T + t) * latent + c] = acc;
+  }
+}
+
+// pack conv weights into MFMA A-fragment order. src element (co, ci, k) at src[co*s_co + ci*s_ci + k*s_k].
+__global__ void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int ntaps, int nphase,
+                                 const int* __restrict__ ktap /*[phase][tap] -> kernel index*/, long long s_co, long long s_ci, long long s_k) {
+  const int cpt = Cin / 16, nk = ntaps * cpt, nstrips = Cout / 16;
+  const size_t total = (size_t)nphase * nstrips * nk * 64;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  size_t r = idx >> 6;
+  const int ks = (int)(r % nk); r /= nk;
+  const int strip = (int)(r % nstrips);
+  const int ph = (int)(r / nstrips);
+  const int tap = ks / cpt, cc = ks % cpt;
+  const int co = strip * 16 + (lane & 15);
+  const int kidx = ktap[ph * MAXTAPS + tap];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ci = cc * 16 + (lane >> 4) * 4 + e;
+    dst[idx * 4 + e] = src[co * s_co + ci * s_ci + kidx * s_k];
+  }
+}
+
+struct ConvLayer {
+  std::string name;        // descript module name, e.g. "decoder.model.1.block.1"
+  std::string alpha_name;  // Snake applied to this conv's OUTPUT (the next layer's input activation), or ""
+  int Cin, Cout, ksize, dil, stride;  // stride > 1 => transposed
+  bool transposed;
+  float *Wp = nullptr, *bias = nullptr, *alpha = nullptr;
+  bool has_skip = false, write_raw = false;
+};
+
+}  // namespace
+
+struct ptts_dac {
+  ptts_dac_config cfg;
+  hipStream_t own_stream = nullptr;
+  std::vector<void*> allocs;
+  std::vector<ConvLayer> convs;  // all MFMA convs in execution order
+  float *out_w = nullptr, *out_b = nullptr;  // final Conv1d(C->1): [7][C], [1]
+  int out_C = 0;
+  float* table = nullptr;  // [K][codes][latent]
+  std::vector<float*> cb, opw, opb;
+  float *bufA0 = nullptr, *bufA1 = nullptr, *bufY = nullptr, *bufS = nullptr, *bufZ = nullptr;
+  int* d_ktap = nullptr;
+  std::set<std::string> loaded, required;
+  bool table_ready = false;
+  int hop = 1;
+
+  template <typename T> int alloc(T** p, size_t n) {
+    void* v = nullptr;
+    hipError_t e = hipMalloc(&v, n * sizeof(T) > 0 ? n * sizeof(T) : 16);
+    if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    allocs.push_back(v);
+    *p = reinterpret_cast<T*>(v);
+    return PTTS_OK;
+  }
+};
+
+extern "C" void ptts_dac_destroy(ptts_dac* d) {
+  if (!d) return;
+  hipSetDevice(d->cfg.device);
+  hipDeviceSynchronize();
+  for (void* p : d->allocs) hipFree(p);
+  if (d->own_stream) hipStreamDestroy(d->own_stream);
+  delete d;
+}
+
+extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
+  PTTS_CHECK(cfg && out, PTTS_E_INVALID, "null argument");
+  const ptts_dac_config& c = *cfg;
+  PTTS_CHECK(c.num_rates >= 1 && c.num_rates <= 8, PTTS_E_INVALID, "num_rates out of range");
+  PTTS_CHECK(c.num_codebooks >= 1 && c.num_codebooks <= 32, PTTS_E_INVALID, "num_codebooks out of range");
+  PTTS_CHECK(c.latent_dim % 16 == 0 && c.decoder_dim % (16 << c.num_rates) == 0, PTTS_E_UNSUPPORTED,
+             "latent_dim and every decoder width must be multiples of 16");
+  PTTS_CHECK(c.compute_dtype == PTTS_F32, PTTS_E_UNSUPPORTED, "only the exact-f32 MFMA mode is implemented (compute_dtype = PTTS_F32)");
+  PTTS_CHECK(c.max_batch >= 1 && c.max_frames >= 1, PTTS_E_INVALID, "bad capacities");
+  for (int i = 0; i < c.num_rates; ++i) PTTS_CHECK(c.rates[i] >= 2 && c.rates[i] <= 8 && c.rates[i] % 2 == 0, PTTS_E_UNSUPPORTED, "decoder rate %d unsupported (need an even stride in [2, 8])", c.rates[i]);
+  PTTS_HIP(hipSetDevice(c.device));
+  ptts_dac* d = new ptts_dac();
+  d->cfg = c;
+  int rc = PTTS_OK;
+  auto fail = [&](int r) { ptts_dac_destroy(d); return r; };
+  if (hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate failed"));
+#define A(expr) if ((rc = (expr)) != PTTS_OK) return fail(rc)
+  auto add_conv = [&](const std::string& name, const std::string& alpha_name, int Cin, int Cout, int k, int dil, int stride, bool tr,
+                      bool has_skip, bool write_raw) -> int {
+    ConvLayer L;
+    L.name = name; L.alpha_name = alpha_name; L.Cin = Cin; L.Cout = Cout; L.ksize = k; L.dil = dil; L.stride = stride; L.transposed = tr;
+    L.has_skip = has_skip; L.write_raw = write_raw;
+    const int ntaps = tr ? 2 : k, nphase = tr ? stride : 1;
+    PTTS_TRY(d->alloc(&L.Wp, (size_t)nphase * Cout * ntaps * Cin));
+    PTTS_TRY(d->alloc(&L.bias, Cout));
+    if (!alpha_name.empty()) PTTS_TRY(d->alloc(&L.alpha, Cout));
+    d->required.insert(name + ".weight");
+    d->required.insert(name + ".bias");
+    if (!alpha_name.empty()) d->required.insert(alpha_name + ".alpha");
+    d->convs.push_back(L);
+    return PTTS_OK;
+  };
+  char nm[128], an[128];
+  int ch = c.decoder_dim;
+  snprintf(an, sizeof an, "decoder.model.1.block.0");
+  A(add_conv("decoder.model.0", an, c.latent_dim, ch, 7, 1, 1, false, false, false));
+  int hop = 1;
+  for (int bi = 0; bi < c.num_rates; ++bi) {
+    const int cin = ch >> bi, cout = ch >> (bi + 1), s = c.rates[bi];
+    hop *= s;
+    snprintf(nm, sizeof nm, "decoder.model.%d.block.1", bi + 1);
+    snprintf(an, sizeof an, "decoder.model.%d.block.2.block.0", bi + 1);
+    A(add_conv(nm, an, cin, cout, 2 * s, 1, s, true, false, true));
+    const int dils[3] = {1, 3, 9};
+    for (int ri = 0; ri < 3; ++ri) {
+      snprintf(nm, sizeof nm, "decoder.model.%d.block.%d.block.1", bi + 1, ri + 2);
+      snprintf(an, sizeof an, "decoder.model.%d.block.%d.block.2", bi + 1, ri + 2);
+      A(add_conv(nm, an, cout, cout, 7, dils[ri], 1, false, false, false));
+      snprintf(nm, sizeof nm, "decoder.model.%d.block.%d.block.3", bi + 1, ri + 2);
+      if (ri < 2) snprintf(an, sizeof an, "decoder.model.%d.block.%d.block.0", bi + 1, ri + 3);
+      else if (bi + 1 < c.num_rates) snprintf(an, sizeof an, "decoder.model.%d.block.0", bi + 2);
+      else snprintf(an, sizeof an, "decoder.model.%d", c.num_rates + 1);
+      A(add_conv(nm, an, cout, cout, 1, 1, 1, false, true, ri < 2));
+    }
+  }
+  d->hop = hop;
+  d->out_C = ch >> c.num_rates;
+  A(d->alloc(&d->out_w, (size_t)7 * d->out_C));
+  A(d->alloc(&d->out_b, 1));
+  snprintf(nm, sizeof nm, "decoder.model.%d", c.num_rates + 2);
+  d->required.insert(std::string(nm) + ".weight");
+  d->required.insert(std::string(nm) + ".bias");
+  A(d->alloc(&d->table, (size_t)c.num_codebooks * c.codebook_size * c.latent_dim));
+  d->cb.resize(c.num_codebooks); d->opw.resize(c.num_codebooks); d->opb.resize(c.num_codebooks);
+  for (int i = 0; i < c.num_codebooks; ++i) {
+    A(d->alloc(&d->cb[i], (size_t)c.codebook_size * c.codebook_dim));
+    A(d->alloc(&d->opw[i], (size_t)c.latent_dim * c.codebook_dim));
+    A(d->alloc(&d->opb[i], c.latent_dim));
+    snprintf(nm, sizeof nm, "quantizer.quantizers.%d.", i);
+    d->required.insert(std::string(nm) + "codebook.weight");
+    d->required.insert(std::string(nm) + "out_proj.weight");
+    d->required.insert(std::string(nm) + "out_proj.bias");
+  }
+  // activation buffers: max over layers of T_l * C_l
+  size_t mx = (size_t)c.max_frames * std::max(c.latent_dim, c.decoder_dim);
+  {
+    size_t T = c.max_frames;
+    for (int bi = 0; bi < c.num_rates; ++bi) { T *= c.rates[bi]; mx = std::max(mx, T * (size_t)(ch >> (bi + 1))); }
+  }
+  mx *= c.max_batch;
+  A(d->alloc(&d->bufA0, mx)); A(d->alloc(&d->bufA1, mx)); A(d->alloc(&d->bufY, mx)); A(d->alloc(&d->bufS, mx));
+  A(d->alloc(&d->bufZ, (size_t)c.max_batch * c.max_frames * c.latent_dim));
+  A(d->alloc(&d->d_ktap, MAXTAPS * 8));
+#undef A
+  *out = d;
+  return PTTS_OK;
+}
+
+extern "C" int ptts_dac_load_weight(ptts_dac* d, const char* name_c, const float* dev_ptr, const int64_t* shape, int32_t ndim, void* stream) {
+  PTTS_CHECK(d && name_c && dev_ptr && shape, PTTS_E_INVALID, "null argument");
+  PTTS_HIP(hipSetDevice(d->cfg.device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : d->own_stream;
+  const ptts_dac_config& c = d->cfg;
+  const std::string name(name_c);
+  auto numel = [&]() { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; };
+  auto copy = [&](float* dst, size_t n) -> int {
+    if (numel() != n) return ptts_fail(PTTS_E_INVALID, "%s: expected %zu elements, got %zu", name_c, n, numel());
+    PTTS_HIP(hipMemcpyAsync(dst, dev_ptr, n * 4, hipMemcpyDeviceToDevice, st));
+    d->loaded.insert(name);
+    return PTTS_OK;
+  };
+  int qi = -1;
+  char tail[64] = {0};
+  if (sscanf(name_c, "quantizer.quantizers.%d.%63s", &qi, tail) == 2) {
+    PTTS_CHECK(qi >= 0 && qi < c.num_codebooks, PTTS_E_INVALID, "%s: quantizer index out of range", name_c);
+    d->table_ready = false;
+    const std::string t(tail);
+    if (t == "codebook.weight") return copy(d->cb[qi], (size_t)c.codebook_size * c.codebook_dim);
+    if (t == "out_proj.weight") return copy(d->opw[qi], (size_t)c.latent_dim * c.codebook_dim);
+    if (t == "out_proj.bias") return copy(d->opb[qi], c.latent_dim);
+    if (t == "in_proj.weight" || t == "in_proj.bias") return PTTS_OK;  // encoder side, not on the decode path
+    return ptts_fail(PTTS_E_INVALID, "unknown tensor name %s", name_c);
+  }
+  char fin[64];
+  snprintf(fin, sizeof fin, "decoder.model.%d", c.num_rates + 2);
+  if (name == std::string(fin) + ".weight") {  // [1][C][7] -> [7][C]
+    PTTS_CHECK(ndim == 3 && shape[0] == 1 && shape[1] == d->out_C && shape[2] == 7, PTTS_E_INVALID, "%s: expected [1,%d,7]", name_c, d->out_C);
+    // transpose on device via strided copies: 7 rows
+    for (int k = 0; k < 7; ++k)
+      PTTS_HIP(hipMemcpy2DAsync(d->out_w + (size_t)k * d->out_C, 4, dev_ptr + k, 7 * 4, 4, d->out_C, hipMemcpyDeviceToDevice, st));
+    d->loaded.insert(name);
+    return PTTS_OK;
+  }
+  if (name == std::string(fin) + ".bias") return copy(d->out_b, 1);
+  for (ConvLayer& L : d->convs) {
+    if (!L.alpha_name.empty() && name == L.alpha_name + ".alpha") return copy(L.alpha, L.Cout);
+    if (name == L.name + ".bias") return copy(L.bias, L.Cout);
+    if (name == L.name + ".weight") {
+      const int k = L.ksize;
+      int ktap[MAXTAPS * 8];
+      memset(ktap, 0, sizeof ktap);
+      long long s_co, s_ci, s_k = 1;
+      int ntaps, nphase;
+      if (!L.transposed) {  // torch Conv1d weight [Cout][Cin][k]
+        PTTS_CHECK(ndim == 3 && shape[0] == L.Cout && shape[1] == L.Cin && shape[2] == k, PTTS_E_INVALID, "%s: expected [%d,%d,%d]", name_c, L.Cout, L.Cin, k);
+        s_co = (long long)L.Cin * k; s_ci = k; ntaps = k; nphase = 1;
+        for (int t = 0; t < k; ++t) ktap[t] = t;
+      } else {  // torch ConvTranspose1d weight [Cin][Cout][2s]
+        PTTS_CHECK(ndim == 3 && shape[0] == L.Cin && shape[1] == L.Cout && shape[2] == k, PTTS_E_INVALID, "%s: expected [%d,%d,%d]", name_c, L.Cin, L.Cout, k);
+        s_ci = (long long)L.Cout * k; s_co = k; ntaps = 2; nphase = L.stride;
+        const int s = L.stride, pad = (s + 1) / 2;
+        for (int ph = 0; ph < s; ++ph) { const int r = (ph + pad) % s; ktap[ph * MAXTAPS + 0] = r; ktap[ph * MAXTAPS + 1] = r + s; }
+      }
+      PTTS_HIP(hipMemcpyAsync(d->d_ktap, ktap, sizeof ktap, hipMemcpyHostToDevice, st));
+      const size_t total = (size_t)nphase * (L.Cout / 16) * ntaps * (L.Cin / 16) * 64;
+      hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dev_ptr, L.Wp, L.Cout, L.Cin, ntaps, nphase,
+                         d->d_ktap, s_co, s_ci, s_k);
+      PTTS_HIP(hipStreamSynchronize(st));  // d_ktap is reused by the next call
+      d->loaded.insert(name);
+      return PTTS_OK;
+    }
+  }
+  if (name.rfind("encoder.", 0) == 0) return PTTS_OK;  // DAC encoder weights are not on the decode path
+  return ptts_fail(PTTS_E_INVALID, "unknown tensor name %s", name_c);
+}
+
+extern "C" int ptts_dac_weights_ready(ptts_dac* d) {
+  PTTS_CHECK(d, PTTS_E_INVALID, "null dac");
+  std::string missing;
+  int n = 0;
+  for (const auto& r : d->required)
+    if (!d->loaded.count(r)) { if (n++ < 8) missing += (missing.empty() ? "" : ", ") + r; }
+  if (n) return ptts_fail(PTTS_E_MISSING, "%d tensors not loaded: %s%s", n, missing.c_str(), n > 8 ? ", ..." : "");
+  return PTTS_OK;
+}
+
+static int run_conv(ptts_dac* d, const ConvLayer& L, const float* x, const float* skip, float* out_raw, float* out_act, int B, int Tin, hipStream_t st) {
+  ConvArgs a = {};
+  a.x = x; a.Wp = L.Wp; a.bias = L.bias; a.skip = skip; a.out_raw = out_raw; a.out_act = out_act; a.alpha = L.alpha;
+  a.B = B; a.Tin = Tin; a.Cin = L.Cin; a.Cout = L.Cout;
+  if (!L.transposed) {
+    a.ntaps = L.ksize; a.nphase = 1;
+    const int pad = (L.ksize - 1) * L.dil / 2;
+    for (int t = 0; t < L.ksize; ++t) a.toff[t] = t * L.dil - pad;
+  } else {
+    a.ntaps = 2; a.nphase = L.stride;
+    const int s = L.stride, pad = (s + 1) / 2;
+    for (int ph = 0; ph < s; ++ph) {  // to = j*s + ph = ti*s - pad + k  =>  k = r: ti = j + c0 ; k = r + s: ti = j + c0 - 1
+      const int c0 = (ph + pad) / s;
+      a.toff[ph * MAXTAPS + 0] = c0;
+      a.toff[ph * MAXTAPS + 1] = c0 - 1;
+    }
+  }
+  const int ntile = (Tin + 31) / 32, nstrips = L.Cout / 16;
+  const int CS = nstrips >= 16 ? 4 : (nstrips >= 8 ? 2 : 1);
+  const dim3 grid((unsigned)(ntile * a.nphase * B), (unsigned)((nstrips + 4 * CS - 1) / (4 * CS)));
+  if (CS == 4) hipLaunchKernelGGL((conv_mfma_kernel<4>), grid, dim3(256), 0, st, a);
+  else if (CS == 2) hipLaunchKernelGGL((conv_mfma_kernel<2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<1>), grid, dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "conv launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream) {
+  PTTS_CHECK(d && codes_dev && wave_dev, PTTS_E_INVALID, "null argument");
+  PTTS_TRY(ptts_dac_weights_ready(d));
+  const ptts_dac_config& c = d->cfg;
+  PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds dac max_batch %d", B, c.max_batch);
+  PTTS_CHECK(T >= 1 && T <= c.max_frames, PTTS_E_CAPACITY, "frames %d exceed dac max_frames %d", T, c.max_frames);
+  PTTS_HIP(hipSetDevice(c.device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : d->own_stream;
+  if (!d->table_ready) {
+    for (int i = 0; i < c.num_codebooks; ++i) {
+      const size_t n = (size_t)c.codebook_size * c.latent_dim;
+      hipLaunchKernelGGL(rvq_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d->cb[i], d->opw[i], d->opb[i],
+                         d->table + (size_t)i * n, c.codebook_size, c.codebook_dim, c.latent_dim);
+    }
+    d->table_ready = true;
+  }
+  hipLaunchKernelGGL(rvq_gather_kernel, dim3(T, B), dim3(256), 0, st, (const long long*)codes_dev, d->table, d->bufZ, c.num_codebooks, T,
+                     c.codebook_size, c.latent_dim);
+  float *cur = d->bufA0, *other = d->bufA1;
+  int Tcur = T;
+  size_t li = 0;
+  PTTS_TRY(run_conv(d, d->convs[li++], d->bufZ, nullptr, nullptr, cur, B, Tcur, st));
+  for (int bi = 0; bi < c.num_rates; ++bi) {
+    const ConvLayer& up = d->convs[li++];
+    PTTS_TRY(run_conv(d, up, cur, nullptr, d->bufY, other, B, Tcur, st));
+    std::swap(cur, other);
+    Tcur *= up.stride;
+    for (int ri = 0; ri < 3; ++ri) {
+      const ConvLayer& c7 = d->convs[li++];
+      PTTS_TRY(run_conv(d, c7, cur, nullptr, nullptr, d->bufS, B, Tcur, st));
+      const ConvLayer& c1 = d->convs[li++];
+      PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st));
+    }
+  }
+  const size_t n = (size_t)B * Tcur;
+  hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)7 * d->out_C * 4, st, cur, d->out_w, d->out_b,
+                     wave_dev, B, Tcur, d->out_C, 7);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}

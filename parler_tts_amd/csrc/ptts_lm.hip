@@ -1,0 +1,610 @@
+// Decoder-LM engine behind the C ABI of include/ptts.h: packed weights, static KV arena, device-resident
+// sampler state, one captured hipGraph per batch size. Replaces ParlerTTSForCausalLM.forward + the
+// transformers `_sample` loop of the reference (modeling_parler_tts.py:1865, :3564).
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+#include <string.h>
+
+#include "ptts_common.h"
+#include "ptts_lm_kernels.h"
+
+thread_local std::string g_ptts_err;
+int ptts_fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_ptts_err = buf;
+  return code;
+}
+extern "C" const char* ptts_last_error(void) { return g_ptts_err.c_str(); }
+extern "C" int ptts_abi_version(void) { return PTTS_ABI_VERSION; }
+
+namespace {
+
+struct LayerW {
+  void *qkv = nullptr, *o = nullptr, *cq = nullptr, *ckv = nullptr, *co = nullptr, *fc1 = nullptr, *fc2 = nullptr;
+  float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
+  void *k_self = nullptr, *v_self = nullptr, *k_cross = nullptr, *v_cross = nullptr;
+};
+
+}  // namespace
+
+struct ptts_engine {
+  ptts_config cfg;
+  int max_prompt = 0;  // P + 1 rows capacity per utterance
+  size_t esize = 4;
+  hipStream_t own_stream = nullptr;
+  std::vector<void*> allocs;
+  std::vector<LayerW> L;
+  void* embed = nullptr;       // [K][V+1][H]
+  float* pos_table = nullptr;  // [max_pos][H]
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  float *lnf_g = nullptr, *lnf_b = nullptr;
+  void* heads = nullptr;  // [K*V][H] packed
+  std::set<std::string> loaded, required;
+  // scratch
+  float *h = nullptr, *qkv = nullptr, *qc = nullptr, *part = nullptr, *stats = nullptr, *ffn = nullptr, *logits = nullptr;
+  float* sort_buf = nullptr;
+  int S_self = 4, S_cross = 1;
+  // state
+  long long* ids = nullptr;
+  int ids_ld = 0;
+  int *cur_len = nullptr, *unfinished = nullptr, *has_eos = nullptr, *first_unf = nullptr;
+  int *enc_mask = nullptr, *prompt_mask = nullptr;
+  DevDims* dims = nullptr;
+  DevGen* gen = nullptr;
+  ptts_gen_params gp;
+  // per-call
+  int B = 0, N = 0, P = 0;
+  bool prefilled = false;
+  std::map<int, hipGraphExec_t> graphs;  // key: batch size
+  int* host_pinned = nullptr;
+
+  template <typename T> int alloc(T** p, size_t n) {
+    void* v = nullptr;
+    hipError_t e = hipMalloc(&v, n * sizeof(T) > 0 ? n * sizeof(T) : 16);
+    if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    allocs.push_back(v);
+    *p = reinterpret_cast<T*>(v);
+    return PTTS_OK;
+  }
+  int alloc_bytes(void** p, size_t bytes) {
+    char* c = nullptr;
+    PTTS_TRY(alloc(&c, bytes));
+    *p = c;
+    return PTTS_OK;
+  }
+};
+
+namespace {
+
+template <typename WT, int PRO, int EPI>
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  constexpr int KT = Elem<WT>::KT;
+  if (a.N % 16 != 0 || a.K % KT != 0) return ptts_fail(PTTS_E_INVALID, "gemm N=%d K=%d not multiples of 16/%d", a.N, a.K, KT);
+  const int nfrag = a.K / KT;
+  int W = (nfrag + 7) / 8;
+  if (W < 2) W = 2;
+  if (W > GemmMaxThreads<PRO>::value / 64) W = GemmMaxThreads<PRO>::value / 64;
+  const dim3 grid(a.N / 16), block(W * 64);
+  if (a.M <= 16) {
+    const size_t sh = ((size_t)W * 1 * 256 + 32 * 1) * sizeof(float);
+    hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, 1>), grid, block, sh, st, a);
+  } else {
+    const size_t sh = ((size_t)W * 2 * 256 + 32 * 2) * sizeof(float);
+    hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, 2>), grid, block, sh, st, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+template <typename WT>
+int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
+  const dim3 grid(a.S, a.nheads, B * a.Q);
+  hipLaunchKernelGGL((attn_kernel<WT, 4>), grid, dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "attn launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+// One decoder forward over Q positions per utterance (Q = P+1 at prefill, 1 at decode) up to the logits.
+template <typename WT>
+int forward(ptts_engine* e, bool prefill, hipStream_t st) {
+  const ptts_config& c = e->cfg;
+  const int H = c.hidden_size, F = c.ffn_dim, nh = c.num_heads, B = e->B;
+  const int Q = prefill ? e->P + 1 : 1;
+  const int M = B * Q;
+  const float scale = 1.0f / sqrtf((float)(H / nh));
+
+  if (prefill) {  // cross-attention K/V of the description, once per call (:877-878 then reused :872-875)
+    for (int l = 0; l < c.num_layers; ++l) {
+      GemmArgs g = {};
+      g.W = e->L[l].ckv; g.x = nullptr; g.M = B * e->N; g.N = 2 * H; g.K = H;
+      g.x_ld = H; g.x_row_mul = 1; g.x_row_off = 0;
+      g.kcache = e->L[l].k_cross; g.vcache = e->L[l].v_cross; g.kv_rows_per_b = e->N; g.kv_cap = c.max_enc; g.nheads = nh;
+      g.x = e->qc;  // encoder states were staged into qc by ptts_prefill (row-major [B*N][H])
+      PTTS_TRY((launch_gemm<WT, PRO_PLAIN, EPI_KV>(g, st)));
+    }
+  }
+  {
+    EmbedArgs ea = {};
+    ea.tables = e->embed; ea.pos_table = c.rope ? nullptr : e->pos_table; ea.prompt = prefill ? e->ffn : nullptr;
+    ea.ids = e->ids; ea.ids_ld = e->ids_ld; ea.cur_len = e->cur_len; ea.dims = e->dims; ea.h = e->h;
+    ea.H = H; ea.K = c.num_codebooks; ea.V1 = c.vocab_size + 1; ea.bos = c.bos_token_id; ea.pad = c.pad_token_id;
+    ea.prefill = prefill ? 1 : 0;
+    hipLaunchKernelGGL((embed_kernel<WT>), dim3(Q, B), dim3(256), 0, st, ea);
+  }
+  for (int l = 0; l < c.num_layers; ++l) {
+    const LayerW& w = e->L[l];
+    {  // LN1 + fused QKV projection
+      GemmArgs g = {};
+      g.W = w.qkv; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
+      g.out = e->qkv; g.out_ld = 3 * H; g.M = M; g.N = 3 * H; g.K = H;
+      PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_STORE>(g, st)));
+    }
+    if (prefill) {
+      hipLaunchKernelGGL((kv_append_kernel<WT>), dim3(Q, nh, B), dim3(64), 0, st, e->qkv + H, e->qkv + 2 * H, 3 * H, w.k_self,
+                         w.v_self, c.max_ctx, Q, nh, c.rope ? e->rope_cos : nullptr, c.rope ? e->rope_sin : nullptr);
+    }
+    {  // causal self-attention over the KV arena
+      AttnArgs a = {};
+      a.q = e->qkv; a.q_ld = 3 * H; a.knew = e->qkv + H; a.vnew = e->qkv + 2 * H; a.kv_ld = 3 * H;
+      a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims;
+      a.mask = e->prompt_mask; a.mask_ld = e->max_prompt;
+      a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
+      a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
+      a.fused_append = prefill ? 0 : 1; a.scale = scale;
+      PTTS_TRY((launch_attn<WT>(a, B, st)));
+    }
+    {  // combine splits + out_proj + residual
+      GemmArgs g = {};
+      g.W = w.o; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
+      g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      PTTS_TRY((launch_gemm<WT, PRO_ATTN, EPI_RESID>(g, st)));
+    }
+    {  // LN2 + cross q projection
+      GemmArgs g = {};
+      g.W = w.cq; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln2_g; g.beta = w.ln2_b;
+      g.out = e->qc; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_STORE>(g, st)));
+    }
+    {  // cross-attention against the static description K/V
+      AttnArgs a = {};
+      a.q = e->qc; a.q_ld = H; a.kcache = w.k_cross; a.vcache = w.v_cross; a.cap = c.max_enc;
+      a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims; a.mask = e->enc_mask; a.mask_ld = c.max_enc;
+      a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;  // quirk: q rotated, keys not (:858 vs :880)
+      a.part = e->part; a.stats = e->stats; a.S = e->S_cross; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 1;
+      a.fused_append = 0; a.scale = scale;
+      PTTS_TRY((launch_attn<WT>(a, B, st)));
+    }
+    {
+      GemmArgs g = {};
+      g.W = w.co; g.part = e->part; g.stats = e->stats; g.S = e->S_cross; g.nheads = nh;
+      g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      PTTS_TRY((launch_gemm<WT, PRO_ATTN, EPI_RESID>(g, st)));
+    }
+    {  // LN3 + fc1 + GELU
+      GemmArgs g = {};
+      g.W = w.fc1; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln3_g; g.beta = w.ln3_b;
+      g.out = e->ffn; g.out_ld = F; g.M = M; g.N = F; g.K = H;
+      PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_GELU>(g, st)));
+    }
+    {  // fc2 + residual
+      GemmArgs g = {};
+      g.W = w.fc2; g.x = e->ffn; g.x_ld = F; g.x_row_mul = 1;
+      g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = F;
+      PTTS_TRY((launch_gemm<WT, PRO_PLAIN, EPI_RESID>(g, st)));
+    }
+  }
+  {  // final LayerNorm + all K LM heads as one [K*V, H] projection, last position of each utterance only
+    GemmArgs g = {};
+    g.W = e->heads; g.x = e->h; g.x_ld = H; g.x_row_mul = Q; g.x_row_off = Q - 1; g.gamma = e->lnf_g; g.beta = e->lnf_b;
+    g.out = e->logits; g.out_ld = c.num_codebooks * c.vocab_size; g.M = B; g.N = c.num_codebooks * c.vocab_size; g.K = H;
+    PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_STORE>(g, st)));
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "forward launch failed: %s", hipGetErrorString(err));
+  return PTTS_OK;
+}
+
+int launch_tail(ptts_engine* e, hipStream_t st) {
+  TailArgs t = {};
+  t.logits = e->logits; t.ids = e->ids; t.ids_ld = e->ids_ld; t.cur_len = e->cur_len; t.unfinished = e->unfinished;
+  t.has_eos = e->has_eos; t.first_unf = e->first_unf; t.gen = e->gen; t.sort_buf = e->sort_buf;
+  t.B = e->B; t.K = e->cfg.num_codebooks; t.V = e->cfg.vocab_size; t.eos = e->cfg.eos_token_id; t.pad = e->cfg.pad_token_id;
+  hipLaunchKernelGGL(tail_kernel, dim3(e->B), dim3(256), 0, st, t);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "tail launch failed: %s", hipGetErrorString(err));
+  return PTTS_OK;
+}
+
+int forward_dispatch(ptts_engine* e, bool prefill, hipStream_t st) {
+  return e->cfg.dtype == PTTS_BF16 ? forward<bf16_t>(e, prefill, st) : forward<float>(e, prefill, st);
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// copy/convert a plain tensor into engine storage
+template <typename DT>
+int convert_into(DT* dst, const void* src, int src_dtype, size_t n, hipStream_t st) {
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+  if (src_dtype == PTTS_F32) hipLaunchKernelGGL((convert_kernel<DT, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, n);
+  else hipLaunchKernelGGL((convert_kernel<DT, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, n);
+  return PTTS_OK;
+}
+
+template <typename WT>
+int pack_into(void* dst, const void* src, int src_dtype, int N, int K, int row0, hipStream_t st) {
+  constexpr int KT = Elem<WT>::KT;
+  if (N % 16 || K % KT || row0 % 16) return ptts_fail(PTTS_E_INVALID, "weight [%d,%d] (row offset %d) not a multiple of the 16x%d MFMA tile", N, K, row0, KT);
+  const size_t total = (size_t)(N / 16) * (K / KT) * 64;
+  const int blocks = (int)((total + 255) / 256);
+  if (src_dtype == PTTS_F32)
+    hipLaunchKernelGGL((pack_weight_kernel<WT, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (WT*)dst, N, K, row0 / 16, K / KT);
+  else
+    hipLaunchKernelGGL((pack_weight_kernel<WT, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, (WT*)dst, N, K, row0 / 16, K / KT);
+  return PTTS_OK;
+}
+
+int pack_dispatch(ptts_engine* e, void* dst, const void* src, int src_dtype, int N, int K, int row0, hipStream_t st) {
+  return e->cfg.dtype == PTTS_BF16 ? pack_into<bf16_t>(dst, src, src_dtype, N, K, row0, st) : pack_into<float>(dst, src, src_dtype, N, K, row0, st);
+}
+
+hipStream_t pick_stream(ptts_engine* e, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : e->own_stream; }
+
+}  // namespace
+
+extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
+  PTTS_CHECK(cfg && out, PTTS_E_INVALID, "null argument");
+  const ptts_config& c = *cfg;
+  PTTS_CHECK(c.hidden_size > 0 && c.num_heads > 0 && c.hidden_size % c.num_heads == 0, PTTS_E_INVALID, "hidden_size %d not divisible by num_heads %d", c.hidden_size, c.num_heads);
+  PTTS_CHECK(c.hidden_size / c.num_heads == 64, PTTS_E_UNSUPPORTED, "head_dim must be 64 (Mini/Large v1), got %d", c.hidden_size / c.num_heads);
+  PTTS_CHECK(c.dtype == PTTS_F32 || c.dtype == PTTS_BF16, PTTS_E_INVALID, "dtype must be PTTS_F32 or PTTS_BF16");
+  PTTS_CHECK(c.hidden_size % 32 == 0 && c.ffn_dim % 32 == 0 && c.vocab_size % 16 == 0, PTTS_E_UNSUPPORTED,
+             "hidden_size/ffn_dim must be multiples of 32 and vocab_size of 16");
+  PTTS_CHECK(c.num_codebooks >= 1 && c.num_codebooks <= 32, PTTS_E_INVALID, "num_codebooks out of range");
+  PTTS_CHECK(c.vocab_size <= PTTS_SORT_N, PTTS_E_UNSUPPORTED, "vocab_size > %d unsupported by the sampler", PTTS_SORT_N);
+  PTTS_CHECK(c.max_batch >= 1 && c.max_ctx >= 2 && c.max_enc >= 1 && c.max_prompt >= 1 && c.max_prompt <= c.max_ctx, PTTS_E_INVALID, "bad capacities");
+  PTTS_HIP(hipSetDevice(c.device));
+  ptts_engine* e = new ptts_engine();
+  e->cfg = c;
+  e->esize = c.dtype == PTTS_BF16 ? 2 : 4;
+  e->max_prompt = c.max_prompt;
+  int rc = PTTS_OK;
+  auto fail = [&](int r) { ptts_engine_destroy(e); return r; };
+  if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate failed"));
+  const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size, nh = c.num_heads;
+  const size_t es = e->esize;
+  e->L.resize(c.num_layers);
+#define A(expr) if ((rc = (expr)) != PTTS_OK) return fail(rc)
+  for (int l = 0; l < c.num_layers; ++l) {
+    LayerW& w = e->L[l];
+    A(e->alloc_bytes(&w.qkv, (size_t)3 * H * H * es));
+    A(e->alloc_bytes(&w.o, (size_t)H * H * es));
+    A(e->alloc_bytes(&w.cq, (size_t)H * H * es));
+    A(e->alloc_bytes(&w.ckv, (size_t)2 * H * H * es));
+    A(e->alloc_bytes(&w.co, (size_t)H * H * es));
+    A(e->alloc_bytes(&w.fc1, (size_t)F * H * es));
+    A(e->alloc_bytes(&w.fc2, (size_t)F * H * es));
+    A(e->alloc(&w.ln1_g, H)); A(e->alloc(&w.ln1_b, H)); A(e->alloc(&w.ln2_g, H)); A(e->alloc(&w.ln2_b, H));
+    A(e->alloc(&w.ln3_g, H)); A(e->alloc(&w.ln3_b, H));
+    const size_t kvs = (size_t)c.max_batch * nh * c.max_ctx * 64 * es, kvc = (size_t)c.max_batch * nh * c.max_enc * 64 * es;
+    A(e->alloc_bytes(&w.k_self, kvs)); A(e->alloc_bytes(&w.v_self, kvs));
+    A(e->alloc_bytes(&w.k_cross, kvc)); A(e->alloc_bytes(&w.v_cross, kvc));
+    char nm[160];
+    const char* mats[] = {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "encoder_attn.q_proj",
+                          "encoder_attn.k_proj", "encoder_attn.v_proj", "encoder_attn.out_proj", "fc1", "fc2"};
+    for (const char* m : mats) { snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.weight", l, m); e->required.insert(nm); }
+    const char* lns[] = {"self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"};
+    for (const char* m : lns) {
+      snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.weight", l, m); e->required.insert(nm);
+      snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.bias", l, m); e->required.insert(nm);
+    }
+  }
+  A(e->alloc_bytes(&e->embed, (size_t)K * (V + 1) * H * es));
+  A(e->alloc_bytes(&e->heads, (size_t)K * V * H * es));
+  A(e->alloc(&e->lnf_g, H)); A(e->alloc(&e->lnf_b, H));
+  e->required.insert("model.decoder.layer_norm.weight");
+  e->required.insert("model.decoder.layer_norm.bias");
+  for (int k = 0; k < K; ++k) {
+    char nm[96];
+    snprintf(nm, sizeof nm, "model.decoder.embed_tokens.%d.weight", k); e->required.insert(nm);
+    snprintf(nm, sizeof nm, "lm_heads.%d.weight", k); e->required.insert(nm);
+  }
+  if (c.rope) {
+    A(e->alloc(&e->rope_cos, (size_t)c.max_positions * 64)); A(e->alloc(&e->rope_sin, (size_t)c.max_positions * 64));
+    e->required.insert("rope_cos"); e->required.insert("rope_sin");
+  } else {
+    A(e->alloc(&e->pos_table, (size_t)c.max_positions * H));
+    e->required.insert("model.decoder.embed_positions.weights");
+  }
+  // split-KV factor: enough workgroups to cover the chip at small batch, none needed at large batch
+  {
+    int s = 256 / (c.max_batch * nh);
+    if (s < 1) s = 1;
+    if (s > 8) s = 8;
+    while (s > 1 && (s - 1) * 4 * 8 * 8 >= c.max_ctx) --s;  // do not split below one 8-deep batch of row groups per wave
+    e->S_self = s;
+    e->S_cross = 1;
+  }
+  const size_t rows = (size_t)c.max_batch * e->max_prompt;
+  const size_t enc_rows = (size_t)c.max_batch * c.max_enc;
+  A(e->alloc(&e->h, rows * H));
+  A(e->alloc(&e->qkv, rows * 3 * H));
+  A(e->alloc(&e->qc, std::max(rows, enc_rows) * H));
+  A(e->alloc(&e->part, rows * e->S_self * H));
+  A(e->alloc(&e->stats, rows * e->S_self * nh * 2));
+  A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));
+  A(e->alloc(&e->logits, (size_t)c.max_batch * K * V));
+  A(e->alloc(&e->sort_buf, 16));
+  e->ids_ld = c.max_ctx + 8;
+  A(e->alloc(&e->ids, (size_t)c.max_batch * K * e->ids_ld));
+  A(e->alloc(&e->cur_len, c.max_batch)); A(e->alloc(&e->unfinished, (size_t)c.max_batch * K));
+  A(e->alloc(&e->has_eos, (size_t)c.max_batch * K)); A(e->alloc(&e->first_unf, c.max_batch));
+  A(e->alloc(&e->enc_mask, enc_rows)); A(e->alloc(&e->prompt_mask, rows));
+  A(e->alloc(&e->dims, 1)); A(e->alloc(&e->gen, 1));
+#undef A
+  if (hipHostMalloc((void**)&e->host_pinned, ((size_t)c.max_batch * K + 16) * 4) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipHostMalloc failed"));
+  ptts_gen_params gp = {};
+  gp.max_length = c.max_ctx; gp.temperature = 1.f; gp.top_p = 1.f; gp.use_eos_gate = 1;
+  e->gp = gp;
+  *out = e;
+  return PTTS_OK;
+}
+
+extern "C" void ptts_engine_destroy(ptts_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->cfg.device);
+  hipDeviceSynchronize();
+  for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
+  for (void* p : e->allocs) hipFree(p);
+  if (e->host_pinned) hipHostFree(e->host_pinned);
+  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* dev_ptr, int32_t src_dtype, const int64_t* shape,
+                                int32_t ndim, void* stream) {
+  PTTS_CHECK(e && name_c && dev_ptr && shape, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(src_dtype == PTTS_F32 || src_dtype == PTTS_BF16, PTTS_E_INVALID, "src_dtype must be f32 or bf16");
+  PTTS_HIP(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  const ptts_config& c = e->cfg;
+  const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size;
+  const std::string name(name_c);
+  auto want = [&](int64_t a, int64_t b) -> int {
+    if (b < 0) { if (ndim != 1 || shape[0] != a) return ptts_fail(PTTS_E_INVALID, "%s: expected shape [%lld]", name_c, (long long)a); }
+    else if (ndim != 2 || shape[0] != a || shape[1] != b) return ptts_fail(PTTS_E_INVALID, "%s: expected shape [%lld, %lld]", name_c, (long long)a, (long long)b);
+    return PTTS_OK;
+  };
+  int l = -1, k = -1;
+  char tail[128] = {0};
+  if (sscanf(name_c, "model.decoder.layers.%d.%127s", &l, tail) == 2) {
+    PTTS_CHECK(l >= 0 && l < c.num_layers, PTTS_E_INVALID, "%s: layer index out of range", name_c);
+    LayerW& w = e->L[l];
+    const std::string t(tail);
+    struct { const char* n; void* dst; int N, Kd, row0; } mats[] = {
+        {"self_attn.q_proj.weight", w.qkv, H, H, 0},       {"self_attn.k_proj.weight", w.qkv, H, H, H},
+        {"self_attn.v_proj.weight", w.qkv, H, H, 2 * H},   {"self_attn.out_proj.weight", w.o, H, H, 0},
+        {"encoder_attn.q_proj.weight", w.cq, H, H, 0},     {"encoder_attn.k_proj.weight", w.ckv, H, H, 0},
+        {"encoder_attn.v_proj.weight", w.ckv, H, H, H},    {"encoder_attn.out_proj.weight", w.co, H, H, 0},
+        {"fc1.weight", w.fc1, F, H, 0},                    {"fc2.weight", w.fc2, H, F, 0}};
+    for (auto& m : mats)
+      if (t == m.n) {
+        PTTS_TRY(want(m.N, m.Kd));
+        PTTS_TRY(pack_dispatch(e, m.dst, dev_ptr, src_dtype, m.N, m.Kd, m.row0, st));
+        e->loaded.insert(name);
+        return PTTS_OK;
+      }
+    struct { const char* n; float* dst; } vecs[] = {
+        {"self_attn_layer_norm.weight", w.ln1_g}, {"self_attn_layer_norm.bias", w.ln1_b},
+        {"encoder_attn_layer_norm.weight", w.ln2_g}, {"encoder_attn_layer_norm.bias", w.ln2_b},
+        {"final_layer_norm.weight", w.ln3_g}, {"final_layer_norm.bias", w.ln3_b}};
+    for (auto& v : vecs)
+      if (t == v.n) {
+        PTTS_TRY(want(H, -1));
+        PTTS_TRY(convert_into<float>(v.dst, dev_ptr, src_dtype, H, st));
+        e->loaded.insert(name);
+        return PTTS_OK;
+      }
+    return ptts_fail(PTTS_E_INVALID, "unknown tensor name %s", name_c);
+  }
+  if (sscanf(name_c, "model.decoder.embed_tokens.%d.weight", &k) == 1) {
+    PTTS_CHECK(k >= 0 && k < K, PTTS_E_INVALID, "%s: codebook index out of range", name_c);
+    PTTS_TRY(want(V + 1, H));
+    char* dst = (char*)e->embed + (size_t)k * (V + 1) * H * e->esize;
+    if (c.dtype == PTTS_BF16) PTTS_TRY(convert_into<bf16_t>((bf16_t*)dst, dev_ptr, src_dtype, (size_t)(V + 1) * H, st));
+    else PTTS_TRY(convert_into<float>((float*)dst, dev_ptr, src_dtype, (size_t)(V + 1) * H, st));
+    e->loaded.insert(name);
+    return PTTS_OK;
+  }
+  if (sscanf(name_c, "lm_heads.%d.weight", &k) == 1) {
+    PTTS_CHECK(k >= 0 && k < K, PTTS_E_INVALID, "%s: codebook index out of range", name_c);
+    PTTS_TRY(want(V, H));
+    PTTS_TRY(pack_dispatch(e, e->heads, dev_ptr, src_dtype, V, H, k * V, st));
+    e->loaded.insert(name);
+    return PTTS_OK;
+  }
+  if (name == "lm_heads.weight") {  // use_fused_lm_heads :1834-1840
+    PTTS_TRY(want((int64_t)K * V, H));
+    PTTS_TRY(pack_dispatch(e, e->heads, dev_ptr, src_dtype, K * V, H, 0, st));
+    for (int i = 0; i < K; ++i) { char nm[64]; snprintf(nm, sizeof nm, "lm_heads.%d.weight", i); e->loaded.insert(nm); }
+    return PTTS_OK;
+  }
+  if (name == "model.decoder.layer_norm.weight" || name == "model.decoder.layer_norm.bias") {
+    PTTS_TRY(want(H, -1));
+    PTTS_TRY(convert_into<float>(ends_with(name, ".weight") ? e->lnf_g : e->lnf_b, dev_ptr, src_dtype, H, st));
+    e->loaded.insert(name);
+    return PTTS_OK;
+  }
+  if (name == "model.decoder.embed_positions.weights") {
+    PTTS_CHECK(!c.rope, PTTS_E_INVALID, "%s given but rope_embeddings is set", name_c);
+    PTTS_CHECK(ndim == 2 && shape[1] == H && shape[0] >= 1 && shape[0] <= c.max_positions, PTTS_E_INVALID, "%s: expected [<=%d, %d]", name_c, c.max_positions, H);
+    PTTS_TRY(convert_into<float>(e->pos_table, dev_ptr, src_dtype, (size_t)shape[0] * H, st));
+    e->loaded.insert(name);
+    return PTTS_OK;
+  }
+  if (name == "rope_cos" || name == "rope_sin") {  // fp32 tables as ParlerTTSRotaryEmbedding.forward computes them (:373-406)
+    PTTS_CHECK(c.rope, PTTS_E_INVALID, "%s given but rope_embeddings is off", name_c);
+    PTTS_CHECK(ndim == 2 && shape[1] == 64 && shape[0] >= 1 && shape[0] <= c.max_positions, PTTS_E_INVALID, "%s: expected [<=%d, 64]", name_c, c.max_positions);
+    PTTS_TRY(convert_into<float>(name == "rope_cos" ? e->rope_cos : e->rope_sin, dev_ptr, src_dtype, (size_t)shape[0] * 64, st));
+    e->loaded.insert(name);
+    return PTTS_OK;
+  }
+  return ptts_fail(PTTS_E_INVALID, "unknown tensor name %s", name_c);
+}
+
+extern "C" int ptts_weights_ready(ptts_engine* e) {
+  PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
+  std::string missing;
+  int n = 0;
+  for (const auto& r : e->required)
+    if (!e->loaded.count(r)) { if (n++ < 8) missing += (missing.empty() ? "" : ", ") + r; }
+  if (n) return ptts_fail(PTTS_E_MISSING, "%d tensors not loaded: %s%s", n, missing.c_str(), n > 8 ? ", ..." : "");
+  return PTTS_OK;
+}
+
+extern "C" int ptts_set_gen_params(ptts_engine* e, const ptts_gen_params* gp) {
+  PTTS_CHECK(e && gp, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(gp->max_length >= 2, PTTS_E_INVALID, "max_length must be >= 2 (BOS column + 1 token)");
+  PTTS_CHECK(gp->max_length <= e->cfg.max_ctx, PTTS_E_CAPACITY, "max_length %d exceeds engine max_ctx %d", gp->max_length, e->cfg.max_ctx);
+  PTTS_CHECK(!gp->do_sample || gp->temperature > 0.f, PTTS_E_INVALID, "temperature must be > 0");
+  PTTS_CHECK(gp->top_p > 0.f && gp->top_p <= 1.f, PTTS_E_INVALID, "top_p must be in (0, 1]");
+  PTTS_CHECK(gp->top_k >= 0, PTTS_E_INVALID, "top_k must be >= 0");
+  e->gp = *gp;
+  return PTTS_OK;
+}
+
+extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_dev, const float* prompt_dev,
+                            const int32_t* prompt_mask_dev, int32_t B, int32_t N, int32_t P, int32_t sample, void* stream) {
+  PTTS_CHECK(e && enc_dev, PTTS_E_INVALID, "null argument");
+  PTTS_TRY(ptts_weights_ready(e));
+  const ptts_config& c = e->cfg;
+  PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds engine max_batch %d", B, c.max_batch);
+  PTTS_CHECK(N >= 1 && N <= c.max_enc, PTTS_E_CAPACITY, "encoder length %d exceeds engine max_enc %d", N, c.max_enc);
+  PTTS_CHECK(P >= 0 && P + 1 <= e->max_prompt, PTTS_E_CAPACITY, "prompt length %d exceeds engine capacity %d", P, e->max_prompt - 1);
+  PTTS_CHECK(P == 0 || prompt_dev, PTTS_E_INVALID, "prompt_dev is null but P > 0");
+  PTTS_CHECK(P + e->gp.max_length <= c.max_ctx, PTTS_E_CAPACITY, "P + max_length = %d exceeds engine max_ctx %d", P + e->gp.max_length, c.max_ctx);
+  PTTS_CHECK(P + e->gp.max_length <= c.max_positions || c.rope, PTTS_E_CAPACITY, "P + max_length = %d exceeds max_position_embeddings %d", P + e->gp.max_length, c.max_positions);
+  PTTS_HIP(hipSetDevice(c.device));
+  hipStream_t st = pick_stream(e, stream);
+  const int H = c.hidden_size, K = c.num_codebooks;
+  e->B = B; e->N = N; e->P = P;
+  // per-call device params travel as kernel arguments (no host staging buffer to keep alive)
+  {
+    DevDims hd; hd.P = P; hd.N = N; hd.max_length = e->gp.max_length;
+    DevGen hg; hg.max_length = e->gp.max_length; hg.min_new_tokens = e->gp.min_new_tokens; hg.do_sample = e->gp.do_sample;
+    hg.top_k = e->gp.top_k; hg.use_eos_gate = e->gp.use_eos_gate; hg.temperature = e->gp.temperature; hg.top_p = e->gp.top_p;
+    hg.seed = e->gp.seed;
+    hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, st, e->dims, e->gen, hd, hg);
+  }
+  // masks (all-ones when absent so the captured graph never changes shape)
+  if (enc_mask_dev) PTTS_HIP(hipMemcpy2DAsync(e->enc_mask, (size_t)c.max_enc * 4, enc_mask_dev, (size_t)N * 4, (size_t)N * 4, B, hipMemcpyDeviceToDevice, st));
+  else hipLaunchKernelGGL(fill_int_kernel, dim3(64), dim3(256), 0, st, e->enc_mask, 1, (size_t)B * c.max_enc);
+  if (prompt_mask_dev && P > 0) PTTS_HIP(hipMemcpy2DAsync(e->prompt_mask, (size_t)e->max_prompt * 4, prompt_mask_dev, (size_t)P * 4, (size_t)P * 4, B, hipMemcpyDeviceToDevice, st));
+  else hipLaunchKernelGGL(fill_int_kernel, dim3(64), dim3(256), 0, st, e->prompt_mask, 1, (size_t)B * e->max_prompt);
+  hipLaunchKernelGGL(reset_state_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->cur_len, e->unfinished,
+                     e->has_eos, e->first_unf, B, K, c.bos_token_id);
+  // stage inputs: encoder states -> qc (consumed by the cross K/V projection), prompt embeddings -> ffn
+  PTTS_HIP(hipMemcpyAsync(e->qc, enc_dev, (size_t)B * N * H * 4, hipMemcpyDeviceToDevice, st));
+  if (P > 0) PTTS_HIP(hipMemcpyAsync(e->ffn, prompt_dev, (size_t)B * P * H * 4, hipMemcpyDeviceToDevice, st));
+  PTTS_TRY(forward_dispatch(e, true, st));
+  if (sample) PTTS_TRY(launch_tail(e, st));
+  e->prefilled = true;
+  return PTTS_OK;
+}
+
+static int get_graph(ptts_engine* e, hipStream_t st, hipGraphExec_t* out) {
+  auto it = e->graphs.find(e->B);
+  if (it != e->graphs.end()) { *out = it->second; return PTTS_OK; }
+  hipGraph_t g = nullptr;
+  PTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = forward_dispatch(e, false, st);
+  if (rc == PTTS_OK) rc = launch_tail(e, st);
+  hipError_t ce = hipStreamEndCapture(st, &g);
+  if (rc != PTTS_OK) { if (g) hipGraphDestroy(g); return rc; }
+  if (ce != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+  hipGraphExec_t ex = nullptr;
+  hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (ie != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+  e->graphs[e->B] = ex;
+  *out = ex;
+  return PTTS_OK;
+}
+
+extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) {
+  PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
+  PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_decode_steps called before ptts_prefill");
+  PTTS_CHECK(n_steps >= 0, PTTS_E_INVALID, "n_steps < 0");
+  PTTS_HIP(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  hipGraphExec_t ex = nullptr;
+  PTTS_TRY(get_graph(e, st, &ex));
+  for (int i = 0; i < n_steps; ++i) PTTS_HIP(hipGraphLaunch(ex, st));
+  return PTTS_OK;
+}
+
+extern "C" int ptts_state(ptts_engine* e, int32_t* cur_len, int32_t* all_finished, void* stream) {
+  PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
+  PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_state called before ptts_prefill");
+  PTTS_HIP(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  const int n = e->B * e->cfg.num_codebooks;
+  int* hp = e->host_pinned;
+  PTTS_HIP(hipMemcpyAsync(hp, e->cur_len, 4, hipMemcpyDeviceToHost, st));
+  PTTS_HIP(hipMemcpyAsync(hp + 1, e->unfinished, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  PTTS_HIP(hipStreamSynchronize(st));
+  if (cur_len) *cur_len = hp[0];
+  int any = 0;
+  for (int i = 0; i < n; ++i) any |= hp[1 + i];
+  if (all_finished) *all_finished = any ? 0 : 1;
+  return PTTS_OK;
+}
+
+extern "C" int ptts_ids(ptts_engine* e, int64_t** ids_dev, int32_t* row_stride) {
+  PTTS_CHECK(e && ids_dev && row_stride, PTTS_E_INVALID, "null argument");
+  *ids_dev = reinterpret_cast<int64_t*>(e->ids);
+  *row_stride = e->ids_ld;
+  return PTTS_OK;
+}
+
+extern "C" int ptts_step_forward(ptts_engine* e, void* stream) {
+  PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
+  PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_step_forward called before ptts_prefill");
+  PTTS_HIP(hipSetDevice(e->cfg.device));
+  return forward_dispatch(e, false, pick_stream(e, stream));
+}
+
+extern "C" int ptts_logits(ptts_engine* e, float** logits_dev) {
+  PTTS_CHECK(e && logits_dev, PTTS_E_INVALID, "null argument");
+  *logits_dev = e->logits;
+  return PTTS_OK;
+}
+
+extern "C" int ptts_push_tokens(ptts_engine* e, const int64_t* tokens_dev, const int32_t* finished_dev, void* stream) {
+  PTTS_CHECK(e && tokens_dev, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_push_tokens called before ptts_prefill");
+  PTTS_HIP(hipSetDevice(e->cfg.device));
+  hipStream_t st = pick_stream(e, stream);
+  const int n = e->B * e->cfg.num_codebooks;
+  hipLaunchKernelGGL(push_tokens_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const long long*)tokens_dev, finished_dev, e->ids,
+                     e->ids_ld, e->cur_len, e->unfinished, e->has_eos, e->B, e->cfg.num_codebooks, e->cfg.eos_token_id);
+  hipLaunchKernelGGL(bump_len_kernel, dim3((e->B + 255) / 256), dim3(256), 0, st, e->cur_len, e->B);
+  return PTTS_OK;
+}
+
+extern "C" int ptts_debug_hidden(ptts_engine* e, float** hidden_dev, int32_t* rows) {
+  PTTS_CHECK(e && hidden_dev && rows, PTTS_E_INVALID, "null argument");
+  *hidden_dev = e->h;
+  *rows = e->B;
+  return PTTS_OK;
+}

@@ -1,0 +1,723 @@
+// Device kernels of the decoder-LM engine (gfx950 / CDNA4, wave64).
+//
+// Data layout in HBM:
+//   packed weights  W[N][K] -> [N/16 strips][K/KT frags][64 lanes][16 B]   one coalesced 1 KiB wave-load per
+//                   MFMA A-fragment (bf16: 16 rows x 32 k, mfma_f32_16x16x32_bf16; f32: 16 rows x 16 k = 4 x
+//                   mfma_f32_16x16x4f32). Lane l holds row (l&15), k = KT*t + (l>>4)*EPL + e.
+//   KV arena        [layer][b][head][position][64] in the engine dtype (128 B / 256 B rows, 16 B per lane)
+//   activations     fp32 row-major [rows][features]; residual stream h stays fp32 in both dtypes
+//   sampler state   ids int64 [B*K][ld], cur_len[B], unfinished[B*K], has_eos[B*K], first_unf[B]
+#pragma once
+#include "ptts_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// device-resident per-call dims and generation parameters (so one captured hipGraph serves every call)
+// ------------------------------------------------------------------------------------------------------
+struct DevDims {
+  int P;           // prompt positions prepended to the self-attention context
+  int N;           // encoder positions
+  int max_length;  // delay-pattern length (GenerationConfig.max_length)
+};
+struct DevGen {
+  int max_length, min_new_tokens, do_sample, top_k, use_eos_gate;
+  float temperature, top_p;
+  unsigned long long seed;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// weight packing / conversion
+// ------------------------------------------------------------------------------------------------------
+template <typename ST> __device__ __forceinline__ float load_as_f32(const ST* p);
+template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename DT> __device__ __forceinline__ void store_from_f32(DT* p, float v);
+template <> __device__ __forceinline__ void store_from_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_from_f32<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+template <typename WT, typename ST>
+__global__ void pack_weight_kernel(const ST* __restrict__ src, WT* __restrict__ dst, int N, int K, int strip0, int nfrag_total) {
+  constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nfrag = K / KT;
+  const size_t total = (size_t)(N / 16) * nfrag * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  const int t = (int)((idx >> 6) % nfrag);
+  const int s = (int)((idx >> 6) / nfrag);
+  const int row = s * 16 + (lane & 15);
+  const int k = t * KT + (lane >> 4) * EPL;
+  WT* d = dst + (((size_t)(strip0 + s) * nfrag_total + t) * 64 + lane) * EPL;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) store_from_f32<WT>(d + e, load_as_f32<ST>(src + (size_t)row * K + k + e));
+}
+
+template <typename DT, typename ST>
+__global__ void convert_kernel(const ST* __restrict__ src, DT* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store_from_f32<DT>(dst + i, load_as_f32<ST>(src + i));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// GEMM strip kernel: out[m][n] = sum_k W[n][k] * x[m][k]  for one 16-row strip of W per workgroup.
+// HBM-bound at decode (every weight byte is read exactly once per step); MFMA is used because it
+// reduces over k in-register (no cross-lane shuffle tree) and makes batch <= 32 free, not for FLOPs.
+//   PRO_PLAIN : x fp32 [M][K]
+//   PRO_LN    : x = LayerNorm(h) (two-pass fp32 stats per row, eps 1e-5, affine)   modeling:1020,:1040,:1059,:1632
+//   PRO_ATTN  : x = softmax-combine of split-KV partials written by attn_kernel (S splits)
+//   EPI_STORE : out = acc            EPI_GELU: out = gelu_erf(acc) (:1060)
+//   EPI_RESID : out += acc (residual stream, :1034/:1052/:1064)
+//   EPI_KV    : scatter into the cross-attention K/V cache [b][head][t][64] (:877-878, cached :872-875)
+// ------------------------------------------------------------------------------------------------------
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2 };
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3 };
+
+struct GemmArgs {
+  const void* W;       // packed strips
+  const float* x;      // PLAIN/LN input; x row index = m * x_row_mul + x_row_off
+  int x_ld, x_row_mul, x_row_off;
+  const float* gamma;
+  const float* beta;
+  const float* part;   // ATTN: [rows][S][K]
+  const float* stats;  // ATTN: [rows][S][heads][2] = (max, sumexp)
+  int S, nheads;
+  float* out;
+  int out_ld;
+  void* kcache;        // EPI_KV
+  void* vcache;
+  int kv_rows_per_b;   // EPI_KV: N (rows of x per batch element)
+  int kv_cap;          // EPI_KV: capacity (positions) of the cache
+  int M, N, K;
+};
+
+template <typename WT> struct MfmaStep;
+template <> struct MfmaStep<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct MfmaStep<float> {
+  static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// B operand fragment: EPL consecutive k of activation row m (lane: m = m_tile + (l&15), k = KT*t + (l>>4)*EPL)
+template <typename WT, int PRO>
+__device__ __forceinline__ uint4 make_bfrag(const GemmArgs& a, int m, int k, const float* s_mean, const float* s_rstd, int mloc) {
+  constexpr int EPL = Elem<WT>::EPL;
+  float v[EPL];
+  if (m >= a.M) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = 0.f;
+  } else if (PRO == PRO_ATTN) {
+    const int head = k >> 6;
+    const float* st = a.stats + ((size_t)m * a.S * a.nheads + head) * 2;
+    float mx = -INFINITY;
+    for (int s = 0; s < a.S; ++s) mx = fmaxf(mx, st[(size_t)s * a.nheads * 2]);
+    float den = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+      const float ms = st[(size_t)s * a.nheads * 2], ls = st[(size_t)s * a.nheads * 2 + 1];
+      const float w = (ms == -INFINITY) ? 0.f : expf(ms - mx);
+      den += w * ls;
+      const float4* p = reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + s) * a.K + k);
+#pragma unroll
+      for (int e4 = 0; e4 < EPL / 4; ++e4) {
+        const float4 t = p[e4];
+        v[e4 * 4 + 0] += w * t.x; v[e4 * 4 + 1] += w * t.y; v[e4 * 4 + 2] += w * t.z; v[e4 * 4 + 3] += w * t.w;
+      }
+    }
+    const float inv = den > 0.f ? 1.0f / den : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] *= inv;
+  } else {
+    const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k;
+#pragma unroll
+    for (int e4 = 0; e4 < EPL / 4; ++e4) {
+      const float4 t = reinterpret_cast<const float4*>(xr)[e4];
+      v[e4 * 4 + 0] = t.x; v[e4 * 4 + 1] = t.y; v[e4 * 4 + 2] = t.z; v[e4 * 4 + 3] = t.w;
+    }
+    if (PRO == PRO_LN) {
+      const float mean = s_mean[mloc], rstd = s_rstd[mloc];
+#pragma unroll
+      for (int e4 = 0; e4 < EPL / 4; ++e4) {
+        const float4 g = reinterpret_cast<const float4*>(a.gamma + k)[e4];
+        const float4 bt = reinterpret_cast<const float4*>(a.beta + k)[e4];
+        v[e4 * 4 + 0] = (v[e4 * 4 + 0] - mean) * rstd * g.x + bt.x;
+        v[e4 * 4 + 1] = (v[e4 * 4 + 1] - mean) * rstd * g.y + bt.y;
+        v[e4 * 4 + 2] = (v[e4 * 4 + 2] - mean) * rstd * g.z + bt.z;
+        v[e4 * 4 + 3] = (v[e4 * 4 + 3] - mean) * rstd * g.w + bt.w;
+      }
+    }
+  }
+  return pack16(v, WT());
+}
+
+// LN / ATTN prologues always reduce over K = hidden_size (<= 8 waves of 8 fragments); only the plain prologue
+// (fc2, K = ffn_dim) wants 16 waves, so only it pays the 128-VGPR cap of a 1024-thread workgroup.
+template <int PRO> struct GemmMaxThreads { static constexpr int value = PRO == PRO_PLAIN ? 1024 : 512; };
+
+template <typename WT, int PRO, int EPI, int MTP>
+__global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(GemmArgs a) {
+  constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL, U = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+  float* s_red = smem;                          // [W][MTP][64][4]
+  float* s_mean = smem + (size_t)W * MTP * 256; // [16*MTP]
+  float* s_rstd = s_mean + 16 * MTP;
+  const int strip = blockIdx.x;
+  const int nfrag = a.K / KT;
+  const int per = (nfrag + W - 1) / W;
+  const int t0 = wave * per, t1 = min(nfrag, t0 + per);
+  const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
+  const int q = lane >> 4, j = lane & 15;
+
+  for (int m0 = 0; m0 < a.M; m0 += 16 * MTP) {
+    // 1. put the first group of weight fragments in flight before anything that depends on activations
+    uint4 afr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+    // 2. LayerNorm statistics of the rows of this pass (two-pass, fp32), redundantly per workgroup
+    if (PRO == PRO_LN) {
+      for (int r = wave; r < 16 * MTP; r += W) {
+        const int m = m0 + r;
+        float mean = 0.f, rstd = 0.f;
+        if (m < a.M) {
+          const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
+          float s = 0.f;
+          for (int k = lane * 4; k < a.K; k += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + k);
+            s += (t.x + t.y) + (t.z + t.w);
+          }
+          mean = wave_sum(s) / (float)a.K;
+          float v = 0.f;
+          for (int k = lane * 4; k < a.K; k += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + k);
+            const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+            v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          }
+          rstd = rsqrtf(wave_sum(v) / (float)a.K + 1e-5f);
+        }
+        if (lane == 0) { s_mean[r] = mean; s_rstd[r] = rstd; }
+      }
+      __syncthreads();
+    }
+    // 3. MFMA over this wave's K slice
+    f32x4 acc[MTP];
+#pragma unroll
+    for (int mt = 0; mt < MTP; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tb = t0; tb < t1; tb += U) {
+      if (tb != t0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (tb + u < t1) afr[u] = ld_nt16(Wp + (size_t)(tb + u) * 64);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (tb + u < t1) {
+          const int k = (tb + u) * KT + q * EPL;
+#pragma unroll
+          for (int mt = 0; mt < MTP; ++mt) {
+            const uint4 bfr = make_bfrag<WT, PRO>(a, m0 + mt * 16 + j, k, s_mean, s_rstd, mt * 16 + j);
+            acc[mt] = MfmaStep<WT>::run(afr[u], bfr, acc[mt]);
+          }
+        }
+      }
+    }
+    // 4. deterministic cross-wave reduction through LDS (fixed wave order)
+#pragma unroll
+    for (int mt = 0; mt < MTP; ++mt)
+      *reinterpret_cast<f32x4*>(s_red + (((size_t)wave * MTP + mt) * 64 + lane) * 4) = acc[mt];
+    __syncthreads();
+    if (wave < MTP) {
+      const int mt = wave;
+      f32x4 r = *reinterpret_cast<const f32x4*>(s_red + ((size_t)mt * 64 + lane) * 4);
+      for (int w = 1; w < W; ++w) r += *reinterpret_cast<const f32x4*>(s_red + (((size_t)w * MTP + mt) * 64 + lane) * 4);
+      const int m = m0 + mt * 16 + j;
+      const int n = strip * 16 + q * 4;  // D[row = (l>>4)*4 + r][col = l&15]
+      if (m < a.M) {
+        if (EPI == EPI_STORE) {
+          *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(r[0], r[1], r[2], r[3]);
+        } else if (EPI == EPI_GELU) {
+          *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) =
+              make_float4(gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
+        } else if (EPI == EPI_RESID) {
+          float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
+          float4 o = *p;
+          o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
+          *p = o;
+        } else {  // EPI_KV: n in [0, 2H): first half K, second half V
+          const int H = a.N >> 1;
+          const int which = n >= H;
+          const int nn = n - which * H;
+          const int head = nn >> 6, d = nn & 63;
+          const int b = m / a.kv_rows_per_b, t = m - b * a.kv_rows_per_b;
+          WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) +
+                     (((size_t)b * a.nheads + head) * a.kv_cap + t) * 64 + d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) store_from_f32<WT>(base + e, r[e]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Attention over the KV cache, one query row per (b, qi): split over S workgroups x NW waves, online
+// softmax per wave, LDS combine per workgroup, unnormalised partial + (max, sumexp) written for the
+// consumer GEMM's PRO_ATTN prologue. HBM-bound: K/V rows are read once, 16 B per lane, a whole
+// wave-instruction covers RPI consecutive rows = 1 KiB contiguous.
+//   self, decode : fused RoPE + KV append of the new position (modeling:858-859, :880-889), causal by length
+//   self, prefill: causal (row qi sees positions <= qi); cache filled beforehand by kv_append_kernel
+//   cross        : static K/V (:872-875), additive padding mask (:1553-1562) as -inf, q rotated if RoPE (quirk)
+// ------------------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const float* q;      // [rows][q_ld], head h at column h*64
+  int q_ld;
+  const float* knew;   // fused append sources (same row indexing), or null
+  const float* vnew;
+  int kv_ld;
+  void* kcache;
+  void* vcache;
+  int cap;             // cache capacity in positions
+  const int* cur_len;  // decode: per-batch column count (position = P + cur_len[b] - 1); null in prefill
+  const DevDims* dims;
+  const int* mask;     // [B][mask_ld] int32 (1 = keep) or null
+  int mask_ld;
+  const float* cos;    // RoPE tables [max_pos][64] or null
+  const float* sin;
+  float* part;         // [rows][S][H]
+  float* stats;        // [rows][S][heads][2]
+  int S, Q, nheads, H;
+  int cross;           // 1: length = dims->N, mask over all positions; 0: causal self-attention, mask over positions < P
+  int fused_append;
+  float scale;
+};
+
+template <typename WT, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
+  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8;
+  __shared__ float s_q[64];
+  __shared__ float s_o[NW][64];
+  __shared__ float s_ml[NW][2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z / a.Q, qi = blockIdx.z % a.Q;
+  const int row = b * a.Q + qi;
+  const int P = a.dims->P;
+  const int pos = (a.cur_len ? P + a.cur_len[b] - 1 : 0) + qi;
+  const int L = a.cross ? a.dims->N : pos + 1;
+  const int mask_len = a.cross ? L : P;
+
+  if (tid < 64) {
+    const float* qr = a.q + (size_t)row * a.q_ld + h * 64;
+    float v = qr[tid];
+    if (a.cos) {
+      const float c = a.cos[(size_t)pos * 64 + tid], sn = a.sin[(size_t)pos * 64 + tid];
+      const float other = tid < 32 ? -qr[tid + 32] : qr[tid - 32];
+      v = v * c + other * sn;
+    }
+    s_q[tid] = v * a.scale;
+  }
+  __syncthreads();
+  const int r = lane / LPR, c = lane % LPR;
+  float qv[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) qv[e] = s_q[c * EPL + e];
+
+  uint4 knew_p = make_uint4(0, 0, 0, 0), vnew_p = make_uint4(0, 0, 0, 0);
+  WT* Kc = reinterpret_cast<WT*>(a.kcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
+  WT* Vc = reinterpret_cast<WT*>(a.vcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
+  if (a.fused_append) {
+    const float* kr = a.knew + (size_t)row * a.kv_ld + h * 64;
+    const float* vr = a.vnew + (size_t)row * a.kv_ld + h * 64;
+    float kk[EPL], vv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int d = c * EPL + e;
+      float kx = kr[d];
+      if (a.cos) {
+        const float cs = a.cos[(size_t)pos * 64 + d], sn = a.sin[(size_t)pos * 64 + d];
+        const float other = d < 32 ? -kr[d + 32] : kr[d - 32];
+        kx = kx * cs + other * sn;
+      }
+      kk[e] = kx;
+      vv[e] = vr[d];
+    }
+    knew_p = pack16(kk, WT());
+    vnew_p = pack16(vv, WT());
+    if (s == 0 && w == 0 && r == 0) {  // single writer of the new cache row
+      reinterpret_cast<uint4*>(Kc + (size_t)pos * 64)[c] = knew_p;
+      reinterpret_cast<uint4*>(Vc + (size_t)pos * 64)[c] = vnew_p;
+    }
+  }
+
+  const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
+  const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
+  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  const int G = (L + RPI - 1) / RPI;
+  const int TW = a.S * NW, wv = s * NW + w;
+  float m_run = -INFINITY, l_run = 0.f, o[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+
+  for (int g0 = wv; g0 < G; g0 += TW * U) {
+    uint4 kf[U], vf[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (g0 + u * TW) * RPI + r;
+      ok[u] = t < L;
+      if (ok[u] && mrow && t < mask_len) ok[u] = mrow[t] != 0;
+      kf[u] = make_uint4(0, 0, 0, 0);
+      vf[u] = make_uint4(0, 0, 0, 0);
+      if (ok[u]) {
+        if (a.fused_append && t == pos) { kf[u] = knew_p; vf[u] = vnew_p; }
+        else { kf[u] = Kb[(size_t)t * LPR + c]; vf[u] = Vb[(size_t)t * LPR + c]; }
+      }
+    }
+    float sc[U], bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float kk[EPL];
+      unpack16(kf[u], kk, WT());
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kk[e], d);
+#pragma unroll
+      for (int off = 1; off < LPR; off <<= 1) d += __shfl_xor(d, off, 64);
+      sc[u] = ok[u] ? d : -INFINITY;
+      bm = fmaxf(bm, sc[u]);
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) bm = fmaxf(bm, __shfl_xor(bm, off, 64));
+    const float m_new = fmaxf(m_run, bm);
+    if (m_new == -INFINITY) continue;  // wave-uniform: nothing visible yet
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float p = ok[u] ? expf(sc[u] - m_new) : 0.f;
+      float vv[EPL];
+      unpack16(vf[u], vv, WT());
+      l_run += p;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, vv[e], o[e]);
+    }
+    m_run = m_new;
+  }
+  // reduce over the RPI row slots of the wave (lanes sharing chunk c)
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    l_run += __shfl_xor(l_run, off, 64);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] += __shfl_xor(o[e], off, 64);
+  }
+  if (r == 0) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s_o[w][c * EPL + e] = o[e];
+    if (c == 0) { s_ml[w][0] = m_run; s_ml[w][1] = l_run; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) M = fmaxf(M, s_ml[i][0]);
+    float ov = 0.f, lv = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const float wgt = (s_ml[i][0] == -INFINITY) ? 0.f : expf(s_ml[i][0] - M);
+      ov += wgt * s_o[i][tid];
+      lv += wgt * s_ml[i][1];
+    }
+    a.part[((size_t)row * a.S + s) * a.H + h * 64 + tid] = ov;
+    if (tid == 0) {
+      float* st = a.stats + (((size_t)row * a.S + s) * a.nheads + h) * 2;
+      st[0] = M;
+      st[1] = lv;
+    }
+  }
+}
+
+// prefill: write all Q new K/V rows (RoPE on k) into the self cache.  grid (Q, heads, B), 64 threads
+template <typename WT>
+__global__ void kv_append_kernel(const float* __restrict__ knew, const float* __restrict__ vnew, int kv_ld, void* kcache,
+                                 void* vcache, int cap, int Q, int nheads, const float* cos, const float* sin) {
+  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+  const int row = b * Q + qi, pos = qi;
+  const float* kr = knew + (size_t)row * kv_ld + h * 64;
+  float kx = kr[d];
+  if (cos) {
+    const float other = d < 32 ? -kr[d + 32] : kr[d - 32];
+    kx = kx * cos[(size_t)pos * 64 + d] + other * sin[(size_t)pos * 64 + d];
+  }
+  const size_t off = (((size_t)b * nheads + h) * cap + pos) * 64 + d;
+  store_from_f32<WT>(reinterpret_cast<WT*>(kcache) + off, kx);
+  store_from_f32<WT>(reinterpret_cast<WT*>(vcache) + off, vnew[(size_t)row * kv_ld + h * 64 + d]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Embedding: h = sum_k E_k[token_k] (+ sinusoidal position)   modeling:1433, :1506-1511; delay mask :205-276
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long delayed_token(const long long* ids, int ld, int rowk, int k, int j, int K,
+                                                   int max_length, int bos, int pad) {
+  if (max_length >= 2 * K - 1) {  // :246-247: short max_length disables the pattern
+    if (j <= k) return bos;                          // tril :260
+    if (j - k >= max_length - K + 1) return pad;     // triu(diagonal = max_length - K + 1) :256-258
+  }
+  return ids[(size_t)rowk * ld + j];
+}
+
+struct EmbedArgs {
+  const void* tables;      // [K][V+1][H] engine dtype
+  const float* pos_table;  // [max_pos][H] or null (RoPE)
+  const float* prompt;     // [B][P][H] or null
+  const long long* ids;
+  int ids_ld;
+  const int* cur_len;
+  const DevDims* dims;
+  float* h;
+  int H, K, V1, bos, pad;
+  int prefill;             // 1: grid (P+1, B) rows; 0: grid (1, B), column cur_len-1 at position P + cur_len - 1
+};
+
+template <typename WT>
+__global__ void embed_kernel(EmbedArgs a) {
+  const int b = blockIdx.y;
+  const int P = a.dims->P;
+  const int qi = blockIdx.x;
+  const int Q = a.prefill ? P + 1 : 1;
+  const int j = a.prefill ? 0 : a.cur_len[b] - 1;      // token column
+  const int pos = a.prefill ? qi : P + j;              // absolute position (padded prompt ids still count, :1470)
+  float* out = a.h + ((size_t)b * Q + qi) * a.H;
+  const WT* tab = reinterpret_cast<const WT*>(a.tables);
+  if (a.prefill && qi < P) {
+    const float* pr = a.prompt + ((size_t)b * P + qi) * a.H;
+    for (int d = threadIdx.x; d < a.H; d += blockDim.x) out[d] = pr[d] + (a.pos_table ? a.pos_table[(size_t)pos * a.H + d] : 0.f);
+    return;
+  }
+  __shared__ int s_tok[32];
+  if (threadIdx.x < a.K)
+    s_tok[threadIdx.x] = (int)delayed_token(a.ids, a.ids_ld, b * a.K + threadIdx.x, threadIdx.x, j, a.K, a.dims->max_length, a.bos, a.pad);
+  __syncthreads();
+  for (int d = threadIdx.x; d < a.H; d += blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k < a.K; ++k) acc += Elem<WT>::ld(tab + ((size_t)k * a.V1 + s_tok[k]) * a.H + d);  // sum([...]) order :1433
+    if (a.pos_table) acc += a.pos_table[(size_t)pos * a.H + d];
+    out[d] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Sampler tail: one workgroup per utterance (K rows). Restates one _sample iteration on device:
+//   fp32 logits -> MinNewTokens -> ParlerTTSLogitsProcessor (logits_processors.py:44-53) -> [temperature, top-k,
+//   top-p] -> argmax | multinomial -> pad finished rows -> append -> EOS / max_length stopping.
+// ------------------------------------------------------------------------------------------------------
+struct TailArgs {
+  const float* logits;  // [B][K][V]
+  long long* ids;
+  int ids_ld;
+  int* cur_len;        // [B]
+  int* unfinished;     // [B*K]
+  int* has_eos;        // [B*K]
+  int* first_unf;      // [B] local codebook index
+  const DevGen* gen;
+  float* sort_buf;     // [B][2][SORT_N] scratch for sampling (values, indices as float bits)
+  int B, K, V, eos, pad;
+};
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+#define PTTS_SORT_N 2048
+
+// block-wide bitonic sort (descending by value, ascending index on ties) of n <= PTTS_SORT_N entries in LDS
+__device__ inline void bitonic_sort_desc(float* val, int* idx, int nthreads, int tid) {
+  for (int k = 2; k <= PTTS_SORT_N; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int i = tid; i < PTTS_SORT_N; i += nthreads) {
+        const int ixj = i ^ jj;
+        if (ixj > i) {
+          const bool up = (i & k) == 0;  // "up" segments sorted descending
+          const float a = val[i], b = val[ixj];
+          const int ia = idx[i], ib = idx[ixj];
+          const bool a_before_b = (a > b) || (a == b && ia < ib);
+          if (up ? !a_before_b : a_before_b) { val[i] = b; val[ixj] = a; idx[i] = ib; idx[ixj] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) tail_kernel(TailArgs a) {
+  __shared__ int s_any;
+  __shared__ float s_val[PTTS_SORT_N];
+  __shared__ int s_idx[PTTS_SORT_N];
+  __shared__ float s_red[8];
+  __shared__ int s_redi[8];
+  __shared__ int s_pick;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_any = 0;
+  __syncthreads();
+  for (int i = tid; i < a.B * a.K; i += blockDim.x)
+    if (a.unfinished[i]) s_any = 1;
+  __syncthreads();
+  if (!s_any) return;  // every row of every utterance finished: the reference loop has exited (no-op step)
+
+  const DevGen g = *a.gen;
+  const int t = a.cur_len[b];  // column the new token is written to; t-1 new tokens generated so far
+  int fu = a.first_unf[b];
+  if (a.has_eos[b * a.K + fu] > 0 && fu < a.K - 1) fu += 1;  // logits_processors.py:48 (advance <= 1 per step)
+  __syncthreads();
+  if (tid == 0) a.first_unf[b] = fu;
+  const bool block_eos_all = (t - 1) < g.min_new_tokens;
+
+  for (int k = 0; k < a.K; ++k) {
+    const int row = b * a.K + k;
+    const float* sc = a.logits + (size_t)row * a.V;
+    const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
+    int tok;
+    if (!g.do_sample) {
+      // argmax, first index on ties (torch.argmax)
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int v = tid; v < a.V; v += blockDim.x) {
+        float x = sc[v];
+        if (eos_blocked && v == a.eos) x = -INFINITY;
+        if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) { s_red[w] = best; s_redi[w] = bi; }
+      __syncthreads();
+      if (tid == 0) {
+        float bb = s_red[0];
+        int ii = s_redi[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i)
+          if (s_red[i] > bb || (s_red[i] == bb && s_redi[i] < ii)) { bb = s_red[i]; ii = s_redi[i]; }
+        s_pick = ii;
+      }
+      __syncthreads();
+      tok = s_pick;
+    } else {
+      const float invT = 1.0f / g.temperature;
+      for (int v = tid; v < PTTS_SORT_N; v += blockDim.x) {
+        float x = -INFINITY;
+        if (v < a.V) {
+          x = sc[v];
+          if (eos_blocked && v == a.eos) x = -INFINITY;
+          else x *= invT;
+        }
+        s_val[v] = x;
+        s_idx[v] = v;
+      }
+      __syncthreads();
+      bitonic_sort_desc(s_val, s_idx, blockDim.x, tid);
+      if (tid == 0) {
+        // top-k: keep values >= k-th largest (TopKLogitsWarper keeps ties); top-p: keep while exclusive prefix < p
+        int n = a.V;
+        if (g.top_k > 0 && g.top_k < a.V) {
+          const float kth = s_val[g.top_k - 1];
+          n = g.top_k;
+          while (n < a.V && s_val[n] >= kth) ++n;
+        }
+        while (n > 1 && s_val[n - 1] == -INFINITY) --n;
+        const float mx = s_val[0];
+        float tot = 0.f;
+        for (int i = 0; i < n; ++i) tot += expf(s_val[i] - mx);
+        if (g.top_p < 1.0f) {
+          float run = 0.f;
+          int keep = 0;
+          for (int i = 0; i < n; ++i) {
+            if (i > 0 && run / tot >= g.top_p) break;
+            run += expf(s_val[i] - mx);
+            keep = i + 1;
+          }
+          n = keep;
+          tot = run;
+        }
+        const unsigned long long hsh = splitmix64(g.seed ^ splitmix64(((unsigned long long)t << 32) ^ (unsigned long long)row));
+        const float u = (float)((hsh >> 40) + 0.5) * (1.0f / 16777216.0f);  // (0,1)
+        const float target = u * tot;
+        float run = 0.f;
+        int pick = s_idx[n - 1];
+        for (int i = 0; i < n; ++i) {
+          run += expf(s_val[i] - mx);
+          if (run >= target) { pick = s_idx[i]; break; }
+        }
+        s_pick = pick;
+      }
+      __syncthreads();
+      tok = s_pick;
+    }
+    if (tid == 0) {
+      const int unf = a.unfinished[row];
+      const int nxt = unf ? tok : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
+      a.ids[(size_t)row * a.ids_ld + t] = nxt;
+      if (nxt == a.eos) a.has_eos[row] = 1;
+      const bool done = (nxt == a.eos) || (t + 1 >= g.max_length);  // EosTokenCriteria | MaxLengthCriteria
+      if (done) a.unfinished[row] = 0;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) a.cur_len[b] = t + 1;
+}
+
+// manual path: append caller-chosen tokens (user LogitsProcessorList / StoppingCriteria ran on the host side)
+__global__ void push_tokens_kernel(const long long* tokens, const int* finished, long long* ids, int ids_ld, int* cur_len,
+                                   int* unfinished, int* has_eos, int B, int K, int eos) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= B * K) return;
+  const int b = row / K;
+  const int t = cur_len[b];
+  const long long tk = tokens[row];
+  ids[(size_t)row * ids_ld + t] = tk;
+  if (tk == eos) has_eos[row] = 1;
+  if (finished && finished[row]) unfinished[row] = 0;
+}
+__global__ void bump_len_kernel(int* cur_len, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) cur_len[b] += 1;
+}
+
+__global__ void reset_state_kernel(long long* ids, int ids_ld, int* cur_len, int* unfinished, int* has_eos, int* first_unf,
+                                   int B, int K, int bos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * K) {
+    ids[(size_t)i * ids_ld] = bos;
+    unfinished[i] = 1;
+    has_eos[i] = 0;
+  }
+  if (i < B) {
+    cur_len[i] = 1;
+    first_unf[i] = 0;
+  }
+}
+
+__global__ void set_params_kernel(DevDims* dd, DevGen* dg, DevDims d, DevGen g) {
+  *dd = d;
+  *dg = g;
+}
+
+__global__ void fill_int_kernel(int* p, int v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}

@@ -1,0 +1,265 @@
+"""Thin Python owners of the two native engines (libptts_hip.so). torch is used only for device memory,
+streams and dtype plumbing: every FLOP of the hot path runs in the HIP library. No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+
+def _stream_ptr(stream: Optional["torch.cuda.Stream"] = None) -> C.c_void_p:
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _shape_arr(t: torch.Tensor):
+    return (C.c_int64 * t.dim())(*t.shape)
+
+
+def rope_tables(head_dim: int, theta: float, num_positions: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 cos/sin exactly as ParlerTTSRotaryEmbedding.forward builds them (modeling_parler_tts.py:373-406):
+    inv_freq = theta^(-2i/d), freqs = inv_freq ⊗ position (fp32 matmul), emb = cat(freqs, freqs)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    pos = torch.arange(num_positions, dtype=torch.int64).float()
+    freqs = (inv_freq[:, None] @ pos[None, :]).transpose(0, 1)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().contiguous(), emb.sin().contiguous()
+
+
+class DecoderEngine:
+    """Owner of a ``ptts_engine``: the autoregressive ParlerTTSDecoder step + sampler on MI355X."""
+
+    def __init__(self, *, hidden_size: int, num_layers: int, num_heads: int, ffn_dim: int, num_codebooks: int,
+                 vocab_size: int, max_positions: int, rope: bool = False, rope_theta: float = 10000.0,
+                 pad_token_id: int = 1024, eos_token_id: int = 1024, bos_token_id: int = 1025,
+                 dtype: torch.dtype = torch.bfloat16, max_batch: int = 1, max_ctx: int = 2700, max_enc: int = 256,
+                 max_prompt: int = 128, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise N.NativeLibraryError("DecoderEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = N.load_library()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"engine dtype must be float32 or bfloat16, got {dtype}")
+        self.dtype = dtype
+        self.K, self.V, self.H = num_codebooks, vocab_size, hidden_size
+        self.rope, self.rope_theta, self.max_positions = rope, rope_theta, max_positions
+        self.cfg = N.PttsConfig(hidden_size, num_layers, num_heads, ffn_dim, num_codebooks, vocab_size, max_positions, int(rope),
+                                float(rope_theta), pad_token_id, eos_token_id, bos_token_id,
+                                N.PTTS_BF16 if dtype == torch.bfloat16 else N.PTTS_F32, max_batch, max_ctx, max_enc, max_prompt,
+                                self.device.index or 0)
+        self._h = C.c_void_p()
+        N.check(self.lib.ptts_engine_create(C.byref(self.cfg), C.byref(self._h)), "ptts_engine_create")
+        self.B = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.ptts_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ---------------------------------------------------------------------------------------
+    def load_weight(self, name: str, tensor: torch.Tensor):
+        t = tensor.detach()
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.float()
+        t = t.to(self.device).contiguous()
+        dt = N.PTTS_BF16 if t.dtype == torch.bfloat16 else N.PTTS_F32
+        N.check(self.lib.ptts_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, _shape_arr(t), t.dim(), _stream_ptr()),
+                f"ptts_load_weight({name})")
+        # the engine re-packs asynchronously on the current stream; keep `t` alive until then
+        torch.cuda.current_stream().synchronize()
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
+        """Accepts the reference's decoder state-dict names, optionally under `prefix`
+        (e.g. ``"decoder."`` for a ParlerTTSForConditionalGeneration checkpoint)."""
+        for k, v in sd.items():
+            if not k.startswith(prefix):
+                continue
+            name = k[len(prefix):]
+            if name.startswith("model.decoder.") or name.startswith("lm_heads."):
+                if "rotary_emb" in name:
+                    continue
+                self.load_weight(name, v)
+        if self.rope:
+            cos, sin = rope_tables(self.H // self.cfg.num_heads, self.rope_theta, self.max_positions)
+            self.load_weight("rope_cos", cos)
+            self.load_weight("rope_sin", sin)
+        N.check(self.lib.ptts_weights_ready(self._h), "ptts_weights_ready")
+
+    # -- generation -------------------------------------------------------------------------------------
+    def set_gen_params(self, *, max_length: int, min_new_tokens: int = 0, do_sample: bool = False, temperature: float = 1.0,
+                       top_k: int = 0, top_p: float = 1.0, use_eos_gate: bool = True, seed: int = 0):
+        gp = N.PttsGenParams(int(max_length), int(min_new_tokens), int(bool(do_sample)), float(temperature), int(top_k or 0), float(top_p),
+                             int(bool(use_eos_gate)), int(seed) & (2 ** 64 - 1))
+        N.check(self.lib.ptts_set_gen_params(self._h, C.byref(gp)), "ptts_set_gen_params")
+        self.max_length = int(max_length)
+
+    def prefill(self, enc: torch.Tensor, enc_mask: Optional[torch.Tensor], prompt: Optional[torch.Tensor],
+                prompt_mask: Optional[torch.Tensor], sample: bool = True):
+        enc = enc.to(self.device, torch.float32).contiguous()
+        B, Nn, H = enc.shape
+        if H != self.H:
+            raise ValueError(f"encoder_hidden_states width {H} != decoder hidden_size {self.H}")
+        P = 0
+        keep = [enc]
+        pm = em = pr = None
+        if prompt is not None and prompt.shape[1] > 0:
+            pr = prompt.to(self.device, torch.float32).contiguous()
+            P = pr.shape[1]
+            keep.append(pr)
+        if enc_mask is not None:
+            em = enc_mask.to(self.device, torch.int32).contiguous()
+            keep.append(em)
+        if prompt_mask is not None and P > 0:
+            pm = prompt_mask.to(self.device, torch.int32).contiguous()
+            keep.append(pm)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+        N.check(self.lib.ptts_prefill(self._h, ptr(enc), ptr(em), ptr(pr), ptr(pm), B, Nn, P, int(sample), _stream_ptr()), "ptts_prefill")
+        self.B, self.P = B, P
+        self._keep = keep  # inputs are consumed asynchronously by the enqueued kernels
+
+    def decode_steps(self, n: int):
+        N.check(self.lib.ptts_decode_steps(self._h, int(n), _stream_ptr()), "ptts_decode_steps")
+
+    def state(self) -> Tuple[int, bool]:
+        cur, fin = C.c_int32(), C.c_int32()
+        N.check(self.lib.ptts_state(self._h, C.byref(cur), C.byref(fin), _stream_ptr()), "ptts_state")
+        return cur.value, bool(fin.value)
+
+    def _copy_out(self, ptr: int, shape, dtype, row_stride: Optional[int] = None) -> torch.Tensor:
+        """Device-to-device copy of engine-owned memory into a fresh torch tensor (async on the current stream)."""
+        out = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+        esz = out.element_size()
+        hip = N.hip_runtime()
+        if row_stride is None or row_stride == shape[-1]:
+            rc = hip.hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(out.numel() * esz), 3, _stream_ptr())
+        else:
+            rc = hip.hipMemcpy2DAsync(C.c_void_p(out.data_ptr()), C.c_size_t(shape[-1] * esz), C.c_void_p(ptr), C.c_size_t(row_stride * esz),
+                                      C.c_size_t(shape[-1] * esz), C.c_size_t(shape[0]), 3, _stream_ptr())
+        if rc != 0:
+            raise N.NativeLibraryError(f"hipMemcpy(D2D) failed with code {rc}")
+        return out
+
+    def ids(self) -> torch.Tensor:
+        """Raw ids [B*K, cur_len] (a copy), exactly what `_sample` returns before the delay mask is applied."""
+        p, ld = C.c_void_p(), C.c_int32()
+        N.check(self.lib.ptts_ids(self._h, C.byref(p), C.byref(ld)), "ptts_ids")
+        cur, _ = self.state()
+        return self._copy_out(p.value, (self.B * self.K, cur), torch.int64, row_stride=ld.value)
+
+    def step_forward(self):
+        N.check(self.lib.ptts_step_forward(self._h, _stream_ptr()), "ptts_step_forward")
+
+    def logits(self) -> torch.Tensor:
+        """fp32 [B*K, V] logits of the last forward (a copy)."""
+        p = C.c_void_p()
+        N.check(self.lib.ptts_logits(self._h, C.byref(p)), "ptts_logits")
+        return self._copy_out(p.value, (self.B * self.K, self.V), torch.float32)
+
+    def push_tokens(self, tokens: torch.Tensor, finished: Optional[torch.Tensor] = None):
+        tk = tokens.to(self.device, torch.int64).contiguous()
+        fn = finished.to(self.device, torch.int32).contiguous() if finished is not None else None
+        N.check(self.lib.ptts_push_tokens(self._h, C.c_void_p(tk.data_ptr()), C.c_void_p(fn.data_ptr()) if fn is not None else C.c_void_p(),
+                                          _stream_ptr()), "ptts_push_tokens")
+        self._keep2 = (tk, fn)
+
+    def generate_ids(self, enc, enc_mask, prompt, prompt_mask, poll_every: int = 64) -> torch.Tensor:
+        """prefill + graph-replayed decode until every row finished; returns raw ids [B*K, Lout]."""
+        self.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)
+        remaining = self.max_length - 2
+        while remaining > 0:
+            n = min(poll_every, remaining)
+            self.decode_steps(n)
+            remaining -= n
+            _, fin = self.state()
+            if fin:
+                break
+        return self.ids()
+
+
+class DacEngine:
+    """Owner of a ``ptts_dac``: DAC codes → waveform on MI355X (exact-f32 MFMA implicit-GEMM convolutions)."""
+
+    def __init__(self, *, num_codebooks: int = 9, codebook_size: int = 1024, codebook_dim: int = 8, latent_dim: int = 1024,
+                 decoder_dim: int = 1536, rates: Iterable[int] = (8, 8, 4, 2), max_batch: int = 1, max_frames: int = 2600,
+                 device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise N.NativeLibraryError("DacEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = N.load_library()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        rates = tuple(int(r) for r in rates)
+        arr = (C.c_int32 * 8)(*(list(rates) + [0] * (8 - len(rates))))
+        self.cfg = N.PttsDacConfig(num_codebooks, codebook_size, codebook_dim, latent_dim, decoder_dim, len(rates), arr, N.PTTS_F32,
+                                   max_batch, max_frames, self.device.index or 0)
+        self.hop = math.prod(rates)
+        self.K = num_codebooks
+        self.codebook_size = codebook_size
+        self.max_batch, self.max_frames = max_batch, max_frames
+        self._h = C.c_void_p()
+        N.check(self.lib.ptts_dac_create(C.byref(self.cfg), C.byref(self._h)), "ptts_dac_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.ptts_dac_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
+        """`sd`: dac.model.DAC names with weight-norm in any of the three formats the reference may hold
+        (folded ``.weight``, legacy ``.weight_g/.weight_v``, ``.parametrizations.weight.original0/1``;
+        dac_wrapper/modeling_dac.py:148-164). Folded here on the host side once."""
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        for name, t in fold_weight_norm(sd).items():
+            if not (name.startswith("quantizer.") or name.startswith("decoder.")):
+                continue
+            t = t.detach().to(self.device, torch.float32).contiguous()
+            if name.endswith(".alpha"):
+                t = t.reshape(-1).contiguous()
+            N.check(self.lib.ptts_dac_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), _shape_arr(t), t.dim(), _stream_ptr()),
+                    f"ptts_dac_load_weight({name})")
+            torch.cuda.current_stream().synchronize()
+        N.check(self.lib.ptts_dac_weights_ready(self._h), "ptts_dac_weights_ready")
+
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes int64 [B, K, T] → waveform float32 [B, 1, hop*T]."""
+        if codes.dim() != 3 or codes.shape[1] != self.K:
+            raise ValueError(f"audio_codes must be [batch, {self.K}, frames], got {tuple(codes.shape)}")
+        codes = codes.to(self.device, torch.int64).contiguous()
+        B, _, T = codes.shape
+        out = torch.empty(B, 1, self.hop * T, dtype=torch.float32, device=self.device)
+        N.check(self.lib.ptts_dac_decode(self._h, C.c_void_p(codes.data_ptr()), C.c_void_p(out.data_ptr()), B, T, _stream_ptr()), "ptts_dac_decode")
+        self._keep = codes
+        return out
+
+
+def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """w = g · v / ‖v‖ (norm over all dims but 0, torch weight_norm's default dim=0) for both key formats."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        for g_suf, v_suf in ((".weight_g", ".weight_v"), (".parametrizations.weight.original0", ".parametrizations.weight.original1")):
+            if k.endswith(g_suf):
+                base = k[: -len(g_suf)]
+                vv = sd[base + v_suf].float()
+                norm = vv.flatten(1).norm(dim=1).view(-1, *([1] * (vv.dim() - 1)))
+                out[base + ".weight"] = v.float() * vv / norm
+                break
+            if k.endswith(v_suf):
+                break
+        else:
+            out[k] = v
+    return out

@@ -1,0 +1,38 @@
+"""Shared test helpers: build native engines from oracle specs + seeded synthetic weights."""
+import numpy as np
+import torch
+
+from oracle import decoder_oracle as DO
+from oracle import dac_oracle as DA
+
+
+def spec_from_gold(arr, **kw):
+    H, L, nh, F, mp, rope = [int(x) for x in arr]
+    return DO.DecoderSpec(hidden_size=H, num_hidden_layers=L, num_attention_heads=nh, ffn_dim=F, max_position_embeddings=mp,
+                          rope_embeddings=bool(rope), **kw)
+
+
+def make_engine(spec, sd, dtype=torch.float32, max_batch=2, max_ctx=128, max_enc=32, max_prompt=16):
+    from parler_tts_amd.engine import DecoderEngine
+
+    eng = DecoderEngine(hidden_size=spec.hidden_size, num_layers=spec.num_hidden_layers, num_heads=spec.num_attention_heads,
+                        ffn_dim=spec.ffn_dim, num_codebooks=spec.num_codebooks, vocab_size=spec.vocab_size,
+                        max_positions=spec.max_position_embeddings, rope=spec.rope_embeddings, rope_theta=spec.rope_theta,
+                        pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id, bos_token_id=spec.bos_token_id, dtype=dtype,
+                        max_batch=max_batch, max_ctx=max_ctx, max_enc=max_enc, max_prompt=max_prompt)
+    eng.load_state_dict(sd)
+    return eng
+
+
+def make_dac(spec, sd, max_batch=2, max_frames=64):
+    from parler_tts_amd.engine import DacEngine
+
+    d = DacEngine(num_codebooks=spec.num_codebooks, codebook_size=spec.codebook_size, codebook_dim=spec.codebook_dim,
+                  latent_dim=spec.latent_dim, decoder_dim=spec.decoder_dim, rates=spec.decoder_rates, max_batch=max_batch,
+                  max_frames=max_frames)
+    d.load_state_dict(sd)
+    return d
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))

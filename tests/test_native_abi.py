@@ -1,0 +1,66 @@
+"""CPU: libptts_hip.so loads, exports every symbol include/ptts.h declares, and argument validation maps
+error classes onto the reference's Python exceptions — no compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _lib():
+    from parler_tts_amd import _native as N
+
+    if not os.path.exists(N.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    return N, N.load_library()
+
+
+def test_exports_every_declared_symbol():
+    N, lib = _lib()
+    hdr = open(os.path.join(ROOT, "include", "ptts.h")).read()
+    declared = set(re.findall(r"\b(ptts_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"ptts_engine", "ptts_dac"}
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ptts_abi_version() == 1
+
+
+def test_invalid_config_is_value_error_not_crash():
+    N, lib = _lib()
+    cfg = N.PttsConfig(1000, 2, 16, 256, 9, 1088, 256, 0, 10000.0, 1024, 1024, 1025, N.PTTS_BF16, 1, 64, 16, 8, 0)  # 1000 % 16 != 0
+    h = C.c_void_p()
+    rc = lib.ptts_engine_create(C.byref(cfg), C.byref(h))
+    assert rc == N.PTTS_E_INVALID
+    with pytest.raises(ValueError, match="hidden_size"):
+        N.check(rc, "ptts_engine_create")
+    cfg = N.PttsConfig(1024, 2, 8, 256, 9, 1088, 256, 0, 10000.0, 1024, 1024, 1025, N.PTTS_BF16, 1, 64, 16, 8, 0)  # head_dim 128
+    rc = lib.ptts_engine_create(C.byref(cfg), C.byref(h))
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        N.check(rc)
+    assert lib.ptts_engine_create(None, C.byref(h)) == N.PTTS_E_INVALID
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from parler_tts_amd import _native as N
+
+    with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+        N.load_library(str(tmp_path / "nope.so"))
+
+
+def test_engines_refuse_to_run_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from parler_tts_amd import _native as N
+    from parler_tts_amd.engine import DacEngine, DecoderEngine
+
+    with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+        DecoderEngine(hidden_size=128, num_layers=1, num_heads=2, ffn_dim=256, num_codebooks=9, vocab_size=1088, max_positions=64)
+    with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+        DacEngine()
