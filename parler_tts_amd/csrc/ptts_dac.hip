@@ -324,7 +324,7 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
 extern "C" int ptts_dac_load_weight(ptts_dac* d, const char* name_c, const float* dev_ptr, const int64_t* shape, int32_t ndim, void* stream) {
   PTTS_CHECK(d && name_c && dev_ptr && shape, PTTS_E_INVALID, "null argument");
   PTTS_HIP(hipSetDevice(d->cfg.device));
-  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : d->own_stream;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = legacy default stream
   const ptts_dac_config& c = d->cfg;
   const std::string name(name_c);
   auto numel = [&]() { size_t n = 1; for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i]; return n; };
@@ -434,7 +434,7 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
   PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds dac max_batch %d", B, c.max_batch);
   PTTS_CHECK(T >= 1 && T <= c.max_frames, PTTS_E_CAPACITY, "frames %d exceed dac max_frames %d", T, c.max_frames);
   PTTS_HIP(hipSetDevice(c.device));
-  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : d->own_stream;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = legacy default stream
   if (!d->table_ready) {
     for (int i = 0; i < c.num_codebooks; ++i) {
       const size_t n = (size_t)c.codebook_size * c.latent_dim;

@@ -82,22 +82,40 @@ struct ptts_engine {
 
 namespace {
 
+template <typename WT, int PRO, int EPI, int MTP>
+int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) {
+  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, MTP>), grid, block, sh, st, a);
+  return PTTS_OK;
+}
+
 template <typename WT, int PRO, int EPI>
-int launch_gemm(const GemmArgs& a, hipStream_t st) {
+int launch_gemm(GemmArgs a, hipStream_t st) {
   constexpr int KT = Elem<WT>::KT;
   if (a.N % 16 != 0 || a.K % KT != 0) return ptts_fail(PTTS_E_INVALID, "gemm N=%d K=%d not multiples of 16/%d", a.N, a.K, KT);
+  if (PRO == PRO_LN && a.K > 64 * 4 * LN_MAX_F4) return ptts_fail(PTTS_E_UNSUPPORTED, "LayerNorm width %d > %d", a.K, 64 * 4 * LN_MAX_F4);
   const int nfrag = a.K / KT;
   int W = (nfrag + 7) / 8;
   if (W < 2) W = 2;
   if (W > GemmMaxThreads<PRO>::value / 64) W = GemmMaxThreads<PRO>::value / 64;
+  // activation rows staged in LDS per pass: as many as fit beside the cross-wave reduction buffer (<= 32)
+  const size_t row_bytes = (size_t)a.K * sizeof(WT) + 16;
+  const size_t lds_cap = 160 * 1024 - 1024;
+  int rpp = a.M < 32 ? a.M : 32;
+  while (rpp > 1 && rpp * row_bytes + (size_t)W * (rpp > 16 ? 2 : 1) * 1024 > lds_cap) --rpp;
+  if (rpp * row_bytes + (size_t)W * 1024 > lds_cap) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm K=%d does not fit in LDS", a.K);
+  a.rows_per_pass = rpp;
+  const int mtp = rpp > 16 ? 2 : 1;
+  const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
   const dim3 grid(a.N / 16), block(W * 64);
-  if (a.M <= 16) {
-    const size_t sh = ((size_t)W * 1 * 256 + 32 * 1) * sizeof(float);
-    hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, 1>), grid, block, sh, st, a);
-  } else {
-    const size_t sh = ((size_t)W * 2 * 256 + 32 * 2) * sizeof(float);
-    hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, 2>), grid, block, sh, st, a);
-  }
+  if (mtp == 1) PTTS_TRY((launch_gemm_inst<WT, PRO, EPI, 1>(a, grid, block, sh, st)));
+  else PTTS_TRY((launch_gemm_inst<WT, PRO, EPI, 2>(a, grid, block, sh, st)));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
@@ -258,7 +276,8 @@ int pack_dispatch(ptts_engine* e, void* dst, const void* src, int src_dtype, int
   return e->cfg.dtype == PTTS_BF16 ? pack_into<bf16_t>(dst, src, src_dtype, N, K, row0, st) : pack_into<float>(dst, src, src_dtype, N, K, row0, st);
 }
 
-hipStream_t pick_stream(ptts_engine* e, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : e->own_stream; }
+// NULL is the legacy default stream (what torch.cuda.current_stream() is on ROCm unless the caller switched): pass through.
+hipStream_t pick_stream(ptts_engine*, void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
 
@@ -270,6 +289,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   PTTS_CHECK(c.dtype == PTTS_F32 || c.dtype == PTTS_BF16, PTTS_E_INVALID, "dtype must be PTTS_F32 or PTTS_BF16");
   PTTS_CHECK(c.hidden_size % 32 == 0 && c.ffn_dim % 32 == 0 && c.vocab_size % 16 == 0, PTTS_E_UNSUPPORTED,
              "hidden_size/ffn_dim must be multiples of 32 and vocab_size of 16");
+  PTTS_CHECK(c.hidden_size <= 64 * 4 * LN_MAX_F4, PTTS_E_UNSUPPORTED, "hidden_size > %d unsupported", 64 * 4 * LN_MAX_F4);
   PTTS_CHECK(c.num_codebooks >= 1 && c.num_codebooks <= 32, PTTS_E_INVALID, "num_codebooks out of range");
   PTTS_CHECK(c.vocab_size <= PTTS_SORT_N, PTTS_E_UNSUPPORTED, "vocab_size > %d unsupported by the sampler", PTTS_SORT_N);
   PTTS_CHECK(c.max_batch >= 1 && c.max_ctx >= 2 && c.max_enc >= 1 && c.max_prompt >= 1 && c.max_prompt <= c.max_ctx, PTTS_E_INVALID, "bad capacities");
@@ -522,10 +542,13 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   return PTTS_OK;
 }
 
-static int get_graph(ptts_engine* e, hipStream_t st, hipGraphExec_t* out) {
+// The decode step (195 kernel nodes for Mini-v1) is captured ONCE per batch size on the engine's private stream
+// (capture records, it does not execute; the legacy NULL stream cannot be captured) and replayed into the caller's.
+static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   auto it = e->graphs.find(e->B);
   if (it != e->graphs.end()) { *out = it->second; return PTTS_OK; }
   hipGraph_t g = nullptr;
+  hipStream_t st = e->own_stream;
   PTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   int rc = forward_dispatch(e, false, st);
   if (rc == PTTS_OK) rc = launch_tail(e, st);
@@ -548,7 +571,7 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
   PTTS_HIP(hipSetDevice(e->cfg.device));
   hipStream_t st = pick_stream(e, stream);
   hipGraphExec_t ex = nullptr;
-  PTTS_TRY(get_graph(e, st, &ex));
+  PTTS_TRY(get_graph(e, &ex));
   for (int i = 0; i < n_steps; ++i) PTTS_HIP(hipGraphLaunch(ex, st));
   return PTTS_OK;
 }

@@ -87,6 +87,7 @@ struct GemmArgs {
   int kv_rows_per_b;   // EPI_KV: N (rows of x per batch element)
   int kv_cap;          // EPI_KV: capacity (positions) of the cache
   int M, N, K;
+  int rows_per_pass;   // activation rows staged in LDS per pass (<= 16 * MTP)
 };
 
 template <typename WT> struct MfmaStep;
@@ -107,71 +108,104 @@ template <> struct MfmaStep<float> {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// B operand fragment: EPL consecutive k of activation row m (lane: m = m_tile + (l&15), k = KT*t + (l>>4)*EPL)
+// ---- activation staging ---------------------------------------------------------------------------------
+// The rows of one pass are brought into LDS ONCE per workgroup, already in their final form (LayerNorm applied /
+// split-KV partials combined) and already in the engine dtype, with a 16-byte row pad (conflict-free b128 reads of
+// 16 different rows). The MFMA loop then only touches registers (weights) and LDS (activations): no global
+// round trip sits between two MFMAs. Profiled motivation: with per-fragment global loads each decode GEMM took
+// 8-16 us for <= 8 MB of weights (profiles/r01_step_bf16_bs1_v0.txt).
+template <typename WT> __device__ __forceinline__ void lds_store4(char* row, int k, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void lds_store4<float>(char* row, int k, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(row + (size_t)k * 4) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void lds_store4<bf16_t>(char* row, int k, float a, float b, float c, float d) {
+  *reinterpret_cast<uint2*>(row + (size_t)k * 2) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+
+constexpr int LN_MAX_F4 = 8;  // LayerNorm rows up to 64 lanes * 8 float4 = 2048 wide live in registers
+
 template <typename WT, int PRO>
-__device__ __forceinline__ uint4 make_bfrag(const GemmArgs& a, int m, int k, const float* s_mean, const float* s_rstd, int mloc) {
-  constexpr int EPL = Elem<WT>::EPL;
-  float v[EPL];
-  if (m >= a.M) {
+__device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
+  if (PRO == PRO_LN) {
+    // one wave per row: the row stays in registers between the mean and the variance pass (two-pass fp32, eps 1e-5)
+    for (int r = wave; r < nrows; r += W) {
+      const float* xr = a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld;
+      float4 v[LN_MAX_F4];
+      float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = 0.f;
-  } else if (PRO == PRO_ATTN) {
-    const int head = k >> 6;
-    const float* st = a.stats + ((size_t)m * a.S * a.nheads + head) * 2;
-    float mx = -INFINITY;
-    for (int s = 0; s < a.S; ++s) mx = fmaxf(mx, st[(size_t)s * a.nheads * 2]);
-    float den = 0.f;
+      for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int k = (lane + 64 * i) * 4;
+        v[i] = k < a.K ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0, 0, 0, 0);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+      const float mean = wave_sum(s) / (float)a.K;
+      float q = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = 0.f;
-    for (int s = 0; s < a.S; ++s) {
-      const float ms = st[(size_t)s * a.nheads * 2], ls = st[(size_t)s * a.nheads * 2 + 1];
-      const float w = (ms == -INFINITY) ? 0.f : expf(ms - mx);
-      den += w * ls;
-      const float4* p = reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + s) * a.K + k);
+      for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int k = (lane + 64 * i) * 4;
+        if (k < a.K) {
+          const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+          q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)a.K + 1e-5f);
+      char* row = s_x + (size_t)r * row_bytes;
 #pragma unroll
-      for (int e4 = 0; e4 < EPL / 4; ++e4) {
-        const float4 t = p[e4];
-        v[e4 * 4 + 0] += w * t.x; v[e4 * 4 + 1] += w * t.y; v[e4 * 4 + 2] += w * t.z; v[e4 * 4 + 3] += w * t.w;
+      for (int i = 0; i < LN_MAX_F4; ++i) {
+        const int k = (lane + 64 * i) * 4;
+        if (k < a.K) {
+          const float4 g = *reinterpret_cast<const float4*>(a.gamma + k);
+          const float4 bt = *reinterpret_cast<const float4*>(a.beta + k);
+          lds_store4<WT>(row, k, (v[i].x - mean) * rstd * g.x + bt.x, (v[i].y - mean) * rstd * g.y + bt.y,
+                         (v[i].z - mean) * rstd * g.z + bt.z, (v[i].w - mean) * rstd * g.w + bt.w);
+        }
       }
     }
-    const float inv = den > 0.f ? 1.0f / den : 0.f;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] *= inv;
   } else {
-    const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k;
-#pragma unroll
-    for (int e4 = 0; e4 < EPL / 4; ++e4) {
-      const float4 t = reinterpret_cast<const float4*>(xr)[e4];
-      v[e4 * 4 + 0] = t.x; v[e4 * 4 + 1] = t.y; v[e4 * 4 + 2] = t.z; v[e4 * 4 + 3] = t.w;
-    }
-    if (PRO == PRO_LN) {
-      const float mean = s_mean[mloc], rstd = s_rstd[mloc];
-#pragma unroll
-      for (int e4 = 0; e4 < EPL / 4; ++e4) {
-        const float4 g = reinterpret_cast<const float4*>(a.gamma + k)[e4];
-        const float4 bt = reinterpret_cast<const float4*>(a.beta + k)[e4];
-        v[e4 * 4 + 0] = (v[e4 * 4 + 0] - mean) * rstd * g.x + bt.x;
-        v[e4 * 4 + 1] = (v[e4 * 4 + 1] - mean) * rstd * g.y + bt.y;
-        v[e4 * 4 + 2] = (v[e4 * 4 + 2] - mean) * rstd * g.z + bt.z;
-        v[e4 * 4 + 3] = (v[e4 * 4 + 3] - mean) * rstd * g.w + bt.w;
+    // element-parallel over (row, 4 columns): no row reduction needed
+    const int k4n = a.K >> 2;
+    const int total = nrows * k4n;
+    for (int idx = wave * 64 + lane; idx < total; idx += W * 64) {
+      const int r = idx / k4n, k = (idx - r * k4n) * 4;
+      const int m = m0 + r;
+      float4 o;
+      if (PRO == PRO_ATTN) {
+        const int head = k >> 6;
+        const float* st = a.stats + ((size_t)m * a.S * a.nheads + head) * 2;
+        float mx = -INFINITY;
+        for (int sp = 0; sp < a.S; ++sp) mx = fmaxf(mx, st[(size_t)sp * a.nheads * 2]);
+        float den = 0.f;
+        o = make_float4(0, 0, 0, 0);
+        for (int sp = 0; sp < a.S; ++sp) {
+          const float ms = st[(size_t)sp * a.nheads * 2], ls = st[(size_t)sp * a.nheads * 2 + 1];
+          const float w = (ms == -INFINITY) ? 0.f : expf(ms - mx);
+          den += w * ls;
+          const float4 t = *reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + sp) * a.K + k);
+          o.x += w * t.x; o.y += w * t.y; o.z += w * t.z; o.w += w * t.w;
+        }
+        const float inv = den > 0.f ? 1.0f / den : 0.f;
+        o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+      } else {
+        o = *reinterpret_cast<const float4*>(a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k);
       }
+      lds_store4<WT>(s_x + (size_t)r * row_bytes, k, o.x, o.y, o.z, o.w);
     }
   }
-  return pack16(v, WT());
 }
 
 // LN / ATTN prologues always reduce over K = hidden_size (<= 8 waves of 8 fragments); only the plain prologue
 // (fc2, K = ffn_dim) wants 16 waves, so only it pays the 128-VGPR cap of a 1024-thread workgroup.
 template <int PRO> struct GemmMaxThreads { static constexpr int value = PRO == PRO_PLAIN ? 1024 : 512; };
 
+// a.rows_per_pass rows (<= 16*MTP) of activations are staged per pass; LDS = staging + cross-wave reduction.
 template <typename WT, int PRO, int EPI, int MTP>
 __global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(GemmArgs a) {
   constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL, U = 8;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
-  float* s_red = smem;                          // [W][MTP][64][4]
-  float* s_mean = smem + (size_t)W * MTP * 256; // [16*MTP]
-  float* s_rstd = s_mean + 16 * MTP;
+  const int row_bytes = a.K * (int)sizeof(WT) + 16;
+  char* s_x = smem_raw;                                                                   // [rows_per_pass][row_bytes]
+  float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)a.rows_per_pass * row_bytes);  // [W][MTP][64][4]
   const int strip = blockIdx.x;
   const int nfrag = a.K / KT;
   const int per = (nfrag + W - 1) / W;
@@ -179,38 +213,21 @@ __global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(
   const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
   const int q = lane >> 4, j = lane & 15;
 
-  for (int m0 = 0; m0 < a.M; m0 += 16 * MTP) {
+  for (int m0 = 0; m0 < a.M; m0 += a.rows_per_pass) {
+    const int nrows = min(a.rows_per_pass, a.M - m0);
     // 1. put the first group of weight fragments in flight before anything that depends on activations
     uint4 afr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
-    // 2. LayerNorm statistics of the rows of this pass (two-pass, fp32), redundantly per workgroup
-    if (PRO == PRO_LN) {
-      for (int r = wave; r < 16 * MTP; r += W) {
-        const int m = m0 + r;
-        float mean = 0.f, rstd = 0.f;
-        if (m < a.M) {
-          const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
-          float s = 0.f;
-          for (int k = lane * 4; k < a.K; k += 256) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + k);
-            s += (t.x + t.y) + (t.z + t.w);
-          }
-          mean = wave_sum(s) / (float)a.K;
-          float v = 0.f;
-          for (int k = lane * 4; k < a.K; k += 256) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + k);
-            const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
-            v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-          }
-          rstd = rsqrtf(wave_sum(v) / (float)a.K + 1e-5f);
-        }
-        if (lane == 0) { s_mean[r] = mean; s_rstd[r] = rstd; }
-      }
-      __syncthreads();
-    }
-    // 3. MFMA over this wave's K slice
+    // 2. activations of this pass -> LDS (final form, engine dtype)
+    stage_rows<WT, PRO>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+    __syncthreads();
+    // 3. MFMA over this wave's K slice; B fragments come from LDS (rows beyond nrows are clamped: their output
+    //    columns are never stored)
+    const char* brow[MTP];
+#pragma unroll
+    for (int mt = 0; mt < MTP; ++mt) brow[mt] = s_x + (size_t)min(mt * 16 + j, nrows - 1) * row_bytes + (size_t)q * 16;
     f32x4 acc[MTP];
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -223,10 +240,9 @@ __global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (tb + u < t1) {
-          const int k = (tb + u) * KT + q * EPL;
 #pragma unroll
           for (int mt = 0; mt < MTP; ++mt) {
-            const uint4 bfr = make_bfrag<WT, PRO>(a, m0 + mt * 16 + j, k, s_mean, s_rstd, mt * 16 + j);
+            const uint4 bfr = *reinterpret_cast<const uint4*>(brow[mt] + (size_t)(tb + u) * (KT * sizeof(WT)));
             acc[mt] = MfmaStep<WT>::run(afr[u], bfr, acc[mt]);
           }
         }
@@ -241,9 +257,10 @@ __global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(
       const int mt = wave;
       f32x4 r = *reinterpret_cast<const f32x4*>(s_red + ((size_t)mt * 64 + lane) * 4);
       for (int w = 1; w < W; ++w) r += *reinterpret_cast<const f32x4*>(s_red + (((size_t)w * MTP + mt) * 64 + lane) * 4);
-      const int m = m0 + mt * 16 + j;
+      const int mloc = mt * 16 + j;
+      const int m = m0 + mloc;
       const int n = strip * 16 + q * 4;  // D[row = (l>>4)*4 + r][col = l&15]
-      if (m < a.M) {
+      if (mloc < nrows) {
         if (EPI == EPI_STORE) {
           *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(r[0], r[1], r[2], r[3]);
         } else if (EPI == EPI_GELU) {
@@ -587,16 +604,15 @@ __global__ void __launch_bounds__(256) tail_kernel(TailArgs a) {
   if (tid == 0) a.first_unf[b] = fu;
   const bool block_eos_all = (t - 1) < g.min_new_tokens;
 
-  for (int k = 0; k < a.K; ++k) {
-    const int row = b * a.K + k;
-    const float* sc = a.logits + (size_t)row * a.V;
-    const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
-    int tok;
-    if (!g.do_sample) {
-      // argmax, first index on ties (torch.argmax)
+  if (!g.do_sample) {
+    // greedy: one wave per codebook row, no workgroup barriers. torch.argmax semantics: first index on ties.
+    for (int k = w; k < a.K; k += (int)(blockDim.x >> 6)) {
+      const int row = b * a.K + k;
+      const float* sc = a.logits + (size_t)row * a.V;
+      const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
       float best = -INFINITY;
       int bi = 0x7fffffff;
-      for (int v = tid; v < a.V; v += blockDim.x) {
+      for (int v = lane; v < a.V; v += 64) {
         float x = sc[v];
         if (eos_blocked && v == a.eos) x = -INFINITY;
         if (x > best || (x == best && v < bi)) { best = x; bi = v; }
@@ -607,18 +623,25 @@ __global__ void __launch_bounds__(256) tail_kernel(TailArgs a) {
         const int oi = __shfl_xor(bi, off, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
       }
-      if (lane == 0) { s_red[w] = best; s_redi[w] = bi; }
-      __syncthreads();
-      if (tid == 0) {
-        float bb = s_red[0];
-        int ii = s_redi[0];
-        for (int i = 1; i < (int)(blockDim.x >> 6); ++i)
-          if (s_red[i] > bb || (s_red[i] == bb && s_redi[i] < ii)) { bb = s_red[i]; ii = s_redi[i]; }
-        s_pick = ii;
+      if (lane == 0) {
+        const int unf = a.unfinished[row];
+        const int nxt = unf ? bi : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
+        a.ids[(size_t)row * a.ids_ld + t] = nxt;
+        if (nxt == a.eos) a.has_eos[row] = 1;
+        if ((nxt == a.eos) || (t + 1 >= g.max_length)) a.unfinished[row] = 0;  // EosTokenCriteria | MaxLengthCriteria
       }
-      __syncthreads();
-      tok = s_pick;
-    } else {
+    }
+    __syncthreads();
+    if (tid == 0) a.cur_len[b] = t + 1;
+    return;
+  }
+
+  for (int k = 0; k < a.K; ++k) {
+    const int row = b * a.K + k;
+    const float* sc = a.logits + (size_t)row * a.V;
+    const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
+    int tok;
+    {
       const float invT = 1.0f / g.temperature;
       for (int v = tid; v < PTTS_SORT_N; v += blockDim.x) {
         float x = -INFINITY;

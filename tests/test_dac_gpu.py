@@ -62,19 +62,21 @@ def test_full_size_44khz_stack():
     assert _rms(wav, ref) <= 1e-4, _rms(wav, ref)
 
 
-def test_linearity_free_property_time_shift():
+def test_shift_equivariance_away_from_edges():
     """Size-independent property: away from the edges the decoder is shift-equivariant — decoding codes shifted by
-    s frames gives the waveform shifted by s*hop (receptive field ≈ 10 latent frames per side)."""
+    s frames gives the waveform shifted by s*hop. The tiny spec's small strides (4,2,2,2) give a receptive field of
+    about 23 latent frames per side (dilation-9 k7 convs at 4x resolution), so compare >= 28 frames from any edge."""
     spec = DA.DAC_TINY
     sd = DA.make_dac_weights(spec, seed=8)
     g = torch.Generator().manual_seed(3)
-    codes = torch.randint(0, 1024, (1, 9, 64), generator=g)
-    dac = make_dac(spec, sd, max_batch=1, max_frames=64)
-    a = dac.decode(codes[:, :, :48].cuda()).cpu()
-    b = dac.decode(codes[:, :, 8:56].cuda()).cpu()
+    codes = torch.randint(0, 1024, (1, 9, 96), generator=g)
+    dac = make_dac(spec, sd, max_batch=1, max_frames=96)
+    a = dac.decode(codes[:, :, :80].cuda()).cpu()     # global frames 0..79
+    b = dac.decode(codes[:, :, 16:96].cuda()).cpu()   # global frames 16..95
     hop = spec.hop_length
-    lo, hi = 20 * hop, 36 * hop  # frames 20..36 of `a` == frames 12..28 of `b`
-    assert (a[..., lo:hi] - b[..., lo - 8 * hop: hi - 8 * hop]).abs().max() < 1e-5
+    lo, hi = 44 * hop, 52 * hop
+    assert (a[..., lo:hi] - b[..., lo - 16 * hop: hi - 16 * hop]).abs().max() < 1e-5
+    assert (a[..., :hop] - b[..., :hop]).abs().max() > 1e-3  # sanity: different content where frames differ
 
 
 def test_errors():

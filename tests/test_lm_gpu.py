@@ -84,19 +84,28 @@ def test_fp32_greedy_ids_bit_exact_with_eos_paths(variant):
 
 
 def test_early_stop_when_all_rows_hit_eos():
-    """Every codebook emits EOS as soon as the gate lets it: the loop must end after K+min_new steps, not max_length."""
+    """Every codebook emits EOS as soon as the gate lets it: the loop must end after min_new + K steps, not at
+    max_length. All non-EOS LM-head rows are zero, so blocked rows see an all-equal score vector: also checks the
+    first-index tie-break of argmax (token 0)."""
     spec = DO.TINY
     sd = DO.make_decoder_weights(spec, seed=3)
+    boost = torch.zeros(spec.hidden_size)
     for k in range(spec.num_codebooks):
-        sd[f"lm_heads.{k}.weight"][spec.eos_token_id] *= 60.0
+        w = sd[f"lm_heads.{k}.weight"]
+        eos_row = w[spec.eos_token_id].clone()
+        w.zero_()
+        w[spec.eos_token_id] = eos_row
+        boost += eos_row
+    sd["model.decoder.layer_norm.bias"] = sd["model.decoder.layer_norm.bias"] + 40.0 * boost  # EOS logit ~ +2 everywhere
     g = torch.Generator().manual_seed(0)
     enc = torch.randn(2, 5, spec.hidden_size, generator=g)
     gp = DO.GenParams(max_length=64, min_new_tokens=2)
     ref = DO.sample_loop(DO.DecoderOracle(spec, sd), enc, None, None, None, gp)
+    assert ref.sequences.shape[1] == 1 + 2 + spec.num_codebooks  # BOS + min_new zeros + one EOS per codebook, staggered
     eng = make_engine(spec, sd, torch.float32)
     eng.set_gen_params(max_length=64, min_new_tokens=2)
     ids = eng.generate_ids(enc, None, None, None, poll_every=4).cpu()
-    assert ids.shape[1] < 40 and torch.equal(ids, ref.sequences)
+    assert torch.equal(ids, ref.sequences)
 
 
 @pytest.mark.parametrize("bsz", [1, 3, 20])
