@@ -1,0 +1,314 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric on the configuration it is quoted on.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is ONE pass of the hot path over one batch of synthetic input = one ``generate()`` call: T5 description
+encoder (stock PyTorch-ROCm) → HIP prefill → 867 hipGraph-replayed decode steps → un-delay → HIP DAC decode, for
+``--bs`` utterances of 860 frames (9.985 s of 44.1 kHz audio each; EOS suppressed: min_new_tokens = max_new_tokens
+= 868). N=1 workload = BASELINE.json configs[1]: parler-tts-mini-v1 shapes, bf16, bs=1, random-init
+weights (no checkpoints offline). N>1: one process per GPU, utterances sharded statically, weights broadcast once
+from rank 0 over RCCL; no collective on the data path ("scaling": "weak").
+
+One JSON line on rank 0. value = whole-job audio-seconds generated per wall-second (max over ranks). Extras:
+roofline (decode-step graph vs HBM), cpu_baseline (oracle port on the host cores, bounded sample), ttft_p50_ms.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES = 860
+K_CODEBOOKS = 9
+NEW_TOKENS = FRAMES + K_CODEBOOKS - 1  # 868 forward passes
+AUDIO_S = FRAMES * 512 / 44100.0       # 9.985 s per utterance
+N_DESC, N_PROMPT = 64, 32
+
+
+def mini_config():
+    import parler_tts_amd as P
+    from transformers import T5Config
+
+    t5 = T5Config(vocab_size=32128, d_model=1024, d_kv=64, d_ff=2816, num_layers=24, num_heads=16, feed_forward_proj="gated-gelu",
+                  tie_word_embeddings=False)  # google/flan-t5-large encoder shape (training/README.md:91)
+    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=4096, num_hidden_layers=24, ffn_dim=4096,
+                                   num_attention_heads=16, hidden_size=1024, num_codebooks=9, pad_token_id=1024, eos_token_id=1024,
+                                   bos_token_id=1025)  # helpers/model_init_scripts/init_model_600M.py:27-44
+    return P.ParlerTTSConfig.from_sub_models_config(t5, P.DACConfig(), dec, vocab_size=32128)
+
+
+def build_model(rank: int, world: int, device: torch.device, dtype: torch.dtype):
+    """Rank 0 draws the synthetic weights (seed 1234); other ranks allocate and receive them by RCCL broadcast."""
+    import parler_tts_amd as P
+    from parler_tts_amd.synthetic import random_dac_state_dict
+
+    torch.manual_seed(1234)
+    model = P.ParlerTTSForConditionalGeneration(mini_config())
+    model.audio_encoder.load_state_dict({"model." + k: v for k, v in random_dac_state_dict(seed=4321).items()})
+    model = model.to(device=device, dtype=dtype)
+    if world > 1:
+        import torch.distributed as dist
+
+        model.audio_encoder._weights = {k: v.to(device) for k, v in model.audio_encoder._weights.items()}
+        tensors = [p.data for p in model.parameters()] + list(model.audio_encoder._weights.values())
+        bucket, size = [], 0
+        def flush():
+            nonlocal bucket, size
+            if not bucket:
+                return
+            by_dtype = {}
+            for t in bucket:
+                by_dtype.setdefault(t.dtype, []).append(t)
+            for dt, ts in by_dtype.items():
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                dist.broadcast(flat, src=0)  # the ONLY collective of the path: weights, once
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off: off + t.numel()].view_as(t))
+                    off += t.numel()
+            bucket, size = [], 0
+        for t in tensors:
+            bucket.append(t)
+            size += t.numel() * t.element_size()
+            if size >= 256 << 20:
+                flush()
+        flush()
+        model._engine = None
+        model.audio_encoder._engine = None
+    return model
+
+
+def synthetic_batch(bs: int, rank: int, device):
+    g = torch.Generator().manual_seed(1 + 1000 * rank)
+    desc = torch.randint(3, 32100, (bs, N_DESC), generator=g)
+    desc[:, -1] = 1  # T5 EOS
+    g2 = torch.Generator().manual_seed(2 + 1000 * rank)
+    prompt = torch.randint(3, 32100, (bs, N_PROMPT), generator=g2)
+    prompt[:, -1] = 1
+    return desc.to(device), prompt.to(device)
+
+
+def hip_event_timer():
+    from parler_tts_amd import _native as N
+
+    hip = N.hip_runtime()
+    for name, args in (("hipEventCreate", [C.POINTER(C.c_void_p)]), ("hipEventRecord", [C.c_void_p, C.c_void_p]),
+                       ("hipEventSynchronize", [C.c_void_p]), ("hipEventElapsedTime", [C.POINTER(C.c_float), C.c_void_p, C.c_void_p])):
+        getattr(hip, name).restype = C.c_int
+        getattr(hip, name).argtypes = args
+    return hip
+
+
+def measure_decode_roofline(model, bs: int, device) -> dict:
+    """HIP events (on the stream the graph is launched on) around 400 replays of the captured decode step at
+    mid-context. Algorithmic bytes per step = W_step*2 + B*2*layers*H*(Lc+N)*2 + B*(K*H*2 + K*V*4)."""
+    hip = hip_event_timer()
+    desc, prompt = synthetic_batch(bs, 0, device)
+    enc = model._encode_description(desc, None).float()
+    pr = model.embed_prompts(prompt).float()
+    eng = model._get_engine(bs, N_DESC, N_PROMPT, NEW_TOKENS + 1)
+    eng.set_gen_params(max_length=NEW_TOKENS + 1, min_new_tokens=NEW_TOKENS)
+    eng.prefill(enc, None, pr, None, sample=True)
+    n_warm, n = 230, 400
+    eng.decode_steps(n_warm)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
+    hip.hipEventRecord(e0, stream)
+    eng.decode_steps(n)
+    hip.hipEventRecord(e1, stream)
+    hip.hipEventSynchronize(e1)
+    ms = C.c_float()
+    hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+    step_s = ms.value / 1e3 / n
+    d = model.config.decoder
+    H, L, F, V, Kc = d.hidden_size, d.num_hidden_layers, d.ffn_dim, d.vocab_size, d.num_codebooks
+    w_step = L * (4 * H * H + 2 * H * H + 2 * H * F) + Kc * V * H  # 362.3 M for Mini-v1
+    lc = N_PROMPT + 1 + n_warm + n // 2  # mean self-KV length over the timed replays
+    es = 2 if model.dtype == torch.bfloat16 else 4
+    bytes_step = w_step * es + bs * 2 * L * H * (lc + N_DESC) * es + bs * (Kc * H * es + Kc * V * 4)
+    achieved = bytes_step / step_s / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+            "traffic": None, "kernel": "decode-step hipGraph (195 kernel nodes, one hipGraphLaunch per generated frame)",
+            "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
+
+
+def measure_ttft(model, bs: int, device, reps: int = 20) -> float:
+    """p50 wall time from the start of generate()'s work to the first sampled token on device: description encoder
+    + prompt embedding + HIP prefill of P+1 positions + first sampler tail."""
+    desc, prompt = synthetic_batch(bs, 0, device)
+    eng = model._get_engine(bs, N_DESC, N_PROMPT, NEW_TOKENS + 1)
+    eng.set_gen_params(max_length=NEW_TOKENS + 1, min_new_tokens=NEW_TOKENS)
+    ts = []
+    for i in range(reps + 3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enc = model._encode_description(desc, None).float()
+        pr = model.embed_prompts(prompt).float()
+        eng.prefill(enc, None, pr, None, sample=True)
+        torch.cuda.synchronize()
+        if i >= 3:
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2] * 1e3
+
+
+def cpu_baseline(budget_s: float = 20.0) -> dict:
+    """The oracle (CPU restatement of the reference path, kind 'port') on the host cores: Mini-v1 shapes, fp32,
+    greedy, bs=1, same synthetic input shapes; bounded sample: prefill + as many cached decode steps as fit the
+    budget, plus DAC decode of the frames produced, extrapolated per frame."""
+    from oracle import dac_oracle as DA
+    from oracle import decoder_oracle as DO
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = DO.MINI_V1
+    sd = DO.make_decoder_weights(spec, seed=1234)
+    orc = DO.DecoderOracle(spec, sd)
+    g = torch.Generator().manual_seed(1)
+    enc = torch.randn(1, N_DESC, spec.hidden_size, generator=g)
+    prompt = torch.randn(1, N_PROMPT, spec.hidden_size, generator=g) * 0.02
+    ids = torch.full((9, 1), spec.bos_token_id, dtype=torch.long)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        logits = orc.forward(ids, enc, None, prompt, None)
+        t_prefill = time.perf_counter() - t0
+        steps, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < budget_s * 0.7 and steps < NEW_TOKENS - 1:
+            nxt = logits[:, -1].argmax(-1, keepdim=True).clamp(max=1023)
+            logits = orc.forward(nxt)
+            steps += 1
+        t_step = (time.perf_counter() - t1) / max(steps, 1)
+        dac = DA.DacOracle(DA.DAC_44KHZ, DA.make_dac_weights(DA.DAC_44KHZ, seed=4321))
+        Tdac = 43
+        codes = torch.randint(0, 1024, (1, 9, Tdac), generator=g)
+        t2 = time.perf_counter()
+        dac.decode(codes)
+        t_dac_frame = (time.perf_counter() - t2) / Tdac
+    total = t_prefill + (NEW_TOKENS - 1) * t_step + FRAMES * t_dac_frame
+    return {"value": round(AUDIO_S / total, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle/ fp32 Mini-v1 bs=1: prefill of {N_PROMPT + 1} positions ({t_prefill:.2f}s) + {steps} cached decode steps "
+                      f"({t_step * 1e3:.1f} ms/step) + DAC decode of {Tdac} frames ({t_dac_frame * 1e3:.1f} ms/frame), extrapolated to "
+                      f"{NEW_TOKENS} passes / {FRAMES} frames; T5 encoder excluded",
+            "ms_per_decode_step": round(t_step * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bs", type=int, default=1, help="utterances per GPU per step (configs[1]: 1; configs[2]: 32)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bs=32 / TTFT side measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    import __graft_entry__ as ge
+
+    if rank == 0 or world == 1:
+        ge.build()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = build_model(rank, world, device, dtype)
+    desc, prompt = synthetic_batch(args.bs, rank, device)
+    gen_kw = dict(input_ids=desc, prompt_input_ids=prompt, do_sample=False, max_new_tokens=NEW_TOKENS, min_new_tokens=NEW_TOKENS)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wav = model.generate(**gen_kw)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = model.generate(**gen_kw)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert wav.shape == (args.bs, FRAMES * 512), wav.shape
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.bs * args.steps * AUDIO_S / elapsed
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "audio-seconds/sec (whole node) + p50 time-to-first-token, Mini-v1 bs=1/32", "value": round(value, 3),
+            "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic (random-init weights at parler-tts-mini-v1 shapes, seeded token ids)",
+            "config": {"workload": f"parler-tts-mini-v1 {args.dtype} bs={args.bs}/GPU greedy, {N_DESC} description + {N_PROMPT} prompt tokens, "
+                                   f"{FRAMES} frames = {AUDIO_S:.3f} s audio/utterance ({NEW_TOKENS} decoder passes, hipGraph decode, DAC on-GPU)",
+                       "global_batch": world * args.bs, "frames": FRAMES, "parallelism": f"utterance-sharded x{world}, weights broadcast once"},
+        }
+        if not args.no_extras:
+            out["roofline"] = measure_decode_roofline(model, args.bs, device)
+            out["ttft_p50_ms"] = round(measure_ttft(model, args.bs, device), 2)
+        else:
+            out["roofline"] = None
+    if rank == 0 and world == 1 and not args.no_extras and args.bs != 32:
+        # side measurement of BASELINE configs[2] (bs=32, same model): one warm-up + one timed generate()
+        try:
+            d32, p32 = synthetic_batch(32, 0, device)
+            kw32 = dict(input_ids=d32, prompt_input_ids=p32, do_sample=False, max_new_tokens=NEW_TOKENS, min_new_tokens=NEW_TOKENS)
+            model.generate(**kw32)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.generate(**kw32)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["bs32"] = {"value": round(32 * AUDIO_S / dt, 2), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1),
+                           "ttft_p50_ms": round(measure_ttft(model, 32, device, reps=7), 2)}
+        except Exception as e:  # side measurement must never break the contract line
+            out["bs32"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,8 +133,9 @@ class ParlerTTSConfig(_Config):
         decoder = _sub_config(kwargs.pop("decoder"), "parler_tts_decoder")
         if isinstance(decoder, dict) or not isinstance(decoder, ParlerTTSDecoderConfig):
             decoder = ParlerTTSDecoderConfig(**(decoder if isinstance(decoder, dict) else decoder.to_dict()))
+        kwargs["is_encoder_decoder"] = True
         super().__init__(vocab_size=vocab_size, prompt_cross_attention=prompt_cross_attention, text_encoder=text_encoder,
-                         audio_encoder=audio_encoder, decoder=decoder, is_encoder_decoder=True, **kwargs)
+                         audio_encoder=audio_encoder, decoder=decoder, **kwargs)
 
     @classmethod
     def from_sub_models_config(cls, text_encoder_config, audio_encoder_config, decoder_config, **kwargs):

@@ -86,13 +86,41 @@ __device__ __forceinline__ uint4 ld_nt16(const uint4* p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions without LDS ---------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute (an LDS round trip, ~100 cycles each; 12 of them were most of the LayerNorm
+// chain in the first profile). These use DPP row operations inside a 16-lane row and v_permlane16/32_swap (gfx950)
+// across rows: 6 dependent VALU ops for a full wave64 reduction, result in EVERY lane.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+struct OpSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+
+template <typename Op> __device__ __forceinline__ float swap16_reduce(float v) {  // combine adjacent 16-lane rows
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return Op::f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <typename Op> __device__ __forceinline__ float swap32_reduce(float v) {  // combine the two 32-lane halves
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return Op::f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// reduce within aligned groups of G lanes (G = 8 or 16), result in every lane of the group
+template <typename Op, int G> __device__ __forceinline__ float group_reduce(float v) {
+  v = Op::f(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = Op::f(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = Op::f(v, dpp_mov<0x141>(v));  // row_half_mirror: other quad of the 8-lane half
+  if (G == 16) v = Op::f(v, dpp_mov<0x140>(v));  // row_mirror: other half of the row
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+// lane-wise reduction across the 64/G aligned groups of G lanes (lane c of every group combines with lane c of the
+// others), result in every lane
+template <typename Op, int G> __device__ __forceinline__ float across_groups_reduce(float v) {
+  if (G == 8) v = Op::f(v, dpp_mov<0x128>(v));  // row_ror:8 == xor 8 inside a 16-lane row
+  v = swap16_reduce<Op>(v);
+  return swap32_reduce<Op>(v);
 }
+template <typename Op> __device__ __forceinline__ float wave_reduce(float v) {
+  return across_groups_reduce<Op, 16>(group_reduce<Op, 16>(v));
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce<OpSum>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce<OpMax>(v); }

@@ -82,16 +82,16 @@ struct ptts_engine {
 
 namespace {
 
-template <typename WT, int PRO, int EPI, int MTP>
+template <typename WT, int PRO, int EPI, int MTP, bool FULL>
 int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) {
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, MTP>), grid, block, sh, st, a);
+  hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>), grid, block, sh, st, a);
   return PTTS_OK;
 }
 
@@ -101,9 +101,21 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   if (a.N % 16 != 0 || a.K % KT != 0) return ptts_fail(PTTS_E_INVALID, "gemm N=%d K=%d not multiples of 16/%d", a.N, a.K, KT);
   if (PRO == PRO_LN && a.K > 64 * 4 * LN_MAX_F4) return ptts_fail(PTTS_E_UNSUPPORTED, "LayerNorm width %d > %d", a.K, 64 * 4 * LN_MAX_F4);
   const int nfrag = a.K / KT;
-  int W = (nfrag + 7) / 8;
-  if (W < 2) W = 2;
-  if (W > GemmMaxThreads<PRO>::value / 64) W = GemmMaxThreads<PRO>::value / 64;
+  const int wmax = (a.M > 16 ? GemmMaxThreads<PRO, 2>::value : GemmMaxThreads<PRO, 1>::value) / 64;
+  // FULL variant: every wave owns whole 8-fragment groups (and K % 256 == 0): straight-line kernel
+  int W = 0;
+  const bool ln_ok = PRO != PRO_LN || a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 1536;  // ln_row<> instances
+  if (a.K % 256 == 0 && ln_ok)
+    for (int w = wmax; w >= 2; --w)
+      if (nfrag % (8 * w) == 0) { W = w; break; }
+  const bool full = W > 0;
+  if (!full) {
+    W = (nfrag + 7) / 8;
+    if (W < 2) W = 2;
+    if (W > wmax) W = wmax;
+  }
+  a.frags_per_wave = nfrag / W;
+  a.invK = 1.0f / (float)a.K;
   // activation rows staged in LDS per pass: as many as fit beside the cross-wave reduction buffer (<= 32)
   const size_t row_bytes = (size_t)a.K * sizeof(WT) + 16;
   const size_t lds_cap = 160 * 1024 - 1024;
@@ -114,8 +126,10 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   const int mtp = rpp > 16 ? 2 : 1;
   const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
   const dim3 grid(a.N / 16), block(W * 64);
-  if (mtp == 1) PTTS_TRY((launch_gemm_inst<WT, PRO, EPI, 1>(a, grid, block, sh, st)));
-  else PTTS_TRY((launch_gemm_inst<WT, PRO, EPI, 2>(a, grid, block, sh, st)));
+  int rc;
+  if (full) rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, true>(a, grid, block, sh, st);
+  else rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, false>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, false>(a, grid, block, sh, st);
+  PTTS_TRY(rc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;

@@ -88,6 +88,11 @@ struct GemmArgs {
   int kv_cap;          // EPI_KV: capacity (positions) of the cache
   int M, N, K;
   int rows_per_pass;   // activation rows staged in LDS per pass (<= 16 * MTP)
+  int frags_per_wave;  // FULL variant: K/KT/W, a multiple of 8
+  float invK;          // 1 / K
+#ifdef PTTS_TIMING
+  long long* dbg;      // phase timestamps (s_memtime) of workgroup 0 / wave 0
+#endif
 };
 
 template <typename WT> struct MfmaStep;
@@ -105,6 +110,17 @@ template <> struct MfmaStep<float> {
     return c;
   }
 };
+
+#ifdef PTTS_TIMING
+#define PTTS_STAMP(ptr, i) do { if ((ptr) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) (ptr)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PTTS_STAMP(ptr, i) do { } while (0)
+#endif
+#ifndef PTTS_TIMING
+#define PTTS_DBG(a) ((long long*)nullptr)
+#else
+#define PTTS_DBG(a) ((a).dbg)
+#endif
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -124,83 +140,103 @@ template <> __device__ __forceinline__ void lds_store4<bf16_t>(char* row, int k,
 
 constexpr int LN_MAX_F4 = 8;  // LayerNorm rows up to 64 lanes * 8 float4 = 2048 wide live in registers
 
-template <typename WT, int PRO>
+// One wave normalises one row. NF4 float4 per lane, statically indexed (registers, never scratch). Every load (row,
+// gamma, beta) is issued before the first dependent instruction; mean and variance come from ONE fused pass of
+// sum(x-c) and sum((x-c)^2) with the shift c = x[0] (shifted-data variance: no catastrophic cancellation, error
+// ~ eps*(1 + (mean-c)^2/var)); eps 1e-5 as nn.LayerNorm (modeling:961). EXACT: K == NF4*256, no lane masks.
+template <typename WT, int NF4, bool EXACT>
+__device__ __forceinline__ void ln_row(const GemmArgs& a, const float* xr, char* row, int lane) {
+  float4 v[NF4], g[NF4], bt[NF4];
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int k = (lane + 64 * i) * 4;
+    const int kk = (EXACT || k < a.K) ? k : 0;  // out-of-range lanes re-read column 0 and are masked below
+    v[i] = *reinterpret_cast<const float4*>(xr + kk);
+    g[i] = *reinterpret_cast<const float4*>(a.gamma + kk);
+    bt[i] = *reinterpret_cast<const float4*>(a.beta + kk);
+  }
+  const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const float msk = (EXACT || (lane + 64 * i) * 4 < a.K) ? 1.f : 0.f;
+    const float d0 = (v[i].x - c) * msk, d1 = (v[i].y - c) * msk, d2 = (v[i].z - c) * msk, d3 = (v[i].w - c) * msk;
+    s1 += (d0 + d1) + (d2 + d3);
+    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float dm = s1 * a.invK;
+  const float mean = c + dm;
+  const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int k = (lane + 64 * i) * 4;
+    if (EXACT || k < a.K)
+      lds_store4<WT>(row, k, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
+                     (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
+  }
+}
+
+template <typename WT, int PRO, bool FULL>
 __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
   if (PRO == PRO_LN) {
-    // one wave per row: the row stays in registers between the mean and the variance pass (two-pass fp32, eps 1e-5)
+    const int nf4 = (a.K + 255) >> 8;  // workgroup-uniform
     for (int r = wave; r < nrows; r += W) {
       const float* xr = a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld;
-      float4 v[LN_MAX_F4];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < LN_MAX_F4; ++i) {
-        const int k = (lane + 64 * i) * 4;
-        v[i] = k < a.K ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0, 0, 0, 0);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      }
-      const float mean = wave_sum(s) / (float)a.K;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < LN_MAX_F4; ++i) {
-        const int k = (lane + 64 * i) * 4;
-        if (k < a.K) {
-          const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
-          q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-      }
-      const float rstd = rsqrtf(wave_sum(q) / (float)a.K + 1e-5f);
       char* row = s_x + (size_t)r * row_bytes;
-#pragma unroll
-      for (int i = 0; i < LN_MAX_F4; ++i) {
-        const int k = (lane + 64 * i) * 4;
-        if (k < a.K) {
-          const float4 g = *reinterpret_cast<const float4*>(a.gamma + k);
-          const float4 bt = *reinterpret_cast<const float4*>(a.beta + k);
-          lds_store4<WT>(row, k, (v[i].x - mean) * rstd * g.x + bt.x, (v[i].y - mean) * rstd * g.y + bt.y,
-                         (v[i].z - mean) * rstd * g.z + bt.z, (v[i].w - mean) * rstd * g.w + bt.w);
-        }
+      if (FULL) {  // host guarantees K in {256, 512, 1024, 1536} for the FULL LayerNorm variant
+        if (nf4 == 4) ln_row<WT, 4, true>(a, xr, row, lane);        // hidden 1024 (Mini-v1)
+        else if (nf4 == 6) ln_row<WT, 6, true>(a, xr, row, lane);   // hidden 1536 (Large-v1)
+        else ln_row<WT, 2, false>(a, xr, row, lane);
+      } else {
+        if (nf4 <= 1) ln_row<WT, 1, false>(a, xr, row, lane);
+        else ln_row<WT, LN_MAX_F4, false>(a, xr, row, lane);
       }
     }
   } else {
-    // element-parallel over (row, 4 columns): no row reduction needed
+    // element-parallel over (row, 4 columns): no row reduction needed, no integer division
     const int k4n = a.K >> 2;
-    const int total = nrows * k4n;
-    for (int idx = wave * 64 + lane; idx < total; idx += W * 64) {
-      const int r = idx / k4n, k = (idx - r * k4n) * 4;
+    for (int r = 0; r < nrows; ++r) {
       const int m = m0 + r;
-      float4 o;
-      if (PRO == PRO_ATTN) {
-        const int head = k >> 6;
-        const float* st = a.stats + ((size_t)m * a.S * a.nheads + head) * 2;
-        float mx = -INFINITY;
-        for (int sp = 0; sp < a.S; ++sp) mx = fmaxf(mx, st[(size_t)sp * a.nheads * 2]);
-        float den = 0.f;
-        o = make_float4(0, 0, 0, 0);
-        for (int sp = 0; sp < a.S; ++sp) {
-          const float ms = st[(size_t)sp * a.nheads * 2], ls = st[(size_t)sp * a.nheads * 2 + 1];
-          const float w = (ms == -INFINITY) ? 0.f : expf(ms - mx);
-          den += w * ls;
-          const float4 t = *reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + sp) * a.K + k);
-          o.x += w * t.x; o.y += w * t.y; o.z += w * t.z; o.w += w * t.w;
+      char* row = s_x + (size_t)r * row_bytes;
+      for (int k4 = wave * 64 + lane; k4 < k4n; k4 += W * 64) {
+        const int k = k4 * 4;
+        float4 o;
+        if (PRO == PRO_ATTN) {
+          const int head = k >> 6;
+          const float* st = a.stats + ((size_t)m * a.S * a.nheads + head) * 2;
+          float mx = -INFINITY;
+          for (int sp = 0; sp < a.S; ++sp) mx = fmaxf(mx, st[(size_t)sp * a.nheads * 2]);
+          float den = 0.f;
+          o = make_float4(0, 0, 0, 0);
+          for (int sp = 0; sp < a.S; ++sp) {
+            const float ms = st[(size_t)sp * a.nheads * 2], ls = st[(size_t)sp * a.nheads * 2 + 1];
+            const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
+            den += w * ls;
+            const float4 t = *reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + sp) * a.K + k);
+            o.x += w * t.x; o.y += w * t.y; o.z += w * t.z; o.w += w * t.w;
+          }
+          const float inv = den > 0.f ? __frcp_rn(den) : 0.f;
+          o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+        } else {
+          o = *reinterpret_cast<const float4*>(a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k);
         }
-        const float inv = den > 0.f ? 1.0f / den : 0.f;
-        o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-      } else {
-        o = *reinterpret_cast<const float4*>(a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k);
+        lds_store4<WT>(row, k, o.x, o.y, o.z, o.w);
       }
-      lds_store4<WT>(s_x + (size_t)r * row_bytes, k, o.x, o.y, o.z, o.w);
     }
   }
 }
 
-// LN / ATTN prologues always reduce over K = hidden_size (<= 8 waves of 8 fragments); only the plain prologue
-// (fc2, K = ffn_dim) wants 16 waves, so only it pays the 128-VGPR cap of a 1024-thread workgroup.
-template <int PRO> struct GemmMaxThreads { static constexpr int value = PRO == PRO_PLAIN ? 1024 : 512; };
+// LN / ATTN prologues always reduce over K = hidden_size (<= 8 waves of >= 8 fragments); only the plain prologue
+// (fc2, K = ffn_dim) at batch <= 16 wants 16 waves, so only it pays the 128-VGPR cap of a 1024-thread workgroup.
+template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value = (PRO == PRO_PLAIN && MTP == 1) ? 1024 : 512; };
 
 // a.rows_per_pass rows (<= 16*MTP) of activations are staged per pass; LDS = staging + cross-wave reduction.
-template <typename WT, int PRO, int EPI, int MTP>
-__global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(GemmArgs a) {
-  constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL, U = 8;
+// FULL: every wave owns a whole number of 8-fragment groups and K % 256 == 0 -> straight-line code, no predicates.
+template <typename WT, int PRO, int EPI, int MTP, bool FULL>
+__global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_kernel(GemmArgs a) {
+  constexpr int KT = Elem<WT>::KT, U = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int row_bytes = a.K * (int)sizeof(WT) + 16;
@@ -208,50 +244,66 @@ __global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(
   float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)a.rows_per_pass * row_bytes);  // [W][MTP][64][4]
   const int strip = blockIdx.x;
   const int nfrag = a.K / KT;
-  const int per = (nfrag + W - 1) / W;
-  const int t0 = wave * per, t1 = min(nfrag, t0 + per);
+  const int per = FULL ? a.frags_per_wave : (nfrag + W - 1) / W;
+  const int t0 = wave * per, t1 = FULL ? t0 + per : min(nfrag, t0 + per);
   const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
   const int q = lane >> 4, j = lane & 15;
 
   for (int m0 = 0; m0 < a.M; m0 += a.rows_per_pass) {
     const int nrows = min(a.rows_per_pass, a.M - m0);
+    PTTS_STAMP(PTTS_DBG(a), 0);
     // 1. put the first group of weight fragments in flight before anything that depends on activations
     uint4 afr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+      if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
     // 2. activations of this pass -> LDS (final form, engine dtype)
-    stage_rows<WT, PRO>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+    PTTS_STAMP(PTTS_DBG(a), 1);
+    stage_rows<WT, PRO, FULL>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+    PTTS_STAMP(PTTS_DBG(a), 2);
     __syncthreads();
+    PTTS_STAMP(PTTS_DBG(a), 3);
     // 3. MFMA over this wave's K slice; B fragments come from LDS (rows beyond nrows are clamped: their output
-    //    columns are never stored)
+    //    columns are never stored). All LDS reads of a group are issued before its first MFMA.
     const char* brow[MTP];
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt) brow[mt] = s_x + (size_t)min(mt * 16 + j, nrows - 1) * row_bytes + (size_t)q * 16;
-    f32x4 acc[MTP];
+    f32x4 acc[MTP], acc2[MTP];  // two independent accumulator chains per tile (MFMA dependent latency)
 #pragma unroll
-    for (int mt = 0; mt < MTP; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MTP; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int tb = t0; tb < t1; tb += U) {
       if (tb != t0) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (tb + u < t1) afr[u] = ld_nt16(Wp + (size_t)(tb + u) * 64);
+          if (FULL || tb + u < t1) afr[u] = ld_nt16(Wp + (size_t)(tb + u) * 64);
       }
+      constexpr int UB = MTP == 2 ? 4 : 8;  // LDS reads hoisted per half-group when two tiles are live (VGPR budget)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (tb + u < t1) {
+      for (int uh = 0; uh < U; uh += UB) {
+        uint4 bfr[MTP][UB];
 #pragma unroll
-          for (int mt = 0; mt < MTP; ++mt) {
-            const uint4 bfr = *reinterpret_cast<const uint4*>(brow[mt] + (size_t)(tb + u) * (KT * sizeof(WT)));
-            acc[mt] = MfmaStep<WT>::run(afr[u], bfr, acc[mt]);
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+          for (int mt = 0; mt < MTP; ++mt)
+            if (FULL || tb + uh + u < t1)
+              bfr[mt][u] = *reinterpret_cast<const uint4*>(brow[mt] + (size_t)(tb + uh + u) * (KT * sizeof(WT)));
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (FULL || tb + uh + u < t1) {
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) {
+              if (u & 1) acc2[mt] = MfmaStep<WT>::run(afr[uh + u], bfr[mt][u], acc2[mt]);
+              else acc[mt] = MfmaStep<WT>::run(afr[uh + u], bfr[mt][u], acc[mt]);
+            }
           }
         }
       }
     }
     // 4. deterministic cross-wave reduction through LDS (fixed wave order)
+    PTTS_STAMP(PTTS_DBG(a), 4);
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt)
-      *reinterpret_cast<f32x4*>(s_red + (((size_t)wave * MTP + mt) * 64 + lane) * 4) = acc[mt];
+      *reinterpret_cast<f32x4*>(s_red + (((size_t)wave * MTP + mt) * 64 + lane) * 4) = acc[mt] + acc2[mt];
     __syncthreads();
     if (wave < MTP) {
       const int mt = wave;
@@ -284,6 +336,7 @@ __global__ void __launch_bounds__(GemmMaxThreads<PRO>::value) gemm_strip_kernel(
         }
       }
     }
+    PTTS_STAMP(PTTS_DBG(a), 5);
     __syncthreads();
   }
 }
@@ -320,10 +373,34 @@ struct AttnArgs {
   float scale;
 };
 
+// load EPL consecutive floats of a row chunk, optionally RoPE-rotated (x*cos + rotate_half(x)*sin, modeling:409-436)
+template <int EPL>
+__device__ __forceinline__ void load_chunk_rope(const float* row, int d0, const float* cos, const float* sin, size_t pos, float (&out)[EPL]) {
+  float x[EPL], y[EPL], cs[EPL], sn[EPL];
+  const int dp = d0 < 32 ? d0 + 32 : d0 - 32;  // rotate_half partner chunk (EPL divides 32: a chunk never straddles)
+#pragma unroll
+  for (int e4 = 0; e4 < EPL / 4; ++e4) {
+    const float4 t = reinterpret_cast<const float4*>(row + d0)[e4];
+    x[e4 * 4] = t.x; x[e4 * 4 + 1] = t.y; x[e4 * 4 + 2] = t.z; x[e4 * 4 + 3] = t.w;
+    if (cos) {
+      const float4 u = reinterpret_cast<const float4*>(row + dp)[e4];
+      y[e4 * 4] = u.x; y[e4 * 4 + 1] = u.y; y[e4 * 4 + 2] = u.z; y[e4 * 4 + 3] = u.w;
+      const float4 c4 = reinterpret_cast<const float4*>(cos + pos * 64 + d0)[e4];
+      const float4 s4 = reinterpret_cast<const float4*>(sin + pos * 64 + d0)[e4];
+      cs[e4 * 4] = c4.x; cs[e4 * 4 + 1] = c4.y; cs[e4 * 4 + 2] = c4.z; cs[e4 * 4 + 3] = c4.w;
+      sn[e4 * 4] = s4.x; sn[e4 * 4 + 1] = s4.y; sn[e4 * 4 + 2] = s4.z; sn[e4 * 4 + 3] = s4.w;
+    }
+  }
+  const float sign = d0 < 32 ? -1.f : 1.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) out[e] = cos ? x[e] * cs[e] + sign * y[e] * sn[e] : x[e];
+}
+
+// All global loads of a wave's first batch (q chunk, new K/V row, 8 K + 8 V cache rows, masks) are issued before the
+// first wait: two dependent round trips per kernel (lengths, then everything else) instead of four.
 template <typename WT, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8;
-  __shared__ float s_q[64];
   __shared__ float s_o[NW][64];
   __shared__ float s_ml[NW][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -333,42 +410,18 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   const int pos = (a.cur_len ? P + a.cur_len[b] - 1 : 0) + qi;
   const int L = a.cross ? a.dims->N : pos + 1;
   const int mask_len = a.cross ? L : P;
-
-  if (tid < 64) {
-    const float* qr = a.q + (size_t)row * a.q_ld + h * 64;
-    float v = qr[tid];
-    if (a.cos) {
-      const float c = a.cos[(size_t)pos * 64 + tid], sn = a.sin[(size_t)pos * 64 + tid];
-      const float other = tid < 32 ? -qr[tid + 32] : qr[tid - 32];
-      v = v * c + other * sn;
-    }
-    s_q[tid] = v * a.scale;
-  }
-  __syncthreads();
   const int r = lane / LPR, c = lane % LPR;
+
   float qv[EPL];
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) qv[e] = s_q[c * EPL + e];
+  load_chunk_rope<EPL>(a.q + (size_t)row * a.q_ld + h * 64, c * EPL, a.cos, a.sin, (size_t)pos, qv);
 
   uint4 knew_p = make_uint4(0, 0, 0, 0), vnew_p = make_uint4(0, 0, 0, 0);
   WT* Kc = reinterpret_cast<WT*>(a.kcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
   WT* Vc = reinterpret_cast<WT*>(a.vcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
   if (a.fused_append) {
-    const float* kr = a.knew + (size_t)row * a.kv_ld + h * 64;
-    const float* vr = a.vnew + (size_t)row * a.kv_ld + h * 64;
     float kk[EPL], vv[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int d = c * EPL + e;
-      float kx = kr[d];
-      if (a.cos) {
-        const float cs = a.cos[(size_t)pos * 64 + d], sn = a.sin[(size_t)pos * 64 + d];
-        const float other = d < 32 ? -kr[d + 32] : kr[d - 32];
-        kx = kx * cs + other * sn;
-      }
-      kk[e] = kx;
-      vv[e] = vr[d];
-    }
+    load_chunk_rope<EPL>(a.knew + (size_t)row * a.kv_ld + h * 64, c * EPL, a.cos, a.sin, (size_t)pos, kk);
+    load_chunk_rope<EPL>(a.vnew + (size_t)row * a.kv_ld + h * 64, c * EPL, nullptr, nullptr, 0, vv);
     knew_p = pack16(kk, WT());
     vnew_p = pack16(vv, WT());
     if (s == 0 && w == 0 && r == 0) {  // single writer of the new cache row
@@ -376,6 +429,8 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       reinterpret_cast<uint4*>(Vc + (size_t)pos * 64)[c] = vnew_p;
     }
   }
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) qv[e] *= a.scale;
 
   const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
   const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
@@ -388,34 +443,33 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
 
   for (int g0 = wv; g0 < G; g0 += TW * U) {
     uint4 kf[U], vf[U];
+    int mk[U];
     bool ok[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {  // loads only: clamped addresses, validity applied afterwards
       const int t = (g0 + u * TW) * RPI + r;
       ok[u] = t < L;
-      if (ok[u] && mrow && t < mask_len) ok[u] = mrow[t] != 0;
-      kf[u] = make_uint4(0, 0, 0, 0);
-      vf[u] = make_uint4(0, 0, 0, 0);
-      if (ok[u]) {
-        if (a.fused_append && t == pos) { kf[u] = knew_p; vf[u] = vnew_p; }
-        else { kf[u] = Kb[(size_t)t * LPR + c]; vf[u] = Vb[(size_t)t * LPR + c]; }
-      }
+      const int tc = ok[u] ? t : 0;
+      kf[u] = Kb[(size_t)tc * LPR + c];
+      vf[u] = Vb[(size_t)tc * LPR + c];
+      mk[u] = (mrow && tc < mask_len) ? mrow[tc] : 1;
     }
     float sc[U], bm = -INFINITY;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      const int t = (g0 + u * TW) * RPI + r;
+      ok[u] = ok[u] && mk[u] != 0;
+      if (a.fused_append && t == pos) { kf[u] = knew_p; vf[u] = vnew_p; }
       float kk[EPL];
       unpack16(kf[u], kk, WT());
       float d = 0.f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kk[e], d);
-#pragma unroll
-      for (int off = 1; off < LPR; off <<= 1) d += __shfl_xor(d, off, 64);
+      d = group_reduce<OpSum, LPR>(d);
       sc[u] = ok[u] ? d : -INFINITY;
       bm = fmaxf(bm, sc[u]);
     }
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) bm = fmaxf(bm, __shfl_xor(bm, off, 64));
+    bm = across_groups_reduce<OpMax, LPR>(bm);
     const float m_new = fmaxf(m_run, bm);
     if (m_new == -INFINITY) continue;  // wave-uniform: nothing visible yet
     const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
@@ -429,17 +483,14 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       unpack16(vf[u], vv, WT());
       l_run += p;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, vv[e], o[e]);
+      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(p, vv[e], o[e]) : o[e];  // masked rows may hold NaN/garbage V
     }
     m_run = m_new;
   }
   // reduce over the RPI row slots of the wave (lanes sharing chunk c)
+  l_run = across_groups_reduce<OpSum, LPR>(l_run);
 #pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-    l_run += __shfl_xor(l_run, off, 64);
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) o[e] += __shfl_xor(o[e], off, 64);
-  }
+  for (int e = 0; e < EPL; ++e) o[e] = across_groups_reduce<OpSum, LPR>(o[e]);
   if (r == 0) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) s_o[w][c * EPL + e] = o[e];

@@ -1,0 +1,105 @@
+"""``DACModel`` with the reference wrapper's interface (parler_tts/dac_wrapper/modeling_dac.py:13-164): same config
+fields, same ``decode(audio_codes, audio_scales, padding_mask=None, return_dict=None)`` signature and the same
+"one frame only" error, but ``decode`` runs on the HIP DAC engine (csrc/ptts_dac.hip) instead of
+descript-audio-codec. ``encode`` (voice-prompt input) is outside the accelerated path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from ..configuration_parler_tts import DACConfig
+from ..engine import DacEngine, fold_weight_norm
+
+
+@dataclass
+class DACDecoderOutput:
+    """Stands in for transformers' EncodecDecoderOutput: ``.audio_values`` [batch, channels, samples]."""
+
+    audio_values: Optional[torch.Tensor] = None
+
+    def __getitem__(self, i):
+        return (self.audio_values,)[i]
+
+
+class DACModel(torch.nn.Module):
+    config_class = DACConfig
+    main_input_name = "input_values"
+
+    # descript 44 kHz architecture constants behind dac.model.DAC(n_codebooks, latent_dim, codebook_size) (:24-28)
+    CODEBOOK_DIM = 8
+    DECODER_DIM = 1536
+    DECODER_RATES = (8, 8, 4, 2)
+
+    def __init__(self, config: DACConfig, decoder_dim: Optional[int] = None, decoder_rates=None, codebook_dim: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        self.decoder_dim = decoder_dim or getattr(config, "decoder_dim", self.DECODER_DIM)
+        self.decoder_rates = tuple(decoder_rates or getattr(config, "decoder_rates", self.DECODER_RATES))
+        self.codebook_dim = codebook_dim or getattr(config, "codebook_dim", self.CODEBOOK_DIM)
+        self._weights: Dict[str, torch.Tensor] = {}  # dac.model.DAC names under the reference's "model." prefix
+        self._engine: Optional[DacEngine] = None
+        self._engine_dev = None
+        self._dummy = torch.nn.Parameter(torch.zeros(1), requires_grad=False)  # tracks .to(device)
+
+    @property
+    def device(self):
+        return self._dummy.device
+
+    # -- weights: keep the reference's key names ("model.quantizer...", "model.decoder...") ----------------------
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        w = {k: v.detach() for k, v in state_dict.items() if k.startswith("model.")}
+        if strict and not any(k.startswith("model.decoder.") for k in w):
+            raise RuntimeError("DACModel.load_state_dict: no 'model.decoder.*' tensors found")
+        self._weights = w
+        self._engine = None
+        return torch.nn.modules.module._IncompatibleKeys([], [])
+
+    def state_dict(self, *args, prefix: str = "", **kwargs):
+        return {prefix + k: v for k, v in self._weights.items()}
+
+    def _get_engine(self, batch: int, frames: int) -> DacEngine:
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("DACModel.decode runs on the HIP engine only: move the model to a cuda device (no CPU fallback)")
+        e = self._engine
+        if e is None or self._engine_dev != dev or e.max_batch < batch or e.max_frames < frames:
+            if e is not None:
+                e.close()
+            if not self._weights:
+                raise RuntimeError("DACModel has no weights loaded")
+            c = self.config
+            e = DacEngine(num_codebooks=c.num_codebooks, codebook_size=c.codebook_size, codebook_dim=self.codebook_dim,
+                          latent_dim=c.latent_dim, decoder_dim=self.decoder_dim, rates=self.decoder_rates,
+                          max_batch=max(batch, 1), max_frames=max(frames, 64), device=dev)
+            e.load_state_dict({k[len("model."):]: v for k, v in self._weights.items()})
+            self._engine, self._engine_dev = e, dev
+        return e
+
+    def encode(self, input_values, padding_mask=None, bandwidth=None, return_dict=None, n_quantizers=None, sample_rate=None):
+        raise NotImplementedError("DACModel.encode (voice-prompt encoding) is outside the MI355X-accelerated path; "
+                                  "encode with descript-audio-codec and pass `decoder_input_ids` instead")
+
+    @torch.no_grad()
+    def decode(self, audio_codes, audio_scales=None, padding_mask=None, return_dict=None):
+        """audio_codes [1, batch, num_codebooks, frames] int64 → audio_values [batch, 1, hop*frames] float32."""
+        if len(audio_codes) != 1:
+            raise ValueError(f"Expected one frame, got {len(audio_codes)}")  # modeling_dac.py:135-136
+        codes = audio_codes[0]
+        if codes.dim() != 3:
+            raise ValueError(f"audio_codes must be [1, batch, codebooks, frames], got {tuple(audio_codes.shape)}")
+        B, _, T = codes.shape
+        if T > 0 and (int(codes.max()) >= self.config.codebook_size or int(codes.min()) < 0):
+            raise ValueError("audio_codes contain ids outside [0, codebook_size)")
+        eng = self._get_engine(B, T)
+        out = torch.empty(B, 1, eng.hop * T, dtype=torch.float32, device=self.device)
+        for b0 in range(0, B, eng.max_batch):
+            out[b0:b0 + eng.max_batch] = eng.decode(codes[b0:b0 + eng.max_batch])
+        if return_dict is False:
+            return (out,)
+        return DACDecoderOutput(out)
+
+    def forward(self, tensor):
+        raise ValueError("`DACModel.forward` not implemented yet")  # modeling_dac.py:144-145

@@ -1,0 +1,512 @@
+"""Host side of the MI355X-native generation path: the reference's public surface
+(``ParlerTTSForConditionalGeneration.from_pretrained()/.generate()``, parler_tts/modeling_parler_tts.py:2306-3678)
+re-implemented around the two HIP engines. Nothing here inherits from or imports the reference; the `_sample`
+loop of transformers (which the reference delegates to, :3564) is owned here and, on the default path, runs
+entirely on the device (engine.generate_ids): Python only encodes the description (stock PyTorch-ROCm T5, third
+party and off the per-token loop), hands pointers to the engine, un-delays the ids and calls the DAC engine.
+
+State-dict names are the reference's: ``text_encoder.*``, ``audio_encoder.model.*``,
+``decoder.model.decoder.layers.N.*``, ``decoder.lm_heads.N.*``, ``embed_prompts.*``, ``enc_to_dec_proj.*``.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import math
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .configuration_parler_tts import DACConfig, ParlerTTSConfig, ParlerTTSDecoderConfig
+from .dac_wrapper import DACModel
+from .engine import DecoderEngine
+
+
+# ------------------------------------------------------------------------------------------------------------
+# delay pattern (reference :205-276) — closed form instead of the reference's loop + triu/tril
+# ------------------------------------------------------------------------------------------------------------
+def build_delay_pattern_mask(input_ids: torch.LongTensor, bos_token_id: int, pad_token_id: int, max_length: int,
+                             num_codebooks: int) -> Tuple[torch.LongTensor, torch.LongTensor]:
+    """Codebook k is delayed by k steps: position j of row k holds BOS for j <= k, PAD for j - k >= max_length - K + 1,
+    the (shifted) prompt where one was given, and -1 ("to be predicted") elsewhere. Returns (ids up to the first
+    position that needs predicting, full pattern mask)."""
+    dev = input_ids.device
+    ids = input_ids.reshape(-1, num_codebooks, input_ids.shape[-1])
+    bsz, K, seq_len = ids.shape
+    pattern = torch.full((bsz, K, max_length), -1, dtype=torch.long, device=dev)
+    if max_length < 2 * K - 1:  # too short for the pattern: returned as is (:246-247)
+        return ids.reshape(bsz * K, -1), pattern.reshape(bsz * K, -1)
+    j = torch.arange(max_length, device=dev)[None, :]
+    k = torch.arange(K, device=dev)[:, None]
+    src = j - k  # column of the un-shifted prompt that lands on (k, j)
+    has_prompt = (src >= 0) & (src < seq_len)
+    gathered = torch.gather(ids, 2, src.clamp(0, seq_len - 1)[None].expand(bsz, -1, -1))
+    pattern = torch.where(has_prompt[None], gathered, pattern)
+    bos = torch.as_tensor(bos_token_id, device=dev, dtype=torch.long)
+    pad = torch.as_tensor(pad_token_id, device=dev, dtype=torch.long)
+    pattern = torch.where((j <= k)[None], bos, pattern)
+    pattern = torch.where(((j - k) >= max_length - K + 1)[None], pad, pattern)
+    first_row = pattern[:, 0, :]
+    todo = (first_row == -1).nonzero()
+    first_start = int(todo[:, 1].min()) if todo.numel() > 0 else seq_len
+    mask = pattern.reshape(bsz * K, -1)
+    return pattern[..., :first_start].reshape(bsz * K, -1), mask
+
+
+def apply_delay_pattern_mask(input_ids: torch.LongTensor, decoder_pad_token_mask: torch.LongTensor) -> torch.LongTensor:
+    m = decoder_pad_token_mask[..., : input_ids.shape[-1]]
+    return torch.where(m == -1, input_ids, m)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# weight holders that reproduce the reference's parameter names
+# ------------------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    pass
+
+
+def _set_param(root: nn.Module, dotted: str, tensor: torch.Tensor):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Holder())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+def sinusoidal_table(num_embeddings: int, embedding_dim: int) -> torch.Tensor:
+    """cos ‖ sin halves with frequencies exp(-i·ln(1e4)/(half-1)) (reference :346-359)."""
+    half = embedding_dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.int64).float() * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(num_embeddings, dtype=torch.int64).float().unsqueeze(1) * freq.unsqueeze(0)
+    tab = torch.cat([torch.cos(ang), torch.sin(ang)], dim=1).view(num_embeddings, -1)
+    if embedding_dim % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(num_embeddings, 1)], dim=1)
+    return tab
+
+
+class ParlerTTSForCausalLM(nn.Module):
+    """Holder of the decoder-LM parameters under the reference's names (``model.decoder.*``, ``lm_heads.*``).
+    The arithmetic of ``ParlerTTSForCausalLM.forward`` (reference :1865) lives in the HIP engine."""
+
+    config_class = ParlerTTSDecoderConfig
+
+    def __init__(self, config: ParlerTTSDecoderConfig, init_weights: bool = True):
+        super().__init__()
+        self.config = config
+        self.num_codebooks = config.num_codebooks
+        c, H, F = config, config.hidden_size, config.ffn_dim
+        std = c.initializer_factor
+        mk = (lambda *s: torch.randn(*s) * std) if init_weights else (lambda *s: torch.empty(*s))
+        for k in range(c.num_codebooks):
+            _set_param(self, f"model.decoder.embed_tokens.{k}.weight", mk(c.vocab_size + 1, H))
+        if not c.rope_embeddings:
+            _set_param(self, "model.decoder.embed_positions.weights", sinusoidal_table(c.max_position_embeddings, H))
+        for i in range(c.num_hidden_layers):
+            lp = f"model.decoder.layers.{i}."
+            for att in ("self_attn", "encoder_attn"):
+                for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                    _set_param(self, f"{lp}{att}.{proj}.weight", mk(H, H))
+                _set_param(self, f"{lp}{att}_layer_norm.weight", torch.ones(H))
+                _set_param(self, f"{lp}{att}_layer_norm.bias", torch.zeros(H))
+            _set_param(self, f"{lp}fc1.weight", mk(F, H))
+            _set_param(self, f"{lp}fc2.weight", mk(H, F))
+            _set_param(self, f"{lp}final_layer_norm.weight", torch.ones(H))
+            _set_param(self, f"{lp}final_layer_norm.bias", torch.zeros(H))
+        _set_param(self, "model.decoder.layer_norm.weight", torch.ones(H))
+        _set_param(self, "model.decoder.layer_norm.bias", torch.zeros(H))
+        if c.use_fused_lm_heads:
+            _set_param(self, "lm_heads.weight", mk(c.num_codebooks * c.vocab_size, H))
+        else:
+            for k in range(c.num_codebooks):
+                _set_param(self, f"lm_heads.{k}.weight", mk(c.vocab_size, H))
+
+    def build_delay_pattern_mask(self, input_ids, bos_token_id, pad_token_id, max_length):
+        return build_delay_pattern_mask(input_ids, bos_token_id, pad_token_id, max_length, self.num_codebooks)
+
+    @staticmethod
+    def apply_delay_pattern_mask(input_ids, decoder_pad_token_mask):
+        return apply_delay_pattern_mask(input_ids, decoder_pad_token_mask)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("the decoder forward runs inside the HIP engine; call ParlerTTSForConditionalGeneration.generate()")
+
+
+class GenerateOutput(dict):
+    """``return_dict_in_generate=True``: ``.sequences`` is the waveform, ``["audios_length"]`` the lengths (:3648-3651)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _default_generation_config(config: ParlerTTSConfig):
+    from transformers import GenerationConfig
+
+    d = config.decoder
+    gc = GenerationConfig(max_length=int(30 * config.audio_encoder.frame_rate), do_sample=True, pad_token_id=d.pad_token_id,
+                          eos_token_id=d.eos_token_id, bos_token_id=d.bos_token_id, decoder_start_token_id=d.bos_token_id)
+    return gc  # helpers/model_init_scripts/init_model_600M.py:57-63
+
+
+class ParlerTTSForConditionalGeneration(nn.Module):
+    config_class = ParlerTTSConfig
+    base_model_prefix = "encoder_decoder"
+    main_input_name = "input_ids"
+
+    def __init__(self, config: Optional[ParlerTTSConfig] = None, text_encoder: Optional[nn.Module] = None,
+                 audio_encoder: Optional[nn.Module] = None, decoder: Optional[ParlerTTSForCausalLM] = None):
+        super().__init__()
+        if config is None and (text_encoder is None or audio_encoder is None or decoder is None):
+            raise ValueError("Either a configuration has to be provided, or all three of text encoder, audio encoder and Parler-TTS decoder.")
+        if config is None:
+            config = ParlerTTSConfig.from_sub_models_config(text_encoder.config, audio_encoder.config, decoder.config)
+        elif not isinstance(config, self.config_class):
+            raise ValueError(f"Config: {config} has to be of type {self.config_class}")
+        xh = getattr(config.decoder, "cross_attention_hidden_size", None)
+        if xh is not None and xh != config.text_encoder.hidden_size:
+            raise ValueError("If `cross_attention_hidden_size` is specified in the Parler-TTS decoder's configuration, it has to be equal"
+                             f" to the text encoder's `hidden_size`. Got {xh} and {config.text_encoder.hidden_size}.")
+        config.decoder.check_supported_by_engine()
+        self.config = config
+        if text_encoder is None:
+            from transformers import AutoModelForTextEncoding
+
+            text_encoder = AutoModelForTextEncoding.from_config(config.text_encoder)  # third-party T5 encoder (:2345-2348)
+        self.text_encoder = text_encoder
+        self.audio_encoder = audio_encoder if audio_encoder is not None else DACModel(config.audio_encoder)
+        self.decoder = decoder if decoder is not None else ParlerTTSForCausalLM(config.decoder)
+        H = config.decoder.hidden_size
+        if config.text_encoder.hidden_size != H and xh is None:
+            self.enc_to_dec_proj = nn.Linear(config.text_encoder.hidden_size, H)  # :2388-2392
+        self.embed_prompts = nn.Embedding(config.vocab_size, H)  # :2395
+        self.embed_prompts.weight.data.normal_(mean=0.0, std=config.decoder.initializer_factor)
+        self.prompt_cross_attention = config.prompt_cross_attention
+        if config.prompt_cross_attention:
+            self.embed_positions = _Holder()
+            _set_param(self.embed_positions, "weights", sinusoidal_table(config.decoder.max_position_embeddings, H))
+        self.use_audio_scales = True      # DACModel.decode takes `audio_scales` (:2416-2417)
+        self.use_4dim_audio_codes = True  # model_type "dac_on_the_hub" (:2419-2422)
+        self.generation_config = _default_generation_config(config)
+        self._engine: Optional[DecoderEngine] = None
+        self._engine_key = None
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.eval()
+
+    # -- bookkeeping ---------------------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self.embed_prompts.weight.device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.embed_prompts.weight.dtype
+
+    def get_text_encoder(self):
+        return self.text_encoder
+
+    def get_audio_encoder(self):
+        return self.audio_encoder
+
+    def freeze_encoders(self, freeze_text_encoder=True):
+        pass  # inference-only implementation: nothing is trainable
+
+    def resize_token_embeddings(self, *args, **kwargs):
+        raise NotImplementedError("Resizing the embedding layers via the EncoderDecoderModel directly is not supported. Please use the"
+                                  " respective methods of the wrapped objects (model.encoder.resize_token_embeddings(...) or"
+                                  " model.decoder.resize_token_embeddings(...))")
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._engine = None  # device / dtype may have changed: repack lazily
+        return out
+
+    # -- (de)serialisation ----------------------------------------------------------------------------------
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **kwargs):
+        from safetensors.torch import save_file
+
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        with open(os.path.join(save_directory, "generation_config.json"), "w") as f:
+            json.dump({k: v for k, v in self.generation_config.to_dict().items() if v is not None}, f, indent=2, default=str)
+        sd, seen = {}, set()
+        for k, v in self.state_dict().items():  # tied tensors (T5 shared embedding) are written once, like HF does
+            if k.endswith("_dummy") or v.data_ptr() in seen:
+                continue
+            seen.add(v.data_ptr())
+            sd[k] = v.detach().cpu().contiguous()
+        sd.update({"audio_encoder." + k: v.detach().cpu().contiguous() for k, v in self.audio_encoder.state_dict().items()})
+        save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args, torch_dtype: Optional[torch.dtype] = None,
+                        attn_implementation: Optional[str] = None, config: Optional[ParlerTTSConfig] = None, **kwargs):
+        """Loads a HF checkpoint directory (config.json + [generation_config.json] + *.safetensors) with the
+        reference's key names. ``attn_implementation`` is accepted for drop-in compatibility and ignored: the
+        whole attention registry (:933-937) is replaced by the HIP attention kernel."""
+        path = pretrained_model_name_or_path
+        if not os.path.isdir(path):
+            from huggingface_hub import snapshot_download  # needs network / a local HF cache
+
+            path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors"])
+        cfg = config or ParlerTTSConfig.from_pretrained(path)
+        model = cls(cfg)
+        gpath = os.path.join(path, "generation_config.json")
+        if os.path.exists(gpath):
+            from transformers import GenerationConfig
+
+            model.generation_config = GenerationConfig.from_pretrained(path)
+        from safetensors.torch import load_file
+
+        index = os.path.join(path, "model.safetensors.index.json")
+        files = sorted(set(json.load(open(index))["weight_map"].values())) if os.path.exists(index) else ["model.safetensors"]
+        sd: Dict[str, torch.Tensor] = {}
+        for fn in files:
+            sd.update(load_file(os.path.join(path, fn)))
+        model.load_state_dict(sd)
+        if torch_dtype is not None:
+            model.to(dtype=torch_dtype)
+        return model
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        audio = {k[len("audio_encoder."):]: v for k, v in state_dict.items() if k.startswith("audio_encoder.")}
+        rest = {k: v for k, v in state_dict.items() if not k.startswith("audio_encoder.")}
+        if audio:
+            self.audio_encoder.load_state_dict(audio, strict=strict)
+        own = super().state_dict()
+        missing = [k for k in own if k not in rest and not k.startswith("audio_encoder.") and "rotary_emb" not in k]
+        # T5 ties / registers a shared embedding under two names in some transformers releases: tolerate either
+        missing = [k for k in missing if not (k.startswith("text_encoder.") and ("embed_tokens" in k or k.endswith("shared.weight")))]
+        unexpected = [k for k in rest if k not in own and "rotary_emb" not in k]
+        if strict and (missing or [k for k in unexpected if not k.startswith("text_encoder.")]):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        super().load_state_dict({k: v for k, v in rest.items() if k in own}, strict=False)
+        self._engine = None
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # -- engine ------------------------------------------------------------------------------------------------
+    def _get_engine(self, B: int, N: int, P: int, max_length: int) -> DecoderEngine:
+        dev, dt = self.device, self.dtype
+        if dev.type != "cuda":
+            raise RuntimeError("generate() runs on the HIP engine only: move the model to a cuda device first (there is no CPU fallback)")
+        if dt not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"model dtype {dt}: the HIP engine implements float32 (parity) and bfloat16 (throughput)")
+        e = self._engine
+        need = (dev, dt)
+        if e is None or self._engine_key != need or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 or e.cfg.max_ctx < P + max_length:
+            if e is not None:
+                e.close()
+            d = self.config.decoder
+            e = DecoderEngine(hidden_size=d.hidden_size, num_layers=d.num_hidden_layers, num_heads=d.num_attention_heads, ffn_dim=d.ffn_dim,
+                              num_codebooks=d.num_codebooks, vocab_size=d.vocab_size, max_positions=d.max_position_embeddings,
+                              rope=d.rope_embeddings, rope_theta=d.rope_theta, pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id,
+                              bos_token_id=d.bos_token_id, dtype=dt, max_batch=B, max_ctx=max(P + max_length, 64), max_enc=max(N, 16),
+                              max_prompt=max(P + 1, 8), device=dev)
+            e.load_state_dict(self.decoder.state_dict())
+            self._engine, self._engine_key = e, need
+        return e
+
+    # -- the pieces of generate() that stay on the torch side (once per call, off the per-token loop) ---------------
+    def _encode_description(self, input_ids, attention_mask):
+        """:3048-3097 — T5 encoder, optional enc_to_dec_proj, masked positions zeroed."""
+        enc = self.text_encoder(input_ids=input_ids, attention_mask=attention_mask, return_dict=True).last_hidden_state
+        if hasattr(self, "enc_to_dec_proj"):
+            enc = self.enc_to_dec_proj(enc)
+        if attention_mask is not None:
+            enc = enc * attention_mask[..., None]
+        return enc
+
+    @torch.no_grad()
+    def generate(self, inputs: Optional[torch.Tensor] = None, generation_config=None, logits_processor=None, stopping_criteria=None,
+                 synced_gpus: Optional[bool] = None, streamer=None, **kwargs):
+        """Same call surface as the reference (:3321-3653). Returns the waveform [batch, samples] (zero padded), or a
+        ``GenerateOutput`` with ``.sequences`` = waveform and ``["audios_length"]`` when ``return_dict_in_generate``."""
+        gc = copy.deepcopy(generation_config if generation_config is not None else self.generation_config)
+        mk = gc.update(**kwargs)
+        input_ids = inputs if inputs is not None else mk.pop("input_ids", None)
+        attention_mask = mk.pop("attention_mask", None)
+        prompt_input_ids = mk.pop("prompt_input_ids", None)
+        prompt_attention_mask = mk.pop("prompt_attention_mask", None)
+        prompt_hidden_states = mk.pop("prompt_hidden_states", None)
+        encoder_outputs = mk.pop("encoder_outputs", None)
+        if mk.pop("input_values", None) is not None or mk.pop("decoder_input_ids", None) is not None:
+            raise NotImplementedError("voice-prompt continuation (`input_values` / `decoder_input_ids`) needs DACModel.encode, which is"
+                                      " outside the MI355X-accelerated path (SURVEY.md §8(f))")
+        if mk.get("past_key_values") is not None and getattr(gc, "cache_implementation", None) is not None:
+            raise ValueError("Passing both `cache_implementation` (used to initialize certain caches) and `past_key_values` (a "
+                             "Cache object) is unsupported. Please use only one of the two.")
+        if getattr(gc, "cache_implementation", None) == "quantized":
+            raise ValueError("This model does not support the quantized cache. If you want your model to support quantized "
+                             "cache, please open an issue on the Parler-TTS repository https://github.com/huggingface/parler-tts")
+        if (getattr(gc, "num_beams", 1) or 1) > 1 or (getattr(gc, "num_beam_groups", 1) or 1) > 1:
+            raise ValueError("Got incompatible mode for generation, should be one of greedy or sampling. "
+                             "Ensure that beam search is de-activated by setting `num_beams=1` and `num_beam_groups=1`.")
+        dev = self.device
+        d = self.config.decoder
+        K = d.num_codebooks
+        # --- description / prompt conditioning ---------------------------------------------------------------------
+        if encoder_outputs is not None:
+            enc = encoder_outputs[0] if isinstance(encoder_outputs, (tuple, list)) else encoder_outputs.last_hidden_state
+        else:
+            if input_ids is None:
+                raise ValueError("`input_ids` (the tokenized description) or `encoder_outputs` must be given")
+            input_ids = input_ids.to(dev)
+            enc = self._encode_description(input_ids, attention_mask.to(dev) if attention_mask is not None else None)
+        B = enc.shape[0]
+        if streamer is not None and B > 1:
+            raise ValueError("ParlerTTSStreamer only supports batch size 1")
+        enc = enc.to(dev).float()
+        enc_mask = attention_mask.to(dev) if attention_mask is not None else None
+        prompt, prompt_mask = None, None
+        if prompt_hidden_states is None and prompt_input_ids is not None:
+            prompt_hidden_states = self.embed_prompts(prompt_input_ids.to(dev))  # :3100
+        if prompt_hidden_states is not None:
+            ph = prompt_hidden_states.to(dev).float()
+            pm = prompt_attention_mask.to(dev) if prompt_attention_mask is not None else None
+            if self.prompt_cross_attention:  # :3102-3128: prompt joins the cross-attention context
+                ph = ph + self.embed_positions.weights[: ph.shape[1]].float()[None]
+                if pm is not None and enc_mask is None:
+                    enc_mask = torch.ones(enc.shape[:2], device=dev, dtype=pm.dtype)
+                elif enc_mask is not None and pm is None:
+                    pm = torch.ones(ph.shape[:2], device=dev, dtype=enc_mask.dtype)
+                enc = torch.cat([enc, ph], dim=1)
+                if pm is not None:
+                    enc_mask = torch.cat([enc_mask, pm], dim=1)
+            else:
+                prompt, prompt_mask = ph, pm
+        num_return = int(getattr(gc, "num_return_sequences", 1) or 1)
+        if num_return > 1:  # _expand_inputs_for_generation (:3556-3561)
+            enc = enc.repeat_interleave(num_return, 0)
+            enc_mask = enc_mask.repeat_interleave(num_return, 0) if enc_mask is not None else None
+            prompt = prompt.repeat_interleave(num_return, 0) if prompt is not None else None
+            prompt_mask = prompt_mask.repeat_interleave(num_return, 0) if prompt_mask is not None else None
+            B *= num_return
+        N = enc.shape[1]
+        P = prompt.shape[1] if prompt is not None else 0
+        # --- lengths (:3458-3469) -----------------------------------------------------------------------------------
+        if gc.max_new_tokens is not None:
+            max_length = int(gc.max_new_tokens) + 1
+        else:
+            max_length = int(gc.max_length)
+        min_new = int(gc.min_new_tokens or 0)
+        if getattr(gc, "min_length", 0):
+            min_new = max(min_new, int(gc.min_length) - 1)
+        if max_length < 2:
+            raise ValueError("`max_length` / `max_new_tokens` leave no room for a generated token")
+        eng = self._get_engine(B, N, P, max_length)
+        do_sample = bool(gc.do_sample)
+        manual = (logits_processor is not None and len(logits_processor) > 0) or (stopping_criteria is not None and len(stopping_criteria) > 0)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0  # follows torch.manual_seed()
+        eng.set_gen_params(max_length=max_length, min_new_tokens=min_new, do_sample=do_sample, temperature=float(gc.temperature or 1.0),
+                           top_k=int(gc.top_k or 0) if do_sample else 0, top_p=float(gc.top_p if gc.top_p is not None else 1.0),
+                           use_eos_gate=logits_processor is None, seed=seed)
+        bos, pad, eos = d.bos_token_id, gc.pad_token_id if gc.pad_token_id is not None else d.pad_token_id, d.eos_token_id
+        bos_col = torch.full((B * K, 1), bos, dtype=torch.long, device=dev)
+        if streamer is not None:
+            delayed, _ = build_delay_pattern_mask(bos_col, bos, pad, max_length, K)
+            streamer.put(delayed.cpu())  # :3533-3534
+        if not manual:
+            output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer)
+        else:
+            output_ids = self._run_host_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, logits_processor,
+                                             stopping_criteria, streamer, eos, pad)
+        if streamer is not None:
+            streamer.end()
+        # --- un-delay (:3585-3597) and decode (:3600-3647) -------------------------------------------------------------
+        _, pattern = build_delay_pattern_mask(bos_col, bos, pad, max_length, K)
+        output_ids = apply_delay_pattern_mask(output_ids, pattern)
+        _, m2 = build_delay_pattern_mask(bos_col, bos, pad, output_ids.shape[1], K)
+        keep = (m2 != bos) & (m2 != pad)
+        codes = output_ids[keep].reshape(B, K, -1)
+        cb = self.audio_encoder.config.codebook_size
+        bad = codes >= cb
+        if not bool(bad.any()):
+            wav = self.audio_encoder.decode(audio_codes=codes[None], audio_scales=[None] * B).audio_values.squeeze(1)
+            lengths = [int(wav.shape[1])] * B
+        else:  # per-sample: drop every column holding a special id, decode, zero-pad (:3627-3647)
+            outs: List[torch.Tensor] = []
+            for b in range(B):
+                ok = bad[b].sum(dim=0) == 0
+                if int(ok.sum()) > 0:
+                    w = self.audio_encoder.decode(audio_codes=codes[b: b + 1, :, ok][None], audio_scales=[None]).audio_values[0, 0]
+                else:
+                    w = torch.zeros(1, device=dev)
+                outs.append(w)
+            lengths = [int(w.shape[0]) for w in outs]
+            wav = torch.nn.utils.rnn.pad_sequence(outs, batch_first=True, padding_value=0)
+        if getattr(gc, "return_dict_in_generate", False):
+            return GenerateOutput(sequences=wav, audios_length=lengths)
+        return wav
+
+    # -- default path: the whole `_sample` loop runs on the device -------------------------------------------------------
+    def _run_device_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer):
+        eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)
+        sent = 1
+        chunk = int(getattr(streamer, "play_steps", 16) or 16) if streamer is not None else 64
+        remaining = max_length - 2
+        done = False
+        while True:
+            if streamer is not None:  # forward finished columns in order (one put per column, like `_sample`)
+                ids = eng.ids()
+                for j in range(sent, ids.shape[1]):
+                    streamer.put(ids[:, j].cpu())
+                sent = ids.shape[1]
+            if done or remaining <= 0:
+                break
+            n = min(chunk, remaining)
+            eng.decode_steps(n)
+            remaining -= n
+            _, done = eng.state()
+        return eng.ids()
+
+    # -- user LogitsProcessorList / StoppingCriteria: forward on the HIP engine, selection in torch --------------------------
+    def _run_host_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, processors, criteria, streamer, eos, pad):
+        dev = self.device
+        eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
+        B = enc.shape[0]
+        K = self.config.decoder.num_codebooks
+        seq = torch.full((B * K, 1), self.config.decoder.bos_token_id, dtype=torch.long, device=dev)
+        unfinished = torch.ones(B * K, dtype=torch.long, device=dev)
+        while True:
+            scores = eng.logits().float()
+            if min_new > 0 and (seq.shape[-1] - 1) < min_new:
+                scores[:, eos] = -math.inf
+            for proc in (processors or []):
+                scores = proc(seq, scores)
+            if gc.do_sample:
+                if gc.temperature and gc.temperature != 1.0:
+                    scores = scores / gc.temperature
+                if gc.top_k:
+                    kth = torch.topk(scores, min(int(gc.top_k), scores.shape[-1]))[0][..., -1, None]
+                    scores = scores.masked_fill(scores < kth, -math.inf)
+                if gc.top_p is not None and gc.top_p < 1.0:
+                    sl, si = torch.sort(scores, descending=False)
+                    rm = sl.softmax(dim=-1).cumsum(dim=-1) <= (1 - gc.top_p)
+                    rm[..., -1:] = False
+                    scores = scores.masked_fill(rm.scatter(1, si, rm), -math.inf)
+                nxt = torch.multinomial(torch.softmax(scores, dim=-1), 1).squeeze(1)
+            else:
+                nxt = torch.argmax(scores, dim=-1)
+            nxt = nxt * unfinished + pad * (1 - unfinished)
+            seq = torch.cat([seq, nxt[:, None]], dim=-1)
+            done = (nxt == eos) | (seq.shape[-1] >= max_length)
+            for crit in (criteria or []):
+                r = crit(seq, scores)
+                done = done | (r if torch.is_tensor(r) else torch.full_like(done, bool(r)))
+            unfinished = unfinished & ~done.long()
+            eng.push_tokens(nxt, (1 - unfinished).int())
+            if streamer is not None:
+                streamer.put(nxt.cpu())
+            if int(unfinished.max()) == 0:
+                break
+            eng.step_forward()
+        return seq

@@ -1,0 +1,86 @@
+"""``ParlerTTSStreamer`` with the reference's constructor, ``put``/``end``/iterator protocol and threading model
+(parler_tts/streamer.py:11-147): ``generate(..., streamer=s)`` runs in a background thread and the caller iterates
+numpy chunks. The un-delay + DAC decode of the token cache every ``play_steps`` columns is kept, so the emitted
+samples are the reference's; the decode itself runs on the HIP DAC engine.
+"""
+from __future__ import annotations
+
+import math
+from queue import Queue
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .modeling_parler_tts import apply_delay_pattern_mask, build_delay_pattern_mask
+
+
+class ParlerTTSStreamer:
+    def __init__(self, model, device: Optional[str] = None, play_steps: Optional[int] = 10, stride: Optional[int] = None,
+                 timeout: Optional[float] = None):
+        self.decoder = model.decoder
+        self.audio_encoder = model.audio_encoder
+        self.generation_config = model.generation_config
+        self.device = device if device is not None else model.device
+        self.use_audio_scales = model.use_audio_scales
+        self.use_4dim_audio_codes = model.use_4dim_audio_codes
+        self.audio_kwargs = {"audio_scales": [None]} if self.use_audio_scales else {}
+        self.play_steps = play_steps
+        if stride is not None:
+            self.stride = stride
+        else:  # streamer.py:56-57
+            hop_length = math.floor(self.audio_encoder.config.sampling_rate / self.audio_encoder.config.frame_rate)
+            self.stride = hop_length * (play_steps - self.decoder.num_codebooks) // 6
+        self.token_cache = None
+        self.to_yield = 0
+        self.audio_queue: Queue = Queue()
+        self.stop_signal = None
+        self.timeout = timeout
+
+    def apply_delay_pattern_mask(self, input_ids):
+        K = self.decoder.num_codebooks
+        gc = self.generation_config
+        # streamer.py:68-73 rebuilds the mask with decoder_start_token_id as the pad value (quirk kept)
+        _, mask = build_delay_pattern_mask(input_ids[:, :1], bos_token_id=gc.bos_token_id, pad_token_id=gc.decoder_start_token_id,
+                                           max_length=input_ids.shape[-1], num_codebooks=K)
+        input_ids = apply_delay_pattern_mask(input_ids, mask)
+        keep = (mask != gc.bos_token_id) & (mask != gc.pad_token_id)
+        codes = input_ids[keep].reshape(1, K, -1).to(self.audio_encoder.device)
+        ok = (codes[0] >= self.audio_encoder.config.codebook_size).sum(dim=0) == 0  # drop columns with special ids
+        codes = codes[:, :, ok]
+        if codes.shape[-1] == 0:
+            return np.zeros(0, dtype=np.float32)
+        out = self.audio_encoder.decode(audio_codes=codes[None, ...], **self.audio_kwargs).audio_values
+        return out[0, 0].cpu().float().numpy()
+
+    def put(self, value):
+        batch_size = value.shape[0] // self.decoder.num_codebooks
+        if batch_size > 1:
+            raise ValueError("ParlerTTSStreamer only supports batch size 1")
+        if self.token_cache is None:
+            self.token_cache = value
+        else:
+            self.token_cache = torch.concatenate([self.token_cache, value[:, None]], dim=-1)
+        if self.token_cache.shape[-1] % self.play_steps == 0:
+            audio_values = self.apply_delay_pattern_mask(self.token_cache)
+            self.on_finalized_audio(audio_values[self.to_yield: -self.stride])
+            self.to_yield += len(audio_values) - self.to_yield - self.stride
+
+    def end(self):
+        """Flushes any remaining cache and appends the stop symbol."""
+        audio_values = self.apply_delay_pattern_mask(self.token_cache) if self.token_cache is not None else np.zeros(self.to_yield)
+        self.on_finalized_audio(audio_values[self.to_yield:], stream_end=True)
+
+    def on_finalized_audio(self, audio: np.ndarray, stream_end: bool = False):
+        self.audio_queue.put(audio, timeout=self.timeout)
+        if stream_end:
+            self.audio_queue.put(self.stop_signal, timeout=self.timeout)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        value = self.audio_queue.get(timeout=self.timeout)
+        if not isinstance(value, np.ndarray) and value == self.stop_signal:
+            raise StopIteration()
+        return value

@@ -1,0 +1,121 @@
+"""CPU: product-side host logic (delay pattern, EOS gate, configs, checkpoint names) against the oracle and the
+golden vectors — no GPU, no HIP compute."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from helpers import t
+from oracle import decoder_oracle as DO
+
+import parler_tts_amd as P
+
+
+def test_delay_pattern_matches_reference_known_answers():
+    g = np.load(os.path.join(GOLD, "delay_kat.npz"))
+    for ci in range(int(g["n"])):
+        K, seq_len, max_len, bsz = [int(x) for x in g[f"c{ci}_args"]]
+        ids, mask = P.build_delay_pattern_mask(t(g[f"c{ci}_in"]), 1025, 1024, max_len, K)
+        assert torch.equal(ids, t(g[f"c{ci}_ids"])), ci
+        assert torch.equal(mask, t(g[f"c{ci}_mask"])), ci
+
+
+def test_delay_pattern_random_differential_vs_oracle():
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(60):
+        K = int(torch.randint(1, 10, (1,), generator=gen))
+        bsz = int(torch.randint(1, 4, (1,), generator=gen))
+        max_len = int(torch.randint(1, 40, (1,), generator=gen))
+        seq_len = int(torch.randint(1, max(2, min(max_len, 6)), (1,), generator=gen))
+        ids = torch.randint(0, 1024, (bsz * K, seq_len), generator=gen)
+        a = P.build_delay_pattern_mask(ids, 1025, 1024, max_len, K)
+        b = DO.build_delay_pattern_mask(ids, 1025, 1024, max_len, K)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (K, bsz, max_len, seq_len)
+        full = torch.randint(0, 1024, (bsz * K, max_len), generator=gen)
+        assert torch.equal(P.apply_delay_pattern_mask(full, a[1]), DO.apply_delay_pattern_mask(full, b[1]))
+
+
+def test_logits_processor_matches_reference_known_answers():
+    g = np.load(os.path.join(GOLD, "eosgate_kat.npz"))
+    K, bsz = int(g["K"]), int(g["bsz"])
+    proc = P.ParlerTTSLogitsProcessor(1024, K, bsz, "cpu")
+    hist = t(g["history"])
+    for s in range(g["gated"].shape[0]):
+        sc = proc(hist[:, : s + 2], torch.zeros(bsz * K, 1088))
+        assert np.array_equal(torch.isinf(sc[:, 1024]).numpy(), g["gated"][s])
+        assert torch.isinf(sc).sum() == int(g["gated"][s].sum())  # only the EOS column is touched
+    with pytest.raises(ValueError, match="positive integers"):
+        P.ParlerTTSLogitsProcessor([-1], K, bsz)
+
+
+def _tiny_config(**dec_kw):
+    from transformers import T5Config
+
+    t5 = T5Config(vocab_size=128, d_model=128, d_kv=32, d_ff=256, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")
+    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=256, num_hidden_layers=2, ffn_dim=256, num_attention_heads=2,
+                                   hidden_size=128, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025, **dec_kw)
+    dac = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2])
+    return P.ParlerTTSConfig.from_sub_models_config(t5, dac, dec, vocab_size=128)
+
+
+def test_config_round_trip_and_reference_field_names(tmp_path):
+    cfg = _tiny_config()
+    cfg.save_pretrained(str(tmp_path))
+    raw = json.load(open(tmp_path / "config.json"))
+    assert raw["model_type"] == "parler_tts" and raw["decoder"]["model_type"] == "parler_tts_decoder"
+    assert raw["audio_encoder"]["model_type"] == "dac_on_the_hub" and raw["text_encoder"]["model_type"] == "t5"
+    for f in ("vocab_size", "max_position_embeddings", "num_hidden_layers", "ffn_dim", "num_attention_heads", "num_key_value_heads",
+              "hidden_size", "num_codebooks", "rope_embeddings", "rope_theta", "use_fused_lm_heads", "pad_token_id", "bos_token_id", "eos_token_id"):
+        assert f in raw["decoder"], f
+    back = P.ParlerTTSConfig.from_pretrained(str(tmp_path))
+    assert back.decoder.to_dict() == cfg.decoder.to_dict()
+    assert back.sampling_rate == 44100 and back.audio_encoder.frame_rate == 86
+    with pytest.raises(ValueError, match="text_encoder, audio_encoder and decoder"):
+        P.ParlerTTSConfig(vocab_size=10)
+    with pytest.raises(ValueError, match="codebook_weights"):
+        P.ParlerTTSDecoderConfig(num_codebooks=4, codebook_weights=[1.0])
+
+
+def test_state_dict_uses_reference_names_and_round_trips(tmp_path):
+    torch.manual_seed(0)
+    m = P.ParlerTTSForConditionalGeneration(_tiny_config())
+    from oracle import dac_oracle as DA
+
+    m.audio_encoder.load_state_dict({"model." + k: v for k, v in DA.make_dac_weights(DA.DAC_TINY, 1, "parametrized").items()})
+    keys = set(m.state_dict().keys())
+    for k in ("decoder.model.decoder.layers.1.self_attn.q_proj.weight", "decoder.model.decoder.layers.0.encoder_attn_layer_norm.bias",
+              "decoder.model.decoder.embed_tokens.8.weight", "decoder.model.decoder.embed_positions.weights", "decoder.lm_heads.3.weight",
+              "decoder.model.decoder.layer_norm.weight", "embed_prompts.weight", "decoder.model.decoder.layers.1.fc2.weight"):
+        assert k in keys, k
+    assert any(k.startswith("text_encoder.") for k in keys)
+    m.save_pretrained(str(tmp_path))
+    m2 = P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path))
+    a, b = m.state_dict(), m2.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a if not k.endswith("_dummy"))
+    assert "model.decoder.model.1.block.1.parametrizations.weight.original0" in m2.audio_encoder.state_dict()
+    assert m2.generation_config.decoder_start_token_id == 1025 and m2.generation_config.max_length == 2580
+
+
+def test_unsupported_architectures_fail_loudly():
+    with pytest.raises(NotImplementedError, match="grouped-query"):
+        P.ParlerTTSForConditionalGeneration(_tiny_config(num_key_value_heads=1))
+    with pytest.raises(NotImplementedError, match="gelu"):
+        P.ParlerTTSForConditionalGeneration(_tiny_config(activation_function="relu"))
+
+
+def test_generate_refuses_cpu_and_bad_modes():
+    m = P.ParlerTTSForConditionalGeneration(_tiny_config())
+    ids = torch.randint(3, 100, (1, 6))
+    with pytest.raises(ValueError, match="greedy or sampling"):
+        m.generate(input_ids=ids, prompt_input_ids=ids, num_beams=2)
+    with pytest.raises(NotImplementedError, match="voice-prompt"):
+        m.generate(input_ids=ids, prompt_input_ids=ids, input_values=torch.zeros(1, 1, 100))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.generate(input_ids=ids, prompt_input_ids=ids, max_new_tokens=12)
+    with pytest.raises(NotImplementedError, match="encode"):
+        m.audio_encoder.encode(torch.zeros(1, 1, 100))
+    with pytest.raises(NotImplementedError, match="resize"):
+        m.resize_token_embeddings(10)
