@@ -29,6 +29,9 @@ def _tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False)
     if eos_gain:
         for k in range(9):
             sd[f"lm_heads.{k}.weight"][1024] *= eos_gain
+    else:  # fixed-length runs: a trained model never emits the 64 padding ids >= codebook_size; random heads would, and
+        for k in range(9):  # generate() (like the reference :3627-3636) drops every frame that contains one
+            sd[f"lm_heads.{k}.weight"][1024:] = 0.0
     m.decoder.load_state_dict(sd, strict=False)
     dsd = DA.make_dac_weights(DA.DAC_TINY, seed=4321, weight_norm_format="parametrized")
     m.audio_encoder.load_state_dict({"model." + k: v for k, v in dsd.items()})
