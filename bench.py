@@ -62,35 +62,10 @@ def build_model(rank: int, world: int, device: torch.device, dtype: torch.dtype)
             getattr(model.decoder.lm_heads, str(k)).weight[1024:] = 0.0
     model.audio_encoder.load_state_dict({"model." + k: v for k, v in random_dac_state_dict(seed=4321).items()})
     model = model.to(device=device, dtype=dtype)
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1:  # the ONLY collective of the path: the weights, once, rank 0 -> all
+        from parler_tts_amd.distributed import broadcast_model_weights
 
-        model.audio_encoder._weights = {k: v.to(device) for k, v in model.audio_encoder._weights.items()}
-        tensors = [p.data for p in model.parameters()] + list(model.audio_encoder._weights.values())
-        bucket, size = [], 0
-        def flush():
-            nonlocal bucket, size
-            if not bucket:
-                return
-            by_dtype = {}
-            for t in bucket:
-                by_dtype.setdefault(t.dtype, []).append(t)
-            for dt, ts in by_dtype.items():
-                flat = torch.cat([t.reshape(-1) for t in ts])
-                dist.broadcast(flat, src=0)  # the ONLY collective of the path: weights, once
-                off = 0
-                for t in ts:
-                    t.copy_(flat[off: off + t.numel()].view_as(t))
-                    off += t.numel()
-            bucket, size = [], 0
-        for t in tensors:
-            bucket.append(t)
-            size += t.numel() * t.element_size()
-            if size >= 256 << 20:
-                flush()
-        flush()
-        model._engine = None
-        model.audio_encoder._engine = None
+        broadcast_model_weights(model, src=0)
     return model
 
 

@@ -1,0 +1,81 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing of the generation path — static utterance sharding, the one-off
+bucketed weight broadcast (rank 0 -> all) and the max-over-ranks timing reduction bench.py uses. No data-path
+collective exists to test: utterances are independent."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from parler_tts_amd.distributed import shard_batch, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 9, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    from parler_tts_amd.distributed import broadcast_tensors, max_over_ranks, shard_batch
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(123)
+        ref = [torch.randn(257, 33, generator=g), torch.randn(1000, generator=g).to(torch.bfloat16), torch.arange(17, dtype=torch.int64),
+               torch.randn(3, 5, 7, generator=g)]
+        mine = [t.clone() if rank == 0 else torch.zeros_like(t) for t in ref]
+        calls = broadcast_tensors(mine, src=0, bucket_bytes=20_000)  # forces several buckets + mixed dtypes per bucket
+        ok = all(torch.equal(a, b) for a, b in zip(mine, ref))
+        batch = torch.arange(9 * 4).reshape(9, 4)
+        part, none = shard_batch([batch, None], rank, world)
+        gathered = [torch.zeros(5, 4, dtype=batch.dtype) for _ in range(world)]
+        pad = torch.zeros(5, 4, dtype=batch.dtype)
+        pad[: part.shape[0]] = part
+        dist.all_gather(gathered, pad)  # test-side check only; the product path never gathers
+        t = max_over_ranks(1.0 + rank)
+        q.put((rank, ok, calls, part.shape[0], none is None, [x.tolist() for x in gathered], t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_broadcast_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, calls0, n0, none0, g0, t0), (r1, ok1, calls1, n1, none1, g1, t1) = res
+    assert ok0 and ok1, "rank 1 did not receive rank 0's weights bit-exactly"
+    assert calls0 == calls1 and calls0 >= 3
+    assert (n0, n1) == (5, 4) and none0 and none1
+    batch = torch.arange(9 * 4).reshape(9, 4)
+    rebuilt = torch.tensor(g0[0])[:5].tolist() + torch.tensor(g0[1])[:4].tolist()
+    assert rebuilt == batch.tolist()
+    assert t0 == t1 == 2.0

@@ -48,6 +48,15 @@ int main() {
     } }
   // 2. launch floor
   printf("empty kernel, dependent launches: %.2f us each\n", time_launches([&] { hipLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, st, (int*)nullptr); }, 2000, st));
+  // 2b. hipGraph replay floor: 195 empty dependent kernel nodes per replay (the decode step has 195 nodes)
+  for (int wg : {64, 256}) {
+    hipGraph_t g; hipGraphExec_t ex;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < 195; ++i) hipLaunchKernelGGL(empty_kernel, dim3(wg), dim3(256), 0, st, (int*)nullptr);
+    CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    float us = time_launches([&] { hipGraphLaunch(ex, st); }, 200, st);
+    printf("graph of 195 empty kernels (%d WGs each): %.1f us per replay = %.2f us per node\n", wg, us, us / 195);
+  }
   // 3. dependent-load latency: pointer chase over 64 MB (HBM) and 256 KB (L2)
   for (size_t bytes : {(size_t)256 << 10, (size_t)64 << 20}) {
     int n = (int)(bytes / 4); std::vector<int> h(n);
