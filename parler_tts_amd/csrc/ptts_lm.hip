@@ -49,6 +49,7 @@ struct ptts_engine {
   // scratch
   float *h = nullptr, *qkv = nullptr, *qc = nullptr, *part = nullptr, *stats = nullptr, *ffn = nullptr, *logits = nullptr;
   float* sort_buf = nullptr;
+  void *xw = nullptr, *xw2 = nullptr;  // engine-dtype activation rows for the M > 8 path: [rows][H], [rows][F]
   int S_self = 4, S_cross = 1;
   // state
   long long* ids = nullptr;
@@ -144,6 +145,24 @@ int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
   return PTTS_OK;
 }
 
+template <typename WT, int PRO>
+int launch_prep(GemmArgs a, void* dst, hipStream_t st) {
+  a.invK = 1.0f / (float)a.K;
+  hipLaunchKernelGGL((rows_prep_kernel<WT, PRO>), dim3((a.M + 3) / 4), dim3(256), 0, st, a, reinterpret_cast<WT*>(dst));
+  return PTTS_OK;
+}
+
+// LN -> GEMM and split-KV-combine -> GEMM: fused prologue at M <= 8 rows, prep kernel + copy staging above (the
+// redundant per-workgroup prologue is 88 % of the GEMM at M = 32: tools/phase_probe, profiles/).
+template <typename WT, int PRO, int EPI>
+int gemm_with_prologue(ptts_engine* e, GemmArgs g, hipStream_t st) {
+  if (g.M <= 8) return launch_gemm<WT, PRO, EPI>(g, st);
+  PTTS_TRY((launch_prep<WT, PRO>(g, e->xw, st)));
+  g.x = reinterpret_cast<const float*>(e->xw);
+  g.x_ld = g.K; g.x_row_mul = 1; g.x_row_off = 0;
+  return launch_gemm<WT, PRO_COPY, EPI>(g, st);
+}
+
 // One decoder forward over Q positions per utterance (Q = P+1 at prefill, 1 at decode) up to the logits.
 template <typename WT>
 int forward(ptts_engine* e, bool prefill, hipStream_t st) {
@@ -151,16 +170,20 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
   const int H = c.hidden_size, F = c.ffn_dim, nh = c.num_heads, B = e->B;
   const int Q = prefill ? e->P + 1 : 1;
   const int M = B * Q;
+  const bool big = M > 8;
   const float scale = 1.0f / sqrtf((float)(H / nh));
 
   if (prefill) {  // cross-attention K/V of the description, once per call (:877-878 then reused :872-875)
+    // encoder states were staged into qc by ptts_prefill (fp32 row-major [B*N][H]); convert once to the engine dtype
+    const size_t n = (size_t)B * e->N * H;
+    hipLaunchKernelGGL((convert_kernel<WT, float>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, e->qc,
+                       reinterpret_cast<WT*>(e->xw2), n);
     for (int l = 0; l < c.num_layers; ++l) {
       GemmArgs g = {};
-      g.W = e->L[l].ckv; g.x = nullptr; g.M = B * e->N; g.N = 2 * H; g.K = H;
-      g.x_ld = H; g.x_row_mul = 1; g.x_row_off = 0;
+      g.W = e->L[l].ckv; g.M = B * e->N; g.N = 2 * H; g.K = H;
+      g.x = reinterpret_cast<const float*>(e->xw2); g.x_ld = H; g.x_row_mul = 1; g.x_row_off = 0;
       g.kcache = e->L[l].k_cross; g.vcache = e->L[l].v_cross; g.kv_rows_per_b = e->N; g.kv_cap = c.max_enc; g.nheads = nh;
-      g.x = e->qc;  // encoder states were staged into qc by ptts_prefill (row-major [B*N][H])
-      PTTS_TRY((launch_gemm<WT, PRO_PLAIN, EPI_KV>(g, st)));
+      PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_KV>(g, st)));
     }
   }
   {
@@ -177,7 +200,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
       GemmArgs g = {};
       g.W = w.qkv; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
       g.out = e->qkv; g.out_ld = 3 * H; g.M = M; g.N = 3 * H; g.K = H;
-      PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_STORE>(g, st)));
+      PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
     if (prefill) {
       hipLaunchKernelGGL((kv_append_kernel<WT>), dim3(Q, nh, B), dim3(64), 0, st, e->qkv + H, e->qkv + 2 * H, 3 * H, w.k_self,
@@ -197,13 +220,13 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
       GemmArgs g = {};
       g.W = w.o; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
-      PTTS_TRY((launch_gemm<WT, PRO_ATTN, EPI_RESID>(g, st)));
+      PTTS_TRY((gemm_with_prologue<WT, PRO_ATTN, EPI_RESID>(e, g, st)));
     }
     {  // LN2 + cross q projection
       GemmArgs g = {};
       g.W = w.cq; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln2_g; g.beta = w.ln2_b;
       g.out = e->qc; g.out_ld = H; g.M = M; g.N = H; g.K = H;
-      PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_STORE>(g, st)));
+      PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
     {  // cross-attention against the static description K/V
       AttnArgs a = {};
@@ -218,26 +241,33 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
       GemmArgs g = {};
       g.W = w.co; g.part = e->part; g.stats = e->stats; g.S = e->S_cross; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
-      PTTS_TRY((launch_gemm<WT, PRO_ATTN, EPI_RESID>(g, st)));
+      PTTS_TRY((gemm_with_prologue<WT, PRO_ATTN, EPI_RESID>(e, g, st)));
     }
-    {  // LN3 + fc1 + GELU
+    {  // LN3 + fc1 + GELU, then fc2 + residual. Above 8 rows the GELU output is written in the engine dtype so fc2
+       // stages it with plain copies too.
       GemmArgs g = {};
       g.W = w.fc1; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln3_g; g.beta = w.ln3_b;
-      g.out = e->ffn; g.out_ld = F; g.M = M; g.N = F; g.K = H;
-      PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_GELU>(g, st)));
-    }
-    {  // fc2 + residual
-      GemmArgs g = {};
-      g.W = w.fc2; g.x = e->ffn; g.x_ld = F; g.x_row_mul = 1;
-      g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = F;
-      PTTS_TRY((launch_gemm<WT, PRO_PLAIN, EPI_RESID>(g, st)));
+      g.out_ld = F; g.M = M; g.N = F; g.K = H;
+      GemmArgs g2 = {};
+      g2.W = w.fc2; g2.x_ld = F; g2.x_row_mul = 1; g2.out = e->h; g2.out_ld = H; g2.M = M; g2.N = H; g2.K = F;
+      if (big) {
+        g.out = reinterpret_cast<float*>(e->xw2);
+        PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
+        g2.x = reinterpret_cast<const float*>(e->xw2);
+        PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g2, st)));
+      } else {
+        g.out = e->ffn;
+        PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_GELU>(g, st)));
+        g2.x = e->ffn;
+        PTTS_TRY((launch_gemm<WT, PRO_PLAIN, EPI_RESID>(g2, st)));
+      }
     }
   }
   {  // final LayerNorm + all K LM heads as one [K*V, H] projection, last position of each utterance only
     GemmArgs g = {};
     g.W = e->heads; g.x = e->h; g.x_ld = H; g.x_row_mul = Q; g.x_row_off = Q - 1; g.gamma = e->lnf_g; g.beta = e->lnf_b;
     g.out = e->logits; g.out_ld = c.num_codebooks * c.vocab_size; g.M = B; g.N = c.num_codebooks * c.vocab_size; g.K = H;
-    PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_STORE>(g, st)));
+    PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "forward launch failed: %s", hipGetErrorString(err));
@@ -379,6 +409,8 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));
   A(e->alloc(&e->logits, (size_t)c.max_batch * K * V));
   A(e->alloc(&e->sort_buf, 16));
+  A(e->alloc_bytes(&e->xw, rows * H * es));
+  A(e->alloc_bytes(&e->xw2, std::max(rows * F, enc_rows * (size_t)H) * es));
   e->ids_ld = c.max_ctx + 8;
   A(e->alloc(&e->ids, (size_t)c.max_batch * K * e->ids_ld));
   A(e->alloc(&e->cur_len, c.max_batch)); A(e->alloc(&e->unfinished, (size_t)c.max_batch * K));

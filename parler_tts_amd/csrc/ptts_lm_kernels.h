@@ -64,12 +64,13 @@ __global__ void convert_kernel(const ST* __restrict__ src, DT* __restrict__ dst,
 //   PRO_PLAIN : x fp32 [M][K]
 //   PRO_LN    : x = LayerNorm(h) (two-pass fp32 stats per row, eps 1e-5, affine)   modeling:1020,:1040,:1059,:1632
 //   PRO_ATTN  : x = softmax-combine of split-KV partials written by attn_kernel (S splits)
+//   PRO_COPY  : x already normalised / combined by rows_prep_kernel, in the engine dtype (M > 8: do it once, not per workgroup)
 //   EPI_STORE : out = acc            EPI_GELU: out = gelu_erf(acc) (:1060)
 //   EPI_RESID : out += acc (residual stream, :1034/:1052/:1064)
 //   EPI_KV    : scatter into the cross-attention K/V cache [b][head][t][64] (:877-878, cached :872-875)
 // ------------------------------------------------------------------------------------------------------
-enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2 };
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3 };
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2, PRO_COPY = 3 };  // PRO_COPY: x already in the engine dtype (prep kernel)
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3, EPI_GELU_WT = 4 };  // _WT: output in the engine dtype
 
 struct GemmArgs {
   const void* W;       // packed strips
@@ -140,89 +141,147 @@ template <> __device__ __forceinline__ void lds_store4<bf16_t>(char* row, int k,
 
 constexpr int LN_MAX_F4 = 8;  // LayerNorm rows up to 64 lanes * 8 float4 = 2048 wide live in registers
 
-// One wave normalises one row. NF4 float4 per lane, statically indexed (registers, never scratch). Every load (row,
-// gamma, beta) is issued before the first dependent instruction; mean and variance come from ONE fused pass of
-// sum(x-c) and sum((x-c)^2) with the shift c = x[0] (shifted-data variance: no catastrophic cancellation, error
-// ~ eps*(1 + (mean-c)^2/var)); eps 1e-5 as nn.LayerNorm (modeling:961). EXACT: K == NF4*256, no lane masks.
+// One wave normalises R rows at a time (R = 1 at bs=1, 2 when a wave owns several rows: two independent latency
+// chains in flight). NF4 float4 per lane, statically indexed (registers, never scratch). gamma/beta are loaded once
+// per wave; every row load is issued before the first dependent instruction; mean and variance come from ONE fused
+// pass of sum(x-c) and sum((x-c)^2) with the shift c = x[0] (shifted-data variance: no catastrophic cancellation,
+// error ~ eps*(1 + (mean-c)^2/var)); eps 1e-5 as nn.LayerNorm (modeling:961). EXACT: K == NF4*256, no lane masks.
+template <typename WT, int NF4, bool EXACT, int R>
+__device__ __forceinline__ void ln_rows(const GemmArgs& a, const float* const (&xr)[R], char* const (&row)[R], const float4 (&g)[NF4],
+                                        const float4 (&bt)[NF4], int lane) {
+  float4 v[R][NF4];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int k = (lane + 64 * i) * 4;
+      v[r][i] = *reinterpret_cast<const float4*>(xr[r] + ((EXACT || k < a.K) ? k : 0));
+    }
+  float c[R], s1[R], s2[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    c[r] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[r][0].x)));
+    s1[r] = 0.f; s2[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const float msk = (EXACT || (lane + 64 * i) * 4 < a.K) ? 1.f : 0.f;
+      const float d0 = (v[r][i].x - c[r]) * msk, d1 = (v[r][i].y - c[r]) * msk, d2 = (v[r][i].z - c[r]) * msk, d3 = (v[r][i].w - c[r]) * msk;
+      s1[r] += (d0 + d1) + (d2 + d3);
+      s2[r] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) { s1[r] = wave_sum(s1[r]); s2[r] = wave_sum(s2[r]); }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float dm = s1[r] * a.invK;
+    const float mean = c[r] + dm;
+    const float rstd = rsqrtf(fmaxf(s2[r] * a.invK - dm * dm, 0.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int k = (lane + 64 * i) * 4;
+      if (EXACT || k < a.K)
+        lds_store4<WT>(row[r], k, (v[r][i].x - mean) * rstd * g[i].x + bt[i].x, (v[r][i].y - mean) * rstd * g[i].y + bt[i].y,
+                       (v[r][i].z - mean) * rstd * g[i].z + bt[i].z, (v[r][i].w - mean) * rstd * g[i].w + bt[i].w);
+    }
+  }
+}
+
 template <typename WT, int NF4, bool EXACT>
-__device__ __forceinline__ void ln_row(const GemmArgs& a, const float* xr, char* row, int lane) {
-  float4 v[NF4], g[NF4], bt[NF4];
+__device__ __forceinline__ void ln_stage(const GemmArgs& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
+  float4 g[NF4], bt[NF4];
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     const int k = (lane + 64 * i) * 4;
-    const int kk = (EXACT || k < a.K) ? k : 0;  // out-of-range lanes re-read column 0 and are masked below
-    v[i] = *reinterpret_cast<const float4*>(xr + kk);
+    const int kk = (EXACT || k < a.K) ? k : 0;
     g[i] = *reinterpret_cast<const float4*>(a.gamma + kk);
     bt[i] = *reinterpret_cast<const float4*>(a.beta + kk);
   }
-  const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < NF4; ++i) {
-    const float msk = (EXACT || (lane + 64 * i) * 4 < a.K) ? 1.f : 0.f;
-    const float d0 = (v[i].x - c) * msk, d1 = (v[i].y - c) * msk, d2 = (v[i].z - c) * msk, d3 = (v[i].w - c) * msk;
-    s1 += (d0 + d1) + (d2 + d3);
-    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  int r = wave;
+  for (; r + W < nrows; r += 2 * W) {  // two rows of this wave in flight
+    const float* const xr[2] = {a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld,
+                                a.x + (size_t)((m0 + r + W) * a.x_row_mul + a.x_row_off) * a.x_ld};
+    char* const row[2] = {s_x + (size_t)r * row_bytes, s_x + (size_t)(r + W) * row_bytes};
+    ln_rows<WT, NF4, EXACT, 2>(a, xr, row, g, bt, lane);
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  const float dm = s1 * a.invK;
-  const float mean = c + dm;
-  const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
-#pragma unroll
-  for (int i = 0; i < NF4; ++i) {
-    const int k = (lane + 64 * i) * 4;
-    if (EXACT || k < a.K)
-      lds_store4<WT>(row, k, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
-                     (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
+  if (r < nrows) {
+    const float* const xr[1] = {a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld};
+    char* const row[1] = {s_x + (size_t)r * row_bytes};
+    ln_rows<WT, NF4, EXACT, 1>(a, xr, row, g, bt, lane);
   }
+}
+
+// one (row, 4-column) element of the PLAIN / ATTN prologue
+template <int PRO>
+__device__ __forceinline__ float4 stage_elem(const GemmArgs& a, int m, int k) {
+  if (PRO == PRO_ATTN) {
+    const int head = k >> 6;
+    const float* st = a.stats + ((size_t)m * a.S * a.nheads + head) * 2;
+    float mx = -INFINITY;
+    for (int sp = 0; sp < a.S; ++sp) mx = fmaxf(mx, st[(size_t)sp * a.nheads * 2]);
+    float den = 0.f;
+    float4 o = make_float4(0, 0, 0, 0);
+    for (int sp = 0; sp < a.S; ++sp) {
+      const float ms = st[(size_t)sp * a.nheads * 2], ls = st[(size_t)sp * a.nheads * 2 + 1];
+      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
+      den += w * ls;
+      const float4 t = *reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + sp) * a.K + k);
+      o.x += w * t.x; o.y += w * t.y; o.z += w * t.z; o.w += w * t.w;
+    }
+    const float inv = den > 0.f ? __frcp_rn(den) : 0.f;
+    return make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+  }
+  return *reinterpret_cast<const float4*>(a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k);
 }
 
 template <typename WT, int PRO, bool FULL>
 __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
   if (PRO == PRO_LN) {
     const int nf4 = (a.K + 255) >> 8;  // workgroup-uniform
-    for (int r = wave; r < nrows; r += W) {
-      const float* xr = a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld;
-      char* row = s_x + (size_t)r * row_bytes;
-      if (FULL) {  // host guarantees K in {256, 512, 1024, 1536} for the FULL LayerNorm variant
-        if (nf4 == 4) ln_row<WT, 4, true>(a, xr, row, lane);        // hidden 1024 (Mini-v1)
-        else if (nf4 == 6) ln_row<WT, 6, true>(a, xr, row, lane);   // hidden 1536 (Large-v1)
-        else ln_row<WT, 2, false>(a, xr, row, lane);
-      } else {
-        if (nf4 <= 1) ln_row<WT, 1, false>(a, xr, row, lane);
-        else ln_row<WT, LN_MAX_F4, false>(a, xr, row, lane);
+    if (FULL) {  // host guarantees K in {256, 512, 1024, 1536} for the FULL LayerNorm variant
+      if (nf4 == 4) ln_stage<WT, 4, true>(a, m0, nrows, s_x, row_bytes, lane, wave, W);        // hidden 1024 (Mini-v1)
+      else if (nf4 == 6) ln_stage<WT, 6, true>(a, m0, nrows, s_x, row_bytes, lane, wave, W);   // hidden 1536 (Large-v1)
+      else ln_stage<WT, 2, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+    } else {
+      if (nf4 <= 1) ln_stage<WT, 1, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+      else ln_stage<WT, LN_MAX_F4, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+    }
+  } else if (PRO == PRO_COPY) {
+    // bulk copy of engine-dtype rows, 16 B per lane, 8 independent loads in flight per thread
+    constexpr int EPV = 16 / (int)sizeof(WT);
+    const int vpr = a.K / EPV;  // 16-byte vectors per row
+    const int total = nrows * vpr;
+    const WT* xb = reinterpret_cast<const WT*>(a.x);
+    for (int i0 = wave * 64 + lane; i0 < total; i0 += 8 * W * 64) {
+      uint4 v[8];
+      int rr[8], cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(i0 + u * W * 64, total - 1);
+        rr[u] = i / vpr;
+        cc[u] = i - rr[u] * vpr;
+        v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)((m0 + rr[u]) * a.x_row_mul + a.x_row_off) * a.x_ld + (size_t)cc[u] * EPV);
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * W * 64 < total) *reinterpret_cast<uint4*>(s_x + (size_t)rr[u] * row_bytes + (size_t)cc[u] * 16) = v[u];
     }
   } else {
-    // element-parallel over (row, 4 columns): no row reduction needed, no integer division
+    // element-parallel: rows in the outer loop (no integer division), two rows in flight per thread
     const int k4n = a.K >> 2;
-    for (int r = 0; r < nrows; ++r) {
-      const int m = m0 + r;
-      char* row = s_x + (size_t)r * row_bytes;
+    int r = 0;
+    for (; r + 1 < nrows; r += 2) {
       for (int k4 = wave * 64 + lane; k4 < k4n; k4 += W * 64) {
-        const int k = k4 * 4;
-        float4 o;
-        if (PRO == PRO_ATTN) {
-          const int head = k >> 6;
-          const float* st = a.stats + ((size_t)m * a.S * a.nheads + head) * 2;
-          float mx = -INFINITY;
-          for (int sp = 0; sp < a.S; ++sp) mx = fmaxf(mx, st[(size_t)sp * a.nheads * 2]);
-          float den = 0.f;
-          o = make_float4(0, 0, 0, 0);
-          for (int sp = 0; sp < a.S; ++sp) {
-            const float ms = st[(size_t)sp * a.nheads * 2], ls = st[(size_t)sp * a.nheads * 2 + 1];
-            const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
-            den += w * ls;
-            const float4 t = *reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + sp) * a.K + k);
-            o.x += w * t.x; o.y += w * t.y; o.z += w * t.z; o.w += w * t.w;
-          }
-          const float inv = den > 0.f ? __frcp_rn(den) : 0.f;
-          o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-        } else {
-          o = *reinterpret_cast<const float4*>(a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k);
-        }
-        lds_store4<WT>(row, k, o.x, o.y, o.z, o.w);
+        const float4 o0 = stage_elem<PRO>(a, m0 + r, k4 * 4);
+        const float4 o1 = stage_elem<PRO>(a, m0 + r + 1, k4 * 4);
+        lds_store4<WT>(s_x + (size_t)r * row_bytes, k4 * 4, o0.x, o0.y, o0.z, o0.w);
+        lds_store4<WT>(s_x + (size_t)(r + 1) * row_bytes, k4 * 4, o1.x, o1.y, o1.z, o1.w);
+      }
+    }
+    if (r < nrows) {
+      for (int k4 = wave * 64 + lane; k4 < k4n; k4 += W * 64) {
+        const float4 o0 = stage_elem<PRO>(a, m0 + r, k4 * 4);
+        lds_store4<WT>(s_x + (size_t)r * row_bytes, k4 * 4, o0.x, o0.y, o0.z, o0.w);
       }
     }
   }
@@ -230,7 +289,7 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
 
 // LN / ATTN prologues always reduce over K = hidden_size (<= 8 waves of >= 8 fragments); only the plain prologue
 // (fc2, K = ffn_dim) at batch <= 16 wants 16 waves, so only it pays the 128-VGPR cap of a 1024-thread workgroup.
-template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value = (PRO == PRO_PLAIN && MTP == 1) ? 1024 : 512; };
+template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value = ((PRO == PRO_PLAIN || PRO == PRO_COPY) && MTP == 1) ? 1024 : 512; };
 
 // a.rows_per_pass rows (<= 16*MTP) of activations are staged per pass; LDS = staging + cross-wave reduction.
 // FULL: every wave owns a whole number of 8-fragment groups and K % 256 == 0 -> straight-line code, no predicates.
@@ -318,6 +377,10 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
         } else if (EPI == EPI_GELU) {
           *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) =
               make_float4(gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
+        } else if (EPI == EPI_GELU_WT) {
+          WT* o = reinterpret_cast<WT*>(a.out) + (size_t)m * a.out_ld + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) store_from_f32<WT>(o + e, gelu_erf(r[e]));
         } else if (EPI == EPI_RESID) {
           float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
           float4 o = *p;
@@ -338,6 +401,51 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     }
     PTTS_STAMP(PTTS_DBG(a), 5);
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// rows_prep_kernel: for M > 8 rows (batch 32, prefill) the LayerNorm / split-KV combine is computed ONCE here
+// (one wave per row) into an engine-dtype [M][K] buffer that the GEMM then stages with plain 16-byte copies
+// (PRO_COPY). At M <= 8 the fused prologues win (one graph node less: 1.58 us + a latency chain).
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, int PRO>
+__global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restrict__ dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= a.M) return;
+  WT* out = dst + (size_t)m * a.K;
+  if (PRO == PRO_LN) {
+    const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
+    float s1 = 0.f, s2 = 0.f;
+    const float c = xr[0];
+    for (int k = lane * 4; k < a.K; k += 256) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + k);
+      const float d0 = t.x - c, d1 = t.y - c, d2 = t.z - c, d3 = t.w - c;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float dm = s1 * a.invK, mean = c + dm;
+    const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+    for (int k = lane * 4; k < a.K; k += 256) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + k);
+      const float4 g = *reinterpret_cast<const float4*>(a.gamma + k);
+      const float4 bt = *reinterpret_cast<const float4*>(a.beta + k);
+      store_from_f32<WT>(out + k + 0, (t.x - mean) * rstd * g.x + bt.x);
+      store_from_f32<WT>(out + k + 1, (t.y - mean) * rstd * g.y + bt.y);
+      store_from_f32<WT>(out + k + 2, (t.z - mean) * rstd * g.z + bt.z);
+      store_from_f32<WT>(out + k + 3, (t.w - mean) * rstd * g.w + bt.w);
+    }
+  } else {
+    for (int k = lane * 4; k < a.K; k += 256) {
+      const float4 o = stage_elem<PRO>(a, m, k);
+      store_from_f32<WT>(out + k + 0, o.x);
+      store_from_f32<WT>(out + k + 1, o.y);
+      store_from_f32<WT>(out + k + 2, o.z);
+      store_from_f32<WT>(out + k + 3, o.w);
+    }
   }
 }
 

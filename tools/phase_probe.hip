@@ -70,22 +70,39 @@ int main() {
     printf("pointer chase over %zu KB: %.0f ticks per dependent load\n", bytes >> 10, cy / 2000.0);
     hipFree(d);
   }
-  // 4. the decode GEMMs (bf16, M = 1)
+  // 4. the decode GEMMs (bf16) at M = 1 and M = 32
   struct Case { const char* name; int N, K, pro; } cases[] = {{"LN+QKV   N=3072 K=1024", 3072, 1024, 1}, {"LN+crossQ N=1024 K=1024", 1024, 1024, 1},
                                                                {"fc2      N=1024 K=4096", 1024, 4096, 0}, {"LN+fc1   N=4096 K=1024", 4096, 1024, 1}};
-  for (auto& cs : cases) {
-    GemmArgs a = {}; a.W = W; a.x = x; a.x_ld = cs.K; a.x_row_mul = 1; a.gamma = gamma; a.beta = beta; a.out = out; a.out_ld = cs.N;
-    a.M = 1; a.N = cs.N; a.K = cs.K; a.rows_per_pass = 1; a.dbg = dbg; a.invK = 1.0f / cs.K;
-    const int nfrag = cs.K / 32; int Wv = (nfrag + 7) / 8; if (Wv > (cs.pro ? 8 : 16)) Wv = cs.pro ? 8 : 16;
-    const size_t sh = (size_t)cs.K * 2 + 16 + (size_t)Wv * 1024; a.frags_per_wave = nfrag / Wv;
-    auto launch = [&] {
-      if (cs.pro) hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a);
-      else hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a);
-    };
-    float us = time_launches(launch, 2000, st);
-    long long t[8]; hipMemcpy(t, dbg, 64, hipMemcpyDeviceToHost);
-    printf("%s: %.2f us/launch | ticks: issue-W %lld, stage %lld, barrier %lld, mfma %lld, reduce+store %lld, total %lld\n", cs.name, us,
-           t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+  for (int M : {1, 32}) {
+    for (auto& cs : cases) {
+      GemmArgs a = {}; a.W = W; a.x = x; a.x_ld = cs.K; a.x_row_mul = 1; a.gamma = gamma; a.beta = beta; a.out = out; a.out_ld = cs.N;
+      a.M = M; a.N = cs.N; a.K = cs.K; a.dbg = dbg; a.invK = 1.0f / cs.K;
+      const int nfrag = cs.K / 32;
+      const int wmax = (cs.pro == 0 && M <= 16) ? 16 : 8;
+      int Wv = 0;
+      for (int w = wmax; w >= 2; --w) if (nfrag % (8 * w) == 0) { Wv = w; break; }
+      a.frags_per_wave = nfrag / Wv;
+      const size_t row_bytes = (size_t)cs.K * 2 + 16;
+      int rpp = M < 32 ? M : 32;
+      while (rpp > 1 && rpp * row_bytes + (size_t)Wv * (rpp > 16 ? 2 : 1) * 1024 > 160 * 1024 - 1024) --rpp;
+      a.rows_per_pass = rpp;
+      const int mtp = rpp > 16 ? 2 : 1;
+      const size_t sh = rpp * row_bytes + (size_t)Wv * mtp * 1024;
+      auto launch = [&] {
+        if (cs.pro && mtp == 1) { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+        else if (cs.pro) { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 2, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+        else if (mtp == 1) { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+        else { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 2, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+      };
+      float us = time_launches(launch, 1000, st);
+      long long t[8]; hipMemcpy(t, dbg, 64, hipMemcpyDeviceToHost);
+      printf("M=%2d %s W=%d rpp=%d: %.2f us/launch | ticks (last pass): issue-W %lld, stage %lld, barrier %lld, mfma %lld, reduce+store %lld, total %lld\n", M, cs.name, Wv, rpp, us,
+             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+    }
   }
   return 0;
 }
