@@ -118,7 +118,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   a.frags_per_wave = nfrag / W;
   a.invK = 1.0f / (float)a.K;
   // activation rows staged in LDS per pass: as many as fit beside the cross-wave reduction buffer (<= 32)
-  const size_t row_bytes = (size_t)a.K * sizeof(WT) + 16;
+  const size_t row_bytes = PRO == PRO_COPY ? 0 : (size_t)a.K * sizeof(WT) + 16;  // PRO_COPY reads B fragments from global
   const size_t lds_cap = 160 * 1024 - 1024;
   int rpp = a.M < 32 ? a.M : 32;
   while (rpp > 1 && rpp * row_bytes + (size_t)W * (rpp > 16 ? 2 : 1) * 1024 > lds_cap) --rpp;
@@ -214,13 +214,19 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
       a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
+      a.direct_out = e->S_self == 1 ? e->xw : nullptr;
       PTTS_TRY((launch_attn<WT>(a, B, st)));
     }
-    {  // combine splits + out_proj + residual
+    {  // [combine splits] + out_proj + residual
       GemmArgs g = {};
       g.W = w.o; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
-      PTTS_TRY((gemm_with_prologue<WT, PRO_ATTN, EPI_RESID>(e, g, st)));
+      if (e->S_self == 1) {
+        g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
+        PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
+      } else {
+        PTTS_TRY((gemm_with_prologue<WT, PRO_ATTN, EPI_RESID>(e, g, st)));
+      }
     }
     {  // LN2 + cross q projection
       GemmArgs g = {};
@@ -233,15 +239,16 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
       a.q = e->qc; a.q_ld = H; a.kcache = w.k_cross; a.vcache = w.v_cross; a.cap = c.max_enc;
       a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims; a.mask = e->enc_mask; a.mask_ld = c.max_enc;
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;  // quirk: q rotated, keys not (:858 vs :880)
-      a.part = e->part; a.stats = e->stats; a.S = e->S_cross; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 1;
+      a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 1;
       a.fused_append = 0; a.scale = scale;
+      a.direct_out = e->xw;  // the description is short: never split, softmax finished in the attention kernel
       PTTS_TRY((launch_attn<WT>(a, B, st)));
     }
-    {
+    {  // cross out_proj + residual, activations read straight from the attention output
       GemmArgs g = {};
-      g.W = w.co; g.part = e->part; g.stats = e->stats; g.S = e->S_cross; g.nheads = nh;
+      g.W = w.co; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
-      PTTS_TRY((gemm_with_prologue<WT, PRO_ATTN, EPI_RESID>(e, g, st)));
+      PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
     }
     {  // LN3 + fc1 + GELU, then fc2 + residual. Above 8 rows the GELU output is written in the engine dtype so fc2
        // stages it with plain copies too.

@@ -300,7 +300,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
   const int row_bytes = a.K * (int)sizeof(WT) + 16;
   char* s_x = smem_raw;                                                                   // [rows_per_pass][row_bytes]
-  float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)a.rows_per_pass * row_bytes);  // [W][MTP][64][4]
+  float* s_red = reinterpret_cast<float*>(smem_raw + (PRO == PRO_COPY ? 0 : (size_t)a.rows_per_pass * row_bytes));  // [W][MTP][64][4]
   const int strip = blockIdx.x;
   const int nfrag = a.K / KT;
   const int per = FULL ? a.frags_per_wave : (nfrag + W - 1) / W;
@@ -316,17 +316,25 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
-    // 2. activations of this pass -> LDS (final form, engine dtype)
+    // 2. activations of this pass -> LDS (final form, engine dtype). PRO_COPY rows are already final and
+    //    L2-resident: their B fragments (16 B per lane) are read straight from global, no staging, no barrier.
     PTTS_STAMP(PTTS_DBG(a), 1);
-    stage_rows<WT, PRO, FULL>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
-    PTTS_STAMP(PTTS_DBG(a), 2);
-    __syncthreads();
+    if (PRO != PRO_COPY) {
+      stage_rows<WT, PRO, FULL>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+      PTTS_STAMP(PTTS_DBG(a), 2);
+      __syncthreads();
+    }
     PTTS_STAMP(PTTS_DBG(a), 3);
     // 3. MFMA over this wave's K slice; B fragments come from LDS (rows beyond nrows are clamped: their output
     //    columns are never stored). All LDS reads of a group are issued before its first MFMA.
     const char* brow[MTP];
 #pragma unroll
-    for (int mt = 0; mt < MTP; ++mt) brow[mt] = s_x + (size_t)min(mt * 16 + j, nrows - 1) * row_bytes + (size_t)q * 16;
+    for (int mt = 0; mt < MTP; ++mt) {
+      const int rloc = min(mt * 16 + j, nrows - 1);
+      brow[mt] = PRO == PRO_COPY
+                     ? reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)((m0 + rloc) * a.x_row_mul + a.x_row_off) * a.x_ld) + (size_t)q * 16
+                     : s_x + (size_t)rloc * row_bytes + (size_t)q * 16;
+    }
     f32x4 acc[MTP], acc2[MTP];  // two independent accumulator chains per tile (MFMA dependent latency)
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -474,6 +482,7 @@ struct AttnArgs {
   const float* cos;    // RoPE tables [max_pos][64] or null
   const float* sin;
   float* part;         // [rows][S][H]
+  void* direct_out;    // S == 1: normalised output [rows][H] in the engine dtype (consumer GEMM uses PRO_COPY), or null
   float* stats;        // [rows][S][heads][2]
   int S, Q, nheads, H;
   int cross;           // 1: length = dims->N, mask over all positions; 0: causal self-attention, mask over positions < P
@@ -615,6 +624,10 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       const float wgt = (s_ml[i][0] == -INFINITY) ? 0.f : expf(s_ml[i][0] - M);
       ov += wgt * s_o[i][tid];
       lv += wgt * s_ml[i][1];
+    }
+    if (a.direct_out) {  // unsplit launch: this workgroup saw every key, finish the softmax here
+      store_from_f32<WT>(reinterpret_cast<WT*>(a.direct_out) + (size_t)row * a.H + h * 64 + tid, lv > 0.f ? ov / lv : 0.f);
+      return;
     }
     a.part[((size_t)row * a.S + s) * a.H + h * 64 + tid] = ov;
     if (tid == 0) {
