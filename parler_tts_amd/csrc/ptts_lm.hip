@@ -62,6 +62,7 @@ struct ptts_engine {
   // per-call
   int B = 0, N = 0, P = 0;
   bool prefilled = false;
+  bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
   std::map<int, hipGraphExec_t> graphs;  // key: batch size
   int* host_pinned = nullptr;
 
@@ -165,7 +166,7 @@ int gemm_with_prologue(ptts_engine* e, GemmArgs g, hipStream_t st) {
 
 // One decoder forward over Q positions per utterance (Q = P+1 at prefill, 1 at decode) up to the logits.
 template <typename WT>
-int forward(ptts_engine* e, bool prefill, hipStream_t st) {
+int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true) {
   const ptts_config& c = e->cfg;
   const int H = c.hidden_size, F = c.ffn_dim, nh = c.num_heads, B = e->B;
   const int Q = prefill ? e->P + 1 : 1;
@@ -186,7 +187,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_KV>(g, st)));
     }
   }
-  {
+  if (with_embed) {
     EmbedArgs ea = {};
     ea.tables = e->embed; ea.pos_table = c.rope ? nullptr : e->pos_table; ea.prompt = prefill ? e->ffn : nullptr;
     ea.ids = e->ids; ea.ids_ld = e->ids_ld; ea.cur_len = e->cur_len; ea.dims = e->dims; ea.h = e->h;
@@ -281,19 +282,25 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st) {
   return PTTS_OK;
 }
 
-int launch_tail(ptts_engine* e, hipStream_t st) {
+int launch_tail(ptts_engine* e, hipStream_t st, bool embed_next) {
   TailArgs t = {};
+  if (embed_next) {
+    t.tables = e->embed; t.pos_table = e->cfg.rope ? nullptr : e->pos_table; t.dims = e->dims; t.h = e->h;
+    t.H = e->cfg.hidden_size; t.bos = e->cfg.bos_token_id; t.bf16_tables = e->cfg.dtype == PTTS_BF16;
+  }
   t.logits = e->logits; t.ids = e->ids; t.ids_ld = e->ids_ld; t.cur_len = e->cur_len; t.unfinished = e->unfinished;
   t.has_eos = e->has_eos; t.first_unf = e->first_unf; t.gen = e->gen; t.sort_buf = e->sort_buf;
   t.B = e->B; t.K = e->cfg.num_codebooks; t.V = e->cfg.vocab_size; t.eos = e->cfg.eos_token_id; t.pad = e->cfg.pad_token_id;
-  hipLaunchKernelGGL(tail_kernel, dim3(e->B), dim3(256), 0, st, t);
+  // greedy: one wave per codebook row; the sampling path sorts block-wide
+  const int nw = e->gp.do_sample ? 4 : std::min(std::max(e->cfg.num_codebooks, 4), 16);
+  hipLaunchKernelGGL(tail_kernel, dim3(e->B), dim3(nw * 64), 0, st, t);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "tail launch failed: %s", hipGetErrorString(err));
   return PTTS_OK;
 }
 
-int forward_dispatch(ptts_engine* e, bool prefill, hipStream_t st) {
-  return e->cfg.dtype == PTTS_BF16 ? forward<bf16_t>(e, prefill, st) : forward<float>(e, prefill, st);
+int forward_dispatch(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true) {
+  return e->cfg.dtype == PTTS_BF16 ? forward<bf16_t>(e, prefill, st, with_embed) : forward<float>(e, prefill, st, with_embed);
 }
 
 bool ends_with(const std::string& s, const char* suf) {
@@ -590,7 +597,8 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   PTTS_HIP(hipMemcpyAsync(e->qc, enc_dev, (size_t)B * N * H * 4, hipMemcpyDeviceToDevice, st));
   if (P > 0) PTTS_HIP(hipMemcpyAsync(e->ffn, prompt_dev, (size_t)B * P * H * 4, hipMemcpyDeviceToDevice, st));
   PTTS_TRY(forward_dispatch(e, true, st));
-  if (sample) PTTS_TRY(launch_tail(e, st));
+  if (sample) PTTS_TRY(launch_tail(e, st, true));  // also embeds the sampled column for the first decode step
+  e->h_ready = sample != 0;
   e->prefilled = true;
   return PTTS_OK;
 }
@@ -603,8 +611,9 @@ static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   hipStream_t st = e->own_stream;
   PTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  int rc = forward_dispatch(e, false, st);
-  if (rc == PTTS_OK) rc = launch_tail(e, st);
+  // decode step = layers + heads + tail; the tail embeds the column it just sampled for the NEXT replay (no embed node)
+  int rc = forward_dispatch(e, false, st, false);
+  if (rc == PTTS_OK) rc = launch_tail(e, st, true);
   hipError_t ce = hipStreamEndCapture(st, &g);
   if (rc != PTTS_OK) { if (g) hipGraphDestroy(g); return rc; }
   if (ce != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
@@ -625,6 +634,12 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
   hipStream_t st = pick_stream(e, stream);
   hipGraphExec_t ex = nullptr;
   PTTS_TRY(get_graph(e, &ex));
+  if (n_steps > 0 && !e->h_ready) {  // previous column came from ptts_push_tokens / an un-sampled prefill: embed it once, eagerly
+    PTTS_TRY(forward_dispatch(e, false, st, true));
+    PTTS_TRY(launch_tail(e, st, true));
+    e->h_ready = true;
+    --n_steps;
+  }
   for (int i = 0; i < n_steps; ++i) PTTS_HIP(hipGraphLaunch(ex, st));
   return PTTS_OK;
 }
@@ -675,6 +690,7 @@ extern "C" int ptts_push_tokens(ptts_engine* e, const int64_t* tokens_dev, const
   hipLaunchKernelGGL(push_tokens_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const long long*)tokens_dev, finished_dev, e->ids,
                      e->ids_ld, e->cur_len, e->unfinished, e->has_eos, e->B, e->cfg.num_codebooks, e->cfg.eos_token_id);
   hipLaunchKernelGGL(bump_len_kernel, dim3((e->B + 255) / 256), dim3(256), 0, st, e->cur_len, e->B);
+  e->h_ready = false;
   return PTTS_OK;
 }
 

@@ -721,8 +721,14 @@ struct TailArgs {
   int* has_eos;        // [B*K]
   int* first_unf;      // [B] local codebook index
   const DevGen* gen;
-  float* sort_buf;     // [B][2][SORT_N] scratch for sampling (values, indices as float bits)
+  float* sort_buf;     // unused (sampling sorts in LDS)
   int B, K, V, eos, pad;
+  // fused embedding of the NEXT step (decode graph): h[b] = sum_k E_k[delayed token of column t] + pos[P + t]
+  const void* tables;      // [K][V+1][H] engine dtype, or null: no fused embedding (manual path / prefill-only probes)
+  const float* pos_table;  // or null (RoPE)
+  const DevDims* dims;
+  float* h;                // [B][H]
+  int H, bos, bf16_tables;
 };
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -753,7 +759,32 @@ __device__ inline void bitonic_sort_desc(float* val, int* idx, int nthreads, int
   }
 }
 
-__global__ void __launch_bounds__(256) tail_kernel(TailArgs a) {
+// Embedding of the token column just produced (column t, fed at position P + t) for the next decode step:
+// the delay pattern is applied exactly as embed_kernel / apply_delay_pattern_mask do (modeling:205-276, :1433).
+__device__ __forceinline__ void tail_embed_next(const TailArgs& a, int b, int t, const int* s_tok, int tid) {
+  if (!a.tables) return;
+  const int max_length = a.dims->max_length, P = a.dims->P;
+  float* out = a.h + (size_t)b * a.H;
+  const bf16_t* tb16 = reinterpret_cast<const bf16_t*>(a.tables);
+  const float* tb32 = reinterpret_cast<const float*>(a.tables);
+  for (int d = tid; d < a.H; d += blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+      int tok = s_tok[k];
+      if (max_length >= 2 * a.K - 1) {
+        if (t <= k) tok = a.bos;
+        else if (t - k >= max_length - a.K + 1) tok = a.pad;
+      }
+      const size_t off = ((size_t)k * (a.V + 1) + tok) * a.H + d;
+      acc += a.bf16_tables ? bf16_to_f32(tb16[off]) : tb32[off];
+    }
+    if (a.pos_table) acc += a.pos_table[(size_t)(P + t) * a.H + d];
+    out[d] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
+  __shared__ int s_tok[32];
   __shared__ int s_any;
   __shared__ float s_val[PTTS_SORT_N];
   __shared__ int s_idx[PTTS_SORT_N];
@@ -789,22 +820,21 @@ __global__ void __launch_bounds__(256) tail_kernel(TailArgs a) {
         if (eos_blocked && v == a.eos) x = -INFINITY;
         if (x > best || (x == best && v < bi)) { best = x; bi = v; }
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-      }
+      const float wbest = wave_max(best);
+      const float cand = (best == wbest) ? (float)bi : 3.0e9f;  // vocabulary indices are exact in fp32
+      const int widx = (int)(-wave_max(-cand));
       if (lane == 0) {
         const int unf = a.unfinished[row];
-        const int nxt = unf ? bi : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
+        const int nxt = unf ? widx : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
         a.ids[(size_t)row * a.ids_ld + t] = nxt;
+        s_tok[k] = nxt;
         if (nxt == a.eos) a.has_eos[row] = 1;
         if ((nxt == a.eos) || (t + 1 >= g.max_length)) a.unfinished[row] = 0;  // EosTokenCriteria | MaxLengthCriteria
       }
     }
     __syncthreads();
     if (tid == 0) a.cur_len[b] = t + 1;
+    tail_embed_next(a, b, t, s_tok, tid);
     return;
   }
 
@@ -868,6 +898,7 @@ __global__ void __launch_bounds__(256) tail_kernel(TailArgs a) {
       const int unf = a.unfinished[row];
       const int nxt = unf ? tok : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
       a.ids[(size_t)row * a.ids_ld + t] = nxt;
+      s_tok[k] = nxt;
       if (nxt == a.eos) a.has_eos[row] = 1;
       const bool done = (nxt == a.eos) || (t + 1 >= g.max_length);  // EosTokenCriteria | MaxLengthCriteria
       if (done) a.unfinished[row] = 0;
@@ -875,6 +906,7 @@ __global__ void __launch_bounds__(256) tail_kernel(TailArgs a) {
     __syncthreads();
   }
   if (tid == 0) a.cur_len[b] = t + 1;
+  tail_embed_next(a, b, t, s_tok, tid);
 }
 
 // manual path: append caller-chosen tokens (user LogitsProcessorList / StoppingCriteria ran on the host side)

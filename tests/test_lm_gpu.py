@@ -162,6 +162,35 @@ def test_mini_width_two_layers_fp32_and_bf16():
         eng.close()
 
 
+def test_large_v1_width_two_layers_bf16_and_fp32_batch():
+    """Large-v1 widths (H=1536, 24 heads, F=6144; init_large_model.py:25-43) with 2 layers, batch 1 and 12:
+    6-float4 LayerNorm rows, 6 / 12-wave K splits, the prep-kernel (M > 8) path."""
+    spec = DO.DecoderSpec(hidden_size=1536, num_attention_heads=24, ffn_dim=6144, num_hidden_layers=2, max_position_embeddings=256)
+    sd = DO.make_decoder_weights(spec, seed=77)
+    g = torch.Generator().manual_seed(4)
+    for bsz in (1, 12):
+        N, P = 10, 5
+        enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
+        prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
+        step_ids = torch.randint(0, 1024, (3, bsz * spec.num_codebooks), generator=g)
+        for dtype, prec, tol in ((torch.float32, "fp32", 6e-5), (torch.bfloat16, "bf16", 3e-2)):
+            orc = DO.DecoderOracle(spec, sd, precision=prec)
+            ref = [orc.forward(torch.full((bsz * 9, 1), 1025), enc, None, prompt, None)[:, -1]]
+            for s in range(3):
+                ref.append(orc.forward(step_ids[s][:, None])[:, -1])
+            eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=64, max_enc=16, max_prompt=8)
+            eng.set_gen_params(max_length=16)
+            eng.prefill(enc, None, prompt, None, sample=False)
+            outs = [eng.logits().cpu()]
+            for s in range(3):
+                eng.push_tokens(step_ids[s])
+                eng.step_forward()
+                outs.append(eng.logits().cpu())
+            for a, b in zip(outs, ref):
+                assert (a - b).abs().max() < tol, (bsz, prec, float((a - b).abs().max()))
+            eng.close()
+
+
 def test_long_context_split_kv_matches_oracle():
     """Self-KV length grows past several 8-row batches per wave and several splits (no prompt, 150 steps)."""
     spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "max_position_embeddings": 512})
