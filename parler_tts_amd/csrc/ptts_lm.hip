@@ -229,6 +229,21 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         PTTS_TRY((gemm_with_prologue<WT, PRO_ATTN, EPI_RESID>(e, g, st)));
       }
     }
+    const int KTw = Elem<WT>::KT;
+    if (!prefill && M <= 8 && (H / KTw) % 16 == 0 && (H == 512 || H == 1024 || H == 1536)) {
+      // decode, small batch: LN2 + cross q projection + cross-attention fused, one workgroup per head
+      XAttnArgs x = {};
+      x.W = w.cq; x.x = e->h; x.x_ld = H; x.x_row_mul = 1; x.x_row_off = 0; x.gamma = w.ln2_g; x.beta = w.ln2_b; x.K = H;
+      x.invK = 1.0f / (float)H; x.kcache = w.k_cross; x.vcache = w.v_cross; x.cap = c.max_enc; x.cur_len = e->cur_len; x.dims = e->dims;
+      x.mask = e->enc_mask; x.mask_ld = c.max_enc; x.cos = c.rope ? e->rope_cos : nullptr; x.sin = c.rope ? e->rope_sin : nullptr;
+      x.out = e->xw; x.B = M; x.nheads = nh; x.scale = scale;
+      const size_t sh = (size_t)M * (H * sizeof(WT) + 16) + 8 * 1024 + (size_t)M * 64 * 4;
+      const bool u16 = ((H / KTw) / 2) % 16 == 0;
+      if (H == 1024 && u16) hipLaunchKernelGGL((xattn_fused_kernel<WT, 16, 4>), dim3(nh), dim3(512), sh, st, x);        // Mini-v1
+      else if (H == 1024) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 4>), dim3(nh), dim3(512), sh, st, x);
+      else if (H == 1536) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 6>), dim3(nh), dim3(512), sh, st, x);           // Large-v1
+      else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 2>), dim3(nh), dim3(512), sh, st, x);                            // hidden 512
+    } else {
     {  // LN2 + cross q projection
       GemmArgs g = {};
       g.W = w.cq; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln2_g; g.beta = w.ln2_b;
@@ -244,6 +259,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.fused_append = 0; a.scale = scale;
       a.direct_out = e->xw;  // the description is short: never split, softmax finished in the attention kernel
       PTTS_TRY((launch_attn<WT>(a, B, st)));
+    }
     }
     {  // cross out_proj + residual, activations read straight from the attention output
       GemmArgs g = {};

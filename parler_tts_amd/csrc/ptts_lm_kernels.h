@@ -146,8 +146,8 @@ constexpr int LN_MAX_F4 = 8;  // LayerNorm rows up to 64 lanes * 8 float4 = 2048
 // per wave; every row load is issued before the first dependent instruction; mean and variance come from ONE fused
 // pass of sum(x-c) and sum((x-c)^2) with the shift c = x[0] (shifted-data variance: no catastrophic cancellation,
 // error ~ eps*(1 + (mean-c)^2/var)); eps 1e-5 as nn.LayerNorm (modeling:961). EXACT: K == NF4*256, no lane masks.
-template <typename WT, int NF4, bool EXACT, int R>
-__device__ __forceinline__ void ln_rows(const GemmArgs& a, const float* const (&xr)[R], char* const (&row)[R], const float4 (&g)[NF4],
+template <typename WT, int NF4, bool EXACT, int R, typename Args>
+__device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[R], char* const (&row)[R], const float4 (&g)[NF4],
                                         const float4 (&bt)[NF4], int lane) {
   float4 v[R][NF4];
 #pragma unroll
@@ -187,8 +187,8 @@ __device__ __forceinline__ void ln_rows(const GemmArgs& a, const float* const (&
   }
 }
 
-template <typename WT, int NF4, bool EXACT>
-__device__ __forceinline__ void ln_stage(const GemmArgs& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
+template <typename WT, int NF4, bool EXACT, typename Args, bool PAIRS = true>
+__device__ __forceinline__ void ln_stage(const Args& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
   float4 g[NF4], bt[NF4];
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
@@ -198,13 +198,13 @@ __device__ __forceinline__ void ln_stage(const GemmArgs& a, int m0, int nrows, c
     bt[i] = *reinterpret_cast<const float4*>(a.beta + kk);
   }
   int r = wave;
-  for (; r + W < nrows; r += 2 * W) {  // two rows of this wave in flight
+  for (; PAIRS && r + W < nrows; r += 2 * W) {  // two rows of this wave in flight
     const float* const xr[2] = {a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld,
                                 a.x + (size_t)((m0 + r + W) * a.x_row_mul + a.x_row_off) * a.x_ld};
     char* const row[2] = {s_x + (size_t)r * row_bytes, s_x + (size_t)(r + W) * row_bytes};
     ln_rows<WT, NF4, EXACT, 2>(a, xr, row, g, bt, lane);
   }
-  if (r < nrows) {
+  for (; r < nrows; r += W) {
     const float* const xr[1] = {a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld};
     char* const row[1] = {s_x + (size_t)r * row_bytes};
     ln_rows<WT, NF4, EXACT, 1>(a, xr, row, g, bt, lane);
@@ -635,6 +635,183 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       st[0] = M;
       st[1] = lv;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// xattn_fused_kernel (decode, batch <= 8): encoder_attn_layer_norm + cross q projection + cross-attention for ONE head
+// per workgroup (modeling:1040-1052, :855-859, :872-875, :906-914). The description K/V is static and short, so the
+// whole chain is head-parallel: 8 waves = 4 weight strips (the head's 64 q rows) x 2 K halves for the projection,
+// then wave b runs the single-query attention of utterance b. Replaces two graph nodes (LN+GEMM, attention) and one
+// cross-XCD round trip by one; output is the normalised context in the engine dtype, read by the out_proj GEMM
+// (PRO_COPY). RoPE quirk kept: q rotated, keys not (:858-859 vs :880).
+// ------------------------------------------------------------------------------------------------------
+struct XAttnArgs {
+  const void* W;       // packed cross q_proj [H/16][K/KT][64][16 B]
+  const float* x;      // residual stream h [B][x_ld]
+  int x_ld, x_row_mul, x_row_off;
+  const float* gamma;
+  const float* beta;
+  int K;               // hidden size
+  float invK;
+  void* kcache;        // cross K/V [B][heads][cap][64]
+  void* vcache;
+  int cap;
+  const int* cur_len;
+  const DevDims* dims;
+  const int* mask;     // [B][mask_ld] or null
+  int mask_ld;
+  const float* cos;
+  const float* sin;
+  void* out;           // [B][K] engine dtype
+  int B, nheads;
+  float scale;
+};
+
+template <typename WT, int UW, int NF4>
+__global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
+  constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8, NWV = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.x;
+  const int row_bytes = a.K * (int)sizeof(WT) + 16;
+  char* s_x = smem_raw;                                                        // [B][row_bytes]
+  float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)a.B * row_bytes);  // [8 waves][64][4]
+  float* s_q = s_red + NWV * 256;                                              // [B][64]
+  const int nfrag = a.K / KT;
+  const int strip = h * 4 + (wave >> 1);
+  const int per = nfrag >> 1;  // host guarantees per % UW == 0
+  const int t0 = (wave & 1) * per, t1 = t0 + per;
+  const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
+  const int q4 = lane >> 4, j = lane & 15;
+  const int r = lane / LPR, c = lane % LPR;
+  const int b = min(wave, a.B - 1);  // attention of utterance b runs on wave b
+  const int N = a.dims->N;
+
+  // ---- t = 0: every independent global load of the kernel goes in flight -----------------------------------------
+  uint4 afr[UW];
+#pragma unroll
+  for (int u = 0; u < UW; ++u) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+  const uint4* Kb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.nheads + h) * a.cap * 64);
+  const uint4* Vb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.nheads + h) * a.cap * 64);
+  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  uint4 kf[U], vf[U];
+  int mk[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // first 8 row groups (covers N <= 64 bf16 / 32 fp32 in one batch)
+    const int t = u * RPI + r;
+    const int tc = t < N ? t : 0;
+    kf[u] = Kb[(size_t)tc * LPR + c];
+    vf[u] = Vb[(size_t)tc * LPR + c];
+    mk[u] = mrow ? mrow[tc] : 1;
+  }
+  // ---- LayerNorm of the B rows -> LDS, then the head's 64 q rows ------------------------------------------------------
+  ln_stage<WT, NF4, true, XAttnArgs, false>(a, 0, a.B, s_x, row_bytes, lane, wave, NWV);  // K == NF4 * 256
+  __syncthreads();
+  const char* brow = s_x + (size_t)min(j, a.B - 1) * row_bytes + (size_t)q4 * 16;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tb = t0; tb < t1; tb += UW) {
+    if (tb != t0) {
+#pragma unroll
+      for (int u = 0; u < UW; ++u) afr[u] = ld_nt16(Wp + (size_t)(tb + u) * 64);
+    }
+#pragma unroll
+    for (int uh = 0; uh < UW; uh += 8) {
+      uint4 bfr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bfr[u] = *reinterpret_cast<const uint4*>(brow + (size_t)(tb + uh + u) * (KT * sizeof(WT)));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u & 1) acc2 = MfmaStep<WT>::run(afr[uh + u], bfr[u], acc2);
+        else acc = MfmaStep<WT>::run(afr[uh + u], bfr[u], acc);
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(s_red + ((size_t)wave * 64 + lane) * 4) = acc + acc2;
+  __syncthreads();
+  if (wave < 4) {  // wave s combines the two K halves of strip s: D[row = q4*4 + e][col = utterance j]
+    const f32x4 rr = *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave) * 64 + lane) * 4) +
+                     *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave + 1) * 64 + lane) * 4);
+    if (j < a.B) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_q[j * 64 + wave * 16 + q4 * 4 + e] = rr[e];
+    }
+  }
+  __syncthreads();
+  if (wave >= a.B) return;
+  // ---- wave b: single-query attention of utterance b over the N description positions -----------------------
+  float qv[EPL];
+  {
+    const float* qs = s_q + b * 64;
+    const int d0 = c * EPL;
+    if (a.cos) {
+      const size_t pos = (size_t)(a.dims->P + a.cur_len[b] - 1);
+      const int dp = d0 < 32 ? d0 + 32 : d0 - 32;
+      const float sign = d0 < 32 ? -1.f : 1.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        qv[e] = (qs[d0 + e] * a.cos[pos * 64 + d0 + e] + sign * qs[dp + e] * a.sin[pos * 64 + d0 + e]) * a.scale;
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) qv[e] = qs[d0 + e] * a.scale;
+    }
+  }
+  const int G = (N + RPI - 1) / RPI;
+  float m_run = -INFINITY, l_run = 0.f, o[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+  for (int g0 = 0; g0 < G; g0 += U) {
+    bool ok[U];
+    if (g0 != 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = (g0 + u) * RPI + r;
+        const int tc = t < N ? t : 0;
+        kf[u] = Kb[(size_t)tc * LPR + c];
+        vf[u] = Vb[(size_t)tc * LPR + c];
+        mk[u] = mrow ? mrow[tc] : 1;
+      }
+    }
+    float sc[U], bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ok[u] = ((g0 + u) * RPI + r) < N && mk[u] != 0;
+      float kk[EPL];
+      unpack16(kf[u], kk, WT());
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kk[e], d);
+      d = group_reduce<OpSum, LPR>(d);
+      sc[u] = ok[u] ? d : -INFINITY;
+      bm = fmaxf(bm, sc[u]);
+    }
+    bm = across_groups_reduce<OpMax, LPR>(bm);
+    const float m_new = fmaxf(m_run, bm);
+    if (m_new == -INFINITY) continue;
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float p = ok[u] ? expf(sc[u] - m_new) : 0.f;
+      float vv[EPL];
+      unpack16(vf[u], vv, WT());
+      l_run += p;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(p, vv[e], o[e]) : o[e];
+    }
+    m_run = m_new;
+  }
+  l_run = across_groups_reduce<OpSum, LPR>(l_run);
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = across_groups_reduce<OpSum, LPR>(o[e]);
+  if (r == 0) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    float res[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) res[e] = o[e] * inv;
+    reinterpret_cast<uint4*>(reinterpret_cast<WT*>(a.out) + (size_t)b * a.K + h * 64)[c] = pack16(res, WT());
   }
 }
 

@@ -191,6 +191,39 @@ def test_large_v1_width_two_layers_bf16_and_fp32_batch():
             eng.close()
 
 
+@pytest.mark.parametrize("rope", [False, True])
+def test_fused_cross_attention_block_masks_and_rope(rope):
+    """Decode at batch <= 8 and Mini width runs LN2 + cross-q + cross-attention as ONE head-parallel kernel: check it
+    with a padded description mask per row, a padded prompt, RoPE on/off (q rotated, keys not) and batch 3."""
+    spec = DO.DecoderSpec(num_hidden_layers=1, max_position_embeddings=128, rope_embeddings=rope)
+    sd = DO.make_decoder_weights(spec, seed=31)
+    g = torch.Generator().manual_seed(6)
+    bsz, N, P = 3, 21, 6
+    enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
+    enc_mask = torch.ones(bsz, N, dtype=torch.long)
+    enc_mask[1, 13:] = 0
+    enc_mask[2, 20:] = 0
+    enc = enc * enc_mask[..., None]
+    prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
+    prompt_mask = torch.ones(bsz, P, dtype=torch.long)
+    prompt_mask[2, :3] = 0
+    step_ids = torch.randint(0, 1024, (5, bsz * spec.num_codebooks), generator=g)
+    orc = DO.DecoderOracle(spec, sd)
+    ref = [orc.forward(torch.full((bsz * 9, 1), 1025), enc, enc_mask, prompt, prompt_mask)[:, -1]]
+    for s_ in range(5):
+        ref.append(orc.forward(step_ids[s_][:, None])[:, -1])
+    eng = make_engine(spec, sd, torch.float32, max_batch=bsz, max_ctx=64, max_enc=32, max_prompt=8)
+    eng.set_gen_params(max_length=16)
+    eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
+    outs = [eng.logits().cpu()]
+    for s_ in range(5):
+        eng.push_tokens(step_ids[s_])
+        eng.step_forward()
+        outs.append(eng.logits().cpu())
+    for a, b in zip(outs, ref):
+        assert (a - b).abs().max() < 5e-5, float((a - b).abs().max())
+
+
 def test_long_context_split_kv_matches_oracle():
     """Self-KV length grows past several 8-row batches per wave and several splits (no prompt, 150 steps)."""
     spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "max_position_embeddings": 512})
