@@ -119,8 +119,15 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
     es = 2 if model.dtype == torch.bfloat16 else 4
     bytes_step = w_step * es + bs * 2 * L * H * (lc + N_DESC) * es + bs * (Kc * H * es + Kc * V * 4)
     achieved = bytes_step / step_s / 1e9
+    traffic, tnote = None, "PMC pass not available"
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_step_bs1.json")
+    if bs == 1 and es == 2 and os.path.exists(pmc):  # committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE summary (separate passes)
+        j = json.load(open(pmc))
+        traffic = int(j["traffic_bytes_per_step"])
+        tnote = f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~735 MB)"
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-            "traffic": None, "kernel": "decode-step hipGraph (195 kernel nodes, one hipGraphLaunch per generated frame)",
+            "traffic": traffic, "traffic_note": tnote,
+            "kernel": "decode-step hipGraph (170 kernel nodes at bs<=8: 24 x 7 per layer + LM heads + sampler/embed tail; one hipGraphLaunch per generated frame)",
             "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
 
 
