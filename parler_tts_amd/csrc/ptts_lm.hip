@@ -103,7 +103,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   if (a.N % 16 != 0 || a.K % KT != 0) return ptts_fail(PTTS_E_INVALID, "gemm N=%d K=%d not multiples of 16/%d", a.N, a.K, KT);
   if (PRO == PRO_LN && a.K > 64 * 4 * LN_MAX_F4) return ptts_fail(PTTS_E_UNSUPPORTED, "LayerNorm width %d > %d", a.K, 64 * 4 * LN_MAX_F4);
   const int nfrag = a.K / KT;
-  const int wmax = (a.M > 16 ? GemmMaxThreads<PRO, 2>::value : GemmMaxThreads<PRO, 1>::value) / 64;
+  const int wmax = (a.M > 16 ? GemmMaxThreads<PRO, 2>::value : GemmMaxThreads<PRO, 1>::value) / 64;  // MTP 2 and 8 share the 512-thread bound
   // FULL variant: every wave owns whole 8-fragment groups (and K % 256 == 0): straight-line kernel
   int W = 0;
   const bool ln_ok = PRO != PRO_LN || a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 1536;  // ln_row<> instances
@@ -121,14 +121,27 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   // activation rows staged in LDS per pass: as many as fit beside the cross-wave reduction buffer (<= 32)
   const size_t row_bytes = PRO == PRO_COPY ? 0 : (size_t)a.K * sizeof(WT) + 16;  // PRO_COPY reads B fragments from global
   const size_t lds_cap = 160 * 1024 - 1024;
-  int rpp = a.M < 32 ? a.M : 32;
-  while (rpp > 1 && rpp * row_bytes + (size_t)W * (rpp > 16 ? 2 : 1) * 1024 > lds_cap) --rpp;
+  // prefill-sized M with prepared (PRO_COPY) activations: 128-row passes (8 MFMA tiles per weight fragment) so the
+  // strip's weights are re-streamed from L2 M/128 times instead of M/32
+  const int max_rows = (PRO == PRO_COPY && a.M > 32) ? 128 : 32;
+  int rpp = a.M < max_rows ? a.M : max_rows;
+  auto tiles = [](int r) { return r > 32 ? 8 : (r > 16 ? 2 : 1); };
+  while (rpp > 1 && rpp * row_bytes + (size_t)W * tiles(rpp) * 1024 > lds_cap) --rpp;
   if (rpp * row_bytes + (size_t)W * 1024 > lds_cap) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm K=%d does not fit in LDS", a.K);
   a.rows_per_pass = rpp;
-  const int mtp = rpp > 16 ? 2 : 1;
+  const int mtp = tiles(rpp);
   const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
   const dim3 grid(a.N / 16), block(W * 64);
   int rc;
+  if constexpr (PRO == PRO_COPY) {
+    if (mtp == 8) {
+      rc = full ? launch_gemm_inst<WT, PRO, EPI, 8, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 8, false>(a, grid, block, sh, st);
+      PTTS_TRY(rc);
+      hipError_t e8 = hipGetLastError();
+      if (e8 != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e8));
+      return PTTS_OK;
+    }
+  }
   if (full) rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, true>(a, grid, block, sh, st);
   else rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, false>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, false>(a, grid, block, sh, st);
   PTTS_TRY(rc);

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
         for (int u = 0; u < U; ++u)
           if (FULL || tb + u < t1) afr[u] = ld_nt16(Wp + (size_t)(tb + u) * 64);
       }
-      constexpr int UB = MTP == 2 ? 4 : 8;  // LDS reads hoisted per half-group when two tiles are live (VGPR budget)
+      constexpr int UB = MTP == 1 ? 8 : (MTP == 2 ? 4 : 2);  // B-fragment reads hoisted per sub-group (VGPR budget: MTP*UB uint4)
 #pragma unroll
       for (int uh = 0; uh < U; uh += UB) {
         uint4 bfr[MTP][UB];
@@ -372,8 +372,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     for (int mt = 0; mt < MTP; ++mt)
       *reinterpret_cast<f32x4*>(s_red + (((size_t)wave * MTP + mt) * 64 + lane) * 4) = acc[mt] + acc2[mt];
     __syncthreads();
-    if (wave < MTP) {
-      const int mt = wave;
+    for (int mt = wave; mt < MTP; mt += W) {
       f32x4 r = *reinterpret_cast<const f32x4*>(s_red + ((size_t)mt * 64 + lane) * 4);
       for (int w = 1; w < W; ++w) r += *reinterpret_cast<const f32x4*>(s_red + (((size_t)w * MTP + mt) * 64 + lane) * 4);
       const int mloc = mt * 16 + j;

@@ -228,6 +228,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._engine = None  # device / dtype may have changed: repack lazily
+        self.__dict__.pop("_enc_graphs", None)  # captured encoder graphs point at the old parameter storage
         return out
 
     # -- (de)serialisation ----------------------------------------------------------------------------------
@@ -316,14 +317,51 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         return e
 
     # -- the pieces of generate() that stay on the torch side (once per call, off the per-token loop) ---------------
-    def _encode_description(self, input_ids, attention_mask):
-        """:3048-3097 — T5 encoder, optional enc_to_dec_proj, masked positions zeroed."""
+    def _encode_description_eager(self, input_ids, attention_mask):
         enc = self.text_encoder(input_ids=input_ids, attention_mask=attention_mask, return_dict=True).last_hidden_state
         if hasattr(self, "enc_to_dec_proj"):
             enc = self.enc_to_dec_proj(enc)
         if attention_mask is not None:
             enc = enc * attention_mask[..., None]
         return enc
+
+    def _encode_description(self, input_ids, attention_mask):
+        """:3048-3097 — T5 encoder (third-party, stock PyTorch-ROCm), optional enc_to_dec_proj, masked positions zeroed.
+        The encoder is ~360 tiny launches (13 ms eager at 64 tokens, launch-bound, on the time-to-first-token path), so
+        on a HIP device it is captured once per (batch, length, masked?) into a torch HIP graph and replayed (~3 ms).
+        Any capture failure falls back to the eager call (same arithmetic either way)."""
+        if input_ids.device.type != "cuda" or not getattr(self, "use_encoder_graph", True):
+            return self._encode_description_eager(input_ids, attention_mask)
+        key = (tuple(input_ids.shape), attention_mask is not None, self.dtype, input_ids.device)
+        cache = self.__dict__.setdefault("_enc_graphs", {})
+        entry = cache.get(key)
+        if entry is None:
+            try:
+                static_ids = input_ids.clone()
+                static_mask = attention_mask.clone() if attention_mask is not None else None
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):  # warm-up outside capture (lazy inits, autotuning)
+                        self._encode_description_eager(static_ids, static_mask)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._encode_description_eager(static_ids, static_mask)
+                entry = (graph, static_ids, static_mask, static_out)
+            except Exception:  # noqa: BLE001 — capture is an optimisation only
+                entry = False
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = entry
+        if entry is False:
+            return self._encode_description_eager(input_ids, attention_mask)
+        graph, static_ids, static_mask, static_out = entry
+        static_ids.copy_(input_ids)
+        if static_mask is not None:
+            static_mask.copy_(attention_mask)
+        graph.replay()
+        return static_out.clone()
 
     @torch.no_grad()
     def generate(self, inputs: Optional[torch.Tensor] = None, generation_config=None, logits_processor=None, stopping_criteria=None,
