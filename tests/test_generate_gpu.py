@@ -143,7 +143,7 @@ def test_streamer_thread_protocol():
     g = torch.Generator().manual_seed(3)
     desc = torch.randint(3, 128, (1, 7), generator=g).cuda()
     prompt_ids = torch.randint(3, 128, (1, 4), generator=g).cuda()
-    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=60, min_new_tokens=60)
+    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=120, min_new_tokens=120)
     full = m.generate(**kw)[0].cpu().numpy()
     streamer = P.ParlerTTSStreamer(m, device="cuda", play_steps=20, stride=8)
     th = threading.Thread(target=m.generate, kwargs=dict(streamer=streamer, **kw))
@@ -155,6 +155,17 @@ def test_streamer_thread_protocol():
     # the final flush decodes the complete token cache: its tail must equal the non-streamed waveform's tail
     n = len(chunks[-1])
     assert n > 0 and np.allclose(audio[-n:], full[-n:], atol=1e-5)
+    # incremental (halo-window) decoding emits exactly the chunks of the reference's full re-decode of the whole cache
+    chunks_by_mode = []
+    for inc in (True, False):
+        st = P.ParlerTTSStreamer(m, device="cuda", play_steps=20, stride=8, incremental=inc)
+        th = threading.Thread(target=m.generate, kwargs=dict(streamer=st, **kw))
+        th.start()
+        chunks_by_mode.append([c for c in st])
+        th.join()
+    assert [len(c) for c in chunks_by_mode[0]] == [len(c) for c in chunks_by_mode[1]]
+    for a_, b_ in zip(*chunks_by_mode):
+        assert np.allclose(a_, b_, atol=1e-6)
     with pytest.raises(ValueError, match="batch size 1"):
         m.generate(input_ids=desc.repeat(2, 1), prompt_input_ids=prompt_ids.repeat(2, 1), streamer=P.ParlerTTSStreamer(m, play_steps=20), max_new_tokens=12)
 
