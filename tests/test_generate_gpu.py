@@ -53,7 +53,8 @@ def _oracle_pipeline(m, spec, sd, dsd, desc, desc_mask, prompt_ids, prompt_mask,
 
 
 def test_generate_greedy_matches_oracle_pipeline_with_eos_and_padding():
-    m, spec, sd, dsd = _tiny_model(seed=6, eos_gain=6.0)
+    # seed 3: margin-safe on this path (min top-2 margin 2.6e-4), 4 rows reach EOS, the two samples keep 6 and 7 frames
+    m, spec, sd, dsd = _tiny_model(seed=3, eos_gain=6.0)
     m = m.to("cuda")
     g = torch.Generator().manual_seed(1)
     desc = torch.randint(3, 128, (2, 9), generator=g)
