@@ -51,6 +51,7 @@ struct ptts_engine {
   float* sort_buf = nullptr;
   void *xw = nullptr, *xw2 = nullptr;  // engine-dtype activation rows for the M > 8 path: [rows][H], [rows][F]
   int S_self = 4, S_cross = 1;
+  int attn_waves = 4;  // waves per self-attention workgroup at decode
   // state
   long long* ids = nullptr;
   int ids_ld = 0;
@@ -151,9 +152,11 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
 }
 
 template <typename WT>
-int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
+int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
   const dim3 grid(a.S, a.nheads, B * a.Q);
-  hipLaunchKernelGGL((attn_kernel<WT, 4>), grid, dim3(256), 0, st, a);
+  if (waves == 8) hipLaunchKernelGGL((attn_kernel<WT, 8>), grid, dim3(512), 0, st, a);
+  else if (waves == 16) hipLaunchKernelGGL((attn_kernel<WT, 16>), grid, dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL((attn_kernel<WT, 4>), grid, dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "attn launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
@@ -229,7 +232,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
       a.direct_out = e->S_self == 1 ? e->xw : nullptr;
-      PTTS_TRY((launch_attn<WT>(a, B, st)));
+      PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
       GemmArgs g = {};
@@ -441,6 +444,8 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
     while (s > 1 && (s - 1) * 4 * 8 * 8 >= c.max_ctx) --s;  // do not split below one 8-deep batch of row groups per wave
     e->S_self = s;
     e->S_cross = 1;
+    if (const char* ev = getenv("PTTS_ATTN_SPLITS")) e->S_self = std::max(1, std::min(8, atoi(ev)));  // tuning knobs (tools/)
+    if (const char* ev = getenv("PTTS_ATTN_WAVES")) e->attn_waves = atoi(ev) == 16 ? 16 : (atoi(ev) == 8 ? 8 : 4);
   }
   const size_t rows = (size_t)c.max_batch * e->max_prompt;
   const size_t enc_rows = (size_t)c.max_batch * c.max_enc;
