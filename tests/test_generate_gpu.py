@@ -171,6 +171,17 @@ def test_streamer_thread_protocol():
         m.generate(input_ids=desc.repeat(2, 1), prompt_input_ids=prompt_ids.repeat(2, 1), streamer=P.ParlerTTSStreamer(m, play_steps=20), max_new_tokens=12)
 
 
+def test_num_return_sequences_expands_batch():
+    m, *_ = _tiny_model(seed=2)
+    m = m.to("cuda")
+    desc = torch.randint(3, 128, (2, 6), generator=torch.Generator().manual_seed(1)).cuda()
+    prompt_ids = torch.randint(3, 128, (2, 3), generator=torch.Generator().manual_seed(2)).cuda()
+    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=20, min_new_tokens=20)
+    a = m.generate(**kw)
+    b = m.generate(num_return_sequences=2, **kw)
+    assert b.shape[0] == 4 and torch.equal(b[0], b[1]) and torch.equal(b[0], a[0]) and torch.equal(b[2], a[1])
+
+
 def test_bf16_model_runs_and_tracks_fp32():
     m, *_ = _tiny_model(seed=2)
     desc = torch.randint(3, 128, (1, 7), generator=torch.Generator().manual_seed(3))

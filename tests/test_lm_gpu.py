@@ -256,6 +256,22 @@ def test_full_mini_v1_fp32_greedy_ids_bit_exact():
     assert torch.equal(ids[:, :safe], ref.sequences[:, :safe])
 
 
+def test_fused_lm_heads_checkpoint_layout():
+    """use_fused_lm_heads (modeling:1834-1840): one [K*V, H] `lm_heads.weight` instead of K `lm_heads.k.weight`."""
+    spec = DO.TINY
+    sd = DO.make_decoder_weights(spec, seed=9)
+    fused = {k: v for k, v in sd.items() if not k.startswith("lm_heads.")}
+    fused["lm_heads.weight"] = torch.cat([sd[f"lm_heads.{k}.weight"] for k in range(spec.num_codebooks)], dim=0)
+    enc = torch.randn(1, 5, spec.hidden_size, generator=torch.Generator().manual_seed(0))
+    outs = []
+    for w in (sd, fused):
+        eng = make_engine(spec, w, torch.float32, max_batch=1)
+        eng.set_gen_params(max_length=16)
+        eng.prefill(enc, None, None, None, sample=False)
+        outs.append(eng.logits().cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_long_context_split_kv_matches_oracle():
     """Self-KV length grows past several 8-row batches per wave and several splits (no prompt, 150 steps)."""
     spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "max_position_embeddings": 512})

@@ -43,10 +43,22 @@ def main():
             cur, fin = eng.state()
             print(f"[lm] {str(dtype):15s} B={B:3d} load {tl:.1f}s prefill {tp*1e3:.1f}/{tp2*1e3:.1f} ms  step {t1/400*1e6:.1f} us (ctx~250) {t2/400*1e6:.1f} us (ctx~650) cur_len={cur}", flush=True)
             eng.close(); del eng
+    # Large-v1 decoder shapes (helpers/model_init_scripts/init_large_model.py:25-43), bf16
+    H2, L2, F2 = 1536, 30, 6144
+    sd2 = rand_sd(H2, L2, F2, K, V, 4096, dev)
+    for B in (1, 8):
+        eng = DecoderEngine(hidden_size=H2, num_layers=L2, num_heads=24, ffn_dim=F2, num_codebooks=K, vocab_size=V, max_positions=4096,
+                            dtype=torch.bfloat16, max_batch=B, max_ctx=940, max_enc=64, max_prompt=40)
+        eng.load_state_dict(sd2); eng.set_gen_params(max_length=869, min_new_tokens=868)
+        eng.prefill(torch.randn(B, 64, H2, device=dev), None, torch.randn(B, 32, H2, device=dev), None)
+        eng.decode_steps(300); torch.cuda.synchronize()
+        t0 = time.time(); eng.decode_steps(300); torch.cuda.synchronize(); t1 = time.time() - t0
+        wb = (L2 * (6 * H2 * H2 + 2 * H2 * F2) + K * V * H2) * 2
+        print(f"[lm-large] bf16 B={B}: step {t1/300*1e6:.1f} us (ctx~480) -> {wb/1e9/(t1/300)/1e3:.2f} TB/s of weights alone ({wb/1e6:.0f} MB/step)", flush=True)
+        eng.close(); del eng
     # DAC full size
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import dac_oracle as DA
-    dsd = {k: v.to(dev) for k, v in DA.make_dac_weights(DA.DAC_44KHZ, 4321).items()}
+    from parler_tts_amd.synthetic import random_dac_state_dict
+    dsd = {k: v.to(dev) for k, v in random_dac_state_dict().items()}
     for B, T in ((1, 860), (4, 860)):
         dac = DacEngine(max_batch=B, max_frames=T)
         dac.load_state_dict(dsd)
