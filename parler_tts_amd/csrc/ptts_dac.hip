@@ -35,8 +35,12 @@ struct ConvArgs {
   int B, Tin, Cin, Cout, ntaps, nphase;
 };
 
-__device__ __noinline__ float snake_f(float x, float al) {  // out of line: 8 * CS call sites per thread
+__device__ __forceinline__ float snake_f(float x, float al) {
+#ifdef PTTS_DAC_FAST_SIN
+  const float s = __sinf(al * x);
+#else
   const float s = sinf(al * x);
+#endif
   return x + (1.0f / (al + 1e-9f)) * (s * s);
 }
 
@@ -48,16 +52,17 @@ template <int CS>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j = lane & 15;
-  const int ntile = (a.Tin + 127) / 128;
+  const int fpb = 32 * (int)(blockDim.x >> 6);  // frames per workgroup: 32 per wave, 1/2/4 waves (host picks for balance)
+  const int ntile = (a.Tin + fpb - 1) / fpb;
   const int tile = blockIdx.x % ntile, ph = (blockIdx.x / ntile) % a.nphase, b = blockIdx.x / (ntile * a.nphase);
   const int strip0 = blockIdx.y * CS;
   const int nstrips = a.Cout / 16;
-  if (tile * 128 + wave * 32 >= a.Tin) return;
+  if (tile * fpb + wave * 32 >= a.Tin) return;
   const int cpt = a.Cin / 16;           // k-steps per tap
   const int nk = a.ntaps * cpt;
   const float* xb = a.x + (size_t)b * a.Tin * a.Cin;
   const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)ph * nstrips * nk) * 64 + lane;
-  const int j0 = tile * 128 + wave * 32;
+  const int j0 = tile * fpb + wave * 32;
 
   f32x4 acc[CS][2];
 #pragma unroll
@@ -423,15 +428,27 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const float* x, const float
   } else {  // to = j*s + ph = ti*s - pad + k  =>  tap 0 (k = r): ti = j + c0 ; tap 1 (k = r + s): ti = j + c0 - 1, c0 = (ph + pad)/s
     a.ntaps = 2; a.nphase = L.stride; a.dil = 1; a.pad = (L.stride + 1) / 2; a.transposed = 1;
   }
-  const int ntile = (Tin + 127) / 128, nstrips = L.Cout / 16;
+  const int nstrips = L.Cout / 16;
+  // waves per workgroup: fewer (finer tiles) when the launch would otherwise put < ~6 workgroups on each CU, so the
+  // 256 CUs finish together (324 four-wave workgroups on 256 CUs = 63 % balance; 1296 one-wave ones = 84 %+)
+  static int forced_nw = getenv("PTTS_DAC_WAVES") ? atoi(getenv("PTTS_DAC_WAVES")) : 0;
+  int nwb = 4;
+  {
+    const int CS0 = nstrips % 8 == 0 ? 8 : (nstrips % 6 == 0 ? 6 : (nstrips % 4 == 0 ? 4 : (nstrips % 2 == 0 ? 2 : 1)));
+    auto blocks = [&](int nw) { return (long long)((Tin + 32 * nw - 1) / (32 * nw)) * a.nphase * B * (nstrips / CS0); };
+    while (nwb > 1 && blocks(nwb) < 256LL * 6) nwb >>= 1;
+    if (forced_nw == 1 || forced_nw == 2 || forced_nw == 4) nwb = forced_nw;
+  }
+  const int ntile = (Tin + 32 * nwb - 1) / (32 * nwb);
   // strips per wave: the largest of {8, 6, 4, 2, 1} that divides the layer (real DAC widths: 96/48/24/12/6 strips)
   const int CS = nstrips % 8 == 0 ? 8 : (nstrips % 6 == 0 ? 6 : (nstrips % 4 == 0 ? 4 : (nstrips % 2 == 0 ? 2 : 1)));
   const dim3 grid((unsigned)(ntile * a.nphase * B), (unsigned)(nstrips / CS));
-  if (CS == 8) hipLaunchKernelGGL((conv_mfma_kernel<8>), grid, dim3(256), 0, st, a);
-  else if (CS == 6) hipLaunchKernelGGL((conv_mfma_kernel<6>), grid, dim3(256), 0, st, a);
-  else if (CS == 4) hipLaunchKernelGGL((conv_mfma_kernel<4>), grid, dim3(256), 0, st, a);
-  else if (CS == 2) hipLaunchKernelGGL((conv_mfma_kernel<2>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<1>), grid, dim3(256), 0, st, a);
+  const dim3 blk(64 * nwb);
+  if (CS == 8) hipLaunchKernelGGL((conv_mfma_kernel<8>), grid, blk, 0, st, a);
+  else if (CS == 6) hipLaunchKernelGGL((conv_mfma_kernel<6>), grid, blk, 0, st, a);
+  else if (CS == 4) hipLaunchKernelGGL((conv_mfma_kernel<4>), grid, blk, 0, st, a);
+  else if (CS == 2) hipLaunchKernelGGL((conv_mfma_kernel<2>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<1>), grid, blk, 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "conv launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
