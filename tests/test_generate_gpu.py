@@ -176,7 +176,8 @@ def test_num_return_sequences_expands_batch():
     m = m.to("cuda")
     desc = torch.randint(3, 128, (2, 6), generator=torch.Generator().manual_seed(1)).cuda()
     prompt_ids = torch.randint(3, 128, (2, 3), generator=torch.Generator().manual_seed(2)).cuda()
-    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=20, min_new_tokens=20)
+    # GenerationConfig rejects greedy + num_return_sequences > 1: sample with top_k=1 (deterministic, equals greedy)
+    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=True, top_k=1, max_new_tokens=20, min_new_tokens=20)
     a = m.generate(**kw)
     b = m.generate(num_return_sequences=2, **kw)
     assert b.shape[0] == 4 and torch.equal(b[0], b[1]) and torch.equal(b[0], a[0]) and torch.equal(b[2], a[1])
