@@ -81,6 +81,9 @@ __device__ __forceinline__ uint4 pack16(const float (&o)[8], bf16_t) {
 
 // 16-byte non-temporal (streamed-once) global load: weights are read exactly once per decode step
 __device__ __forceinline__ uint4 ld_nt16(const uint4* p) {
+#ifdef PTTS_WEIGHT_CACHED  // A/B experiment only (tools/l2_probe.py): let weight lines allocate in L2
+  return *p;
+#endif
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
   return make_uint4(v.x, v.y, v.z, v.w);

@@ -146,9 +146,11 @@ constexpr int LN_MAX_F4 = 8;  // LayerNorm rows up to 64 lanes * 8 float4 = 2048
 // per wave; every row load is issued before the first dependent instruction; mean and variance come from ONE fused
 // pass of sum(x-c) and sum((x-c)^2) with the shift c = x[0] (shifted-data variance: no catastrophic cancellation,
 // error ~ eps*(1 + (mean-c)^2/var)); eps 1e-5 as nn.LayerNorm (modeling:961). EXACT: K == NF4*256, no lane masks.
-template <typename WT, int NF4, bool EXACT, int R, typename Args>
-__device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[R], char* const (&row)[R], const float4 (&g)[NF4],
-                                        const float4 (&bt)[NF4], int lane) {
+template <typename WT, int NF4, bool EXACT, int R, typename Args, typename Hook>
+__device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[R], char* const (&row)[R], int lane, Hook&& after_x_issued) {
+  // Issue order = need order: the CU returns loads in issue order, so the 4 KB row (critical path) goes first, the
+  // caller's bulk weight loads (hook) next, gamma/beta (needed only after the reductions) last. With the weights
+  // first the row queued behind 32-128 KB per CU: +0.7 us per LayerNorm kernel (tools/chain_probe.hip).
   float4 v[R][NF4];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -157,6 +159,15 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
       const int k = (lane + 64 * i) * 4;
       v[r][i] = *reinterpret_cast<const float4*>(xr[r] + ((EXACT || k < a.K) ? k : 0));
     }
+  float4 g[NF4], bt[NF4];
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int k = (lane + 64 * i) * 4;
+    const int kk = (EXACT || k < a.K) ? k : 0;
+    g[i] = *reinterpret_cast<const float4*>(a.gamma + kk);
+    bt[i] = *reinterpret_cast<const float4*>(a.beta + kk);
+  }
+  after_x_issued();
   float c[R], s1[R], s2[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -187,27 +198,34 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
   }
 }
 
-template <typename WT, int NF4, bool EXACT, typename Args, bool PAIRS = true>
-__device__ __forceinline__ void ln_stage(const Args& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
-  float4 g[NF4], bt[NF4];
-#pragma unroll
-  for (int i = 0; i < NF4; ++i) {
-    const int k = (lane + 64 * i) * 4;
-    const int kk = (EXACT || k < a.K) ? k : 0;
-    g[i] = *reinterpret_cast<const float4*>(a.gamma + kk);
-    bt[i] = *reinterpret_cast<const float4*>(a.beta + kk);
-  }
+// `first` runs exactly once per wave: right after the wave's first row loads are in flight, or at once if it owns no row.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <typename WT, int NF4, bool EXACT, typename Args, bool PAIRS = true, typename Hook>
+__device__ __forceinline__ void ln_stage(const Args& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W, Hook&& first) {
+  auto xrow = [&](int r) { return a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld; };
   int r = wave;
-  for (; PAIRS && r + W < nrows; r += 2 * W) {  // two rows of this wave in flight
-    const float* const xr[2] = {a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld,
-                                a.x + (size_t)((m0 + r + W) * a.x_row_mul + a.x_row_off) * a.x_ld};
+  if (PAIRS && r + W < nrows) {
+    const float* const xr[2] = {xrow(r), xrow(r + W)};
     char* const row[2] = {s_x + (size_t)r * row_bytes, s_x + (size_t)(r + W) * row_bytes};
-    ln_rows<WT, NF4, EXACT, 2>(a, xr, row, g, bt, lane);
+    ln_rows<WT, NF4, EXACT, 2>(a, xr, row, lane, first);
+    r += 2 * W;
+  } else if (r < nrows) {
+    const float* const xr[1] = {xrow(r)};
+    char* const row[1] = {s_x + (size_t)r * row_bytes};
+    ln_rows<WT, NF4, EXACT, 1>(a, xr, row, lane, first);
+    r += W;
+  } else {
+    first();
+  }
+  for (; PAIRS && r + W < nrows; r += 2 * W) {  // two rows of this wave in flight
+    const float* const xr[2] = {xrow(r), xrow(r + W)};
+    char* const row[2] = {s_x + (size_t)r * row_bytes, s_x + (size_t)(r + W) * row_bytes};
+    ln_rows<WT, NF4, EXACT, 2>(a, xr, row, lane, NoHook());
   }
   for (; r < nrows; r += W) {
-    const float* const xr[1] = {a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld};
+    const float* const xr[1] = {xrow(r)};
     char* const row[1] = {s_x + (size_t)r * row_bytes};
-    ln_rows<WT, NF4, EXACT, 1>(a, xr, row, g, bt, lane);
+    ln_rows<WT, NF4, EXACT, 1>(a, xr, row, lane, NoHook());
   }
 }
 
@@ -234,19 +252,22 @@ __device__ __forceinline__ float4 stage_elem(const GemmArgs& a, int m, int k) {
   return *reinterpret_cast<const float4*>(a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld + k);
 }
 
-template <typename WT, int PRO, bool FULL>
-__device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W) {
+// `first` (the caller's bulk weight loads) runs exactly once per thread, right after the thread's first activation
+// loads are in flight: the CU returns loads in issue order and the activations are the critical path.
+template <typename WT, int PRO, bool FULL, typename Hook>
+__device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W, Hook&& first) {
   if (PRO == PRO_LN) {
     const int nf4 = (a.K + 255) >> 8;  // workgroup-uniform
     if (FULL) {  // host guarantees K in {256, 512, 1024, 1536} for the FULL LayerNorm variant
-      if (nf4 == 4) ln_stage<WT, 4, true>(a, m0, nrows, s_x, row_bytes, lane, wave, W);        // hidden 1024 (Mini-v1)
-      else if (nf4 == 6) ln_stage<WT, 6, true>(a, m0, nrows, s_x, row_bytes, lane, wave, W);   // hidden 1536 (Large-v1)
-      else ln_stage<WT, 2, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+      if (nf4 == 4) ln_stage<WT, 4, true>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);        // hidden 1024 (Mini-v1)
+      else if (nf4 == 6) ln_stage<WT, 6, true>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);   // hidden 1536 (Large-v1)
+      else ln_stage<WT, 2, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);
     } else {
-      if (nf4 <= 1) ln_stage<WT, 1, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
-      else ln_stage<WT, LN_MAX_F4, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+      if (nf4 <= 1) ln_stage<WT, 1, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);
+      else ln_stage<WT, LN_MAX_F4, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);
     }
   } else if (PRO == PRO_COPY) {
+    first();
     // bulk copy of engine-dtype rows, 16 B per lane, 8 independent loads in flight per thread
     constexpr int EPV = 16 / (int)sizeof(WT);
     const int vpr = a.K / EPV;  // 16-byte vectors per row
@@ -267,11 +288,34 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
         if (i0 + u * W * 64 < total) *reinterpret_cast<uint4*>(s_x + (size_t)rr[u] * row_bytes + (size_t)cc[u] * 16) = v[u];
     }
   } else {
-    // element-parallel: rows in the outer loop (no integer division), two rows in flight per thread
-    const int k4n = a.K >> 2;
-    int r = 0;
+    // element-parallel: rows in the outer loop (no integer division), two rows in flight per thread. The thread's first
+    // element(s) are peeled so that `first` sits in straight-line code between their loads and their LDS stores (the
+    // compiler then waits with an exact vmcnt for the activation loads only, not for the weights issued behind them).
+    const int k4n = a.K >> 2, k4s = wave * 64 + lane, step = W * 64;
+    const bool two = nrows >= 2;
+    {
+      float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+      if (k4s < k4n) {
+        o0 = stage_elem<PRO>(a, m0, k4s * 4);
+        if (two) o1 = stage_elem<PRO>(a, m0 + 1, k4s * 4);
+      }
+      first();
+      if (k4s < k4n) {
+        lds_store4<WT>(s_x, k4s * 4, o0.x, o0.y, o0.z, o0.w);
+        if (two) lds_store4<WT>(s_x + (size_t)row_bytes, k4s * 4, o1.x, o1.y, o1.z, o1.w);
+      }
+    }
+    for (int k4 = k4s + step; k4 < k4n; k4 += step) {
+      const float4 o0 = stage_elem<PRO>(a, m0, k4 * 4);
+      lds_store4<WT>(s_x, k4 * 4, o0.x, o0.y, o0.z, o0.w);
+      if (two) {
+        const float4 o1 = stage_elem<PRO>(a, m0 + 1, k4 * 4);
+        lds_store4<WT>(s_x + (size_t)row_bytes, k4 * 4, o1.x, o1.y, o1.z, o1.w);
+      }
+    }
+    int r = 2;
     for (; r + 1 < nrows; r += 2) {
-      for (int k4 = wave * 64 + lane; k4 < k4n; k4 += W * 64) {
+      for (int k4 = k4s; k4 < k4n; k4 += step) {
         const float4 o0 = stage_elem<PRO>(a, m0 + r, k4 * 4);
         const float4 o1 = stage_elem<PRO>(a, m0 + r + 1, k4 * 4);
         lds_store4<WT>(s_x + (size_t)r * row_bytes, k4 * 4, o0.x, o0.y, o0.z, o0.w);
@@ -279,7 +323,7 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
       }
     }
     if (r < nrows) {
-      for (int k4 = wave * 64 + lane; k4 < k4n; k4 += W * 64) {
+      for (int k4 = k4s; k4 < k4n; k4 += step) {
         const float4 o0 = stage_elem<PRO>(a, m0 + r, k4 * 4);
         lds_store4<WT>(s_x + (size_t)r * row_bytes, k4 * 4, o0.x, o0.y, o0.z, o0.w);
       }
@@ -311,18 +355,26 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   for (int m0 = 0; m0 < a.M; m0 += a.rows_per_pass) {
     const int nrows = min(a.rows_per_pass, a.M - m0);
     PTTS_STAMP(PTTS_DBG(a), 0);
-    // 1. put the first group of weight fragments in flight before anything that depends on activations
+    // 1. the first group of weight fragments goes in flight as early as possible - but AFTER this thread's first
+    //    activation loads (issue order = return order; the activations are the critical path, the weights are bulk).
     uint4 afr[U];
+    auto issue_w = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // no fence: every wave's activation loads are queued before anybody's weights
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+      for (int u = 0; u < U; ++u)
+        if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+      __builtin_amdgcn_sched_barrier(0);  // keep the issue order: nothing that waits on a load moves above these
+    };
     // 2. activations of this pass -> LDS (final form, engine dtype). PRO_COPY rows are already final and
     //    L2-resident: their B fragments (16 B per lane) are read straight from global, no staging, no barrier.
     PTTS_STAMP(PTTS_DBG(a), 1);
     if (PRO != PRO_COPY) {
-      stage_rows<WT, PRO, FULL>(a, m0, nrows, s_x, row_bytes, lane, wave, W);
+      stage_rows<WT, PRO, FULL>(a, m0, nrows, s_x, row_bytes, lane, wave, W, issue_w);
       PTTS_STAMP(PTTS_DBG(a), 2);
       __syncthreads();
+    } else {
+      issue_w();
     }
     PTTS_STAMP(PTTS_DBG(a), 3);
     // 3. MFMA over this wave's K slice; B fragments come from LDS (rows beyond nrows are clamped: their output
@@ -687,25 +739,32 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   const int b = min(wave, a.B - 1);  // attention of utterance b runs on wave b
   const int N = a.dims->N;
 
-  // ---- t = 0: every independent global load of the kernel goes in flight -----------------------------------------
+  // ---- t = 0: every independent global load of the kernel goes in flight; the residual rows first (critical path:
+  // LayerNorm -> projection), then the bulk loads nobody waits for yet. Addresses are clamped by the cache capacity
+  // (a kernel argument), NOT by dims->N (device memory: would put a dependent round trip in front of every K/V load).
   uint4 afr[UW];
-#pragma unroll
-  for (int u = 0; u < UW; ++u) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
   const uint4* Kb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.nheads + h) * a.cap * 64);
   const uint4* Vb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.nheads + h) * a.cap * 64);
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
   uint4 kf[U], vf[U];
   int mk[U];
+  auto issue_bulk = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // no fence: the residual-row loads of every wave are queued before the bulk loads
 #pragma unroll
-  for (int u = 0; u < U; ++u) {  // first 8 row groups (covers N <= 64 bf16 / 32 fp32 in one batch)
-    const int t = u * RPI + r;
-    const int tc = t < N ? t : 0;
-    kf[u] = Kb[(size_t)tc * LPR + c];
-    vf[u] = Vb[(size_t)tc * LPR + c];
-    mk[u] = mrow ? mrow[tc] : 1;
-  }
+    for (int u = 0; u < UW; ++u) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // first 8 row groups (covers N <= 64 bf16 / 32 fp32 in one batch)
+      const int t = u * RPI + r;
+      const int tc = t < a.cap ? t : 0;
+      kf[u] = Kb[(size_t)tc * LPR + c];
+      vf[u] = Vb[(size_t)tc * LPR + c];
+      mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
   // ---- LayerNorm of the B rows -> LDS, then the head's 64 q rows ------------------------------------------------------
-  ln_stage<WT, NF4, true, XAttnArgs, false>(a, 0, a.B, s_x, row_bytes, lane, wave, NWV);  // K == NF4 * 256
+  ln_stage<WT, NF4, true, XAttnArgs, false>(a, 0, a.B, s_x, row_bytes, lane, wave, NWV, issue_bulk);  // K == NF4 * 256
   __syncthreads();
   const char* brow = s_x + (size_t)min(j, a.B - 1) * row_bytes + (size_t)q4 * 16;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
