@@ -147,7 +147,7 @@ constexpr int LN_MAX_F4 = 8;  // LayerNorm rows up to 64 lanes * 8 float4 = 2048
 // pass of sum(x-c) and sum((x-c)^2) with the shift c = x[0] (shifted-data variance: no catastrophic cancellation,
 // error ~ eps*(1 + (mean-c)^2/var)); eps 1e-5 as nn.LayerNorm (modeling:961). EXACT: K == NF4*256, no lane masks.
 template <typename WT, int NF4, bool EXACT, int R, typename Args, typename Hook>
-__device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[R], char* const (&row)[R], int lane, Hook&& after_x_issued) {
+__device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[R], char* const (&row)[R], int lane, Hook&& hook) {
   // Issue order = need order: the CU returns loads in issue order, so the 4 KB row (critical path) goes first, the
   // caller's bulk weight loads (hook) next, gamma/beta (needed only after the reductions) last. With the weights
   // first the row queued behind 32-128 KB per CU: +0.7 us per LayerNorm kernel (tools/chain_probe.hip).
@@ -167,7 +167,7 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
     g[i] = *reinterpret_cast<const float4*>(a.gamma + kk);
     bt[i] = *reinterpret_cast<const float4*>(a.beta + kk);
   }
-  after_x_issued();
+  hook(0);  // workgroup rendezvous: every wave's row loads are queued before any wave's weight loads
   float c[R], s1[R], s2[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -183,6 +183,7 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) { s1[r] = wave_sum(s1[r]); s2[r] = wave_sum(s2[r]); }
+  hook(1);  // this wave's weight loads: after its rows have arrived and been reduced (best of the orders measured)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const float dm = s1[r] * a.invK;
@@ -199,7 +200,7 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
 }
 
 // `first` runs exactly once per wave: right after the wave's first row loads are in flight, or at once if it owns no row.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 template <typename WT, int NF4, bool EXACT, typename Args, bool PAIRS = true, typename Hook>
 __device__ __forceinline__ void ln_stage(const Args& a, int m0, int nrows, char* s_x, int row_bytes, int lane, int wave, int W, Hook&& first) {
   auto xrow = [&](int r) { return a.x + (size_t)((m0 + r) * a.x_row_mul + a.x_row_off) * a.x_ld; };
@@ -215,7 +216,7 @@ __device__ __forceinline__ void ln_stage(const Args& a, int m0, int nrows, char*
     ln_rows<WT, NF4, EXACT, 1>(a, xr, row, lane, first);
     r += W;
   } else {
-    first();
+    first(2);
   }
   for (; PAIRS && r + W < nrows; r += 2 * W) {  // two rows of this wave in flight
     const float* const xr[2] = {xrow(r), xrow(r + W)};
@@ -267,7 +268,7 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
       else ln_stage<WT, LN_MAX_F4, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);
     }
   } else if (PRO == PRO_COPY) {
-    first();
+    first(2);
     // bulk copy of engine-dtype rows, 16 B per lane, 8 independent loads in flight per thread
     constexpr int EPV = 16 / (int)sizeof(WT);
     const int vpr = a.K / EPV;  // 16-byte vectors per row
@@ -299,7 +300,7 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
         o0 = stage_elem<PRO>(a, m0, k4s * 4);
         if (two) o1 = stage_elem<PRO>(a, m0 + 1, k4s * 4);
       }
-      first();
+      first(2);
       if (k4s < k4n) {
         lds_store4<WT>(s_x, k4s * 4, o0.x, o0.y, o0.z, o0.w);
         if (two) lds_store4<WT>(s_x + (size_t)row_bytes, k4s * 4, o1.x, o1.y, o1.z, o1.w);
@@ -333,7 +334,7 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
 
 // LN / ATTN prologues always reduce over K = hidden_size (<= 8 waves of >= 8 fragments); only the plain prologue
 // (fc2, K = ffn_dim) at batch <= 16 wants 16 waves, so only it pays the 128-VGPR cap of a 1024-thread workgroup.
-template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value = ((PRO == PRO_PLAIN || PRO == PRO_COPY) && MTP == 1) ? 1024 : 512; };
+template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value = (PRO == PRO_PLAIN && MTP == 1) ? 1024 : 512; };
 
 // a.rows_per_pass rows (<= 16*MTP) of activations are staged per pass; LDS = staging + cross-wave reduction.
 // FULL: every wave owns a whole number of 8-fragment groups and K % 256 == 0 -> straight-line code, no predicates.
@@ -355,16 +356,26 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   for (int m0 = 0; m0 < a.M; m0 += a.rows_per_pass) {
     const int nrows = min(a.rows_per_pass, a.M - m0);
     PTTS_STAMP(PTTS_DBG(a), 0);
+    // 0. EPI_RESID: the residual values this wave will update are fetched now, not after the reduction (one cold
+    //    round trip off the tail of the kernel)
+    float4 resid_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_RESID && wave < MTP && wave * 16 + j < nrows)
+      resid_pre = *reinterpret_cast<const float4*>(a.out + (size_t)(m0 + wave * 16 + j) * a.out_ld + strip * 16 + q * 4);
     // 1. the first group of weight fragments goes in flight as early as possible - but AFTER this thread's first
     //    activation loads (issue order = return order; the activations are the critical path, the weights are bulk).
     uint4 afr[U];
-    auto issue_w = [&]() __attribute__((always_inline)) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // no fence: every wave's activation loads are queued before anybody's weights
+    // stage 0 = rendezvous only, 1 = loads only, 2 = both (see ln_rows for why LayerNorm waves split the two)
+    auto issue_w = [&](int stage) __attribute__((always_inline)) {
+      if (stage != 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // no fence: every wave's activation loads are queued before anybody's weights
+      }
+      if (stage != 0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
-      __builtin_amdgcn_sched_barrier(0);  // keep the issue order: nothing that waits on a load moves above these
+        for (int u = 0; u < U; ++u)
+          if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+        __builtin_amdgcn_sched_barrier(0);  // keep the issue order: nothing that waits on a load moves above these
+      }
     };
     // 2. activations of this pass -> LDS (final form, engine dtype). PRO_COPY rows are already final and
     //    L2-resident: their B fragments (16 B per lane) are read straight from global, no staging, no barrier.
@@ -374,7 +385,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
       PTTS_STAMP(PTTS_DBG(a), 2);
       __syncthreads();
     } else {
-      issue_w();
+      issue_w(1);
     }
     PTTS_STAMP(PTTS_DBG(a), 3);
     // 3. MFMA over this wave's K slice; B fragments come from LDS (rows beyond nrows are clamped: their output
@@ -442,7 +453,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
           for (int e = 0; e < 4; ++e) store_from_f32<WT>(o + e, gelu_erf(r[e]));
         } else if (EPI == EPI_RESID) {
           float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
-          float4 o = *p;
+          float4 o = mt == wave ? resid_pre : *p;
           o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
           *p = o;
         } else {  // EPI_KV: n in [0, 2H): first half K, second half V
@@ -564,8 +575,39 @@ __device__ __forceinline__ void load_chunk_rope(const float* row, int d0, const 
   for (int e = 0; e < EPL; ++e) out[e] = cos ? x[e] * cs[e] + sign * y[e] * sn[e] : x[e];
 }
 
-// All global loads of a wave's first batch (q chunk, new K/V row, 8 K + 8 V cache rows, masks) are issued before the
-// first wait: two dependent round trips per kernel (lengths, then everything else) instead of four.
+// raw loads of a row chunk and (for RoPE) of its rotate_half partner chunk; the rotation is applied later, once the
+// position is known, so that these loads do not wait for the device-resident lengths
+template <int EPL>
+__device__ __forceinline__ void load_chunk_raw(const float* row, int d0, bool partner, float (&x)[EPL], float (&y)[EPL]) {
+  const int dp = d0 < 32 ? d0 + 32 : d0 - 32;
+#pragma unroll
+  for (int e4 = 0; e4 < EPL / 4; ++e4) {
+    const float4 t = reinterpret_cast<const float4*>(row + d0)[e4];
+    x[e4 * 4] = t.x; x[e4 * 4 + 1] = t.y; x[e4 * 4 + 2] = t.z; x[e4 * 4 + 3] = t.w;
+    if (partner) {
+      const float4 u = reinterpret_cast<const float4*>(row + dp)[e4];
+      y[e4 * 4] = u.x; y[e4 * 4 + 1] = u.y; y[e4 * 4 + 2] = u.z; y[e4 * 4 + 3] = u.w;
+    }
+  }
+}
+template <int EPL>
+__device__ __forceinline__ void rope_apply(float (&x)[EPL], const float (&y)[EPL], int d0, const float* cos, const float* sin, size_t pos) {
+  if (!cos) return;
+  const float sign = d0 < 32 ? -1.f : 1.f;
+#pragma unroll
+  for (int e4 = 0; e4 < EPL / 4; ++e4) {
+    const float4 c4 = reinterpret_cast<const float4*>(cos + pos * 64 + d0)[e4];
+    const float4 s4 = reinterpret_cast<const float4*>(sin + pos * 64 + d0)[e4];
+    x[e4 * 4 + 0] = x[e4 * 4 + 0] * c4.x + sign * y[e4 * 4 + 0] * s4.x;
+    x[e4 * 4 + 1] = x[e4 * 4 + 1] * c4.y + sign * y[e4 * 4 + 1] * s4.y;
+    x[e4 * 4 + 2] = x[e4 * 4 + 2] * c4.z + sign * y[e4 * 4 + 2] * s4.z;
+    x[e4 * 4 + 3] = x[e4 * 4 + 3] * c4.w + sign * y[e4 * 4 + 3] * s4.w;
+  }
+}
+
+// ONE dependent round trip per kernel: every global load of a wave's first batch (q chunk, new K/V row, 8 K + 8 V cache
+// rows, masks) is issued together with the loads of the device-resident lengths. Addresses are clamped by the cache
+// capacity (a kernel argument); validity against the lengths is applied when the data is used.
 template <typename WT, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8;
@@ -574,22 +616,42 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z / a.Q, qi = blockIdx.z % a.Q;
   const int row = b * a.Q + qi;
-  const int P = a.dims->P;
-  const int pos = (a.cur_len ? P + a.cur_len[b] - 1 : 0) + qi;
-  const int L = a.cross ? a.dims->N : pos + 1;
-  const int mask_len = a.cross ? L : P;
   const int r = lane / LPR, c = lane % LPR;
+  const int TW = a.S * NW, wv = s * NW + w;
 
-  float qv[EPL];
-  load_chunk_rope<EPL>(a.q + (size_t)row * a.q_ld + h * 64, c * EPL, a.cos, a.sin, (size_t)pos, qv);
-
-  uint4 knew_p = make_uint4(0, 0, 0, 0), vnew_p = make_uint4(0, 0, 0, 0);
+  // ---- t = 0: all loads ---------------------------------------------------------------------------------------------
+  const int P = a.dims->P;
+  const int Nenc = a.cross ? a.dims->N : 0;
+  const int cl = a.cur_len ? a.cur_len[b] : 0;
+  float qv[EPL], qy[EPL], kk[EPL], ky[EPL], vv[EPL], vy[EPL];
+  load_chunk_raw<EPL>(a.q + (size_t)row * a.q_ld + h * 64, c * EPL, a.cos != nullptr, qv, qy);
+  if (a.fused_append) {
+    load_chunk_raw<EPL>(a.knew + (size_t)row * a.kv_ld + h * 64, c * EPL, a.cos != nullptr, kk, ky);
+    load_chunk_raw<EPL>(a.vnew + (size_t)row * a.kv_ld + h * 64, c * EPL, false, vv, vy);
+  }
   WT* Kc = reinterpret_cast<WT*>(a.kcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
   WT* Vc = reinterpret_cast<WT*>(a.vcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
+  const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
+  const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
+  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  uint4 kf[U], vf[U];
+  int mk[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int t = (wv + u * TW) * RPI + r;
+    const int tc = t < a.cap ? t : 0;
+    kf[u] = Kb[(size_t)tc * LPR + c];
+    vf[u] = Vb[(size_t)tc * LPR + c];
+    mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
+  }
+  // ---- lengths known from here on -------------------------------------------------------------------------------------
+  const int pos = (a.cur_len ? P + cl - 1 : 0) + qi;
+  const int L = a.cross ? Nenc : pos + 1;
+  const int mask_len = a.cross ? L : P;
+  rope_apply<EPL>(qv, qy, c * EPL, a.cos, a.sin, (size_t)pos);
+  uint4 knew_p = make_uint4(0, 0, 0, 0), vnew_p = make_uint4(0, 0, 0, 0);
   if (a.fused_append) {
-    float kk[EPL], vv[EPL];
-    load_chunk_rope<EPL>(a.knew + (size_t)row * a.kv_ld + h * 64, c * EPL, a.cos, a.sin, (size_t)pos, kk);
-    load_chunk_rope<EPL>(a.vnew + (size_t)row * a.kv_ld + h * 64, c * EPL, nullptr, nullptr, 0, vv);
+    rope_apply<EPL>(kk, ky, c * EPL, a.cos, a.sin, (size_t)pos);
     knew_p = pack16(kk, WT());
     vnew_p = pack16(vv, WT());
     if (s == 0 && w == 0 && r == 0) {  // single writer of the new cache row
@@ -600,39 +662,34 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
 #pragma unroll
   for (int e = 0; e < EPL; ++e) qv[e] *= a.scale;
 
-  const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
-  const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
-  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
   const int G = (L + RPI - 1) / RPI;
-  const int TW = a.S * NW, wv = s * NW + w;
   float m_run = -INFINITY, l_run = 0.f, o[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] = 0.f;
 
   for (int g0 = wv; g0 < G; g0 += TW * U) {
-    uint4 kf[U], vf[U];
-    int mk[U];
     bool ok[U];
+    if (g0 != wv) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {  // loads only: clamped addresses, validity applied afterwards
-      const int t = (g0 + u * TW) * RPI + r;
-      ok[u] = t < L;
-      const int tc = ok[u] ? t : 0;
-      kf[u] = Kb[(size_t)tc * LPR + c];
-      vf[u] = Vb[(size_t)tc * LPR + c];
-      mk[u] = (mrow && tc < mask_len) ? mrow[tc] : 1;
+      for (int u = 0; u < U; ++u) {  // loads only: clamped addresses, validity applied afterwards
+        const int t = (g0 + u * TW) * RPI + r;
+        const int tc = t < L ? t : 0;
+        kf[u] = Kb[(size_t)tc * LPR + c];
+        vf[u] = Vb[(size_t)tc * LPR + c];
+        mk[u] = (mrow && tc < mask_len) ? mrow[tc] : 1;
+      }
     }
     float sc[U], bm = -INFINITY;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = (g0 + u * TW) * RPI + r;
-      ok[u] = ok[u] && mk[u] != 0;
+      ok[u] = t < L && (t >= mask_len || mk[u] != 0);
       if (a.fused_append && t == pos) { kf[u] = knew_p; vf[u] = vnew_p; }
-      float kk[EPL];
-      unpack16(kf[u], kk, WT());
+      float kx[EPL];
+      unpack16(kf[u], kx, WT());
       float d = 0.f;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kk[e], d);
+      for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kx[e], d);
       d = group_reduce<OpSum, LPR>(d);
       sc[u] = ok[u] ? d : -INFINITY;
       bm = fmaxf(bm, sc[u]);
@@ -647,11 +704,11 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float p = ok[u] ? expf(sc[u] - m_new) : 0.f;
-      float vv[EPL];
-      unpack16(vf[u], vv, WT());
+      float vx[EPL];
+      unpack16(vf[u], vx, WT());
       l_run += p;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(p, vv[e], o[e]) : o[e];  // masked rows may hold NaN/garbage V
+      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(p, vx[e], o[e]) : o[e];  // masked rows may hold NaN/garbage V
     }
     m_run = m_new;
   }
@@ -748,20 +805,24 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
   uint4 kf[U], vf[U];
   int mk[U];
-  auto issue_bulk = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();  // no fence: the residual-row loads of every wave are queued before the bulk loads
-#pragma unroll
-    for (int u = 0; u < UW; ++u) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {  // first 8 row groups (covers N <= 64 bf16 / 32 fp32 in one batch)
-      const int t = u * RPI + r;
-      const int tc = t < a.cap ? t : 0;
-      kf[u] = Kb[(size_t)tc * LPR + c];
-      vf[u] = Vb[(size_t)tc * LPR + c];
-      mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
+  auto issue_bulk = [&](int stage) __attribute__((always_inline)) {
+    if (stage != 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // no fence: the residual-row loads of every wave are queued before the bulk loads
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (stage != 0) {
+#pragma unroll
+      for (int u = 0; u < UW; ++u) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // first 8 row groups (covers N <= 64 bf16 / 32 fp32 in one batch)
+        const int t = u * RPI + r;
+        const int tc = t < a.cap ? t : 0;
+        kf[u] = Kb[(size_t)tc * LPR + c];
+        vf[u] = Vb[(size_t)tc * LPR + c];
+        mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   // ---- LayerNorm of the B rows -> LDS, then the head's 64 q rows ------------------------------------------------------
   ln_stage<WT, NF4, true, XAttnArgs, false>(a, 0, a.B, s_x, row_bytes, lane, wave, NWV, issue_bulk);  // K == NF4 * 256
