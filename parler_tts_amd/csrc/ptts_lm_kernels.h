@@ -117,12 +117,21 @@ template <> struct MfmaStep<float> {
 #else
 #define PTTS_STAMP(ptr, i) do { } while (0)
 #endif
+#ifdef PTTS_TIMING
+template <typename A> __device__ __forceinline__ long long* ptts_dbg_of(const A&) { return nullptr; }
+#define PTTS_LN_STAMP(a, i) PTTS_STAMP(ptts_dbg_of(a), i)
+#else
+#define PTTS_LN_STAMP(a, i) do { } while (0)
+#endif
 #ifndef PTTS_TIMING
 #define PTTS_DBG(a) ((long long*)nullptr)
 #else
 #define PTTS_DBG(a) ((a).dbg)
 #endif
 
+#ifdef PTTS_TIMING
+template <> __device__ __forceinline__ long long* ptts_dbg_of<GemmArgs>(const GemmArgs& a) { return a.dbg; }
+#endif
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ---- activation staging ---------------------------------------------------------------------------------
@@ -167,7 +176,9 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
     g[i] = *reinterpret_cast<const float4*>(a.gamma + kk);
     bt[i] = *reinterpret_cast<const float4*>(a.beta + kk);
   }
+  PTTS_LN_STAMP(a, 6);
   hook(0);  // workgroup rendezvous: every wave's row loads are queued before any wave's weight loads
+  PTTS_LN_STAMP(a, 7);
   float c[R], s1[R], s2[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -182,8 +193,11 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
     }
   }
 #pragma unroll
+  PTTS_LN_STAMP(a, 8);
   for (int r = 0; r < R; ++r) { s1[r] = wave_sum(s1[r]); s2[r] = wave_sum(s2[r]); }
-  hook(1);  // this wave's weight loads: after its rows have arrived and been reduced (best of the orders measured)
+  PTTS_LN_STAMP(a, 9);
+  // normalise in registers (consumes gamma/beta: every load of this wave has landed), THEN start this wave's weight
+  // stream, then write LDS: no wait on a row/gamma/beta load can end up behind the weight loads
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const float dm = s1[r] * a.invK;
@@ -191,12 +205,21 @@ __device__ __forceinline__ void ln_rows(const Args& a, const float* const (&xr)[
     const float rstd = rsqrtf(fmaxf(s2[r] * a.invK - dm * dm, 0.f) + 1e-5f);
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
-      const int k = (lane + 64 * i) * 4;
-      if (EXACT || k < a.K)
-        lds_store4<WT>(row[r], k, (v[r][i].x - mean) * rstd * g[i].x + bt[i].x, (v[r][i].y - mean) * rstd * g[i].y + bt[i].y,
-                       (v[r][i].z - mean) * rstd * g[i].z + bt[i].z, (v[r][i].w - mean) * rstd * g[i].w + bt[i].w);
+      v[r][i].x = (v[r][i].x - mean) * rstd * g[i].x + bt[i].x;
+      v[r][i].y = (v[r][i].y - mean) * rstd * g[i].y + bt[i].y;
+      v[r][i].z = (v[r][i].z - mean) * rstd * g[i].z + bt[i].z;
+      v[r][i].w = (v[r][i].w - mean) * rstd * g[i].w + bt[i].w;
     }
   }
+  PTTS_LN_STAMP(a, 10);
+  hook(1);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int k = (lane + 64 * i) * 4;
+      if (EXACT || k < a.K) lds_store4<WT>(row[r], k, v[r][i].x, v[r][i].y, v[r][i].z, v[r][i].w);
+    }
 }
 
 // `first` runs exactly once per wave: right after the wave's first row loads are in flight, or at once if it owns no row.

@@ -54,9 +54,11 @@ int main() {
     for (int i = 0; i < 100; ++i) hipGraphLaunch(ex, st);
     hipEventRecord(e1, st); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    long long t[8]; hipMemcpy(t, dbg, 64, hipMemcpyDeviceToHost);
-    printf("%s W=%2d: %.2f us per node | ticks@100MHz?: issue-W %lld, stage %lld, barrier %lld, mfma(+W wait) %lld, reduce+store %lld, total %lld\n", cs.name, Wv,
+    long long t[16]; hipMemcpy(t, dbg, 128, hipMemcpyDeviceToHost);
+    printf("%s W=%2d: %.2f us per node | ticks: issue-W %lld, stage %lld, barrier %lld, mfma(+W wait) %lld, reduce+store %lld, total %lld\n", cs.name, Wv,
            ms * 1e3f / 100 / NODES, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+    if (cs.pro == PRO_LN) printf("      LN stage: loads issued +%lld, rendezvous +%lld, rows arrived+accumulated +%lld, wave reductions +%lld, normalise +%lld, weight issue + LDS stores +%lld\n",
+           t[6] - t[1], t[7] - t[6], t[8] - t[7], t[9] - t[8], t[10] - t[9], t[2] - t[10]);
     hipGraphExecDestroy(ex); hipGraphDestroy(g);
   }
   return 0;
