@@ -50,6 +50,7 @@ struct ptts_engine {
   float *h = nullptr, *qkv = nullptr, *qc = nullptr, *part = nullptr, *stats = nullptr, *ffn = nullptr, *logits = nullptr;
   float* sort_buf = nullptr;
   void *xw = nullptr, *xw2 = nullptr;  // engine-dtype activation rows for the M > 8 path: [rows][H], [rows][F]
+  float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
   // state
@@ -151,6 +152,36 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   return PTTS_OK;
 }
 
+// fc2 at 8 < batch <= 32 (decode): 64 strips x 128 KB of weights on 64 CUs is bound by what ONE CU can pull (~50 GB/s:
+// 12.8 us for 8 MB). Split K over blockIdx.y -> 256 workgroups x 32 KB; the partial products go to part[split][M][N] and
+// the next LayerNorm prep kernel adds them (and the residual) in a fixed order: deterministic, no atomics.
+constexpr int FC2_KSPLIT = 4;
+template <typename WT>
+bool splitk_ok(int M, int N, int K) {
+  const int nfrag = K / Elem<WT>::KT;
+  return M > 8 && M <= 32 && N % 16 == 0 && nfrag % (FC2_KSPLIT * 16) == 0;
+}
+template <typename WT>
+int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of partials
+  const int per_split = a.K / Elem<WT>::KT / FC2_KSPLIT;
+  int W = 0;
+  for (int w = 8; w >= 2; --w)
+    if (per_split % (8 * w) == 0) { W = w; break; }
+  if (!W) return ptts_fail(PTTS_E_INVALID, "split-K gemm K=%d", a.K);
+  a.ksplit = per_split; a.frags_per_wave = per_split / W; a.invK = 1.0f / (float)a.K;
+  a.out_split_stride = (long long)a.M * a.out_ld;
+  a.rows_per_pass = a.M;
+  const int mtp = a.M > 16 ? 2 : 1;
+  const dim3 grid(a.N / 16, FC2_KSPLIT), block(W * 64);
+  const size_t sh = (size_t)W * mtp * 1024;
+  int rc = mtp == 1 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 1, true>(a, grid, block, sh, st)
+                    : launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 2, true>(a, grid, block, sh, st);
+  PTTS_TRY(rc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
 template <typename WT>
 int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
   const dim3 grid(a.S, a.nheads, B * a.Q);
@@ -211,12 +242,14 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     ea.prefill = prefill ? 1 : 0;
     hipLaunchKernelGGL((embed_kernel<WT>), dim3(Q, B), dim3(256), 0, st, ea);
   }
+  bool fc2_pending = false;
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
     {  // LN1 + fused QKV projection
       GemmArgs g = {};
       g.W = w.qkv; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
       g.out = e->qkv; g.out_ld = 3 * H; g.M = M; g.N = 3 * H; g.K = H;
+      if (fc2_pending) { g.part = e->hpart; g.S = FC2_KSPLIT; fc2_pending = false; }  // folded by the prep kernel (M > 8)
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
     if (prefill) {
@@ -294,7 +327,13 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         g.out = reinterpret_cast<float*>(e->xw2);
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
         g2.x = reinterpret_cast<const float*>(e->xw2);
-        PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g2, st)));
+        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F)) {
+          g2.out = e->hpart;  // h += sum of the partials happens in the next layer's LN1 prep kernel
+          PTTS_TRY((launch_gemm_splitk<WT>(g2, st)));
+          fc2_pending = true;
+        } else {
+          PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g2, st)));
+        }
       } else {
         g.out = e->ffn;
         PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_GELU>(g, st)));
@@ -459,6 +498,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->sort_buf, 16));
   A(e->alloc_bytes(&e->xw, rows * H * es));
   A(e->alloc_bytes(&e->xw2, std::max(rows * F, enc_rows * (size_t)H) * es));
+  A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
   e->ids_ld = c.max_ctx + 8;
   A(e->alloc(&e->ids, (size_t)c.max_batch * K * e->ids_ld));
   A(e->alloc(&e->cur_len, c.max_batch)); A(e->alloc(&e->unfinished, (size_t)c.max_batch * K));

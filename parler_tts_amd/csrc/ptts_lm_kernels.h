@@ -91,6 +91,8 @@ struct GemmArgs {
   int rows_per_pass;   // activation rows staged in LDS per pass (<= 16 * MTP)
   int frags_per_wave;  // FULL variant: K/KT/W, a multiple of 8
   float invK;          // 1 / K
+  int ksplit;          // split-K over blockIdx.y (PRO_COPY only): weight fragments per split, 0 = off
+  long long out_split_stride;  // elements between the partial outputs of two splits
 #ifdef PTTS_TIMING
   long long* dbg;      // phase timestamps (s_memtime) of workgroup 0 / wave 0
 #endif
@@ -373,8 +375,10 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   const int nfrag = a.K / KT;
   const int per = FULL ? a.frags_per_wave : (nfrag + W - 1) / W;
   const int t0 = wave * per, t1 = FULL ? t0 + per : min(nfrag, t0 + per);
-  const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
+  const int kb = PRO == PRO_COPY ? a.ksplit * (int)blockIdx.y : 0;  // split-K: this workgroup's first weight fragment
+  const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + ((size_t)strip * nfrag + kb) * 64 + lane;
   const int q = lane >> 4, j = lane & 15;
+  if (PRO == PRO_COPY) a.out += (size_t)blockIdx.y * a.out_split_stride;
 
   for (int m0 = 0; m0 < a.M; m0 += a.rows_per_pass) {
     const int nrows = min(a.rows_per_pass, a.M - m0);
@@ -418,7 +422,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     for (int mt = 0; mt < MTP; ++mt) {
       const int rloc = min(mt * 16 + j, nrows - 1);
       brow[mt] = PRO == PRO_COPY
-                     ? reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)((m0 + rloc) * a.x_row_mul + a.x_row_off) * a.x_ld) + (size_t)q * 16
+                     ? reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)((m0 + rloc) * a.x_row_mul + a.x_row_off) * a.x_ld + (size_t)kb * KT) + (size_t)q * 16
                      : s_x + (size_t)rloc * row_bytes + (size_t)q * 16;
     }
     f32x4 acc[MTP], acc2[MTP];  // two independent accumulator chains per tile (MFMA dependent latency)
@@ -510,6 +514,17 @@ __global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restri
   WT* out = dst + (size_t)m * a.K;
   if (PRO == PRO_LN) {
     const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
+    if (a.part) {  // pending split-K partials of the previous fc2 (+ residual): h += sum_s part[s], in fixed order
+      float* xw = const_cast<float*>(xr);
+      for (int k = lane * 4; k < a.K; k += 256) {
+        float4 t = *reinterpret_cast<const float4*>(xr + k);
+        for (int sp = 0; sp < a.S; ++sp) {
+          const float4 u = *reinterpret_cast<const float4*>(a.part + ((size_t)sp * a.M + m) * a.K + k);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(xw + k) = t;  // re-read below by the same lane only
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
     const float c = xr[0];
     for (int k = lane * 4; k < a.K; k += 256) {
