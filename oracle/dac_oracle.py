@@ -1,4 +1,5 @@
-"""TEST INFRASTRUCTURE ONLY — CPU restatement (torch fp32) of DAC ``decode`` (codes → waveform).
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (torch fp32) of DAC ``decode`` (codes → waveform) and ``encode``
+(waveform → codes, the voice-prompt path: dac_wrapper/modeling_dac.py:33-104 → ``model.preprocess`` :64, ``model.encode`` :95).
 
 Reference call sites: parler_tts/dac_wrapper/modeling_dac.py:138 (``quantizer.from_codes``) and :139
 (``model.decode``). The arithmetic lives in the third-party package ``descript-audio-codec``
@@ -9,6 +10,12 @@ stride s, pad ⌈s/2⌉), 3 × ResidualUnit(dil 1,3,9: Snake, Conv k7 dilated, S
 strides (8,8,4,2) → Snake → Conv1d(96→1,k7) → tanh; Snake(x) = x + (α+1e-9)⁻¹·sin²(αx); every conv is
 weight-normalised (w = g·v/‖v‖ per output channel; modeling_dac.py:148-164 re-applies it), folded here
 once at load.
+
+Encode: ``preprocess`` right-pads with zeros to a multiple of the hop; encoder = Conv1d(1→64,k7) → 4 × [3 × ResidualUnit
+(dil 1,3,9) at dim/2, Snake, Conv1d(dim/2→dim, k=2s, stride s, pad ⌈s/2⌉)] with strides (2,4,8,8) → Snake → Conv1d(1024→latent,
+k3); RVQ: per stage e = in_proj(residual) (1×1 conv to codebook_dim 8), nearest code by cosine similarity of the
+L2-normalised e and codebook (ViT-VQGAN trick), z_q = out_proj(e + (codebook[idx] − e)) (the straight-through expression is
+kept: it is not bit-identical to codebook[idx]), residual −= z_q.
 
 Pinning status: "parity unpinned" against descript-audio-codec itself (absent). The restatement is
 cross-checked against the only other on-disk statement of the same model — the independent
@@ -38,17 +45,22 @@ class DacSpec:
     decoder_rates: Tuple[int, ...] = (8, 8, 4, 2)
     sampling_rate: int = 44100
     frame_rate: int = 86
+    encoder_dim: int = 64  # descript 44 kHz default; encoder strides are the decoder's reversed
 
     @property
     def hop_length(self) -> int:
         return int(math.prod(self.decoder_rates))
 
+    @property
+    def encoder_rates(self) -> Tuple[int, ...]:
+        return tuple(reversed(self.decoder_rates))
+
 
 DAC_44KHZ = DacSpec()
-DAC_TINY = DacSpec(num_codebooks=9, latent_dim=64, decoder_dim=256, decoder_rates=(4, 2, 2, 2))
+DAC_TINY = DacSpec(num_codebooks=9, latent_dim=64, decoder_dim=256, decoder_rates=(4, 2, 2, 2), encoder_dim=16)
 
 
-def make_dac_weights(spec: DacSpec, seed: int = 4321, weight_norm_format: str = "folded") -> Dict[str, torch.Tensor]:
+def make_dac_weights(spec: DacSpec, seed: int = 4321, weight_norm_format: str = "folded", with_encoder: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded synthetic DAC weights under descript's module names (``quantizer.quantizers.i.*``,
     ``decoder.model.N.*``). Variance-preserving init (std = 1/sqrt(fan_in)) instead of N(0,0.02): with 0.02
     the 30-conv stack underflows to ~1e-12 and a waveform RMS tolerance would be vacuous.
@@ -101,6 +113,26 @@ def make_dac_weights(spec: DacSpec, seed: int = 4321, weight_norm_format: str = 
     cl = ch // 2 ** len(spec.decoder_rates)
     snake(f"{d}{len(spec.decoder_rates) + 1}", cl)
     conv(f"{d}{len(spec.decoder_rates) + 2}", 1, cl, 7)
+    if with_encoder:  # drawn AFTER everything above: the decode-only fixtures keep their values
+        for i in range(spec.num_codebooks):
+            conv(f"quantizer.quantizers.{i}.in_proj", spec.codebook_dim, spec.latent_dim, 1)
+        e = "encoder.block."
+        dim = spec.encoder_dim
+        conv(e + "0", dim, 1, 7)
+        for bi, st in enumerate(spec.encoder_rates):
+            b = f"{e}{bi + 1}.block."
+            for ri in range(3):
+                r = f"{b}{ri}.block."
+                snake(r + "0", dim)
+                conv(r + "1", dim, dim, 7, gain=0.5)
+                snake(r + "2", dim)
+                conv(r + "3", dim, dim, 1, gain=0.5)
+            snake(b + "3", dim)
+            conv(b + "4", 2 * dim, dim, 2 * st)
+            dim *= 2
+        n = len(spec.encoder_rates)
+        snake(f"{e}{n + 1}", dim)
+        conv(f"{e}{n + 2}", spec.latent_dim, dim, 3, gain=4.0)
     return sd
 
 
@@ -161,3 +193,56 @@ class DacOracle:
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
         """codes [B, K, T] → waveform [B, 1, hop·T]  (DACModel.decode, modeling_dac.py:138-139)."""
         return self.decode_latents(self.from_codes(codes))
+
+    # ---- encode (voice prompt) ------------------------------------------------------------------------------------
+    def preprocess(self, wave: torch.Tensor) -> torch.Tensor:
+        """Right-pad to a multiple of the hop (descript ``DAC.preprocess``; modeling_dac.py:64)."""
+        L = wave.shape[-1]
+        hop = self.spec.hop_length
+        return F.pad(wave, (0, math.ceil(L / hop) * hop - L))
+
+    def encode_latents(self, wave: torch.Tensor) -> torch.Tensor:
+        """wave [B, 1, L] (L a multiple of the hop) → z [B, latent, L / hop]."""
+        w, e = self.w, "encoder.block."
+        x = F.conv1d(wave, w[e + "0.weight"], w[e + "0.bias"], padding=3)
+        for bi, st in enumerate(self.spec.encoder_rates):
+            b = f"{e}{bi + 1}.block."
+            for ri, dil in enumerate((1, 3, 9)):
+                r = f"{b}{ri}.block."
+                y = snake1d(x, w[r + "0.alpha"])
+                y = F.conv1d(y, w[r + "1.weight"], w[r + "1.bias"], dilation=dil, padding=3 * dil)
+                y = snake1d(y, w[r + "2.alpha"])
+                y = F.conv1d(y, w[r + "3.weight"], w[r + "3.bias"])
+                x = x + y
+            x = snake1d(x, w[b + "3.alpha"])
+            x = F.conv1d(x, w[b + "4.weight"], w[b + "4.bias"], stride=st, padding=math.ceil(st / 2))
+        n = len(self.spec.encoder_rates)
+        x = snake1d(x, w[f"{e}{n + 1}.alpha"])
+        return F.conv1d(x, w[f"{e}{n + 2}.weight"], w[f"{e}{n + 2}.bias"], padding=1)
+
+    def quantize(self, z: torch.Tensor, n_quantizers: int | None = None):
+        """Residual VQ encode: z [B, latent, T] → (codes [B, nq, T] int64, min top-2 score margin per (b, t) over stages)."""
+        nq = self.spec.num_codebooks if n_quantizers is None else min(n_quantizers, self.spec.num_codebooks)
+        residual = z
+        codes, margins = [], []
+        for i in range(nq):
+            q = f"quantizer.quantizers.{i}."
+            cb = self.w[q + "codebook.weight"]
+            p = F.conv1d(residual, self.w[q + "in_proj.weight"], self.w[q + "in_proj.bias"])  # [B, cd, T]
+            B, cd, T = p.shape
+            enc = F.normalize(p.permute(0, 2, 1).reshape(B * T, cd))
+            cbn = F.normalize(cb)
+            dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cbn.t() + cbn.pow(2).sum(1, keepdim=True).t()
+            top2 = (-dist).topk(2, dim=1)
+            idx = (-dist).max(1)[1].reshape(B, T)
+            margins.append((top2.values[:, 0] - top2.values[:, 1]).reshape(B, T))
+            zq = F.embedding(idx, cb).transpose(1, 2)
+            zq = p + (zq - p)  # straight-through expression, evaluated as written
+            zq = F.conv1d(zq, self.w[q + "out_proj.weight"], self.w[q + "out_proj.bias"])
+            residual = residual - zq
+            codes.append(idx)
+        return torch.stack(codes, dim=1), torch.stack(margins, 0).min(0).values
+
+    def encode(self, wave: torch.Tensor, n_quantizers: int | None = None) -> torch.Tensor:
+        """wave [B, 1, L] → codes [B, K, ceil(L / hop)] (DACModel.encode with one chunk, modeling_dac.py:88-99)."""
+        return self.quantize(self.encode_latents(self.preprocess(wave)), n_quantizers)[0]

@@ -237,7 +237,7 @@ def hf_dac_port(spec: DA.DacSpec, sd):
     same folded weights — used only as a cross-check of the restatement."""
     from transformers import DacConfig, DacModel
 
-    cfg = DacConfig(encoder_hidden_size=16, downsampling_ratios=list(reversed(spec.decoder_rates)),
+    cfg = DacConfig(encoder_hidden_size=spec.encoder_dim, downsampling_ratios=list(reversed(spec.decoder_rates)),
                     decoder_hidden_size=spec.decoder_dim, n_codebooks=spec.num_codebooks,
                     codebook_size=spec.codebook_size, codebook_dim=spec.codebook_dim,
                     upsampling_ratios=list(spec.decoder_rates), hidden_size=spec.latent_dim, sampling_rate=spec.sampling_rate)
@@ -263,6 +263,24 @@ def hf_dac_port(spec: DA.DacSpec, sd):
     n = len(spec.decoder_rates)
     mp["decoder.snake1.alpha"] = w[f"decoder.model.{n + 1}.alpha"]
     mp["decoder.conv2.weight"], mp["decoder.conv2.bias"] = w[f"decoder.model.{n + 2}.weight"], w[f"decoder.model.{n + 2}.bias"]
+    if "encoder.block.0.weight" in w:  # encode side (voice prompt)
+        for i in range(spec.num_codebooks):
+            mp[f"quantizer.quantizers.{i}.in_proj.weight"] = w[f"quantizer.quantizers.{i}.in_proj.weight"]
+            mp[f"quantizer.quantizers.{i}.in_proj.bias"] = w[f"quantizer.quantizers.{i}.in_proj.bias"]
+        mp["encoder.conv1.weight"], mp["encoder.conv1.bias"] = w["encoder.block.0.weight"], w["encoder.block.0.bias"]
+        ne = len(spec.encoder_rates)
+        for bi in range(ne):
+            b, t = f"encoder.block.{bi + 1}.block.", f"encoder.block.{bi}."
+            for ri in range(3):
+                r, u = f"{b}{ri}.block.", f"{t}res_unit{ri + 1}."
+                mp[u + "snake1.alpha"] = w[r + "0.alpha"]
+                mp[u + "conv1.weight"], mp[u + "conv1.bias"] = w[r + "1.weight"], w[r + "1.bias"]
+                mp[u + "snake2.alpha"] = w[r + "2.alpha"]
+                mp[u + "conv2.weight"], mp[u + "conv2.bias"] = w[r + "3.weight"], w[r + "3.bias"]
+            mp[t + "snake1.alpha"] = w[b + "3.alpha"]
+            mp[t + "conv1.weight"], mp[t + "conv1.bias"] = w[b + "4.weight"], w[b + "4.bias"]
+        mp["encoder.snake1.alpha"] = w[f"encoder.block.{ne + 1}.alpha"]
+        mp["encoder.conv2.weight"], mp["encoder.conv2.bias"] = w[f"encoder.block.{ne + 2}.weight"], w[f"encoder.block.{ne + 2}.bias"]
     for k, v in mp.items():
         assert tgt[k].shape == v.shape, (k, tgt[k].shape, v.shape)
     m.load_state_dict({**tgt, **mp})
@@ -288,6 +306,33 @@ def gen_dac():
                         latents=orc.from_codes(codes).numpy())
 
 
+@torch.no_grad()
+def gen_dac_encode():
+    """DAC encode (voice prompt): restatement vs the transformers DacModel port on the same weights and waveform."""
+    spec = DA.DAC_TINY
+    sd = DA.make_dac_weights(spec, seed=4321, weight_norm_format="parametrized", with_encoder=True)
+    g = torch.Generator().manual_seed(11)
+    t = torch.arange(32 * 40 + 9) / 400.0
+    wave = (0.4 * torch.sin(2 * math.pi * 3.0 * t)[None, None] * torch.tensor([1.0, 0.6])[:, None, None]
+            + 0.2 * torch.randn(2, 1, t.numel(), generator=g))
+    orc = DA.DacOracle(spec, sd)
+    padded = orc.preprocess(wave)
+    z = orc.encode_latents(padded)
+    codes, margin = orc.quantize(z)
+    port = hf_dac_port(spec, sd)
+    z2 = port.encoder(padded)
+    codes2 = port.encode(padded).audio_codes
+    errz = float((z - z2).abs().max())
+    same = float((codes == codes2).float().mean())
+    safe = margin >= 1e-4  # a frame is margin-safe if every stage's top-2 score gap is clear of fp32 rounding
+    assert errz < 1e-4 * float(z.abs().max()), errz
+    assert bool((codes == codes2)[safe[:, None, :].expand_as(codes)].all()), "codes differ on margin-safe frames"
+    print(f"[dac-encode] latents max|Δ| = {errz:.3e} (|z|max {float(z.abs().max()):.2f}); codes identical on {same * 100:.2f}% of entries, "
+          f"all {int(safe.sum())}/{safe.numel()} margin-safe frames identical")
+    np.savez_compressed(os.path.join(GOLD, "dac_tiny_encode.npz"), weight_seed=4321, wave=wave.numpy(), latents=z.numpy(),
+                        codes=codes.numpy(), margin=margin.numpy())
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -299,6 +344,7 @@ def main():
         gen_decoder(ref, v)
         gen_greedy(ref, v)
     gen_dac()
+    gen_dac_encode()
     print("golden vectors written to", GOLD)
 
 

@@ -69,6 +69,23 @@ def test_dac_restatement_matches_golden():
     assert (orc.decode(t(g["codes"])) - t(g["wav"])).abs().max() < 1e-5
 
 
+def test_dac_encode_restatement_matches_golden():
+    """Voice-prompt path: latents to fp32 rounding, codes identical on every frame whose top-2 score gap is clear of it."""
+    g = np.load(os.path.join(GOLD, "dac_tiny_encode.npz"))
+    sd = DA.make_dac_weights(DA.DAC_TINY, seed=int(g["weight_seed"]), weight_norm_format="parametrized", with_encoder=True)
+    orc = DA.DacOracle(DA.DAC_TINY, sd)
+    wave = t(g["wave"])
+    padded = orc.preprocess(wave)
+    assert padded.shape[-1] % DA.DAC_TINY.hop_length == 0 and padded.shape[-1] - wave.shape[-1] < DA.DAC_TINY.hop_length
+    z = orc.encode_latents(padded)
+    assert (z - t(g["latents"])).abs().max() < 1e-5
+    codes, margin = orc.quantize(z)
+    safe = (t(g["margin"]) >= 1e-4)[:, None, :].expand_as(codes)
+    assert torch.equal(codes[safe], t(g["codes"])[safe])
+    assert torch.equal(orc.encode(wave), codes)
+    assert orc.encode(wave, n_quantizers=3).shape[1] == 3 and torch.equal(orc.encode(wave, n_quantizers=3), codes[:, :3])
+
+
 def test_weight_norm_formats_fold_identically():
     a = DA.fold_weight_norm(DA.make_dac_weights(DA.DAC_TINY, 7, "legacy"))
     b = DA.fold_weight_norm(DA.make_dac_weights(DA.DAC_TINY, 7, "parametrized"))
