@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 1
+#define PTTS_ABI_VERSION 2
 
 enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
 
@@ -95,6 +95,12 @@ int ptts_weights_ready(ptts_engine* e);
 
 int ptts_set_gen_params(ptts_engine* e, const ptts_gen_params* gp);
 
+/* Voice prompt (modeling_parler_tts.py:3136-3194: `input_values` -> audio codes -> `decoder_input_ids`; delay pattern over a
+ * given prefix :205-276): codes_dev int64 [B*K, T] = the un-delayed codes of T prompt frames. Applies to the NEXT
+ * ptts_prefill only, which then also runs the T prefix columns (teacher-forced) before the first sampled column;
+ * min_new_tokens / max_length count from the 1 + T given columns as `_sample` does. T = 0 clears a pending prefix. */
+int ptts_set_audio_prefix(ptts_engine* e, const int64_t* codes_dev, int32_t B, int32_t T, void* stream);
+
 /* Prefill = the first _sample iteration (:3564; forward :1392-1655 with prompt_hidden_states prepended
  * :1437-1439): computes cross K/V from the (already projected + masked, :3086-3093) encoder states, runs
  * P+1 positions (prompt embeddings + the BOS column) through the stack, fills the self KV cache, leaves
@@ -142,6 +148,7 @@ typedef struct {
   int32_t compute_dtype; /* PTTS_F32: exact-f32 MFMA (parity, RMS <= 1e-4); PTTS_BF16: bf16 MFMA operands, fp32 accumulate */
   int32_t max_batch, max_frames;
   int32_t device;
+  int32_t encoder_dim;   /* 0: decode only; > 0: also build the encoder (descript default 64) for ptts_dac_encode */
 } ptts_dac_config;
 
 int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out);
@@ -153,6 +160,13 @@ int ptts_dac_load_weight(ptts_dac* d, const char* name, const float* dev_ptr, co
 int ptts_dac_weights_ready(ptts_dac* d);
 /* codes_dev int64 [B, K, T] -> wave_dev float32 [B, hop*T]  (hop = prod(rates)). */
 int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream);
+/* DACModel.encode for voice prompts (dac_wrapper/modeling_dac.py:33-104, used by modeling_parler_tts.py:3136-3194):
+ * wave_dev float32 [B, L], L a multiple of the hop (the caller applies model.preprocess's right zero padding, :64)
+ * -> codes_dev int64 [B, n_quantizers, L/hop]  (model.encode :95: encoder stack + residual VQ nearest-neighbour search).
+ * n_quantizers <= 0 means all. Extra weights: "encoder.block...", "quantizer.quantizers.i.in_proj.{weight,bias}". */
+int ptts_dac_encode(ptts_dac* d, const float* wave_dev, int64_t* codes_dev, int32_t B, int32_t L, int32_t n_quantizers, void* stream);
+/* Debug / parity probe: latents z of the last encode, channels-last fp32 [B, L/hop, latent_dim]. */
+int ptts_dac_debug_latents(ptts_dac* d, float** latents_dev);
 
 #ifdef __cplusplus
 }

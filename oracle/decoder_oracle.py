@@ -373,14 +373,21 @@ class GenTrace:
 
 def sample_loop(model: DecoderOracle, enc: torch.Tensor, enc_mask: Optional[torch.Tensor],
                 prompt: Optional[torch.Tensor], prompt_mask: Optional[torch.Tensor], gp: GenParams,
-                generator: Optional[torch.Generator] = None, keep_logits: bool = False) -> GenTrace:
+                generator: Optional[torch.Generator] = None, keep_logits: bool = False,
+                decoder_input_ids: Optional[torch.Tensor] = None) -> GenTrace:
+    """``decoder_input_ids`` [bsz*K, T]: un-delayed audio codes of a voice prompt (modeling:3136-3194); the BOS column is
+    prepended (:3017-3018), the delay pattern built over the prefix (:3523-3530) and the first forward runs over all given
+    columns at once, as the reference does."""
     spec = model.spec
     K = spec.num_codebooks
     bsz = enc.shape[0]
     eos, pad, bos = spec.eos_token_id, spec.pad_token_id, spec.bos_token_id
     model.reset()
     seq = torch.full((bsz * K, 1), bos, dtype=torch.long)  # :3011-3014
-    _, pattern = build_delay_pattern_mask(seq, bos, pad, gp.max_length, K)  # :3523-3530
+    if decoder_input_ids is not None and decoder_input_ids.shape[-1] > 0:
+        seq = torch.cat([seq, decoder_input_ids.long()], dim=-1)
+    seq, pattern = build_delay_pattern_mask(seq, bos, pad, gp.max_length, K)  # :3523-3530
+    given = seq.shape[-1]
     gate = EosGate(eos, K, bsz) if gp.use_eos_gate else None
     unfinished = torch.ones(bsz * K, dtype=torch.long)
     tr = GenTrace(sequences=seq)
@@ -395,7 +402,7 @@ def sample_loop(model: DecoderOracle, enc: torch.Tensor, enc_mask: Optional[torc
         if keep_logits:
             tr.step_logits.append(scores.clone())
         # processors: [MinNewTokensLength] + [ParlerTTSLogitsProcessor] + warpers (4.46.1 _get_logits_processor order)
-        if gp.min_new_tokens > 0 and (seq.shape[-1] - 1) < gp.min_new_tokens:
+        if gp.min_new_tokens > 0 and (seq.shape[-1] - given) < gp.min_new_tokens:
             scores[:, eos] = -math.inf
         if gate is not None:
             scores = gate(seq, scores)

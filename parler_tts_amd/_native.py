@@ -39,9 +39,11 @@ class PttsDacConfig(C.Structure):
     _fields_ = [
         ("num_codebooks", C.c_int32), ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("latent_dim", C.c_int32),
         ("decoder_dim", C.c_int32), ("num_rates", C.c_int32), ("rates", C.c_int32 * 8), ("compute_dtype", C.c_int32),
-        ("max_batch", C.c_int32), ("max_frames", C.c_int32), ("device", C.c_int32),
+        ("max_batch", C.c_int32), ("max_frames", C.c_int32), ("device", C.c_int32), ("encoder_dim", C.c_int32),
     ]
 
+
+ABI_VERSION = 2  # PTTS_ABI_VERSION in include/ptts.h
 
 # every symbol include/ptts.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64P = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
@@ -61,11 +63,14 @@ SYMBOLS = {
     "ptts_logits": (C.c_int, [_VP, C.POINTER(_VP)]),
     "ptts_push_tokens": (C.c_int, [_VP, _VP, _VP, _VP]),
     "ptts_debug_hidden": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I32)]),
+    "ptts_set_audio_prefix": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
     "ptts_dac_create": (C.c_int, [C.POINTER(PttsDacConfig), C.POINTER(_VP)]),
     "ptts_dac_destroy": (None, [_VP]),
     "ptts_dac_load_weight": (C.c_int, [_VP, C.c_char_p, _VP, _I64P, _I32, _VP]),
     "ptts_dac_weights_ready": (C.c_int, [_VP]),
     "ptts_dac_decode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
+    "ptts_dac_encode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
+    "ptts_dac_debug_latents": (C.c_int, [_VP, C.POINTER(_VP)]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -96,8 +101,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             raise NativeLibraryError(f"{p} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.ptts_abi_version() != 1:
-        raise NativeLibraryError(f"ABI version mismatch: library {lib.ptts_abi_version()} != binding 1")
+    if lib.ptts_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {lib.ptts_abi_version()} != binding {ABI_VERSION}")
     if path is None:
         _lib = lib
     return lib

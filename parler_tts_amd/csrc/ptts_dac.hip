@@ -1,5 +1,6 @@
-// DAC decode engine (codes -> waveform) behind include/ptts.h. Replaces DACModel.decode
-// (dac_wrapper/modeling_dac.py:106-142): quantizer.from_codes (:138) + the descript-audio-codec decoder (:139).
+// DAC engine behind include/ptts.h. Replaces DACModel.decode (dac_wrapper/modeling_dac.py:106-142): quantizer.from_codes
+// (:138) + the descript-audio-codec decoder (:139); and DACModel.encode (:33-104, voice prompts): model.preprocess (:64,
+// done by the caller: right-pad to a hop multiple) + model.encode (:95) = encoder stack + residual VQ search.
 //
 // Design:
 //   * activations are channels-last fp32 [b][t][c]: a B-operand fragment (16 consecutive channels of one frame and
@@ -10,7 +11,10 @@
 //   * Snake is evaluated ONCE per element in the producer's epilogue (x + sin^2(ax)/(a+1e-9)), never in a consumer
 //     prologue (7 taps x Cout/16 strips would recompute each sin dozens of times); bias, residual skip and the
 //     next layer's Snake are fused into the same epilogue; weight-norm is folded by the caller at load;
-//   * RVQ from_codes is a gather-sum over K precomputed [codebook_size][latent] tables (out_proj(codebook_i)+bias_i).
+//   * RVQ from_codes is a gather-sum over K precomputed [codebook_size][latent] tables (out_proj(codebook_i)+bias_i);
+//   * encode: the encoder's stride-s Conv1d(k = 2s) is the same implicit GEMM with input frame t*s + tap - pad; the
+//     residual VQ runs one workgroup per frame through all stages (in_proj, cosine nearest neighbour over the
+//     L2-normalised codebook, straight-through expression p + (c - p), out_proj, residual update).
 #include <map>
 #include <set>
 #include <string>
@@ -33,6 +37,7 @@ struct ConvArgs {
   const float* alpha;  // [Cout] for out_act
   int dil, pad, transposed;  // tap offset: conv  tap*dil - pad ; transposed (stride = nphase)  (ph + pad)/nphase - tap
   int B, Tin, Cin, Cout, ntaps, nphase;
+  int stride, Tn;      // input stride of a down-sampling conv (else 1); output frames per phase (Tin unless strided)
 };
 
 __device__ __forceinline__ float snake_f(float x, float al) {
@@ -53,11 +58,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j = lane & 15;
   const int fpb = 32 * (int)(blockDim.x >> 6);  // frames per workgroup: 32 per wave, 1/2/4 waves (host picks for balance)
-  const int ntile = (a.Tin + fpb - 1) / fpb;
+  const int ntile = (a.Tn + fpb - 1) / fpb;
   const int tile = blockIdx.x % ntile, ph = (blockIdx.x / ntile) % a.nphase, b = blockIdx.x / (ntile * a.nphase);
   const int strip0 = blockIdx.y * CS;
   const int nstrips = a.Cout / 16;
-  if (tile * fpb + wave * 32 >= a.Tin) return;
+  if (tile * fpb + wave * 32 >= a.Tn) return;
   const int cpt = a.Cin / 16;           // k-steps per tap
   const int nk = a.ntaps * cpt;
   const float* xb = a.x + (size_t)b * a.Tin * a.Cin;
@@ -76,7 +81,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   do {                                                                                                                  \
     const int tap_ = (KS) / cpt, cc_ = (KS) - tap_ * cpt;                                                                \
     const int off_ = a.transposed ? (ph + a.pad) / a.nphase - tap_ : tap_ * a.dil - a.pad;                               \
-    const int ti0_ = j0 + j + off_, ti1_ = ti0_ + 16;                                                                    \
+    const int ti0_ = (j0 + j) * a.stride + off_, ti1_ = ti0_ + 16 * a.stride;                                            \
     B0 = make_float4(0, 0, 0, 0);                                                                                        \
     B1 = make_float4(0, 0, 0, 0);                                                                                        \
     if (ti0_ >= 0 && ti0_ < a.Tin) B0 = *reinterpret_cast<const float4*>(xb + (size_t)ti0_ * a.Cin + q * 4 + cc_ * 16);   \
@@ -108,10 +113,10 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   }
   // epilogue: D[row = co_local = q*4 + r][col = frame j]. A helper called with compile-time (s, half) keeps `acc`
   // statically indexed: the big inlined snake bodies otherwise stop the unroller at CS = 8 and push acc to scratch.
-  const int Tout = a.Tin * a.nphase;
+  const int Tout = a.Tn * a.nphase;
   auto emit = [&](const f32x4& av, int s, int half) {
     const int jj = j0 + half * 16 + j;
-    if (jj >= a.Tin) return;
+    if (jj >= a.Tn) return;
     const int co = (strip0 + s) * 16 + q * 4;
     const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
     const size_t o = ((size_t)b * Tout + (size_t)jj * a.nphase + ph) * a.Cout + co;
@@ -154,6 +159,133 @@ __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* _
     }
   }
   out[idx] = tanhf(acc);
+}
+
+// first encoder Conv1d(1 -> C, k7, pad 3) on the raw waveform: one thread per (sample, 4 channels); writes the raw
+// result (residual skip of the first unit) and its Snake. HBM-bound (C floats out per sample), trivially parallel.
+__global__ void conv_in_kernel(const float* __restrict__ wave, const float* __restrict__ w /*[C][7]*/, const float* __restrict__ bias,
+                               const float* __restrict__ alpha, float* __restrict__ out_raw, float* __restrict__ out_act, int B, int L, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = C / 4;
+  if (idx >= (size_t)B * L * c4n) return;
+  const int c4 = (int)(idx % c4n);
+  const size_t bt = idx / c4n;
+  const int t = (int)(bt % L), b = (int)(bt / L);
+  float xs[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { const int ti = t + k - 3; xs[k] = (ti >= 0 && ti < L) ? wave[(size_t)b * L + ti] : 0.f; }
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c4 * 4 + e;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc = fmaf(w[c * 7 + k], xs[k], acc);
+    o[e] = acc + bias[c];
+  }
+  const size_t off = bt * C + c4 * 4;
+  *reinterpret_cast<float4*>(out_raw + off) = make_float4(o[0], o[1], o[2], o[3]);
+  const float4 al = *reinterpret_cast<const float4*>(alpha + c4 * 4);
+  *reinterpret_cast<float4*>(out_act + off) = make_float4(snake_f(o[0], al.x), snake_f(o[1], al.y), snake_f(o[2], al.z), snake_f(o[3], al.w));
+}
+
+// F.normalize(codebook) rows: c / max(||c||_2, 1e-12)
+__global__ void cb_normalize_kernel(const float* __restrict__ cb, float* __restrict__ cbn, float* __restrict__ cbn_sq, int ncodes, int cdim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncodes) return;
+  float ss = 0.f;
+  for (int d = 0; d < cdim; ++d) ss += cb[(size_t)i * cdim + d] * cb[(size_t)i * cdim + d];
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  float s2 = 0.f;
+  for (int d = 0; d < cdim; ++d) { const float v = cb[(size_t)i * cdim + d] * inv; cbn[(size_t)i * cdim + d] = v; s2 += v * v; }
+  cbn_sq[i] = s2;  // the ||c||^2 term of the reference's distance (1 up to rounding, kept so that near-ties order the same way)
+}
+
+// Residual VQ encode (ResidualVectorQuantize.forward, eval mode), one workgroup per latent frame, all stages in sequence:
+//   p = in_proj_i(residual); idx = argmax_c <normalize(p), normalize(codebook_i[c])> (first index on ties);
+//   z_q = out_proj_i(p + (codebook_i[idx] - p));  residual -= z_q.
+// in_w [K][cdim][latent], in_b [K][cdim], cb/cbn [K][codes][cdim], out_w [K][latent][cdim], out_b [K][latent]. cdim <= 16.
+constexpr int RVQ_MAXD = 16;
+__global__ void __launch_bounds__(256) rvq_encode_kernel(const float* __restrict__ z /*[B][T][latent]*/, const float* __restrict__ in_w,
+                                                         const float* __restrict__ in_b, const float* __restrict__ cb, const float* __restrict__ cbn,
+                                                         const float* __restrict__ cbn_sq, const float* __restrict__ out_w, const float* __restrict__ out_b,
+                                                         long long* __restrict__ codes /*[B][nq][T]*/, int T, int latent, int cdim, int ncodes, int nq) {
+  extern __shared__ float s_res[];  // [latent] residual, then [4 waves][RVQ_MAXD] partials
+  __shared__ float s_part[4][RVQ_MAXD];
+  __shared__ float s_p[RVQ_MAXD], s_e[RVQ_MAXD], s_q[RVQ_MAXD];
+  __shared__ float s_ee;
+  __shared__ float s_best[4];
+  __shared__ int s_bidx[4];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* zr = z + ((size_t)b * T + t) * latent;
+  for (int c = tid; c < latent; c += 256) s_res[c] = zr[c];
+  __syncthreads();
+  for (int i = 0; i < nq; ++i) {
+    const float* W = in_w + (size_t)i * cdim * latent;
+    // 1. p[d] = b[d] + sum_c W[d][c] * r[c]
+    float part[RVQ_MAXD];
+#pragma unroll
+    for (int d = 0; d < RVQ_MAXD; ++d) part[d] = 0.f;
+    for (int c = tid; c < latent; c += 256) {
+      const float r = s_res[c];
+#pragma unroll
+      for (int d = 0; d < RVQ_MAXD; ++d)
+        if (d < cdim) part[d] = fmaf(W[(size_t)d * latent + c], r, part[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < RVQ_MAXD; ++d) {
+      if (d < cdim) {
+        const float v = wave_sum(part[d]);
+        if (lane == 0) s_part[wave][d] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < cdim) s_p[tid] = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + in_b[(size_t)i * cdim + tid];
+    __syncthreads();
+    if (tid == 0) {
+      float ss = 0.f;
+      for (int d = 0; d < cdim; ++d) ss += s_p[d] * s_p[d];
+      const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+      float ee = 0.f;
+      for (int d = 0; d < cdim; ++d) { s_e[d] = s_p[d] * inv; ee += s_e[d] * s_e[d]; }
+      s_ee = ee;
+    }
+    __syncthreads();
+    // 2. nearest code: argmax of -(||e||^2 - 2 e.c + ||c||^2) over the normalised codebook, first index on ties
+    float best = -INFINITY;
+    int bidx = 0;
+    const float ee = s_ee;
+    for (int c = tid; c < ncodes; c += 256) {
+      const float* cr = cbn + ((size_t)i * ncodes + c) * cdim;
+      float dot = 0.f;
+      for (int d = 0; d < cdim; ++d) dot = fmaf(s_e[d], cr[d], dot);
+      const float score = -((ee - 2.0f * dot) + cbn_sq[(size_t)i * ncodes + c]);
+      if (score > best) { best = score; bidx = c; }
+    }
+    const float wb = wave_max(best);
+    // lowest code index among the lanes holding the wave maximum
+    int cand = best == wb ? bidx : 0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+    if (lane == 0) { s_best[wave] = wb; s_bidx[wave] = cand; }
+    __syncthreads();
+    if (tid == 0) {
+      float bb = s_best[0]; int bi = s_bidx[0];
+      for (int w2 = 1; w2 < 4; ++w2)
+        if (s_best[w2] > bb || (s_best[w2] == bb && s_bidx[w2] < bi)) { bb = s_best[w2]; bi = s_bidx[w2]; }
+      codes[((size_t)b * nq + i) * T + t] = bi;
+      const float* cr = cb + ((size_t)i * ncodes + bi) * cdim;
+      for (int d = 0; d < cdim; ++d) { const float diff = cr[d] - s_p[d]; s_q[d] = s_p[d] + diff; }  // straight-through expression
+    }
+    __syncthreads();
+    // 3. residual -= out_proj(q)
+    const float* OW = out_w + (size_t)i * latent * cdim;
+    for (int c = tid; c < latent; c += 256) {
+      float acc = 0.f;
+      for (int d = 0; d < cdim; ++d) acc = fmaf(OW[(size_t)c * cdim + d], s_q[d], acc);
+      s_res[c] -= acc + out_b[(size_t)i * latent + c];
+    }
+    __syncthreads();
+  }
 }
 
 // RVQ table: table[i][code][c] = bias_i[c] + sum_d W_i[c][d] * codebook_i[code][d]
@@ -215,6 +347,7 @@ struct ConvLayer {
   bool transposed;
   float *Wp = nullptr, *bias = nullptr, *alpha = nullptr;
   bool has_skip = false, write_raw = false;
+  int pad = -1;            // explicit padding (down-sampling convs, k3 final conv); -1: "same" padding (k-1)*dil/2
 };
 
 }  // namespace
@@ -229,6 +362,12 @@ struct ptts_dac {
   float* table = nullptr;  // [K][codes][latent]
   std::vector<float*> cb, opw, opb;
   float *bufA0 = nullptr, *bufA1 = nullptr, *bufY = nullptr, *bufS = nullptr, *bufZ = nullptr;
+  // encode side (cfg.encoder_dim > 0)
+  std::vector<ConvLayer> enc_convs;             // MFMA convs of the encoder in execution order
+  float *in0_w = nullptr, *in0_b = nullptr, *in0_alpha = nullptr;  // encoder.block.0: Conv1d(1 -> encoder_dim, k7) + Snake of the first unit
+  float *ipw = nullptr, *ipb = nullptr;         // in_proj [K][cdim][latent], [K][cdim]
+  float *cb_all = nullptr, *cbn = nullptr, *cbn_sq = nullptr, *opw_all = nullptr, *opb_all = nullptr;  // contiguous copies for the VQ search
+  bool vq_ready = false;
   int* d_ktap = nullptr;
   std::set<std::string> loaded, required;
   bool table_ready = false;
@@ -260,6 +399,8 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
   PTTS_CHECK(c.num_codebooks >= 1 && c.num_codebooks <= 32, PTTS_E_INVALID, "num_codebooks out of range");
   PTTS_CHECK(c.latent_dim % 16 == 0 && c.decoder_dim % (16 << c.num_rates) == 0, PTTS_E_UNSUPPORTED,
              "latent_dim and every decoder width must be multiples of 16");
+  PTTS_CHECK(c.encoder_dim >= 0 && c.encoder_dim % 16 == 0 && c.codebook_dim <= RVQ_MAXD, PTTS_E_UNSUPPORTED,
+             "encoder_dim must be 0 (decode only) or a multiple of 16, codebook_dim <= %d", RVQ_MAXD);
   PTTS_CHECK(c.compute_dtype == PTTS_F32, PTTS_E_UNSUPPORTED, "only the exact-f32 MFMA mode is implemented (compute_dtype = PTTS_F32)");
   PTTS_CHECK(c.max_batch >= 1 && c.max_frames >= 1, PTTS_E_INVALID, "bad capacities");
   for (int i = 0; i < c.num_rates; ++i) PTTS_CHECK(c.rates[i] >= 2 && c.rates[i] <= 8 && c.rates[i] % 2 == 0, PTTS_E_UNSUPPORTED, "decoder rate %d unsupported (need an even stride in [2, 8])", c.rates[i]);
@@ -270,19 +411,21 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
   auto fail = [&](int r) { ptts_dac_destroy(d); return r; };
   if (hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate failed"));
 #define A(expr) if ((rc = (expr)) != PTTS_OK) return fail(rc)
+  std::vector<ConvLayer>* target = &d->convs;
   auto add_conv = [&](const std::string& name, const std::string& alpha_name, int Cin, int Cout, int k, int dil, int stride, bool tr,
                       bool has_skip, bool write_raw) -> int {
     ConvLayer L;
     L.name = name; L.alpha_name = alpha_name; L.Cin = Cin; L.Cout = Cout; L.ksize = k; L.dil = dil; L.stride = stride; L.transposed = tr;
     L.has_skip = has_skip; L.write_raw = write_raw;
     const int ntaps = tr ? 2 : k, nphase = tr ? stride : 1;
+    if (ntaps > 16) return ptts_fail(PTTS_E_UNSUPPORTED, "%s: kernel size %d unsupported", name.c_str(), k);
     PTTS_TRY(d->alloc(&L.Wp, (size_t)nphase * Cout * ntaps * Cin));
     PTTS_TRY(d->alloc(&L.bias, Cout));
     if (!alpha_name.empty()) PTTS_TRY(d->alloc(&L.alpha, Cout));
     d->required.insert(name + ".weight");
     d->required.insert(name + ".bias");
     if (!alpha_name.empty()) d->required.insert(alpha_name + ".alpha");
-    d->convs.push_back(L);
+    target->push_back(L);
     return PTTS_OK;
   };
   char nm[128], an[128];
@@ -326,8 +469,49 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
     d->required.insert(std::string(nm) + "out_proj.weight");
     d->required.insert(std::string(nm) + "out_proj.bias");
   }
+  if (c.encoder_dim > 0) {  // encode side: descript Encoder, strides = the decoder's reversed
+    target = &d->enc_convs;
+    const int n = c.num_rates;
+    int dim = c.encoder_dim;
+    A(d->alloc(&d->in0_w, (size_t)dim * 7)); A(d->alloc(&d->in0_b, dim)); A(d->alloc(&d->in0_alpha, dim));
+    d->required.insert("encoder.block.0.weight"); d->required.insert("encoder.block.0.bias");
+    d->required.insert("encoder.block.1.block.0.block.0.alpha");
+    for (int bi = 0; bi < n; ++bi) {
+      const int st = c.rates[n - 1 - bi];
+      const int dils[3] = {1, 3, 9};
+      for (int ri = 0; ri < 3; ++ri) {
+        snprintf(nm, sizeof nm, "encoder.block.%d.block.%d.block.1", bi + 1, ri);
+        snprintf(an, sizeof an, "encoder.block.%d.block.%d.block.2", bi + 1, ri);
+        A(add_conv(nm, an, dim, dim, 7, dils[ri], 1, false, false, false));
+        snprintf(nm, sizeof nm, "encoder.block.%d.block.%d.block.3", bi + 1, ri);
+        if (ri < 2) snprintf(an, sizeof an, "encoder.block.%d.block.%d.block.0", bi + 1, ri + 1);
+        else snprintf(an, sizeof an, "encoder.block.%d.block.3", bi + 1);
+        A(add_conv(nm, an, dim, dim, 1, 1, 1, false, true, ri < 2));
+      }
+      snprintf(nm, sizeof nm, "encoder.block.%d.block.4", bi + 1);
+      if (bi + 1 < n) snprintf(an, sizeof an, "encoder.block.%d.block.0.block.0", bi + 2);
+      else snprintf(an, sizeof an, "encoder.block.%d", n + 1);
+      A(add_conv(nm, an, dim, 2 * dim, 2 * st, 1, st, false, false, true));
+      d->enc_convs.back().pad = (st + 1) / 2;
+      dim *= 2;
+    }
+    snprintf(nm, sizeof nm, "encoder.block.%d", n + 2);
+    A(add_conv(nm, "", dim, c.latent_dim, 3, 1, 1, false, false, true));
+    const size_t K = c.num_codebooks;
+    A(d->alloc(&d->ipw, K * c.codebook_dim * c.latent_dim)); A(d->alloc(&d->ipb, K * c.codebook_dim));
+    A(d->alloc(&d->cb_all, K * c.codebook_size * c.codebook_dim)); A(d->alloc(&d->cbn, K * c.codebook_size * c.codebook_dim));
+    A(d->alloc(&d->cbn_sq, K * c.codebook_size));
+    A(d->alloc(&d->opw_all, K * c.latent_dim * c.codebook_dim)); A(d->alloc(&d->opb_all, K * c.latent_dim));
+    for (int i = 0; i < c.num_codebooks; ++i) {
+      snprintf(nm, sizeof nm, "quantizer.quantizers.%d.in_proj.", i);
+      d->required.insert(std::string(nm) + "weight");
+      d->required.insert(std::string(nm) + "bias");
+    }
+    target = &d->convs;
+  }
   // activation buffers: max over layers of T_l * C_l
   size_t mx = (size_t)c.max_frames * std::max(c.latent_dim, c.decoder_dim);
+  if (c.encoder_dim > 0) mx = std::max(mx, (size_t)c.max_frames * hop * c.encoder_dim);
   {
     size_t T = c.max_frames;
     for (int bi = 0; bi < c.num_rates; ++bi) { T *= c.rates[bi]; mx = std::max(mx, T * (size_t)(ch >> (bi + 1))); }
@@ -359,11 +543,13 @@ extern "C" int ptts_dac_load_weight(ptts_dac* d, const char* name_c, const float
   if (sscanf(name_c, "quantizer.quantizers.%d.%63s", &qi, tail) == 2) {
     PTTS_CHECK(qi >= 0 && qi < c.num_codebooks, PTTS_E_INVALID, "%s: quantizer index out of range", name_c);
     d->table_ready = false;
+    d->vq_ready = false;
     const std::string t(tail);
     if (t == "codebook.weight") return copy(d->cb[qi], (size_t)c.codebook_size * c.codebook_dim);
     if (t == "out_proj.weight") return copy(d->opw[qi], (size_t)c.latent_dim * c.codebook_dim);
     if (t == "out_proj.bias") return copy(d->opb[qi], c.latent_dim);
-    if (t == "in_proj.weight" || t == "in_proj.bias") return PTTS_OK;  // encoder side, not on the decode path
+    if (t == "in_proj.weight") { d->vq_ready = false; return c.encoder_dim > 0 ? copy(d->ipw + (size_t)qi * c.codebook_dim * c.latent_dim, (size_t)c.codebook_dim * c.latent_dim) : PTTS_OK; }
+    if (t == "in_proj.bias") return c.encoder_dim > 0 ? copy(d->ipb + (size_t)qi * c.codebook_dim, c.codebook_dim) : PTTS_OK;
     return ptts_fail(PTTS_E_INVALID, "unknown tensor name %s", name_c);
   }
   char fin[64];
@@ -377,13 +563,22 @@ extern "C" int ptts_dac_load_weight(ptts_dac* d, const char* name_c, const float
     return PTTS_OK;
   }
   if (name == std::string(fin) + ".bias") return copy(d->out_b, 1);
-  for (ConvLayer& L : d->convs) {
+  if (c.encoder_dim > 0) {
+    if (name == "encoder.block.0.weight") return copy(d->in0_w, (size_t)c.encoder_dim * 7);
+    if (name == "encoder.block.0.bias") return copy(d->in0_b, c.encoder_dim);
+    if (name == "encoder.block.1.block.0.block.0.alpha") return copy(d->in0_alpha, c.encoder_dim);
+  }
+  std::vector<ConvLayer*> all;
+  for (ConvLayer& L : d->convs) all.push_back(&L);
+  for (ConvLayer& L : d->enc_convs) all.push_back(&L);
+  for (ConvLayer* Lp : all) {
+    ConvLayer& L = *Lp;
     if (!L.alpha_name.empty() && name == L.alpha_name + ".alpha") return copy(L.alpha, L.Cout);
     if (name == L.name + ".bias") return copy(L.bias, L.Cout);
     if (name == L.name + ".weight") {
       const int k = L.ksize;
       int ktap[MAXTAPS * 8];
-      memset(ktap, 0, sizeof ktap);
+      memset(ktap, 0, sizeof ktap);  // a plain conv (one phase) may use up to 16 entries of row 0/1
       long long s_co, s_ci, s_k = 1;
       int ntaps, nphase;
       if (!L.transposed) {  // torch Conv1d weight [Cout][Cin][k]
@@ -424,9 +619,11 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const float* x, const float
   a.x = x; a.Wp = L.Wp; a.bias = L.bias; a.skip = skip; a.out_raw = out_raw; a.out_act = out_act; a.alpha = L.alpha;
   a.B = B; a.Tin = Tin; a.Cin = L.Cin; a.Cout = L.Cout;
   if (!L.transposed) {
-    a.ntaps = L.ksize; a.nphase = 1; a.dil = L.dil; a.pad = (L.ksize - 1) * L.dil / 2; a.transposed = 0;
+    a.ntaps = L.ksize; a.nphase = 1; a.dil = L.dil; a.pad = L.pad >= 0 ? L.pad : (L.ksize - 1) * L.dil / 2; a.transposed = 0;
+    a.stride = L.stride; a.Tn = L.stride > 1 ? (Tin + 2 * a.pad - L.ksize) / L.stride + 1 : Tin;
   } else {  // to = j*s + ph = ti*s - pad + k  =>  tap 0 (k = r): ti = j + c0 ; tap 1 (k = r + s): ti = j + c0 - 1, c0 = (ph + pad)/s
     a.ntaps = 2; a.nphase = L.stride; a.dil = 1; a.pad = (L.stride + 1) / 2; a.transposed = 1;
+    a.stride = 1; a.Tn = Tin;
   }
   const int nstrips = L.Cout / 16;
   // waves per workgroup: fewer (finer tiles) when the launch would otherwise put < ~6 workgroups on each CU, so the
@@ -435,11 +632,11 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const float* x, const float
   int nwb = 4;
   {
     const int CS0 = nstrips % 8 == 0 ? 8 : (nstrips % 6 == 0 ? 6 : (nstrips % 4 == 0 ? 4 : (nstrips % 2 == 0 ? 2 : 1)));
-    auto blocks = [&](int nw) { return (long long)((Tin + 32 * nw - 1) / (32 * nw)) * a.nphase * B * (nstrips / CS0); };
+    auto blocks = [&](int nw) { return (long long)((a.Tn + 32 * nw - 1) / (32 * nw)) * a.nphase * B * (nstrips / CS0); };
     while (nwb > 1 && blocks(nwb) < 256LL * 6) nwb >>= 1;
     if (forced_nw == 1 || forced_nw == 2 || forced_nw == 4) nwb = forced_nw;
   }
-  const int ntile = (Tin + 32 * nwb - 1) / (32 * nwb);
+  const int ntile = (a.Tn + 32 * nwb - 1) / (32 * nwb);
   // strips per wave: the largest of {8, 6, 4, 2, 1} that divides the layer (real DAC widths: 96/48/24/12/6 strips)
   const int CS = nstrips % 8 == 0 ? 8 : (nstrips % 6 == 0 ? 6 : (nstrips % 4 == 0 ? 4 : (nstrips % 2 == 0 ? 2 : 1)));
   const dim3 grid((unsigned)(ntile * a.nphase * B), (unsigned)(nstrips / CS));
@@ -493,5 +690,66 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
                      wave_dev, B, Tcur, d->out_C, 7);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+// DACModel.encode (dac_wrapper/modeling_dac.py:33-104) for one chunk: wave_dev float32 [B][L] with L a multiple of the hop
+// (the caller applies model.preprocess's right padding, :64) -> codes_dev int64 [B][nq][L / hop].
+extern "C" int ptts_dac_encode(ptts_dac* d, const float* wave_dev, int64_t* codes_dev, int32_t B, int32_t L, int32_t n_quantizers, void* stream) {
+  PTTS_CHECK(d && wave_dev && codes_dev, PTTS_E_INVALID, "null argument");
+  const ptts_dac_config& c = d->cfg;
+  PTTS_CHECK(c.encoder_dim > 0, PTTS_E_UNSUPPORTED, "this dac engine was created without the encoder (encoder_dim = 0)");
+  PTTS_TRY(ptts_dac_weights_ready(d));
+  PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds dac max_batch %d", B, c.max_batch);
+  PTTS_CHECK(L >= d->hop && L % d->hop == 0, PTTS_E_INVALID, "waveform length %d is not a positive multiple of the hop %d (apply preprocess padding)", L, d->hop);
+  const int T = L / d->hop;
+  PTTS_CHECK(T <= c.max_frames, PTTS_E_CAPACITY, "frames %d exceed dac max_frames %d", T, c.max_frames);
+  const int nq = n_quantizers <= 0 || n_quantizers > c.num_codebooks ? c.num_codebooks : n_quantizers;
+  PTTS_HIP(hipSetDevice(c.device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!d->vq_ready) {  // contiguous [K][...] copies for the search kernel + the normalised codebooks
+    for (int i = 0; i < c.num_codebooks; ++i) {
+      const size_t ncb = (size_t)c.codebook_size * c.codebook_dim, nw = (size_t)c.latent_dim * c.codebook_dim;
+      PTTS_HIP(hipMemcpyAsync(d->cb_all + i * ncb, d->cb[i], ncb * 4, hipMemcpyDeviceToDevice, st));
+      PTTS_HIP(hipMemcpyAsync(d->opw_all + i * nw, d->opw[i], nw * 4, hipMemcpyDeviceToDevice, st));
+      PTTS_HIP(hipMemcpyAsync(d->opb_all + (size_t)i * c.latent_dim, d->opb[i], (size_t)c.latent_dim * 4, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(cb_normalize_kernel, dim3((c.codebook_size + 255) / 256), dim3(256), 0, st, d->cb_all + i * ncb, d->cbn + i * ncb,
+                         d->cbn_sq + (size_t)i * c.codebook_size, c.codebook_size, c.codebook_dim);
+    }
+    d->vq_ready = true;
+  }
+  float *cur = d->bufA0, *other = d->bufA1;
+  int Tcur = L;
+  {
+    const size_t n = (size_t)B * L * (c.encoder_dim / 4);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wave_dev, d->in0_w, d->in0_b, d->in0_alpha, d->bufY, cur, B,
+                       L, c.encoder_dim);
+  }
+  size_t li = 0;
+  for (int bi = 0; bi < c.num_rates; ++bi) {
+    for (int ri = 0; ri < 3; ++ri) {
+      const ConvLayer& c7 = d->enc_convs[li++];
+      PTTS_TRY(run_conv(d, c7, cur, nullptr, nullptr, d->bufS, B, Tcur, st));
+      const ConvLayer& c1 = d->enc_convs[li++];
+      PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st));
+    }
+    const ConvLayer& down = d->enc_convs[li++];
+    PTTS_TRY(run_conv(d, down, cur, nullptr, d->bufY, other, B, Tcur, st));
+    std::swap(cur, other);
+    Tcur = (Tcur + 2 * down.pad - down.ksize) / down.stride + 1;
+  }
+  PTTS_CHECK(Tcur == T, PTTS_E_INVALID, "encoder produced %d frames for %d expected", Tcur, T);
+  PTTS_TRY(run_conv(d, d->enc_convs[li++], cur, nullptr, d->bufZ, nullptr, B, Tcur, st));
+  hipLaunchKernelGGL(rvq_encode_kernel, dim3(T, B), dim3(256), (size_t)c.latent_dim * 4, st, d->bufZ, d->ipw, d->ipb, d->cb_all, d->cbn, d->cbn_sq,
+                     d->opw_all, d->opb_all, (long long*)codes_dev, T, c.latent_dim, c.codebook_dim, c.codebook_size, nq);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac encode launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+// Debug / parity probe: the latents z of the last ptts_dac_encode, channels-last fp32 [B][T][latent].
+extern "C" int ptts_dac_debug_latents(ptts_dac* d, float** latents_dev) {
+  PTTS_CHECK(d && latents_dev, PTTS_E_INVALID, "null argument");
+  *latents_dev = d->bufZ;
   return PTTS_OK;
 }

@@ -50,6 +50,8 @@ struct ptts_engine {
   float *h = nullptr, *qkv = nullptr, *qc = nullptr, *part = nullptr, *stats = nullptr, *ffn = nullptr, *logits = nullptr;
   float* sort_buf = nullptr;
   void *xw = nullptr, *xw2 = nullptr;  // engine-dtype activation rows for the M > 8 path: [rows][H], [rows][F]
+  long long* prefix = nullptr;         // voice-prompt codes [max_batch*K][max_ctx], valid for the next prefill when pending_T > 0
+  int pending_T = 0;
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
@@ -499,6 +501,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc_bytes(&e->xw, rows * H * es));
   A(e->alloc_bytes(&e->xw2, std::max(rows * F, enc_rows * (size_t)H) * es));
   A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
+  A(e->alloc(&e->prefix, (size_t)c.max_batch * K * c.max_ctx));
   e->ids_ld = c.max_ctx + 8;
   A(e->alloc(&e->ids, (size_t)c.max_batch * K * e->ids_ld));
   A(e->alloc(&e->cur_len, c.max_batch)); A(e->alloc(&e->unfinished, (size_t)c.max_batch * K));
@@ -637,6 +640,20 @@ extern "C" int ptts_set_gen_params(ptts_engine* e, const ptts_gen_params* gp) {
   return PTTS_OK;
 }
 
+extern "C" int ptts_set_audio_prefix(ptts_engine* e, const int64_t* codes_dev, int32_t B, int32_t T, void* stream) {
+  PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
+  const ptts_config& c = e->cfg;
+  PTTS_CHECK(T >= 0 && (T == 0 || codes_dev), PTTS_E_INVALID, "bad audio prefix");
+  PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds engine max_batch %d", B, c.max_batch);
+  PTTS_CHECK(T + 2 <= c.max_ctx, PTTS_E_CAPACITY, "voice prompt of %d frames exceeds engine max_ctx %d", T, c.max_ctx);
+  PTTS_HIP(hipSetDevice(c.device));
+  if (T > 0)
+    PTTS_HIP(hipMemcpy2DAsync(e->prefix, (size_t)c.max_ctx * 8, codes_dev, (size_t)T * 8, (size_t)T * 8, (size_t)B * c.num_codebooks,
+                              hipMemcpyDeviceToDevice, pick_stream(e, stream)));
+  e->pending_T = T;
+  return PTTS_OK;
+}
+
 extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_dev, const float* prompt_dev,
                             const int32_t* prompt_mask_dev, int32_t B, int32_t N, int32_t P, int32_t sample, void* stream) {
   PTTS_CHECK(e && enc_dev, PTTS_E_INVALID, "null argument");
@@ -646,6 +663,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   PTTS_CHECK(N >= 1 && N <= c.max_enc, PTTS_E_CAPACITY, "encoder length %d exceeds engine max_enc %d", N, c.max_enc);
   PTTS_CHECK(P >= 0 && P + 1 <= e->max_prompt, PTTS_E_CAPACITY, "prompt length %d exceeds engine capacity %d", P, e->max_prompt - 1);
   PTTS_CHECK(P == 0 || prompt_dev, PTTS_E_INVALID, "prompt_dev is null but P > 0");
+  PTTS_CHECK(e->pending_T + 2 <= e->gp.max_length, PTTS_E_INVALID, "voice prompt of %d frames leaves no room below max_length %d", e->pending_T, e->gp.max_length);
   PTTS_CHECK(P + e->gp.max_length <= c.max_ctx, PTTS_E_CAPACITY, "P + max_length = %d exceeds engine max_ctx %d", P + e->gp.max_length, c.max_ctx);
   PTTS_CHECK(P + e->gp.max_length <= c.max_positions || c.rope, PTTS_E_CAPACITY, "P + max_length = %d exceeds max_position_embeddings %d", P + e->gp.max_length, c.max_positions);
   PTTS_HIP(hipSetDevice(c.device));
@@ -655,6 +673,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   // per-call device params travel as kernel arguments (no host staging buffer to keep alive)
   {
     DevDims hd; hd.P = P; hd.N = N; hd.max_length = e->gp.max_length;
+    hd.T_prefix = e->pending_T; hd.prefix = e->prefix; hd.prefix_ld = c.max_ctx;
     DevGen hg; hg.max_length = e->gp.max_length; hg.min_new_tokens = e->gp.min_new_tokens; hg.do_sample = e->gp.do_sample;
     hg.top_k = e->gp.top_k; hg.use_eos_gate = e->gp.use_eos_gate; hg.temperature = e->gp.temperature; hg.top_p = e->gp.top_p;
     hg.seed = e->gp.seed;
@@ -671,6 +690,15 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   PTTS_HIP(hipMemcpyAsync(e->qc, enc_dev, (size_t)B * N * H * 4, hipMemcpyDeviceToDevice, st));
   if (P > 0) PTTS_HIP(hipMemcpyAsync(e->ffn, prompt_dev, (size_t)B * P * H * 4, hipMemcpyDeviceToDevice, st));
   PTTS_TRY(forward_dispatch(e, true, st));
+  // voice prompt (ptts_set_audio_prefix): the T given code columns are teacher-forced one position at a time through the
+  // decode path - the same numbers as the reference's single multi-column forward (causal attention over the same cache)
+  const int T = e->pending_T;
+  e->pending_T = 0;
+  for (int j = 1; j <= T; ++j) {
+    hipLaunchKernelGGL(push_prefix_col_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, j, B, K, c.bos_token_id);
+    hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, j + 1);
+    PTTS_TRY(forward_dispatch(e, false, st, true));
+  }
   if (sample) PTTS_TRY(launch_tail(e, st, true));  // also embeds the sampled column for the first decode step
   e->h_ready = sample != 0;
   e->prefilled = true;

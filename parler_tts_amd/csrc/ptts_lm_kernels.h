@@ -17,6 +17,9 @@ struct DevDims {
   int P;           // prompt positions prepended to the self-attention context
   int N;           // encoder positions
   int max_length;  // delay-pattern length (GenerationConfig.max_length)
+  int T_prefix;    // voice prompt: audio-code frames given as decoder_input_ids (0 = none), modeling:3136-3194
+  const long long* prefix;  // [B*K][prefix_ld] un-delayed codes of the voice prompt
+  int prefix_ld;
 };
 struct DevGen {
   int max_length, min_new_tokens, do_sample, top_k, use_eos_gate;
@@ -992,11 +995,14 @@ __global__ void kv_append_kernel(const float* __restrict__ knew, const float* __
 // ------------------------------------------------------------------------------------------------------
 // Embedding: h = sum_k E_k[token_k] (+ sinusoidal position)   modeling:1433, :1506-1511; delay mask :205-276
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ long long delayed_token(const long long* ids, int ld, int rowk, int k, int j, int K,
-                                                   int max_length, int bos, int pad) {
-  if (max_length >= 2 * K - 1) {  // :246-247: short max_length disables the pattern
-    if (j <= k) return bos;                          // tril :260
-    if (j - k >= max_length - K + 1) return pad;     // triu(diagonal = max_length - K + 1) :256-258
+// value the model sees at (codebook k, column j): BOS / PAD of the delay pattern, the shifted voice-prompt code where the
+// pattern holds one (input_ids_shifted[:, k, k : seq_len + k] = prompt, :250-252; BOS / PAD win, :263), else the raw id
+__device__ __forceinline__ long long delayed_token(const long long* ids, int ld, int rowk, int k, int j, int K, const DevDims& dd, int bos,
+                                                   int pad) {
+  if (dd.max_length >= 2 * K - 1) {  // :246-247: short max_length disables the pattern
+    if (j <= k) return bos;                             // tril :260
+    if (j - k >= dd.max_length - K + 1) return pad;     // triu(diagonal = max_length - K + 1) :256-258
+    if (j - k - 1 < dd.T_prefix) return dd.prefix[(size_t)rowk * dd.prefix_ld + (j - k - 1)];
   }
   return ids[(size_t)rowk * ld + j];
 }
@@ -1031,7 +1037,7 @@ __global__ void embed_kernel(EmbedArgs a) {
   }
   __shared__ int s_tok[32];
   if (threadIdx.x < a.K)
-    s_tok[threadIdx.x] = (int)delayed_token(a.ids, a.ids_ld, b * a.K + threadIdx.x, threadIdx.x, j, a.K, a.dims->max_length, a.bos, a.pad);
+    s_tok[threadIdx.x] = (int)delayed_token(a.ids, a.ids_ld, b * a.K + threadIdx.x, threadIdx.x, j, a.K, *a.dims, a.bos, a.pad);
   __syncthreads();
   for (int d = threadIdx.x; d < a.H; d += blockDim.x) {
     float acc = 0.f;
@@ -1097,7 +1103,8 @@ __device__ inline void bitonic_sort_desc(float* val, int* idx, int nthreads, int
 // the delay pattern is applied exactly as embed_kernel / apply_delay_pattern_mask do (modeling:205-276, :1433).
 __device__ __forceinline__ void tail_embed_next(const TailArgs& a, int b, int t, const int* s_tok, int tid) {
   if (!a.tables) return;
-  const int max_length = a.dims->max_length, P = a.dims->P;
+  const DevDims dd = *a.dims;
+  const int max_length = dd.max_length, P = dd.P;
   float* out = a.h + (size_t)b * a.H;
   const bf16_t* tb16 = reinterpret_cast<const bf16_t*>(a.tables);
   const float* tb32 = reinterpret_cast<const float*>(a.tables);
@@ -1108,6 +1115,7 @@ __device__ __forceinline__ void tail_embed_next(const TailArgs& a, int b, int t,
       if (max_length >= 2 * a.K - 1) {
         if (t <= k) tok = a.bos;
         else if (t - k >= max_length - a.K + 1) tok = a.pad;
+        else if (t - k - 1 < dd.T_prefix) tok = (int)dd.prefix[(size_t)(b * a.K + k) * dd.prefix_ld + (t - k - 1)];  // voice prompt
       }
       const size_t off = ((size_t)k * (a.V + 1) + tok) * a.H + d;
       acc += a.bf16_tables ? bf16_to_f32(tb16[off]) : tb32[off];
@@ -1139,7 +1147,7 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
   if (a.has_eos[b * a.K + fu] > 0 && fu < a.K - 1) fu += 1;  // logits_processors.py:48 (advance <= 1 per step)
   __syncthreads();
   if (tid == 0) a.first_unf[b] = fu;
-  const bool block_eos_all = (t - 1) < g.min_new_tokens;
+  const bool block_eos_all = (t - 1 - a.dims->T_prefix) < g.min_new_tokens;  // new tokens = columns after the (1 + T_prefix) given ones
 
   if (!g.do_sample) {
     // greedy: one wave per codebook row, no workgroup barriers. torch.argmax semantics: first index on ties.
@@ -1260,6 +1268,18 @@ __global__ void bump_len_kernel(int* cur_len, int B) {
   if (b < B) cur_len[b] += 1;
 }
 
+// voice prompt, teacher forcing: column j (1 <= j <= T_prefix) of the raw ids = the delay pattern's value there
+__global__ void push_prefix_col_kernel(long long* ids, int ids_ld, const DevDims* dims, int j, int B, int K, int bos) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= B * K) return;
+  const int k = row % K;
+  const DevDims dd = *dims;
+  ids[(size_t)row * ids_ld + j] = j <= k ? (long long)bos : dd.prefix[(size_t)row * dd.prefix_ld + (j - k - 1)];
+}
+__global__ void set_len_kernel(int* cur_len, int B, int v) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) cur_len[b] = v;
+}
 __global__ void reset_state_kernel(long long* ids, int ids_ld, int* cur_len, int* unfinished, int* has_eos, int* first_unf,
                                    int B, int K, int bos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,7 +1,7 @@
 """``DACModel`` with the reference wrapper's interface (parler_tts/dac_wrapper/modeling_dac.py:13-164): same config
 fields, same ``decode(audio_codes, audio_scales, padding_mask=None, return_dict=None)`` signature and the same
-"one frame only" error, but ``decode`` runs on the HIP DAC engine (csrc/ptts_dac.hip) instead of
-descript-audio-codec. ``encode`` (voice-prompt input) is outside the accelerated path.
+"one frame only" error, but ``decode`` and ``encode`` (voice-prompt input, :33-104) run on the HIP DAC engine
+(csrc/ptts_dac.hip) instead of descript-audio-codec.
 """
 from __future__ import annotations
 
@@ -12,6 +12,20 @@ import torch
 
 from ..configuration_parler_tts import DACConfig
 from ..engine import DacEngine, fold_weight_norm
+
+
+@dataclass
+class DACEncoderOutput:
+    """Stands in for transformers' EncodecEncoderOutput: ``.audio_codes`` [chunks=1, batch, codebooks, frames], ``.audio_scales``."""
+
+    audio_codes: Optional[torch.Tensor] = None
+    audio_scales: Optional[list] = None
+
+    def __getitem__(self, i):
+        return (self.audio_codes, self.audio_scales)[i]
+
+    def get(self, k, default=None):
+        return getattr(self, k, default)
 
 
 @dataclass
@@ -32,6 +46,7 @@ class DACModel(torch.nn.Module):
     CODEBOOK_DIM = 8
     DECODER_DIM = 1536
     DECODER_RATES = (8, 8, 4, 2)
+    ENCODER_DIM = 64
 
     def __init__(self, config: DACConfig, decoder_dim: Optional[int] = None, decoder_rates=None, codebook_dim: Optional[int] = None):
         super().__init__()
@@ -39,6 +54,7 @@ class DACModel(torch.nn.Module):
         self.decoder_dim = decoder_dim or getattr(config, "decoder_dim", self.DECODER_DIM)
         self.decoder_rates = tuple(decoder_rates or getattr(config, "decoder_rates", self.DECODER_RATES))
         self.codebook_dim = codebook_dim or getattr(config, "codebook_dim", self.CODEBOOK_DIM)
+        self.encoder_dim = getattr(config, "encoder_dim", self.ENCODER_DIM)
         self._weights: Dict[str, torch.Tensor] = {}  # dac.model.DAC names under the reference's "model." prefix
         self._engine: Optional[DacEngine] = None
         self._engine_dev = None
@@ -60,27 +76,55 @@ class DACModel(torch.nn.Module):
     def state_dict(self, *args, prefix: str = "", **kwargs):
         return {prefix + k: v for k, v in self._weights.items()}
 
-    def _get_engine(self, batch: int, frames: int) -> DacEngine:
+    def _get_engine(self, batch: int, frames: int, need_encoder: bool = False) -> DacEngine:
         dev = self.device
         if dev.type != "cuda":
-            raise RuntimeError("DACModel.decode runs on the HIP engine only: move the model to a cuda device (no CPU fallback)")
+            raise RuntimeError("DACModel runs on the HIP engine only: move the model to a cuda device (no CPU fallback)")
         e = self._engine
-        if e is None or self._engine_dev != dev or e.max_batch < batch or e.max_frames < frames:
+        if e is None or self._engine_dev != dev or e.max_batch < batch or e.max_frames < frames or (need_encoder and e.encoder_dim <= 0):
             if e is not None:
                 e.close()
             if not self._weights:
                 raise RuntimeError("DACModel has no weights loaded")
             c = self.config
+            has_enc = any(k.startswith("model.encoder.") for k in self._weights)
+            if need_encoder and not has_enc:
+                raise RuntimeError("DACModel.encode: the checkpoint holds no 'model.encoder.*' tensors")
+            keep_enc = need_encoder or (e is not None and e.encoder_dim > 0)  # the encoder is built on first use only
             e = DacEngine(num_codebooks=c.num_codebooks, codebook_size=c.codebook_size, codebook_dim=self.codebook_dim,
                           latent_dim=c.latent_dim, decoder_dim=self.decoder_dim, rates=self.decoder_rates,
-                          max_batch=max(batch, 1), max_frames=max(frames, 64), device=dev)
+                          max_batch=max(batch, 1), max_frames=max(frames, 64), device=dev,
+                          encoder_dim=self.encoder_dim if keep_enc else 0)
             e.load_state_dict({k[len("model."):]: v for k, v in self._weights.items()})
             self._engine, self._engine_dev = e, dev
         return e
 
+    @torch.no_grad()
     def encode(self, input_values, padding_mask=None, bandwidth=None, return_dict=None, n_quantizers=None, sample_rate=None):
-        raise NotImplementedError("DACModel.encode (voice-prompt encoding) is outside the MI355X-accelerated path; "
-                                  "encode with descript-audio-codec and pass `decoder_input_ids` instead")
+        """input_values [batch, channels, samples] float → ``audio_codes`` [1, batch, n_quantizers, ceil(samples / hop)] int64
+        (one chunk, like the reference with ``chunk_length=None``; modeling_dac.py:33-104). ``padding_mask`` and
+        ``bandwidth`` are accepted and unused, as there; scales are ``[None]``."""
+        if input_values.dim() != 3:
+            raise ValueError(f"input_values must be [batch, channels, samples], got {tuple(input_values.shape)}")
+        _, channels, input_length = input_values.shape
+        if channels < 1 or channels > 2:
+            raise ValueError(f"Number of audio channels must be 1 or 2, but got {channels}")  # modeling_dac.py:61-62
+        if channels != 1:
+            raise NotImplementedError("the DAC encoder is mono (Conv1d(1, ...)): pass [batch, 1, samples]")
+        if sample_rate is not None and sample_rate != self.config.sampling_rate:
+            raise ValueError(f"sample_rate {sample_rate} != codec sampling rate {self.config.sampling_rate}")  # dac preprocess asserts
+        hop = 1
+        for r in self.decoder_rates:
+            hop *= int(r)
+        frames = -(-input_length // hop)
+        B = input_values.shape[0]
+        eng = self._get_engine(B, frames, need_encoder=True)
+        wave = torch.nn.functional.pad(input_values.to(self.device, torch.float32), (0, frames * hop - input_length))  # model.preprocess (:64)
+        codes = torch.cat([eng.encode(wave[b0:b0 + eng.max_batch], n_quantizers) for b0 in range(0, B, eng.max_batch)], dim=0)
+        encoded_frames = codes[None]
+        if return_dict is False:
+            return (encoded_frames, [None])
+        return DACEncoderOutput(encoded_frames, [None])
 
     @torch.no_grad()
     def decode(self, audio_codes, audio_scales=None, padding_mask=None, return_dict=None):

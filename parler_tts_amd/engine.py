@@ -128,6 +128,18 @@ class DecoderEngine:
         self.B, self.P = B, P
         self._keep = keep  # inputs are consumed asynchronously by the enqueued kernels
 
+    def set_audio_prefix(self, codes: Optional[torch.Tensor]):
+        """Voice prompt for the NEXT ``prefill``: un-delayed audio codes int64 [B, K, T] (or [B*K, T]); ``None`` clears it."""
+        if codes is None or codes.shape[-1] == 0:
+            N.check(self.lib.ptts_set_audio_prefix(self._h, C.c_void_p(), 1, 0, _stream_ptr()), "ptts_set_audio_prefix")
+            return
+        codes = codes.to(self.device, torch.int64).reshape(-1, codes.shape[-1]).contiguous()
+        if codes.shape[0] % self.K:
+            raise ValueError(f"audio prefix rows {codes.shape[0]} not a multiple of num_codebooks {self.K}")
+        N.check(self.lib.ptts_set_audio_prefix(self._h, C.c_void_p(codes.data_ptr()), codes.shape[0] // self.K, codes.shape[1], _stream_ptr()),
+                "ptts_set_audio_prefix")
+        self._keep_prefix = codes
+
     def decode_steps(self, n: int):
         N.check(self.lib.ptts_decode_steps(self._h, int(n), _stream_ptr()), "ptts_decode_steps")
 
@@ -173,10 +185,12 @@ class DecoderEngine:
                                           _stream_ptr()), "ptts_push_tokens")
         self._keep2 = (tk, fn)
 
-    def generate_ids(self, enc, enc_mask, prompt, prompt_mask, poll_every: int = 64) -> torch.Tensor:
-        """prefill + graph-replayed decode until every row finished; returns raw ids [B*K, Lout]."""
+    def generate_ids(self, enc, enc_mask, prompt, prompt_mask, poll_every: int = 64, audio_prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """prefill + graph-replayed decode until every row finished; returns raw ids [B*K, Lout]. ``audio_prefix``:
+        un-delayed voice-prompt codes [B, K, T] continued by the decoder."""
+        self.set_audio_prefix(audio_prefix)
         self.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)
-        remaining = self.max_length - 2
+        remaining = self.max_length - 2 - (0 if audio_prefix is None else int(audio_prefix.shape[-1]))
         while remaining > 0:
             n = min(poll_every, remaining)
             self.decode_steps(n)
@@ -188,11 +202,12 @@ class DecoderEngine:
 
 
 class DacEngine:
-    """Owner of a ``ptts_dac``: DAC codes → waveform on MI355X (exact-f32 MFMA implicit-GEMM convolutions)."""
+    """Owner of a ``ptts_dac``: DAC codes → waveform (and, with ``encoder_dim`` > 0, waveform → codes for voice prompts)
+    on MI355X (exact-f32 MFMA implicit-GEMM convolutions)."""
 
     def __init__(self, *, num_codebooks: int = 9, codebook_size: int = 1024, codebook_dim: int = 8, latent_dim: int = 1024,
                  decoder_dim: int = 1536, rates: Iterable[int] = (8, 8, 4, 2), max_batch: int = 1, max_frames: int = 2600,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, encoder_dim: int = 0):
         if not torch.cuda.is_available():
             raise N.NativeLibraryError("DacEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = N.load_library()
@@ -200,7 +215,9 @@ class DacEngine:
         rates = tuple(int(r) for r in rates)
         arr = (C.c_int32 * 8)(*(list(rates) + [0] * (8 - len(rates))))
         self.cfg = N.PttsDacConfig(num_codebooks, codebook_size, codebook_dim, latent_dim, decoder_dim, len(rates), arr, N.PTTS_F32,
-                                   max_batch, max_frames, self.device.index or 0)
+                                   max_batch, max_frames, self.device.index or 0, int(encoder_dim))
+        self.encoder_dim = int(encoder_dim)
+        self.latent_dim = latent_dim
         self.hop = math.prod(rates)
         self.K = num_codebooks
         self.codebook_size = codebook_size
@@ -225,7 +242,7 @@ class DacEngine:
         dac_wrapper/modeling_dac.py:148-164). Folded here on the host side once."""
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         for name, t in fold_weight_norm(sd).items():
-            if not (name.startswith("quantizer.") or name.startswith("decoder.")):
+            if not (name.startswith("quantizer.") or name.startswith("decoder.") or (self.encoder_dim > 0 and name.startswith("encoder."))):
                 continue
             t = t.detach().to(self.device, torch.float32).contiguous()
             if name.endswith(".alpha"):
@@ -245,6 +262,33 @@ class DacEngine:
         N.check(self.lib.ptts_dac_decode(self._h, C.c_void_p(codes.data_ptr()), C.c_void_p(out.data_ptr()), B, T, _stream_ptr()), "ptts_dac_decode")
         self._keep = codes
         return out
+
+
+    def encode(self, wave: torch.Tensor, n_quantizers: Optional[int] = None) -> torch.Tensor:
+        """waveform float32 [B, 1, L] (L a multiple of the hop) → codes int64 [B, n_quantizers, L / hop]."""
+        if self.encoder_dim <= 0:
+            raise NotImplementedError("this DacEngine was built without the encoder (encoder_dim=0)")
+        if wave.dim() != 3 or wave.shape[1] != 1:
+            raise ValueError(f"input_values must be [batch, 1, samples], got {tuple(wave.shape)}")
+        wave = wave.to(self.device, torch.float32).contiguous()
+        B, _, L = wave.shape
+        if L == 0 or L % self.hop:
+            raise ValueError(f"waveform length {L} is not a positive multiple of the hop {self.hop} (apply the preprocess padding)")
+        nq = self.K if n_quantizers is None else max(1, min(int(n_quantizers), self.K))
+        codes = torch.empty(B, nq, L // self.hop, dtype=torch.int64, device=self.device)
+        N.check(self.lib.ptts_dac_encode(self._h, C.c_void_p(wave.data_ptr()), C.c_void_p(codes.data_ptr()), B, L, nq, _stream_ptr()), "ptts_dac_encode")
+        self._keep = wave
+        return codes
+
+    def debug_latents(self, B: int, T: int) -> torch.Tensor:
+        """Latents z of the last ``encode`` as [B, latent, T] (parity probe)."""
+        p = C.c_void_p()
+        N.check(self.lib.ptts_dac_debug_latents(self._h, C.byref(p)), "ptts_dac_debug_latents")
+        out = torch.empty(B, T, self.latent_dim, dtype=torch.float32, device=self.device)
+        rc = N.hip_runtime().hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(p.value), C.c_size_t(out.numel() * 4), 3, _stream_ptr())
+        if rc != 0:
+            raise N.NativeLibraryError(f"hipMemcpy(D2D) failed with code {rc}")
+        return out.transpose(1, 2).contiguous()
 
 
 def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

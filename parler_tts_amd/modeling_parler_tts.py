@@ -376,9 +376,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         prompt_attention_mask = mk.pop("prompt_attention_mask", None)
         prompt_hidden_states = mk.pop("prompt_hidden_states", None)
         encoder_outputs = mk.pop("encoder_outputs", None)
-        if mk.pop("input_values", None) is not None or mk.pop("decoder_input_ids", None) is not None:
-            raise NotImplementedError("voice-prompt continuation (`input_values` / `decoder_input_ids`) needs DACModel.encode, which is"
-                                      " outside the MI355X-accelerated path (SURVEY.md §8(f))")
+        input_values = mk.pop("input_values", None)
+        decoder_input_ids = mk.pop("decoder_input_ids", None)
         if mk.get("past_key_values") is not None and getattr(gc, "cache_implementation", None) is not None:
             raise ValueError("Passing both `cache_implementation` (used to initialize certain caches) and `past_key_values` (a "
                              "Cache object) is unsupported. Please use only one of the two.")
@@ -430,14 +429,41 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             B *= num_return
         N = enc.shape[1]
         P = prompt.shape[1] if prompt is not None else 0
-        # --- lengths (:3458-3469) -----------------------------------------------------------------------------------
+        bos = d.bos_token_id
+        # --- voice prompt (:3136-3194): `input_values` -> DAC codes -> `decoder_input_ids`, continued by the decoder --------------
+        if input_values is not None:
+            enc_out = self.audio_encoder.encode(input_values.to(dev), n_quantizers=K)
+            audio_codes = enc_out.audio_codes
+            if audio_codes.dim() == 4:
+                if audio_codes.shape[0] != 1:  # :3182-3186
+                    raise ValueError(f"Expected 1 frame in the audio code outputs, got {audio_codes.shape[0]} frames. Ensure chunking is "
+                                     "disabled by setting `chunk_length=None` in the audio encoder.")
+                audio_codes = audio_codes[0]
+            decoder_input_ids = audio_codes.reshape(audio_codes.shape[0] * K, audio_codes.shape[-1])
+        prefix = None
+        if decoder_input_ids is not None:
+            decoder_input_ids = decoder_input_ids.to(dev).long()
+            if decoder_input_ids.dim() != 2 or decoder_input_ids.shape[0] % K:
+                raise ValueError(f"decoder_input_ids must be [batch * num_codebooks, frames], got {tuple(decoder_input_ids.shape)}")
+            if not bool((decoder_input_ids[..., 0] != bos).all()):  # already starts with the BOS column (:3017-3018)
+                decoder_input_ids = decoder_input_ids[:, 1:]
+            if decoder_input_ids.shape[0] // K == B // num_return and num_return > 1:
+                decoder_input_ids = decoder_input_ids.reshape(-1, K, decoder_input_ids.shape[-1]).repeat_interleave(num_return, 0).reshape(B * K, -1)
+            if decoder_input_ids.shape[0] != B * K:
+                raise ValueError(f"decoder_input_ids batch {decoder_input_ids.shape[0] // K} != batch {B}")
+            if decoder_input_ids.shape[-1] > 0:
+                prefix = decoder_input_ids
+        T0 = prefix.shape[-1] if prefix is not None else 0
+        # --- lengths (:3458-3469): counted from the 1 + T0 given decoder columns ---------------------------------------------------
         if gc.max_new_tokens is not None:
-            max_length = int(gc.max_new_tokens) + 1
+            max_length = int(gc.max_new_tokens) + 1 + T0
         else:
             max_length = int(gc.max_length)
         min_new = int(gc.min_new_tokens or 0)
         if getattr(gc, "min_length", 0):
-            min_new = max(min_new, int(gc.min_length) - 1)
+            min_new = max(min_new, int(gc.min_length) - 1 - T0)
+        if max_length < T0 + 2:
+            raise ValueError(f"Input length of decoder_input_ids is {T0 + 1}, but `max_length` is set to {max_length}: no room for a generated token")
         if max_length < 2:
             raise ValueError("`max_length` / `max_new_tokens` leave no room for a generated token")
         eng = self._get_engine(B, N, P, max_length)
@@ -447,20 +473,24 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         eng.set_gen_params(max_length=max_length, min_new_tokens=min_new, do_sample=do_sample, temperature=float(gc.temperature or 1.0),
                            top_k=int(gc.top_k or 0) if do_sample else 0, top_p=float(gc.top_p if gc.top_p is not None else 1.0),
                            use_eos_gate=logits_processor is None, seed=seed)
-        bos, pad, eos = d.bos_token_id, gc.pad_token_id if gc.pad_token_id is not None else d.pad_token_id, d.eos_token_id
+        pad, eos = gc.pad_token_id if gc.pad_token_id is not None else d.pad_token_id, d.eos_token_id
         bos_col = torch.full((B * K, 1), bos, dtype=torch.long, device=dev)
+        dec_ids = bos_col if prefix is None else torch.cat([bos_col, prefix], dim=-1)  # :3011-3018
+        delayed, pattern = build_delay_pattern_mask(dec_ids, bos, pad, max_length, K)  # :3523-3530
         if streamer is not None:
-            delayed, _ = build_delay_pattern_mask(bos_col, bos, pad, max_length, K)
             streamer.put(delayed.cpu())  # :3533-3534
+        eng.set_audio_prefix(prefix)
         if not manual:
-            output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer)
+            output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, delayed.shape[1])
         else:
             output_ids = self._run_host_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, logits_processor,
-                                             stopping_criteria, streamer, eos, pad)
+                                             stopping_criteria, streamer, eos, pad, delayed)
         if streamer is not None:
             streamer.end()
         # --- un-delay (:3585-3597) and decode (:3600-3647) -------------------------------------------------------------
-        _, pattern = build_delay_pattern_mask(bos_col, bos, pad, max_length, K)
+        # With a voice prompt the reference re-builds the un-delay mask from the ALREADY delayed ids (:3589-3594), which
+        # drops the first k prompt codes of codebook k and misaligns the rows; the mask here is the one
+        # that inverts the delay pattern: BOS triangle + PAD triangle, independent of the prompt.
         output_ids = apply_delay_pattern_mask(output_ids, pattern)
         _, m2 = build_delay_pattern_mask(bos_col, bos, pad, output_ids.shape[1], K)
         keep = (m2 != bos) & (m2 != pad)
@@ -486,11 +516,11 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         return wav
 
     # -- default path: the whole `_sample` loop runs on the device -------------------------------------------------------
-    def _run_device_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer):
-        eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)
-        sent = 1
+    def _run_device_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, given: int = 1):
+        eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)  # BOS column + voice-prompt columns, then the first sampled one
+        sent = given
         chunk = int(getattr(streamer, "play_steps", 16) or 16) if streamer is not None else 64
-        remaining = max_length - 2
+        remaining = max_length - given - 1
         done = False
         while True:
             if streamer is not None:  # forward finished columns in order (one put per column, like `_sample`)
@@ -507,16 +537,18 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         return eng.ids()
 
     # -- user LogitsProcessorList / StoppingCriteria: forward on the HIP engine, selection in torch --------------------------
-    def _run_host_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, processors, criteria, streamer, eos, pad):
+    def _run_host_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, processors, criteria, streamer, eos, pad,
+                       given_ids):
         dev = self.device
         eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
         B = enc.shape[0]
         K = self.config.decoder.num_codebooks
-        seq = torch.full((B * K, 1), self.config.decoder.bos_token_id, dtype=torch.long, device=dev)
+        seq = given_ids.clone()  # BOS column (+ the delayed voice-prompt columns)
+        given = seq.shape[-1]
         unfinished = torch.ones(B * K, dtype=torch.long, device=dev)
         while True:
             scores = eng.logits().float()
-            if min_new > 0 and (seq.shape[-1] - 1) < min_new:
+            if min_new > 0 and (seq.shape[-1] - given) < min_new:
                 scores[:, eos] = -math.inf
             for proc in (processors or []):
                 scores = proc(seq, scores)

@@ -79,6 +79,79 @@ def test_shift_equivariance_away_from_edges():
     assert (a[..., :hop] - b[..., :hop]).abs().max() > 1e-3  # sanity: different content where frames differ
 
 
+def _enc_engine(max_batch=2, max_frames=64):
+    from parler_tts_amd.engine import DacEngine
+
+    spec = DA.DAC_TINY
+    sd = DA.make_dac_weights(spec, seed=4321, weight_norm_format="parametrized", with_encoder=True)
+    d = DacEngine(num_codebooks=spec.num_codebooks, codebook_size=spec.codebook_size, codebook_dim=spec.codebook_dim, latent_dim=spec.latent_dim,
+                  decoder_dim=spec.decoder_dim, rates=spec.decoder_rates, max_batch=max_batch, max_frames=max_frames, encoder_dim=spec.encoder_dim)
+    d.load_state_dict(sd)
+    return d, DA.DacOracle(spec, sd)
+
+
+def test_encode_matches_golden_latents_and_codes():
+    """Voice-prompt path (DACModel.encode, modeling_dac.py:33-104). Bars: latents |Δ| <= 1e-4 * max|z| (fp32 summation order);
+    codes bit-exact on every frame whose top-2 VQ score gap is clear of that noise (margin >= 1e-4 at all 9 stages; a flip at
+    one stage changes the residual of the later ones, so whole frames are compared), and >= 95 % of all entries."""
+    g = np.load(os.path.join(GOLD, "dac_tiny_encode.npz"))
+    d, orc = _enc_engine()
+    wave = orc.preprocess(t(g["wave"]))
+    codes = d.encode(wave.cuda()).cpu()
+    B, _, T = codes.shape
+    z = d.debug_latents(B, T).cpu()
+    zr = t(g["latents"])
+    assert (z - zr).abs().max() <= 1e-4 * zr.abs().max()
+    ref = t(g["codes"])
+    safe = (t(g["margin"]) >= 1e-4)[:, None, :].expand_as(ref)
+    assert torch.equal(codes[safe], ref[safe])
+    assert (codes == ref).float().mean() >= 0.95
+    assert torch.equal(d.encode(wave.cuda(), n_quantizers=4).cpu(), codes[:, :4])  # residual stages are a prefix (n_quantizers)
+    # decode(encode(x)) runs end to end on the same engine
+    assert d.decode(codes.cuda()).shape == (B, 1, wave.shape[-1])
+
+
+@pytest.mark.parametrize("frames", [1, 3, 47])
+def test_encode_ragged_lengths(frames):
+    d, orc = _enc_engine(max_batch=1)
+    gen = torch.Generator().manual_seed(frames)
+    wave = 0.3 * torch.randn(1, 1, frames * DA.DAC_TINY.hop_length, generator=gen)
+    codes = d.encode(wave.cuda()).cpu()
+    z = d.debug_latents(1, frames).cpu()
+    zr = orc.encode_latents(wave)
+    assert (z - zr).abs().max() <= 1e-4 * zr.abs().max()
+    ref, margin = orc.quantize(zr)
+    safe = (margin >= 1e-4)[:, None, :].expand_as(ref)
+    assert torch.equal(codes[safe], ref[safe])
+
+
+def test_encode_wrapper_semantics_and_errors():
+    import parler_tts_amd as P
+
+    cfg = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2], encoder_dim=16)
+    m = P.DACModel(cfg)
+    sd = DA.make_dac_weights(DA.DAC_TINY, seed=4321, weight_norm_format="parametrized", with_encoder=True)
+    m.load_state_dict({"model." + k: v for k, v in sd.items()})
+    m = m.to("cuda")
+    wave = 0.3 * torch.randn(2, 1, 32 * 5 + 7)
+    out = m.encode(wave.cuda())
+    assert out.audio_codes.shape == (1, 2, 9, 6) and out.audio_scales == [None]  # right-padded to a hop multiple (:64)
+    orc = DA.DacOracle(DA.DAC_TINY, sd)
+    ref, margin = orc.quantize(orc.encode_latents(orc.preprocess(wave)))
+    safe = (margin >= 1e-4)[:, None, :].expand_as(ref)
+    assert torch.equal(out.audio_codes[0].cpu()[safe], ref[safe])
+    assert m.encode(wave.cuda(), return_dict=False)[0].shape == (1, 2, 9, 6)
+    with pytest.raises(ValueError, match="channels"):
+        m.encode(torch.zeros(1, 3, 64).cuda())
+    with pytest.raises(ValueError, match="sample_rate"):
+        m.encode(wave.cuda(), sample_rate=16000)
+    # decode-only checkpoints refuse loudly
+    m2 = P.DACModel(cfg)
+    m2.load_state_dict({"model." + k: v for k, v in DA.make_dac_weights(DA.DAC_TINY, seed=4321).items()})
+    with pytest.raises(RuntimeError, match="encoder"):
+        m2.to("cuda").encode(wave.cuda())
+
+
 def test_errors():
     spec = DA.DAC_TINY
     sd = DA.make_dac_weights(spec, seed=5)

@@ -21,7 +21,7 @@ def _tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False)
     t5 = T5Config(vocab_size=128, d_model=128, d_kv=32, d_ff=256, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")
     dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=256, num_hidden_layers=2, ffn_dim=256, num_attention_heads=2,
                                    hidden_size=128, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025, rope_embeddings=rope)
-    dac = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2])
+    dac = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2], encoder_dim=16)
     cfg = P.ParlerTTSConfig.from_sub_models_config(t5, dac, dec, vocab_size=128, prompt_cross_attention=prompt_cross_attention)
     m = P.ParlerTTSForConditionalGeneration(cfg)
     spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "rope_embeddings": rope})
@@ -33,7 +33,7 @@ def _tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False)
         for k in range(9):  # generate() (like the reference :3627-3636) drops every frame that contains one
             sd[f"lm_heads.{k}.weight"][1024:] = 0.0
     m.decoder.load_state_dict(sd, strict=False)
-    dsd = DA.make_dac_weights(DA.DAC_TINY, seed=4321, weight_norm_format="parametrized")
+    dsd = DA.make_dac_weights(DA.DAC_TINY, seed=4321, weight_norm_format="parametrized", with_encoder=True)
     m.audio_encoder.load_state_dict({"model." + k: v for k, v in dsd.items()})
     return m, spec, sd, dsd
 
@@ -181,6 +181,41 @@ def test_num_return_sequences_expands_batch():
     a = m.generate(**kw)
     b = m.generate(num_return_sequences=2, **kw)
     assert b.shape[0] == 4 and torch.equal(b[0], b[1]) and torch.equal(b[0], a[0]) and torch.equal(b[2], a[1])
+
+
+def test_voice_prompt_input_values_and_decoder_input_ids():
+    """`input_values` (voice prompt, modeling:3136-3194): DAC-encode on the HIP engine, continue the codes, decode everything.
+    Checked against the oracle pipeline fed the SAME prefix codes (ids margin-safe -> identical frames, waveform RMS <= 1e-4),
+    and `decoder_input_ids` (with or without a leading BOS column) must give the same audio as `input_values`."""
+    m, spec, sd, dsd = _tiny_model(seed=0)
+    m = m.to("cuda")
+    g = torch.Generator().manual_seed(4)
+    desc = torch.randint(3, 128, (1, 8), generator=g)
+    prompt_ids = torch.randint(3, 128, (1, 5), generator=g)
+    voice = 0.3 * torch.randn(1, 1, 32 * 6 - 5, generator=g)  # 6 frames after the preprocess padding
+    codes = m.audio_encoder.encode(voice.cuda()).audio_codes[0]  # [1, 9, 6]
+    assert codes.shape == (1, 9, 6)
+    kw = dict(input_ids=desc.cuda(), prompt_input_ids=prompt_ids.cuda(), do_sample=False, max_new_tokens=20, min_new_tokens=20)
+    out = m.generate(input_values=voice.cuda(), return_dict_in_generate=True, **kw)
+    frames = 6 + 20 - 9 + 1 - 0  # 1 + 6 + 20 columns -> Lout - K frames
+    assert out.sequences.shape == (1, 32 * (27 - 9)) and out["audios_length"] == [32 * 18], (out.sequences.shape, frames)
+    ids2 = codes.reshape(9, 6)
+    w2 = m.generate(decoder_input_ids=ids2, **kw)
+    w3 = m.generate(decoder_input_ids=torch.cat([torch.full((9, 1), 1025, device="cuda"), ids2], 1), **kw)
+    assert torch.equal(out.sequences, w2) and torch.equal(w2, w3)
+    # oracle pipeline on the same prefix
+    enc = m._encode_description(desc.cuda(), None).float().cpu()
+    prompt = m.embed_prompts(prompt_ids.cuda()).float().cpu()
+    gp = DO.GenParams(max_length=27, min_new_tokens=20)
+    tr = DO.sample_loop(DO.DecoderOracle(spec, sd), enc, None, prompt, None, gp, decoder_input_ids=ids2.cpu())
+    if tr.min_margin > 2e-4:
+        ref_codes = DO.undelay(tr.sequences, spec, 27)
+        assert torch.equal(ref_codes[0, :, :6], ids2.cpu())  # the voice prompt survives the delay / un-delay round trip intact
+        wav_ref = DA.DacOracle(DA.DAC_TINY, dsd).decode(DO.valid_frames(ref_codes[0])[None])[0, 0]
+        assert wav_ref.shape[0] == out.sequences.shape[1]
+        assert float((out.sequences[0].cpu() - wav_ref).pow(2).mean().sqrt()) <= 1e-4
+    with pytest.raises(ValueError, match="no room"):
+        m.generate(decoder_input_ids=ids2, input_ids=desc.cuda(), prompt_input_ids=prompt_ids.cuda(), max_length=7)
 
 
 def test_bf16_model_runs_and_tracks_fp32():

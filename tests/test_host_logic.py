@@ -111,11 +111,11 @@ def test_generate_refuses_cpu_and_bad_modes():
     ids = torch.randint(3, 100, (1, 6))
     with pytest.raises(ValueError, match="greedy or sampling"):
         m.generate(input_ids=ids, prompt_input_ids=ids, num_beams=2)
-    with pytest.raises(NotImplementedError, match="voice-prompt"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # voice prompt: DAC encode is HIP-only too
         m.generate(input_ids=ids, prompt_input_ids=ids, input_values=torch.zeros(1, 1, 100))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.generate(input_ids=ids, prompt_input_ids=ids, max_new_tokens=12)
-    with pytest.raises(NotImplementedError, match="encode"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.audio_encoder.encode(torch.zeros(1, 1, 100))
     with pytest.raises(NotImplementedError, match="resize"):
         m.resize_token_embeddings(10)

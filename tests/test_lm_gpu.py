@@ -83,6 +83,32 @@ def test_fp32_greedy_ids_bit_exact_with_eos_paths(variant):
     assert fin and cur == g["sequences"].shape[1]
 
 
+@pytest.mark.parametrize("seed", [6, 17])
+def test_voice_prompt_prefix_continuation_ids_bit_exact(seed):
+    """decoder_input_ids prefix (modeling:3136-3194, :205-276): the engine teacher-forces the given code columns one position
+    at a time; the oracle (like the reference) runs them in ONE multi-column forward. Same raw ids, incl. the forced
+    delayed prompt values the model sees beyond the prefix, MinNewTokens counted from the given length, EOS paths."""
+    spec = DO.TINY
+    sd = DO.make_decoder_weights(spec, seed=1234)
+    for k in range(spec.num_codebooks):
+        sd[f"lm_heads.{k}.weight"][spec.eos_token_id] *= 6.0
+    g = torch.Generator().manual_seed(seed)
+    enc = torch.randn(1, 7, spec.hidden_size, generator=g)
+    prompt = torch.randn(1, 3, spec.hidden_size, generator=g) * 0.5
+    pre = torch.randint(0, 1024, (spec.num_codebooks, 7), generator=g)
+    gp = DO.GenParams(max_length=36, min_new_tokens=6)
+    ref = DO.sample_loop(DO.DecoderOracle(spec, sd), enc, None, prompt, None, gp, decoder_input_ids=pre)
+    assert ref.min_margin > 5e-4  # margin-safe (seeds scanned on the oracle)
+    eng = make_engine(spec, sd, torch.float32, max_batch=1)
+    eng.set_gen_params(max_length=36, min_new_tokens=6)
+    ids = eng.generate_ids(enc, None, prompt, None, poll_every=5, audio_prefix=pre[None]).cpu()
+    assert torch.equal(ids, ref.sequences)
+    # a following call without a prefix must not see the old one
+    ref0 = DO.sample_loop(DO.DecoderOracle(spec, sd), enc, None, prompt, None, gp)
+    if ref0.min_margin > 2e-4:
+        assert torch.equal(eng.generate_ids(enc, None, prompt, None).cpu(), ref0.sequences)
+
+
 def test_early_stop_when_all_rows_hit_eos():
     """Every codebook emits EOS as soon as the gate lets it: the loop must end after min_new + K steps, not at
     max_length. All non-EOS LM-head rows are zero, so blocked rows see an all-equal score vector: also checks the
