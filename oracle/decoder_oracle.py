@@ -436,12 +436,16 @@ def sample_loop(model: DecoderOracle, enc: torch.Tensor, enc_mask: Optional[torc
     return tr
 
 
-def undelay(seq: torch.Tensor, spec: DecoderSpec, max_length: int) -> torch.Tensor:
-    """generate() post-processing :3585-3597 → codes [B, K, Lout-K] (may still contain ids >= codebook_size)."""
+def undelay(seq: torch.Tensor, spec: DecoderSpec, max_length: int, decoder_input_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """generate() post-processing :3585-3597 → codes [B, K, Lout-K] (may still contain ids >= codebook_size). With a voice
+    prompt (``decoder_input_ids``) the pattern applied to the raw ids is the one built over the prefix (:3523-3530, :3586);
+    the un-delay mask is the BOS/PAD triangle pair (the reference rebuilds it from already-delayed ids, :3589-3594, which
+    misaligns codebooks k >= 1 — not reproduced)."""
     K = spec.num_codebooks
     bos, pad = spec.bos_token_id, spec.pad_token_id
     bsz = seq.shape[0] // K
-    _, pattern = build_delay_pattern_mask(seq[:, :1], bos, pad, max_length, K)
+    first = seq[:, :1] if decoder_input_ids is None else torch.cat([seq[:, :1], decoder_input_ids.long()], dim=-1)
+    _, pattern = build_delay_pattern_mask(first, bos, pad, max_length, K)
     out = apply_delay_pattern_mask(seq, pattern)
     _, m2 = build_delay_pattern_mask(seq[:, :1], bos, pad, out.shape[1], K)
     keep = (m2 != bos) & (m2 != pad)

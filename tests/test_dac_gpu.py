@@ -62,6 +62,28 @@ def test_full_size_44khz_stack():
     assert _rms(wav, ref) <= 1e-4, _rms(wav, ref)
 
 
+def test_encode_full_size_44khz_stack():
+    """The real 44 kHz encoder (1→64→…→1024, strides 2,4,8,8, k up to 16) + 9-stage RVQ on 12 frames of audio."""
+    from parler_tts_amd.engine import DacEngine
+
+    spec = DA.DAC_44KHZ
+    sd = DA.make_dac_weights(spec, seed=4321, with_encoder=True)
+    gen = torch.Generator().manual_seed(9)
+    tt = torch.arange(512 * 12) / 44100.0
+    wave = (0.3 * torch.sin(2 * torch.pi * 220.0 * tt) + 0.05 * torch.randn(tt.numel(), generator=gen))[None, None]
+    orc = DA.DacOracle(spec, sd)
+    zr = orc.encode_latents(wave)
+    ref, margin = orc.quantize(zr)
+    d = DacEngine(max_batch=1, max_frames=16, encoder_dim=spec.encoder_dim)
+    d.load_state_dict(sd)
+    codes = d.encode(wave.cuda()).cpu()
+    z = d.debug_latents(1, 12).cpu()
+    assert codes.shape == (1, 9, 12)
+    assert (z - zr).abs().max() <= 1e-4 * zr.abs().max(), float((z - zr).abs().max() / zr.abs().max())
+    safe = (margin >= 1e-4)[:, None, :].expand_as(ref)
+    assert torch.equal(codes[safe], ref[safe]) and int(safe.sum()) > 0
+
+
 def test_shift_equivariance_away_from_edges():
     """Size-independent property: away from the edges the decoder is shift-equivariant — decoding codes shifted by
     s frames gives the waveform shifted by s*hop. The tiny spec's small strides (4,2,2,2) give a receptive field of

@@ -197,8 +197,8 @@ def test_voice_prompt_input_values_and_decoder_input_ids():
     assert codes.shape == (1, 9, 6)
     kw = dict(input_ids=desc.cuda(), prompt_input_ids=prompt_ids.cuda(), do_sample=False, max_new_tokens=20, min_new_tokens=20)
     out = m.generate(input_values=voice.cuda(), return_dict_in_generate=True, **kw)
-    frames = 6 + 20 - 9 + 1 - 0  # 1 + 6 + 20 columns -> Lout - K frames
-    assert out.sequences.shape == (1, 32 * (27 - 9)) and out["audios_length"] == [32 * 18], (out.sequences.shape, frames)
+    # 1 BOS + 6 prompt + 20 new columns = 27 -> Lout - K = 18 frames
+    assert out.sequences.shape == (1, 32 * (27 - 9)) and out["audios_length"] == [32 * 18], out.sequences.shape
     ids2 = codes.reshape(9, 6)
     w2 = m.generate(decoder_input_ids=ids2, **kw)
     w3 = m.generate(decoder_input_ids=torch.cat([torch.full((9, 1), 1025, device="cuda"), ids2], 1), **kw)
@@ -209,7 +209,7 @@ def test_voice_prompt_input_values_and_decoder_input_ids():
     gp = DO.GenParams(max_length=27, min_new_tokens=20)
     tr = DO.sample_loop(DO.DecoderOracle(spec, sd), enc, None, prompt, None, gp, decoder_input_ids=ids2.cpu())
     if tr.min_margin > 2e-4:
-        ref_codes = DO.undelay(tr.sequences, spec, 27)
+        ref_codes = DO.undelay(tr.sequences, spec, 27, decoder_input_ids=ids2.cpu())
         assert torch.equal(ref_codes[0, :, :6], ids2.cpu())  # the voice prompt survives the delay / un-delay round trip intact
         wav_ref = DA.DacOracle(DA.DAC_TINY, dsd).decode(DO.valid_frames(ref_codes[0])[None])[0, 0]
         assert wav_ref.shape[0] == out.sequences.shape[1]
