@@ -28,12 +28,13 @@ namespace {
 constexpr int MAXTAPS = 8;
 
 struct ConvArgs {
-  const float* x;      // activated input, channels-last [B][Tin][Cin]
-  const float* Wp;     // packed [phase][Cout/16][ntaps*Cin/16][64][4]
+  const void* x;       // activated input, channels-last [B][Tin][Cin]: fp32, or bf16 in the bf16-operand mode
+  const void* Wp;      // packed [phase][Cout/16][ntaps*Cin/16][64][4] fp32, or [..][ntaps*Cin/32][64][8] bf16
   const float* bias;   // [Cout]
   const float* skip;   // optional residual [B][Tout][Cout] (may alias out_raw)
   float* out_raw;      // optional
-  float* out_act;      // optional: snake(alpha) of the result
+  void* out_act;       // optional: snake(alpha) of the result (bf16 in the bf16-operand mode unless act_f32)
+  int act_f32;         // bf16 mode: write out_act as fp32 (the layer feeding the final Conv1d(C -> 1) + tanh)
   const float* alpha;  // [Cout] for out_act
   int dil, pad, transposed;  // tap offset: conv  tap*dil - pad ; transposed (stride = nphase)  (ph + pad)/nphase - tap
   int B, Tin, Cin, Cout, ntaps, nphase;
@@ -53,7 +54,10 @@ __device__ __forceinline__ float snake_f(float x, float al) {
 // divides every decoder width / 16: 96, 48, 24, 12, 6 strips), so each activation fragment is reused CS times from
 // registers and the 4 waves read identical weight fragments (L1 broadcast). First mapping (waves over strips, one
 // shared tile) left 25 % of the waves idle on the 6/12/24-strip layers and ran at 43 % of the f32-MFMA peak.
-template <int CS>
+// BF: bf16 MFMA operands (v_mfma_f32_16x16x32_bf16: 32 channels per step, activations and weights stored in bf16), fp32
+// accumulate, bias / skip / Snake in fp32 - at least the precision of the reference run in bf16, where every conv output
+// is rounded to bf16. BF = false is the exact-f32 parity mode.
+template <int CS, bool BF>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j = lane & 15;
@@ -63,10 +67,11 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int strip0 = blockIdx.y * CS;
   const int nstrips = a.Cout / 16;
   if (tile * fpb + wave * 32 >= a.Tn) return;
-  const int cpt = a.Cin / 16;           // k-steps per tap
+  constexpr int KC = BF ? 32 : 16;      // channels per k-step
+  const int cpt = a.Cin / KC;           // k-steps per tap
   const int nk = a.ntaps * cpt;
-  const float* xb = a.x + (size_t)b * a.Tin * a.Cin;
-  const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)ph * nstrips * nk) * 64 + lane;
+  const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)b * a.Tin * a.Cin * (BF ? 2 : 4);
+  const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)ph * nstrips * nk) * 64 + lane;  // 16 B per lane either way
   const int j0 = tile * fpb + wave * 32;
 
   f32x4 acc[CS][2];
@@ -84,8 +89,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int ti0_ = (j0 + j) * a.stride + off_, ti1_ = ti0_ + 16 * a.stride;                                            \
     B0 = make_float4(0, 0, 0, 0);                                                                                        \
     B1 = make_float4(0, 0, 0, 0);                                                                                        \
-    if (ti0_ >= 0 && ti0_ < a.Tin) B0 = *reinterpret_cast<const float4*>(xb + (size_t)ti0_ * a.Cin + q * 4 + cc_ * 16);   \
-    if (ti1_ >= 0 && ti1_ < a.Tin) B1 = *reinterpret_cast<const float4*>(xb + (size_t)ti1_ * a.Cin + q * 4 + cc_ * 16);   \
+    if (ti0_ >= 0 && ti0_ < a.Tin) B0 = *reinterpret_cast<const float4*>(xb + ((size_t)ti0_ * a.Cin + cc_ * KC) * (BF ? 2 : 4) + q * 16);  \
+    if (ti1_ >= 0 && ti1_ < a.Tin) B1 = *reinterpret_cast<const float4*>(xb + ((size_t)ti1_ * a.Cin + cc_ * KC) * (BF ? 2 : 4) + q * 16);  \
     _Pragma("unroll") for (int s_ = 0; s_ < CS; ++s_) WF[s_] = Wp[((size_t)(strip0 + s_) * nk + (KS)) * 64];             \
   } while (0)
   float4 wf[CS], b0, b1;
@@ -95,14 +100,19 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     if (ks + 1 < nks) PTTS_DAC_LOAD_STEP(ks + 1, wn, n0, n1);
 #pragma unroll
     for (int s = 0; s < CS; ++s) {
-      acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, b0.x, acc[s][0], 0, 0, 0);
-      acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, b1.x, acc[s][1], 0, 0, 0);
-      acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, b0.y, acc[s][0], 0, 0, 0);
-      acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, b1.y, acc[s][1], 0, 0, 0);
-      acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, b0.z, acc[s][0], 0, 0, 0);
-      acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, b1.z, acc[s][1], 0, 0, 0);
-      acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, b0.w, acc[s][0], 0, 0, 0);
-      acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, b1.w, acc[s][1], 0, 0, 0);
+      if constexpr (BF) {
+        acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, b0), acc[s][0], 0, 0, 0);
+        acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, b1), acc[s][1], 0, 0, 0);
+      } else {
+        acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, b0.x, acc[s][0], 0, 0, 0);
+        acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].x, b1.x, acc[s][1], 0, 0, 0);
+        acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, b0.y, acc[s][0], 0, 0, 0);
+        acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].y, b1.y, acc[s][1], 0, 0, 0);
+        acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, b0.z, acc[s][0], 0, 0, 0);
+        acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].z, b1.z, acc[s][1], 0, 0, 0);
+        acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, b0.w, acc[s][0], 0, 0, 0);
+        acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s].w, b1.w, acc[s][1], 0, 0, 0);
+      }
     }
     if (ks + 1 < nks) {
 #pragma unroll
@@ -128,7 +138,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
     if (a.out_act) {
       const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
-      *reinterpret_cast<float4*>(a.out_act + o) = make_float4(snake_f(v.x, al.x), snake_f(v.y, al.y), snake_f(v.z, al.z), snake_f(v.w, al.w));
+      const float4 sv = make_float4(snake_f(v.x, al.x), snake_f(v.y, al.y), snake_f(v.z, al.z), snake_f(v.w, al.w));
+      if (BF && !a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
     }
   };
   if (CS >= 1) { emit(acc[0][0], 0, 0); emit(acc[0][1], 0, 1); }
@@ -300,8 +312,8 @@ __global__ void rvq_table_kernel(const float* __restrict__ cb, const float* __re
 }
 
 // z[b][t][c] = sum_i table[i][codes[b][i][t]][c]   (sequential over i, like from_codes)
-__global__ void rvq_gather_kernel(const long long* __restrict__ codes, const float* __restrict__ table, float* __restrict__ z,
-                                  int K, int T, int ncodes, int latent) {
+__global__ void rvq_gather_kernel(const long long* __restrict__ codes, const float* __restrict__ table, void* __restrict__ z,
+                                  int K, int T, int ncodes, int latent, int z_bf16) {
   const int t = blockIdx.x, b = blockIdx.y;
   __shared__ int s_code[32];
   if (threadIdx.x < K) {
@@ -314,7 +326,8 @@ __global__ void rvq_gather_kernel(const long long* __restrict__ codes, const flo
   for (int c = threadIdx.x; c < latent; c += blockDim.x) {
     float acc = 0.f;
     for (int i = 0; i < K; ++i) acc += table[((size_t)i * ncodes + s_code[i]) * latent + c];
-    z[((size_t)b * T + t) * latent + c] = acc;
+    if (z_bf16) reinterpret_cast<bf16_t*>(z)[((size_t)b * T + t) * latent + c] = f32_to_bf16(acc);
+    else reinterpret_cast<float*>(z)[((size_t)b * T + t) * latent + c] = acc;
   }
 }
 
@@ -340,6 +353,28 @@ __global__ void pack_conv_kernel(const float* __restrict__ src, float* __restric
   }
 }
 
+// bf16-operand mode: [phase][Cout/16][ntaps*Cin/32][64 lanes][8 bf16]; lane: row = lane & 15, channels (lane >> 4) * 8 .. + 8
+__global__ void pack_conv_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int Cout, int Cin, int ntaps, int nphase,
+                                      const int* __restrict__ ktap, long long s_co, long long s_ci, long long s_k) {
+  const int cpt = Cin / 32, nk = ntaps * cpt, nstrips = Cout / 16;
+  const size_t total = (size_t)nphase * nstrips * nk * 64;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  size_t r = idx >> 6;
+  const int ks = (int)(r % nk); r /= nk;
+  const int strip = (int)(r % nstrips);
+  const int ph = (int)(r / nstrips);
+  const int tap = ks / cpt, cc = ks % cpt;
+  const int co = strip * 16 + (lane & 15);
+  const int kidx = ktap[ph * MAXTAPS + tap];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = cc * 32 + (lane >> 4) * 8 + e;
+    dst[idx * 8 + e] = f32_to_bf16(src[co * s_co + ci * s_ci + kidx * s_k]);
+  }
+}
+
 struct ConvLayer {
   std::string name;        // descript module name, e.g. "decoder.model.1.block.1"
   std::string alpha_name;  // Snake applied to this conv's OUTPUT (the next layer's input activation), or ""
@@ -347,6 +382,7 @@ struct ConvLayer {
   bool transposed;
   float *Wp = nullptr, *bias = nullptr, *alpha = nullptr;
   bool has_skip = false, write_raw = false;
+  bool bf16 = false;       // bf16-operand mode (decoder layers of a PTTS_BF16 engine)
   int pad = -1;            // explicit padding (down-sampling convs, k3 final conv); -1: "same" padding (k-1)*dil/2
 };
 
@@ -401,7 +437,10 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
              "latent_dim and every decoder width must be multiples of 16");
   PTTS_CHECK(c.encoder_dim >= 0 && c.encoder_dim % 16 == 0 && c.codebook_dim <= RVQ_MAXD, PTTS_E_UNSUPPORTED,
              "encoder_dim must be 0 (decode only) or a multiple of 16, codebook_dim <= %d", RVQ_MAXD);
-  PTTS_CHECK(c.compute_dtype == PTTS_F32, PTTS_E_UNSUPPORTED, "only the exact-f32 MFMA mode is implemented (compute_dtype = PTTS_F32)");
+  PTTS_CHECK(c.compute_dtype == PTTS_F32 || c.compute_dtype == PTTS_BF16, PTTS_E_INVALID, "compute_dtype must be PTTS_F32 or PTTS_BF16");
+  if (c.compute_dtype == PTTS_BF16)
+    PTTS_CHECK(c.latent_dim % 32 == 0 && c.decoder_dim % (32 << c.num_rates) == 0, PTTS_E_UNSUPPORTED,
+               "bf16-operand mode needs latent_dim and every decoder width to be multiples of 32");
   PTTS_CHECK(c.max_batch >= 1 && c.max_frames >= 1, PTTS_E_INVALID, "bad capacities");
   for (int i = 0; i < c.num_rates; ++i) PTTS_CHECK(c.rates[i] >= 2 && c.rates[i] <= 8 && c.rates[i] % 2 == 0, PTTS_E_UNSUPPORTED, "decoder rate %d unsupported (need an even stride in [2, 8])", c.rates[i]);
   PTTS_HIP(hipSetDevice(c.device));
@@ -417,6 +456,7 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
     ConvLayer L;
     L.name = name; L.alpha_name = alpha_name; L.Cin = Cin; L.Cout = Cout; L.ksize = k; L.dil = dil; L.stride = stride; L.transposed = tr;
     L.has_skip = has_skip; L.write_raw = write_raw;
+    L.bf16 = target == &d->convs && c.compute_dtype == PTTS_BF16;  // the encoder always runs the exact-f32 kernels
     const int ntaps = tr ? 2 : k, nphase = tr ? stride : 1;
     if (ntaps > 16) return ptts_fail(PTTS_E_UNSUPPORTED, "%s: kernel size %d unsupported", name.c_str(), k);
     PTTS_TRY(d->alloc(&L.Wp, (size_t)nphase * Cout * ntaps * Cin));
@@ -593,8 +633,14 @@ extern "C" int ptts_dac_load_weight(ptts_dac* d, const char* name_c, const float
       }
       PTTS_HIP(hipMemcpyAsync(d->d_ktap, ktap, sizeof ktap, hipMemcpyHostToDevice, st));
       const size_t total = (size_t)nphase * (L.Cout / 16) * ntaps * (L.Cin / 16) * 64;
-      hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dev_ptr, L.Wp, L.Cout, L.Cin, ntaps, nphase,
-                         d->d_ktap, s_co, s_ci, s_k);
+      if (L.bf16) {
+        const size_t tb = (size_t)nphase * (L.Cout / 16) * ntaps * (L.Cin / 32) * 64;
+        hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3((unsigned)((tb + 255) / 256)), dim3(256), 0, st, dev_ptr, reinterpret_cast<bf16_t*>(L.Wp), L.Cout,
+                           L.Cin, ntaps, nphase, d->d_ktap, s_co, s_ci, s_k);
+      } else {
+        hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dev_ptr, L.Wp, L.Cout, L.Cin, ntaps, nphase,
+                           d->d_ktap, s_co, s_ci, s_k);
+      }
       PTTS_HIP(hipStreamSynchronize(st));  // d_ktap is reused by the next call
       d->loaded.insert(name);
       return PTTS_OK;
@@ -614,8 +660,10 @@ extern "C" int ptts_dac_weights_ready(ptts_dac* d) {
   return PTTS_OK;
 }
 
-static int run_conv(ptts_dac* d, const ConvLayer& L, const float* x, const float* skip, float* out_raw, float* out_act, int B, int Tin, hipStream_t st) {
+static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float* skip, float* out_raw, void* out_act, int B, int Tin, hipStream_t st,
+                    bool act_f32 = false) {
   ConvArgs a = {};
+  a.act_f32 = act_f32 ? 1 : 0;
   a.x = x; a.Wp = L.Wp; a.bias = L.bias; a.skip = skip; a.out_raw = out_raw; a.out_act = out_act; a.alpha = L.alpha;
   a.B = B; a.Tin = Tin; a.Cin = L.Cin; a.Cout = L.Cout;
   if (!L.transposed) {
@@ -641,11 +689,19 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const float* x, const float
   const int CS = nstrips % 8 == 0 ? 8 : (nstrips % 6 == 0 ? 6 : (nstrips % 4 == 0 ? 4 : (nstrips % 2 == 0 ? 2 : 1)));
   const dim3 grid((unsigned)(ntile * a.nphase * B), (unsigned)(nstrips / CS));
   const dim3 blk(64 * nwb);
-  if (CS == 8) hipLaunchKernelGGL((conv_mfma_kernel<8>), grid, blk, 0, st, a);
-  else if (CS == 6) hipLaunchKernelGGL((conv_mfma_kernel<6>), grid, blk, 0, st, a);
-  else if (CS == 4) hipLaunchKernelGGL((conv_mfma_kernel<4>), grid, blk, 0, st, a);
-  else if (CS == 2) hipLaunchKernelGGL((conv_mfma_kernel<2>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<1>), grid, blk, 0, st, a);
+  if (L.bf16) {
+    if (CS == 8) hipLaunchKernelGGL((conv_mfma_kernel<8, true>), grid, blk, 0, st, a);
+    else if (CS == 6) hipLaunchKernelGGL((conv_mfma_kernel<6, true>), grid, blk, 0, st, a);
+    else if (CS == 4) hipLaunchKernelGGL((conv_mfma_kernel<4, true>), grid, blk, 0, st, a);
+    else if (CS == 2) hipLaunchKernelGGL((conv_mfma_kernel<2, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_mfma_kernel<1, true>), grid, blk, 0, st, a);
+  } else {
+    if (CS == 8) hipLaunchKernelGGL((conv_mfma_kernel<8, false>), grid, blk, 0, st, a);
+    else if (CS == 6) hipLaunchKernelGGL((conv_mfma_kernel<6, false>), grid, blk, 0, st, a);
+    else if (CS == 4) hipLaunchKernelGGL((conv_mfma_kernel<4, false>), grid, blk, 0, st, a);
+    else if (CS == 2) hipLaunchKernelGGL((conv_mfma_kernel<2, false>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_mfma_kernel<1, false>), grid, blk, 0, st, a);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "conv launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
@@ -667,8 +723,9 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
     }
     d->table_ready = true;
   }
-  hipLaunchKernelGGL(rvq_gather_kernel, dim3(T, B), dim3(256), 0, st, (const long long*)codes_dev, d->table, d->bufZ, c.num_codebooks, T,
-                     c.codebook_size, c.latent_dim);
+  const bool bf = c.compute_dtype == PTTS_BF16;
+  hipLaunchKernelGGL(rvq_gather_kernel, dim3(T, B), dim3(256), 0, st, (const long long*)codes_dev, d->table, (void*)d->bufZ, c.num_codebooks, T,
+                     c.codebook_size, c.latent_dim, bf ? 1 : 0);
   float *cur = d->bufA0, *other = d->bufA1;
   int Tcur = T;
   size_t li = 0;
@@ -682,7 +739,8 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
       const ConvLayer& c7 = d->convs[li++];
       PTTS_TRY(run_conv(d, c7, cur, nullptr, nullptr, d->bufS, B, Tcur, st));
       const ConvLayer& c1 = d->convs[li++];
-      PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st));
+      const bool last = bi + 1 == c.num_rates && ri == 2;  // feeds the final Conv1d(C -> 1): fp32 activations
+      PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st, last));
     }
   }
   const size_t n = (size_t)B * Tcur;

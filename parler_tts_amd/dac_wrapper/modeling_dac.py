@@ -81,7 +81,12 @@ class DACModel(torch.nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("DACModel runs on the HIP engine only: move the model to a cuda device (no CPU fallback)")
         e = self._engine
-        if e is None or self._engine_dev != dev or e.max_batch < batch or e.max_frames < frames or (need_encoder and e.encoder_dim <= 0):
+        # `.to(dtype=torch.bfloat16)` (INFERENCE.md:29-32 casts the whole model): bf16 MFMA operands with fp32 accumulation -
+        # at least the precision of the reference's bf16 codec; float32 is the exact-f32 parity mode
+        ok32 = self.config.latent_dim % 32 == 0 and self.decoder_dim % (32 << len(self.decoder_rates)) == 0  # 16x16x32 MFMA steps
+        compute = torch.bfloat16 if (self._dummy.dtype == torch.bfloat16 and ok32) else torch.float32
+        if (e is None or self._engine_dev != dev or e.max_batch < batch or e.max_frames < frames or (need_encoder and e.encoder_dim <= 0)
+                or e.compute_dtype != compute):
             if e is not None:
                 e.close()
             if not self._weights:
@@ -94,7 +99,7 @@ class DACModel(torch.nn.Module):
             e = DacEngine(num_codebooks=c.num_codebooks, codebook_size=c.codebook_size, codebook_dim=self.codebook_dim,
                           latent_dim=c.latent_dim, decoder_dim=self.decoder_dim, rates=self.decoder_rates,
                           max_batch=max(batch, 1), max_frames=max(frames, 64), device=dev,
-                          encoder_dim=self.encoder_dim if keep_enc else 0)
+                          encoder_dim=self.encoder_dim if keep_enc else 0, compute_dtype=compute)
             e.load_state_dict({k[len("model."):]: v for k, v in self._weights.items()})
             self._engine, self._engine_dev = e, dev
         return e

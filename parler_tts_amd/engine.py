@@ -207,14 +207,18 @@ class DacEngine:
 
     def __init__(self, *, num_codebooks: int = 9, codebook_size: int = 1024, codebook_dim: int = 8, latent_dim: int = 1024,
                  decoder_dim: int = 1536, rates: Iterable[int] = (8, 8, 4, 2), max_batch: int = 1, max_frames: int = 2600,
-                 device: Optional[torch.device] = None, encoder_dim: int = 0):
+                 device: Optional[torch.device] = None, encoder_dim: int = 0, compute_dtype: torch.dtype = torch.float32):
         if not torch.cuda.is_available():
             raise N.NativeLibraryError("DacEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = N.load_library()
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         rates = tuple(int(r) for r in rates)
         arr = (C.c_int32 * 8)(*(list(rates) + [0] * (8 - len(rates))))
-        self.cfg = N.PttsDacConfig(num_codebooks, codebook_size, codebook_dim, latent_dim, decoder_dim, len(rates), arr, N.PTTS_F32,
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"DAC compute dtype {compute_dtype} is not supported (float32: exact-f32 MFMA, bfloat16: bf16 MFMA operands)")
+        self.compute_dtype = compute_dtype
+        self.cfg = N.PttsDacConfig(num_codebooks, codebook_size, codebook_dim, latent_dim, decoder_dim, len(rates), arr,
+                                   N.PTTS_BF16 if compute_dtype == torch.bfloat16 else N.PTTS_F32,
                                    max_batch, max_frames, self.device.index or 0, int(encoder_dim))
         self.encoder_dim = int(encoder_dim)
         self.latent_dim = latent_dim

@@ -84,6 +84,47 @@ def test_encode_full_size_44khz_stack():
     assert torch.equal(codes[safe], ref[safe]) and int(safe.sum()) > 0
 
 
+def _rel_rms(a, b):
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+def test_bf16_operand_mode_tracks_fp32_oracle():
+    """compute_dtype = bf16 (what `.to(dtype=torch.bfloat16)` selects): bf16 MFMA operands, fp32 accumulate / bias / skip / Snake.
+    Bar: waveform RMS error <= 3 % of the signal RMS against the fp32 oracle (operand rounding 2^-9 per factor through ~30
+    layers; the reference's bf16 codec additionally rounds every conv OUTPUT to bf16)."""
+    from parler_tts_amd.engine import DacEngine
+
+    spec = DA.DacSpec(num_codebooks=9, latent_dim=64, decoder_dim=512, decoder_rates=(4, 2, 2, 2))  # every width a multiple of 32
+    sd = DA.make_dac_weights(spec, seed=4321)
+    codes = torch.randint(0, 1024, (2, 9, 37), generator=torch.Generator().manual_seed(5))
+    ref = DA.DacOracle(spec, sd).decode(codes)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        d = DacEngine(num_codebooks=9, codebook_size=1024, codebook_dim=8, latent_dim=64, decoder_dim=512, rates=spec.decoder_rates, max_batch=2,
+                      max_frames=64, compute_dtype=dt)
+        d.load_state_dict(sd)
+        outs[dt] = d.decode(codes.cuda()).cpu()
+        d.close()
+    assert _rms(outs[torch.float32], ref) <= 1e-4
+    r = _rel_rms(outs[torch.bfloat16], ref)
+    assert 1e-5 < r <= 3e-2, r  # really the bf16 path (not bit-identical to fp32), and within the bar
+    with pytest.raises(NotImplementedError, match="multiples of 32"):
+        DacEngine(latent_dim=64, decoder_dim=256, rates=(4, 2, 2, 2), compute_dtype=torch.bfloat16)
+
+
+def test_bf16_operand_mode_full_size_44khz():
+    from parler_tts_amd.engine import DacEngine
+
+    spec = DA.DAC_44KHZ
+    sd = DA.make_dac_weights(spec, seed=4321)
+    codes = torch.randint(0, 1024, (1, 9, 24), generator=torch.Generator().manual_seed(2))
+    ref = DA.DacOracle(spec, sd).decode(codes)
+    d = DacEngine(max_batch=1, max_frames=32, compute_dtype=torch.bfloat16)
+    d.load_state_dict(sd)
+    r = _rel_rms(d.decode(codes.cuda()).cpu(), ref)
+    assert r <= 3e-2, r
+
+
 def test_shift_equivariance_away_from_edges():
     """Size-independent property: away from the edges the decoder is shift-equivariant — decoding codes shifted by
     s frames gives the waveform shifted by s*hop. The tiny spec's small strides (4,2,2,2) give a receptive field of
