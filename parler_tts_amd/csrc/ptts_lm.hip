@@ -138,6 +138,20 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   const dim3 grid(a.N / 16), block(W * 64);
   int rc;
   if constexpr (PRO == PRO_COPY) {
+    static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
+    // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
+    if (a.M > block_min_m && EPI != EPI_GELU) {  // prefill-sized: register-blocked kernel, no K split
+      const int nstrips = a.N / 16;
+      const int ns = (nstrips % 4 == 0 && nstrips >= 128) ? 4 : (nstrips % 2 == 0 ? 2 : 0);  // N = 1024: 2 strips per wave keeps > 500 waves in flight
+      if (ns) {
+        const dim3 g2(nstrips / ns, (a.M + 255) / 256), b2(256);
+        if (ns == 4) hipLaunchKernelGGL((gemm_block_kernel<WT, EPI, 4>), g2, b2, 0, st, a);
+        else hipLaunchKernelGGL((gemm_block_kernel<WT, EPI, 2>), g2, b2, 0, st, a);
+        hipError_t eb = hipGetLastError();
+        if (eb != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(eb));
+        return PTTS_OK;
+      }
+    }
     if (mtp == 8) {
       rc = full ? launch_gemm_inst<WT, PRO, EPI, 8, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 8, false>(a, grid, block, sh, st);
       PTTS_TRY(rc);

@@ -505,6 +505,96 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
 }
 
 // ------------------------------------------------------------------------------------------------------
+// gemm_block_kernel: prefill-sized M (> 128 rows, e.g. batch 32 x 33 prompt positions): compute-bound, so every
+// fragment has to feed many MFMAs. One wave owns NS weight strips x 4 row tiles (NS*16 x 64 outputs) over the whole K:
+// per 32/16-wide k step it loads NS A fragments (weights, already in fragment order) and 4 B fragments (prepared
+// engine-dtype rows, PRO_COPY layout) straight from L1/L2 and issues 4*NS MFMAs (0.5 KB of operand loads per MFMA
+// at NS = 4, vs 1.1 KB in the strip kernel's 128-row passes); no K split, so no cross-wave reduction. The 4 waves
+// of a workgroup take 4 consecutive row groups of the same strips (weight fragments shared through L1).
+// Measured motivation: the strip kernel ran the batch-32 prefill GEMMs at 33-96 TFLOP/s (profiles/r01_step_bf16_bs32_v2.txt).
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, int EPI>
+__device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int m, int n, const f32x4& r) {
+  if (EPI == EPI_STORE) {
+    *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(r[0], r[1], r[2], r[3]);
+  } else if (EPI == EPI_GELU) {
+    *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
+  } else if (EPI == EPI_GELU_WT) {
+    WT* o = reinterpret_cast<WT*>(a.out) + (size_t)m * a.out_ld + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) store_from_f32<WT>(o + e, gelu_erf(r[e]));
+  } else if (EPI == EPI_RESID) {
+    float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
+    float4 o = *p;
+    o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
+    *p = o;
+  } else {  // EPI_KV: n in [0, 2H): first half K, second half V
+    const int H = a.N >> 1;
+    const int which = n >= H;
+    const int nn = n - which * H;
+    const int head = nn >> 6, d = nn & 63;
+    const int b = m / a.kv_rows_per_b, t = m - b * a.kv_rows_per_b;
+    WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) + (((size_t)b * a.nheads + head) * a.kv_cap + t) * 64 + d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) store_from_f32<WT>(base + e, r[e]);
+  }
+}
+
+template <typename WT, int EPI, int NS>
+__global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
+  constexpr int KT = Elem<WT>::KT, MT = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int strip0 = blockIdx.x * NS;
+  const int m0 = (blockIdx.y * 4 + wave) * (16 * MT);
+  if (m0 >= a.M) return;
+  const int nfrag = a.K / KT;
+  const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip0 * nfrag * 64 + lane;
+  const char* brow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = min(m0 + mt * 16 + j, a.M - 1);  // clamped rows are computed and dropped
+    brow[mt] = reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld) + (size_t)q * 16;
+  }
+  f32x4 acc[NS][MT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 af[NS], bf[MT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) af[s] = Wp[(size_t)s * nfrag * 64];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bf[mt] = *reinterpret_cast<const uint4*>(brow[mt]);
+  for (int t = 0; t < nfrag; ++t) {
+    uint4 an[NS], bn[MT];
+    if (t + 1 < nfrag) {  // next step's fragments in flight while this step's MFMAs issue
+#pragma unroll
+      for (int s = 0; s < NS; ++s) an[s] = Wp[((size_t)s * nfrag + t + 1) * 64];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bn[mt] = *reinterpret_cast<const uint4*>(brow[mt] + (size_t)(t + 1) * (KT * sizeof(WT)));
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[s][mt] = MfmaStep<WT>::run(af[s], bf[mt], acc[s][mt]);
+    if (t + 1 < nfrag) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = an[s];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = bn[mt];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + j;
+      if (m < a.M) gemm_store_tile<WT, EPI>(a, m, (strip0 + s) * 16 + q * 4, acc[s][mt]);  // D[row = q*4 + r][col = j]
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // rows_prep_kernel: for M > 8 rows (batch 32, prefill) the LayerNorm / split-KV combine is computed ONCE here
 // (one wave per row) into an engine-dtype [M][K] buffer that the GEMM then stages with plain 16-byte copies
 // (PRO_COPY). At M <= 8 the fused prologues win (one graph node less: 1.58 us + a latency chain).

@@ -161,6 +161,35 @@ def test_batch_sizes_and_two_mfma_tiles(bsz):
         assert torch.equal(ids, ref.sequences)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prefill_block_gemm_path(dtype):
+    """Prefill with > 128 rows (8 utterances x 24 positions; cross K/V over 8 x 40 encoder rows) runs the register-blocked
+    GEMM kernel (gemm_block_kernel): first-step logits vs the oracle, ragged masks, then free-running ids."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=256, hidden_size=256, num_attention_heads=4, ffn_dim=512)
+    sd = DO.make_decoder_weights(spec, seed=21)
+    g = torch.Generator().manual_seed(3)
+    bsz, N, P = 8, 40, 23
+    enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
+    prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
+    enc_mask = torch.ones(bsz, N, dtype=torch.long)
+    prompt_mask = torch.ones(bsz, P, dtype=torch.long)
+    for b in range(bsz):
+        enc_mask[b, N - 3 * (b % 4):] = 0 if b % 4 else 1
+        prompt_mask[b, : b % 5] = 0
+    enc = enc * enc_mask[..., None]
+    gp = DO.GenParams(max_length=20, min_new_tokens=19)
+    quant = dtype == torch.bfloat16
+    orc = DO.DecoderOracle(spec, sd, precision="bf16" if quant else "fp32")  # bf16: the same bf16-quantised model
+    ref = DO.sample_loop(orc, enc, enc_mask, prompt, prompt_mask, gp, keep_logits=True)
+    eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=64, max_enc=48, max_prompt=32)
+    eng.set_gen_params(max_length=20, min_new_tokens=19)
+    eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
+    err = (eng.logits().cpu() - ref.step_logits[0]).abs().max()
+    assert err < (1e-2 if quant else 2e-5), float(err)
+    if not quant and ref.min_margin > 1e-4:
+        assert torch.equal(eng.generate_ids(enc, enc_mask, prompt, prompt_mask).cpu(), ref.sequences)
+
+
 def test_mini_width_two_layers_fp32_and_bf16():
     """Mini-v1 widths (H=1024, 16 heads, F=4096, V=1088, K=9) with 2 layers: kernel tiling at the real shapes."""
     spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
