@@ -163,12 +163,12 @@ def test_batch_sizes_and_two_mfma_tiles(bsz):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_prefill_block_gemm_path(dtype):
-    """Prefill with > 128 rows (8 utterances x 24 positions; cross K/V over 8 x 40 encoder rows) runs the register-blocked
+    """Prefill with > 256 rows (12 utterances x 24 positions; cross K/V over 12 x 40 encoder rows) runs the register-blocked
     GEMM kernel (gemm_block_kernel): first-step logits vs the oracle, ragged masks, then free-running ids."""
     spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=256, hidden_size=256, num_attention_heads=4, ffn_dim=512)
     sd = DO.make_decoder_weights(spec, seed=21)
     g = torch.Generator().manual_seed(3)
-    bsz, N, P = 8, 40, 23
+    bsz, N, P = 12, 40, 23
     enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
     prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
     enc_mask = torch.ones(bsz, N, dtype=torch.long)
