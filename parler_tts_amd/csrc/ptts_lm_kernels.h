@@ -1217,46 +1217,61 @@ __device__ __forceinline__ void tail_embed_next(const TailArgs& a, int b, int t,
 
 __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
   __shared__ int s_tok[32];
-  __shared__ int s_any;
   __shared__ float s_val[PTTS_SORT_N];
   __shared__ int s_idx[PTTS_SORT_N];
   __shared__ float s_red[8];
   __shared__ int s_redi[8];
   __shared__ int s_pick;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) s_any = 0;
-  __syncthreads();
-  for (int i = tid; i < a.B * a.K; i += blockDim.x)
-    if (a.unfinished[i]) s_any = 1;
-  __syncthreads();
-  if (!s_any) return;  // every row of every utterance finished: the reference loop has exited (no-op step)
-
+  // ---- t = 0: every load that does not depend on another load goes in flight together (the step's critical path ends
+  // here: lengths / flags / parameters / this wave's logits row are ONE round trip, the embedding rows a second one)
+  int any_local = 0;
+  for (int i = tid; i < a.B * a.K; i += blockDim.x) any_local |= a.unfinished[i];
   const DevGen g = *a.gen;
   const int t = a.cur_len[b];  // column the new token is written to; t-1 new tokens generated so far
-  int fu = a.first_unf[b];
-  if (a.has_eos[b * a.K + fu] > 0 && fu < a.K - 1) fu += 1;  // logits_processors.py:48 (advance <= 1 per step)
-  __syncthreads();
+  const int fu0 = a.first_unf[b];
+  const int t_prefix = a.dims->T_prefix;
+  const int he = lane < a.K ? a.has_eos[b * a.K + lane] : 0;  // every wave: the K EOS flags of this utterance
+  constexpr int NV = PTTS_SORT_N / 64;                         // logits per lane (vocab <= PTTS_SORT_N)
+  float lg[NV];
+  const int k0 = w;  // greedy: wave w starts with codebook row w
+  if (k0 < a.K) {
+    const float* sc0 = a.logits + (size_t)(b * a.K + k0) * a.V;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lg[i] = (lane + 64 * i < a.V) ? sc0[lane + 64 * i] : -INFINITY;
+  }
+  const int unf0 = k0 < a.K ? a.unfinished[b * a.K + k0] : 0;
+  if (!__syncthreads_or(any_local)) return;  // every row of every utterance finished: the reference loop has exited (no-op step)
+
+  int fu = fu0;
+  if (__shfl(he, fu0) > 0 && fu0 < a.K - 1) fu += 1;  // logits_processors.py:48 (advance <= 1 per step)
   if (tid == 0) a.first_unf[b] = fu;
-  const bool block_eos_all = (t - 1 - a.dims->T_prefix) < g.min_new_tokens;  // new tokens = columns after the (1 + T_prefix) given ones
+  const bool block_eos_all = (t - 1 - t_prefix) < g.min_new_tokens;  // new tokens = columns after the (1 + T_prefix) given ones
 
   if (!g.do_sample) {
     // greedy: one wave per codebook row, no workgroup barriers. torch.argmax semantics: first index on ties.
     for (int k = w; k < a.K; k += (int)(blockDim.x >> 6)) {
       const int row = b * a.K + k;
-      const float* sc = a.logits + (size_t)row * a.V;
+      if (k != k0) {
+        const float* sc = a.logits + (size_t)row * a.V;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lg[i] = (lane + 64 * i < a.V) ? sc[lane + 64 * i] : -INFINITY;
+      }
       const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
       float best = -INFINITY;
       int bi = 0x7fffffff;
-      for (int v = lane; v < a.V; v += 64) {
-        float x = sc[v];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        float x = lg[i];
         if (eos_blocked && v == a.eos) x = -INFINITY;
-        if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+        if (v < a.V && (x > best || (x == best && v < bi))) { best = x; bi = v; }
       }
       const float wbest = wave_max(best);
       const float cand = (best == wbest) ? (float)bi : 3.0e9f;  // vocabulary indices are exact in fp32
       const int widx = (int)(-wave_max(-cand));
       if (lane == 0) {
-        const int unf = a.unfinished[row];
+        const int unf = k == k0 ? unf0 : a.unfinished[row];
         const int nxt = unf ? widx : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
         a.ids[(size_t)row * a.ids_ld + t] = nxt;
         s_tok[k] = nxt;
