@@ -599,12 +599,56 @@ __global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
 // (one wave per row) into an engine-dtype [M][K] buffer that the GEMM then stages with plain 16-byte copies
 // (PRO_COPY). At M <= 8 the fused prologues win (one graph node less: 1.58 us + a latency chain).
 // ------------------------------------------------------------------------------------------------------
+// one pass, row held in registers (K == NF4 * 256): every load of the row (+ pending split-K partials + gamma/beta) is in
+// flight at once - one dependent round trip instead of the three of the generic two-pass loop below
+template <typename WT, int NF4>
+__device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* out, int lane) {
+  float* xr = const_cast<float*>(a.x) + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
+  float4 v[NF4], g[NF4], bt[NF4];
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+  if (a.part) {  // pending split-K partials of the previous fc2: h += sum_s part[s] in fixed order, written back
+    for (int sp = 0; sp < a.S; ++sp) {
+      float4 u[NF4];
+#pragma unroll
+      for (int i = 0; i < NF4; ++i) u[i] = *reinterpret_cast<const float4*>(a.part + ((size_t)sp * a.M + m) * a.K + (lane + 64 * i) * 4);
+#pragma unroll
+      for (int i = 0; i < NF4; ++i) { v[i].x += u[i].x; v[i].y += u[i].y; v[i].z += u[i].z; v[i].w += u[i].w; }
+    }
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) *reinterpret_cast<float4*>(xr + (lane + 64 * i) * 4) = v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+    bt[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+  }
+  const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const float d0 = v[i].x - c, d1 = v[i].y - c, d2 = v[i].z - c, d3 = v[i].w - c;
+    s1 += (d0 + d1) + (d2 + d3);
+    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float dm = s1 * a.invK, mean = c + dm;
+  const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < NF4; ++i)
+    lds_store4<WT>(reinterpret_cast<char*>(out), (lane + 64 * i) * 4, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
+                   (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
+}
+
 template <typename WT, int PRO>
 __global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restrict__ dst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= a.M) return;
   WT* out = dst + (size_t)m * a.K;
+  if (PRO == PRO_LN && a.K == 1024) { prep_ln_row_regs<WT, 4>(a, m, out, lane); return; }  // Mini-v1
+  if (PRO == PRO_LN && a.K == 1536) { prep_ln_row_regs<WT, 6>(a, m, out, lane); return; }  // Large-v1
   if (PRO == PRO_LN) {
     const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
     if (a.part) {  // pending split-K partials of the previous fc2 (+ residual): h += sum_s part[s], in fixed order
