@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 2
+#define PTTS_ABI_VERSION 3
 
 enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
 
@@ -45,7 +45,7 @@ typedef struct ptts_dac ptts_dac;       /* DAC codes -> waveform engine */
 typedef struct {
   int32_t hidden_size;
   int32_t num_layers;
-  int32_t num_heads;     /* MHA only (num_key_value_heads == num_attention_heads; Mini/Large v1) */
+  int32_t num_heads;     /* query heads; head_dim = hidden_size / num_heads must be 64 */
   int32_t ffn_dim;
   int32_t num_codebooks;
   int32_t vocab_size;    /* LM-head rows per codebook; embedding tables have vocab_size+1 rows (:1353) */
@@ -59,6 +59,8 @@ typedef struct {
   int32_t max_enc;       /* cross-attention capacity: description (+ prompt if prompt_cross_attention) tokens */
   int32_t max_prompt;    /* prefill capacity in positions per utterance: P + 1 (prompt tokens + the BOS column) */
   int32_t device;        /* HIP device ordinal */
+  int32_t num_kv_heads;       /* grouped-query attention, self (repeat_kv :280-289, :449-452): 0 = num_heads (Mini/Large v1) */
+  int32_t num_cross_kv_heads; /* cross-attention K/V heads: 0 = num_kv_heads */
 } ptts_config;
 
 /* Generation parameters: the subset of GenerationConfig that generate() consumes (:3395-3552). */

@@ -48,10 +48,20 @@ class DecoderSpec:
     eos_token_id: int = 1024
     bos_token_id: int = 1025
     use_fused_lm_heads: bool = False
+    num_key_value_heads: int = 0                  # 0 = num_attention_heads (MHA); configuration_parler_tts.py:152-158
+    num_cross_attention_key_value_heads: int = 0  # 0 = num_key_value_heads
 
     @property
     def head_dim(self) -> int:
         return self.hidden_size // self.num_attention_heads
+
+    @property
+    def kv_heads(self) -> int:
+        return self.num_key_value_heads or self.num_attention_heads
+
+    @property
+    def cross_kv_heads(self) -> int:
+        return self.num_cross_attention_key_value_heads or self.kv_heads
 
 
 MINI_V1 = DecoderSpec()  # helpers/model_init_scripts/init_model_600M.py:27-44
@@ -108,9 +118,10 @@ def make_decoder_weights(spec: DecoderSpec, seed: int = 1234, prefix: str = "") 
         sd[f"{p}embed_positions.weights"] = sinusoidal_table(spec.max_position_embeddings, H)
     for i in range(spec.num_hidden_layers):
         lp = f"{p}layers.{i}."
-        for att in ("self_attn", "encoder_attn"):
+        for att, nkv in (("self_attn", spec.kv_heads), ("encoder_attn", spec.cross_kv_heads)):
             for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
-                sd[f"{lp}{att}.{proj}.weight"] = normal(H, H)  # bias=False :952
+                rows = nkv * spec.head_dim if proj in ("k_proj", "v_proj") else H  # grouped-query attention: fewer K/V heads (:449-452)
+                sd[f"{lp}{att}.{proj}.weight"] = normal(rows, H)  # bias=False :952
             ln(f"{lp}{att}_layer_norm")
         sd[f"{lp}fc1.weight"] = normal(Fd, H)
         sd[f"{lp}fc2.weight"] = normal(H, Fd)
@@ -237,8 +248,16 @@ class DecoderOracle:
     def _ln(self, x, name):
         return F.layer_norm(x, (self.spec.hidden_size,), self.w[name + ".weight"], self.w[name + ".bias"], 1e-5)
 
-    def _heads(self, t, bsz, q):
-        return t.view(bsz, q, self.spec.num_attention_heads, self.spec.head_dim).transpose(1, 2)
+    def _heads(self, t, bsz, q, n=None):
+        return t.view(bsz, q, n or self.spec.num_attention_heads, self.spec.head_dim).transpose(1, 2)
+
+    def _repeat_kv(self, t):
+        """repeat_kv :280-289: [B, n_kv, L, d] -> [B, n_heads, L, d], query head h reads K/V head h // n_rep."""
+        n_rep = self.spec.num_attention_heads // t.shape[1]
+        if n_rep == 1:
+            return t
+        b, nkv, L, d = t.shape
+        return t[:, :, None].expand(b, nkv, n_rep, L, d).reshape(b, nkv * n_rep, L, d)
 
     def _attend(self, q, k, v, add_mask, causal):
         """q [B,h,Q,d], k/v [B,h,L,d]; add_mask broadcastable additive [B,1,Q,L] or None."""
@@ -301,8 +320,8 @@ class DecoderOracle:
             r = x
             hn = self._ln(x, lp + "self_attn_layer_norm")
             q = self._heads(self._linear(hn, lp + "self_attn.q_proj.weight"), bsz, T)
-            k = self._heads(self._linear(hn, lp + "self_attn.k_proj.weight"), bsz, T)
-            v = self._heads(self._linear(hn, lp + "self_attn.v_proj.weight"), bsz, T)
+            k = self._heads(self._linear(hn, lp + "self_attn.k_proj.weight"), bsz, T, spec.kv_heads)
+            v = self._heads(self._linear(hn, lp + "self_attn.v_proj.weight"), bsz, T, spec.kv_heads)
             if spec.rope_embeddings:
                 q = q * cos + _rotate_half(q) * sin  # :858-859
                 k = k * cos + _rotate_half(k) * sin  # :880-882
@@ -312,7 +331,7 @@ class DecoderOracle:
             else:
                 self.k_self[i] = torch.cat([self.k_self[i], k], dim=2)  # DynamicCache.update :887-889
                 self.v_self[i] = torch.cat([self.v_self[i], v], dim=2)
-            a = self._attend(q, self.k_self[i], self.v_self[i], self_mask, causal=T > 1)
+            a = self._attend(q, self._repeat_kv(self.k_self[i]), self._repeat_kv(self.v_self[i]), self_mask, causal=T > 1)
             a = a.transpose(1, 2).reshape(bsz, T, H)
             x = r + self._linear(a, lp + "self_attn.out_proj.weight")
             if trace:
@@ -326,9 +345,9 @@ class DecoderOracle:
             if self.k_cross[i] is None:  # computed once, then reused (:872-875)
                 e = encoder_hidden_states.to(torch.float32)
                 N = e.shape[1]
-                self.k_cross[i] = self._act(self._heads(self._linear(e, lp + "encoder_attn.k_proj.weight"), bsz, N))
-                self.v_cross[i] = self._act(self._heads(self._linear(e, lp + "encoder_attn.v_proj.weight"), bsz, N))
-            a = self._attend(q, self.k_cross[i], self.v_cross[i], cross_mask, causal=False)
+                self.k_cross[i] = self._act(self._heads(self._linear(e, lp + "encoder_attn.k_proj.weight"), bsz, N, spec.cross_kv_heads))
+                self.v_cross[i] = self._act(self._heads(self._linear(e, lp + "encoder_attn.v_proj.weight"), bsz, N, spec.cross_kv_heads))
+            a = self._attend(q, self._repeat_kv(self.k_cross[i]), self._repeat_kv(self.v_cross[i]), cross_mask, causal=False)
             a = a.transpose(1, 2).reshape(bsz, T, H)
             x = r + self._linear(a, lp + "encoder_attn.out_proj.weight")
             if trace:

@@ -54,7 +54,8 @@ def build_reference_lm(ref, spec: DO.DecoderSpec, sd, attn="sdpa"):
         num_attention_heads=spec.num_attention_heads, hidden_size=spec.hidden_size,
         num_codebooks=spec.num_codebooks, pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id,
         bos_token_id=spec.bos_token_id, rope_embeddings=spec.rope_embeddings, rope_theta=spec.rope_theta,
-        use_fused_lm_heads=spec.use_fused_lm_heads)
+        use_fused_lm_heads=spec.use_fused_lm_heads, num_key_value_heads=spec.kv_heads,
+        num_cross_attention_key_value_heads=spec.cross_kv_heads)
     cfg._attn_implementation = attn
     m = ref.ParlerTTSForCausalLM(cfg).eval()
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -85,6 +86,10 @@ def gen_decoder(ref, variant: str):
 
     rope = variant == "rope"
     spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "rope_embeddings": rope})
+    if variant == "gqa":  # grouped-query attention (:280-289, :449-452): 4 query heads, 2 self K/V heads, 1 cross K/V head, RoPE on
+        spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "hidden_size": 256, "num_attention_heads": 4, "ffn_dim": 512, "rope_embeddings": True,
+                                 "num_key_value_heads": 2, "num_cross_attention_key_value_heads": 1})
+        rope = True
     sd = DO.make_decoder_weights(spec, seed=1234)
     bsz, N, P, steps = 2, 11, 5, 6
     enc, enc_mask, prompt, prompt_mask = synth_inputs(spec, bsz, N, P, seed=7, padded=True)
@@ -116,7 +121,7 @@ def gen_decoder(ref, variant: str):
     np.savez_compressed(
         os.path.join(GOLD, f"decoder_{variant}.npz"),
         spec=np.array([spec.hidden_size, spec.num_hidden_layers, spec.num_attention_heads, spec.ffn_dim,
-                       spec.max_position_embeddings, int(rope)]),
+                       spec.max_position_embeddings, int(rope), spec.kv_heads, spec.cross_kv_heads]),
         weight_seed=1234, enc=enc.numpy(), enc_mask=enc_mask.numpy(), prompt=prompt.numpy(),
         prompt_mask=prompt_mask.numpy(), step_ids=step_ids.numpy(),
         prefill_logits=ref_logits[0][:, -1].numpy(), step_logits=np.stack([l[:, -1].numpy() for l in ref_logits[1:]]))
@@ -343,6 +348,7 @@ def main():
     for v in ("sin", "rope"):
         gen_decoder(ref, v)
         gen_greedy(ref, v)
+    gen_decoder(ref, "gqa")
     gen_dac()
     gen_dac_encode()
     print("golden vectors written to", GOLD)

@@ -24,7 +24,7 @@ class PttsConfig(C.Structure):
         ("num_codebooks", C.c_int32), ("vocab_size", C.c_int32), ("max_positions", C.c_int32), ("rope", C.c_int32),
         ("rope_theta", C.c_float), ("pad_token_id", C.c_int32), ("eos_token_id", C.c_int32), ("bos_token_id", C.c_int32),
         ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_ctx", C.c_int32), ("max_enc", C.c_int32),
-        ("max_prompt", C.c_int32), ("device", C.c_int32),
+        ("max_prompt", C.c_int32), ("device", C.c_int32), ("num_kv_heads", C.c_int32), ("num_cross_kv_heads", C.c_int32),
     ]
 
 
@@ -43,7 +43,7 @@ class PttsDacConfig(C.Structure):
     ]
 
 
-ABI_VERSION = 2  # PTTS_ABI_VERSION in include/ptts.h
+ABI_VERSION = 3  # PTTS_ABI_VERSION in include/ptts.h
 
 # every symbol include/ptts.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64P = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)

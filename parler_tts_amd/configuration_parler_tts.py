@@ -82,8 +82,9 @@ class ParlerTTSDecoderConfig(_Config):
 
     def check_supported_by_engine(self):
         """The HIP engine implements the released Mini/Large-v1 architecture family; anything else fails loudly."""
-        if self.num_key_value_heads != self.num_attention_heads or self.num_cross_attention_key_value_heads != self.num_attention_heads:
-            raise NotImplementedError("grouped-query attention (num_key_value_heads != num_attention_heads) is not implemented by the HIP engine")
+        for n in (self.num_key_value_heads, self.num_cross_attention_key_value_heads):  # grouped-query attention (repeat_kv :280-289)
+            if n < 1 or self.num_attention_heads % n:
+                raise ValueError(f"num_attention_heads {self.num_attention_heads} must be divisible by the K/V head count {n}")
         if self.activation_function != "gelu":
             raise NotImplementedError(f"activation_function={self.activation_function!r}: only exact-erf 'gelu' is implemented by the HIP engine")
         if self.hidden_size // self.num_attention_heads != 64:

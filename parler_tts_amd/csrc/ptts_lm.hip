@@ -50,6 +50,7 @@ struct ptts_engine {
   float *h = nullptr, *qkv = nullptr, *qc = nullptr, *part = nullptr, *stats = nullptr, *ffn = nullptr, *logits = nullptr;
   float* sort_buf = nullptr;
   void *xw = nullptr, *xw2 = nullptr;  // engine-dtype activation rows for the M > 8 path: [rows][H], [rows][F]
+  int nkv = 0, nkc = 0;                // self / cross K/V heads (== num_heads unless grouped-query attention)
   long long* prefix = nullptr;         // voice-prompt codes [max_batch*K][max_ctx], valid for the next prefill when pending_T > 0
   int pending_T = 0;
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
@@ -232,6 +233,7 @@ template <typename WT>
 int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true) {
   const ptts_config& c = e->cfg;
   const int H = c.hidden_size, F = c.ffn_dim, nh = c.num_heads, B = e->B;
+  const int nkv = e->nkv, nkc = e->nkc, Hkv = nkv * 64, QKV = H + 2 * Hkv;  // grouped-query attention: fewer K/V heads
   const int Q = prefill ? e->P + 1 : 1;
   const int M = B * Q;
   const bool big = M > 8;
@@ -244,9 +246,9 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
                        reinterpret_cast<WT*>(e->xw2), n);
     for (int l = 0; l < c.num_layers; ++l) {
       GemmArgs g = {};
-      g.W = e->L[l].ckv; g.M = B * e->N; g.N = 2 * H; g.K = H;
+      g.W = e->L[l].ckv; g.M = B * e->N; g.N = 2 * nkc * 64; g.K = H;
       g.x = reinterpret_cast<const float*>(e->xw2); g.x_ld = H; g.x_row_mul = 1; g.x_row_off = 0;
-      g.kcache = e->L[l].k_cross; g.vcache = e->L[l].v_cross; g.kv_rows_per_b = e->N; g.kv_cap = c.max_enc; g.nheads = nh;
+      g.kcache = e->L[l].k_cross; g.vcache = e->L[l].v_cross; g.kv_rows_per_b = e->N; g.kv_cap = c.max_enc; g.nheads = nkc;
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_KV>(g, st)));
     }
   }
@@ -264,17 +266,18 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     {  // LN1 + fused QKV projection
       GemmArgs g = {};
       g.W = w.qkv; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
-      g.out = e->qkv; g.out_ld = 3 * H; g.M = M; g.N = 3 * H; g.K = H;
+      g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H;
       if (fc2_pending) { g.part = e->hpart; g.S = FC2_KSPLIT; fc2_pending = false; }  // folded by the prep kernel (M > 8)
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
     if (prefill) {
-      hipLaunchKernelGGL((kv_append_kernel<WT>), dim3(Q, nh, B), dim3(64), 0, st, e->qkv + H, e->qkv + 2 * H, 3 * H, w.k_self,
-                         w.v_self, c.max_ctx, Q, nh, c.rope ? e->rope_cos : nullptr, c.rope ? e->rope_sin : nullptr);
+      hipLaunchKernelGGL((kv_append_kernel<WT>), dim3(Q, nkv, B), dim3(64), 0, st, e->qkv + H, e->qkv + H + Hkv, QKV, w.k_self,
+                         w.v_self, c.max_ctx, Q, nkv, c.rope ? e->rope_cos : nullptr, c.rope ? e->rope_sin : nullptr);
     }
     {  // causal self-attention over the KV arena
       AttnArgs a = {};
-      a.q = e->qkv; a.q_ld = 3 * H; a.knew = e->qkv + H; a.vnew = e->qkv + 2 * H; a.kv_ld = 3 * H;
+      a.q = e->qkv; a.q_ld = QKV; a.knew = e->qkv + H; a.vnew = e->qkv + H + Hkv; a.kv_ld = QKV;
+      a.kv_heads = nkv; a.n_rep = nh / nkv;
       a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims;
       a.mask = e->prompt_mask; a.mask_ld = e->max_prompt;
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
@@ -301,7 +304,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       x.W = w.cq; x.x = e->h; x.x_ld = H; x.x_row_mul = 1; x.x_row_off = 0; x.gamma = w.ln2_g; x.beta = w.ln2_b; x.K = H;
       x.invK = 1.0f / (float)H; x.kcache = w.k_cross; x.vcache = w.v_cross; x.cap = c.max_enc; x.cur_len = e->cur_len; x.dims = e->dims;
       x.mask = e->enc_mask; x.mask_ld = c.max_enc; x.cos = c.rope ? e->rope_cos : nullptr; x.sin = c.rope ? e->rope_sin : nullptr;
-      x.out = e->xw; x.B = M; x.nheads = nh; x.scale = scale;
+      x.out = e->xw; x.B = M; x.nheads = nh; x.kv_heads = nkc; x.n_rep = nh / nkc; x.scale = scale;
       const size_t sh = (size_t)M * (H * sizeof(WT) + 16) + 8 * 1024 + (size_t)M * 64 * 4;
       const bool u16 = ((H / KTw) / 2) % 16 == 0;
       if (H == 1024 && u16) hipLaunchKernelGGL((xattn_fused_kernel<WT, 16, 4>), dim3(nh), dim3(512), sh, st, x);        // Mini-v1
@@ -321,6 +324,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims; a.mask = e->enc_mask; a.mask_ld = c.max_enc;
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;  // quirk: q rotated, keys not (:858 vs :880)
       a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 1;
+      a.kv_heads = nkc; a.n_rep = nh / nkc;
       a.fused_append = 0; a.scale = scale;
       a.direct_out = e->xw;  // the description is short: never split, softmax finished in the attention kernel
       PTTS_TRY((launch_attn<WT>(a, B, st)));
@@ -438,9 +442,12 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   PTTS_CHECK(c.num_codebooks >= 1 && c.num_codebooks <= 32, PTTS_E_INVALID, "num_codebooks out of range");
   PTTS_CHECK(c.vocab_size <= PTTS_SORT_N, PTTS_E_UNSUPPORTED, "vocab_size > %d unsupported by the sampler", PTTS_SORT_N);
   PTTS_CHECK(c.max_batch >= 1 && c.max_ctx >= 2 && c.max_enc >= 1 && c.max_prompt >= 1 && c.max_prompt <= c.max_ctx, PTTS_E_INVALID, "bad capacities");
+  const int nkv_ = c.num_kv_heads > 0 ? c.num_kv_heads : c.num_heads, nkc_ = c.num_cross_kv_heads > 0 ? c.num_cross_kv_heads : nkv_;
+  PTTS_CHECK(c.num_heads % nkv_ == 0 && c.num_heads % nkc_ == 0, PTTS_E_INVALID, "num_heads %d not divisible by the K/V head counts %d / %d", c.num_heads, nkv_, nkc_);
   PTTS_HIP(hipSetDevice(c.device));
   ptts_engine* e = new ptts_engine();
   e->cfg = c;
+  e->nkv = nkv_; e->nkc = nkc_;
   e->esize = c.dtype == PTTS_BF16 ? 2 : 4;
   e->max_prompt = c.max_prompt;
   int rc = PTTS_OK;
@@ -452,16 +459,16 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
 #define A(expr) if ((rc = (expr)) != PTTS_OK) return fail(rc)
   for (int l = 0; l < c.num_layers; ++l) {
     LayerW& w = e->L[l];
-    A(e->alloc_bytes(&w.qkv, (size_t)3 * H * H * es));
+    A(e->alloc_bytes(&w.qkv, (size_t)(H + 2 * e->nkv * 64) * H * es));
     A(e->alloc_bytes(&w.o, (size_t)H * H * es));
     A(e->alloc_bytes(&w.cq, (size_t)H * H * es));
-    A(e->alloc_bytes(&w.ckv, (size_t)2 * H * H * es));
+    A(e->alloc_bytes(&w.ckv, (size_t)2 * e->nkc * 64 * H * es));
     A(e->alloc_bytes(&w.co, (size_t)H * H * es));
     A(e->alloc_bytes(&w.fc1, (size_t)F * H * es));
     A(e->alloc_bytes(&w.fc2, (size_t)F * H * es));
     A(e->alloc(&w.ln1_g, H)); A(e->alloc(&w.ln1_b, H)); A(e->alloc(&w.ln2_g, H)); A(e->alloc(&w.ln2_b, H));
     A(e->alloc(&w.ln3_g, H)); A(e->alloc(&w.ln3_b, H));
-    const size_t kvs = (size_t)c.max_batch * nh * c.max_ctx * 64 * es, kvc = (size_t)c.max_batch * nh * c.max_enc * 64 * es;
+    const size_t kvs = (size_t)c.max_batch * e->nkv * c.max_ctx * 64 * es, kvc = (size_t)c.max_batch * e->nkc * c.max_enc * 64 * es;
     A(e->alloc_bytes(&w.k_self, kvs)); A(e->alloc_bytes(&w.v_self, kvs));
     A(e->alloc_bytes(&w.k_cross, kvc)); A(e->alloc_bytes(&w.v_cross, kvc));
     char nm[160];
@@ -563,10 +570,10 @@ extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* 
     LayerW& w = e->L[l];
     const std::string t(tail);
     struct { const char* n; void* dst; int N, Kd, row0; } mats[] = {
-        {"self_attn.q_proj.weight", w.qkv, H, H, 0},       {"self_attn.k_proj.weight", w.qkv, H, H, H},
-        {"self_attn.v_proj.weight", w.qkv, H, H, 2 * H},   {"self_attn.out_proj.weight", w.o, H, H, 0},
-        {"encoder_attn.q_proj.weight", w.cq, H, H, 0},     {"encoder_attn.k_proj.weight", w.ckv, H, H, 0},
-        {"encoder_attn.v_proj.weight", w.ckv, H, H, H},    {"encoder_attn.out_proj.weight", w.co, H, H, 0},
+        {"self_attn.q_proj.weight", w.qkv, H, H, 0},       {"self_attn.k_proj.weight", w.qkv, e->nkv * 64, H, H},
+        {"self_attn.v_proj.weight", w.qkv, e->nkv * 64, H, H + e->nkv * 64}, {"self_attn.out_proj.weight", w.o, H, H, 0},
+        {"encoder_attn.q_proj.weight", w.cq, H, H, 0},     {"encoder_attn.k_proj.weight", w.ckv, e->nkc * 64, H, 0},
+        {"encoder_attn.v_proj.weight", w.ckv, e->nkc * 64, H, e->nkc * 64}, {"encoder_attn.out_proj.weight", w.co, H, H, 0},
         {"fc1.weight", w.fc1, F, H, 0},                    {"fc2.weight", w.fc2, H, F, 0}};
     for (auto& m : mats)
       if (t == m.n) {

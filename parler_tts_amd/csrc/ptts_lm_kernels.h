@@ -722,6 +722,7 @@ struct AttnArgs {
   void* direct_out;    // S == 1: normalised output [rows][H] in the engine dtype (consumer GEMM uses PRO_COPY), or null
   float* stats;        // [rows][S][heads][2]
   int S, Q, nheads, H;
+  int kv_heads, n_rep; // grouped-query attention (repeat_kv :280-289): query head h reads K/V head h / n_rep
   int cross;           // 1: length = dims->N, mask over all positions; 0: causal self-attention, mask over positions < P
   int fused_append;
   float scale;
@@ -793,6 +794,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   const int row = b * a.Q + qi;
   const int r = lane / LPR, c = lane % LPR;
   const int TW = a.S * NW, wv = s * NW + w;
+  const int kvh = h / a.n_rep;
 
   // ---- t = 0: all loads ---------------------------------------------------------------------------------------------
   const int P = a.dims->P;
@@ -801,11 +803,11 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   float qv[EPL], qy[EPL], kk[EPL], ky[EPL], vv[EPL], vy[EPL];
   load_chunk_raw<EPL>(a.q + (size_t)row * a.q_ld + h * 64, c * EPL, a.cos != nullptr, qv, qy);
   if (a.fused_append) {
-    load_chunk_raw<EPL>(a.knew + (size_t)row * a.kv_ld + h * 64, c * EPL, a.cos != nullptr, kk, ky);
-    load_chunk_raw<EPL>(a.vnew + (size_t)row * a.kv_ld + h * 64, c * EPL, false, vv, vy);
+    load_chunk_raw<EPL>(a.knew + (size_t)row * a.kv_ld + kvh * 64, c * EPL, a.cos != nullptr, kk, ky);
+    load_chunk_raw<EPL>(a.vnew + (size_t)row * a.kv_ld + kvh * 64, c * EPL, false, vv, vy);
   }
-  WT* Kc = reinterpret_cast<WT*>(a.kcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
-  WT* Vc = reinterpret_cast<WT*>(a.vcache) + ((size_t)b * a.nheads + h) * a.cap * 64;
+  WT* Kc = reinterpret_cast<WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
+  WT* Vc = reinterpret_cast<WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
   const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
   const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
@@ -829,7 +831,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     rope_apply<EPL>(kk, ky, c * EPL, a.cos, a.sin, (size_t)pos);
     knew_p = pack16(kk, WT());
     vnew_p = pack16(vv, WT());
-    if (s == 0 && w == 0 && r == 0) {  // single writer of the new cache row
+    if (s == 0 && w == 0 && r == 0 && h == kvh * a.n_rep) {  // single writer of the new cache row (first query head of the group)
       reinterpret_cast<uint4*>(Kc + (size_t)pos * 64)[c] = knew_p;
       reinterpret_cast<uint4*>(Vc + (size_t)pos * 64)[c] = vnew_p;
     }
@@ -948,6 +950,7 @@ struct XAttnArgs {
   const float* sin;
   void* out;           // [B][K] engine dtype
   int B, nheads;
+  int kv_heads, n_rep; // cross K/V heads (grouped-query attention)
   float scale;
 };
 
@@ -975,8 +978,8 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   // LayerNorm -> projection), then the bulk loads nobody waits for yet. Addresses are clamped by the cache capacity
   // (a kernel argument), NOT by dims->N (device memory: would put a dependent round trip in front of every K/V load).
   uint4 afr[UW];
-  const uint4* Kb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.nheads + h) * a.cap * 64);
-  const uint4* Vb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.nheads + h) * a.cap * 64);
+  const uint4* Kb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.kv_heads + h / a.n_rep) * a.cap * 64);
+  const uint4* Vb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.kv_heads + h / a.n_rep) * a.cap * 64);
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
   uint4 kf[U], vf[U];
   int mk[U];

@@ -38,7 +38,7 @@ class DecoderEngine:
                  vocab_size: int, max_positions: int, rope: bool = False, rope_theta: float = 10000.0,
                  pad_token_id: int = 1024, eos_token_id: int = 1024, bos_token_id: int = 1025,
                  dtype: torch.dtype = torch.bfloat16, max_batch: int = 1, max_ctx: int = 2700, max_enc: int = 256,
-                 max_prompt: int = 128, device: Optional[torch.device] = None):
+                 max_prompt: int = 128, device: Optional[torch.device] = None, num_kv_heads: int = 0, num_cross_kv_heads: int = 0):
         if not torch.cuda.is_available():
             raise N.NativeLibraryError("DecoderEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = N.load_library()
@@ -51,7 +51,7 @@ class DecoderEngine:
         self.cfg = N.PttsConfig(hidden_size, num_layers, num_heads, ffn_dim, num_codebooks, vocab_size, max_positions, int(rope),
                                 float(rope_theta), pad_token_id, eos_token_id, bos_token_id,
                                 N.PTTS_BF16 if dtype == torch.bfloat16 else N.PTTS_F32, max_batch, max_ctx, max_enc, max_prompt,
-                                self.device.index or 0)
+                                self.device.index or 0, int(num_kv_heads or 0), int(num_cross_kv_heads or 0))
         self._h = C.c_void_p()
         N.check(self.lib.ptts_engine_create(C.byref(self.cfg), C.byref(self._h)), "ptts_engine_create")
         self.B = 0

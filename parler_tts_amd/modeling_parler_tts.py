@@ -107,9 +107,10 @@ class ParlerTTSForCausalLM(nn.Module):
             _set_param(self, "model.decoder.embed_positions.weights", sinusoidal_table(c.max_position_embeddings, H))
         for i in range(c.num_hidden_layers):
             lp = f"model.decoder.layers.{i}."
-            for att in ("self_attn", "encoder_attn"):
-                for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
-                    _set_param(self, f"{lp}{att}.{proj}.weight", mk(H, H))
+            hd = H // c.num_attention_heads
+            for att, nkv in (("self_attn", c.num_key_value_heads), ("encoder_attn", c.num_cross_attention_key_value_heads)):
+                for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):  # grouped-query attention: K/V projections have nkv * head_dim rows (:449-452)
+                    _set_param(self, f"{lp}{att}.{proj}.weight", mk(nkv * hd if proj in ("k_proj", "v_proj") else H, H))
                 _set_param(self, f"{lp}{att}_layer_norm.weight", torch.ones(H))
                 _set_param(self, f"{lp}{att}_layer_norm.bias", torch.zeros(H))
             _set_param(self, f"{lp}fc1.weight", mk(F, H))
@@ -311,7 +312,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                               num_codebooks=d.num_codebooks, vocab_size=d.vocab_size, max_positions=d.max_position_embeddings,
                               rope=d.rope_embeddings, rope_theta=d.rope_theta, pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id,
                               bos_token_id=d.bos_token_id, dtype=dt, max_batch=B, max_ctx=max(P + max_length, 64), max_enc=max(N, 16),
-                              max_prompt=max(P + 1, 8), device=dev)
+                              max_prompt=max(P + 1, 8), device=dev, num_kv_heads=d.num_key_value_heads,
+                              num_cross_kv_heads=d.num_cross_attention_key_value_heads)
             e.load_state_dict(self.decoder.state_dict())
             self._engine, self._engine_key = e, need
         return e

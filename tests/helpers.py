@@ -7,7 +7,9 @@ from oracle import dac_oracle as DA
 
 
 def spec_from_gold(arr, **kw):
-    H, L, nh, F, mp, rope = [int(x) for x in arr]
+    H, L, nh, F, mp, rope = [int(x) for x in arr[:6]]
+    if len(arr) > 6:  # grouped-query fixtures also record the K/V head counts
+        kw = {"num_key_value_heads": int(arr[6]), "num_cross_attention_key_value_heads": int(arr[7]), **kw}
     return DO.DecoderSpec(hidden_size=H, num_hidden_layers=L, num_attention_heads=nh, ffn_dim=F, max_position_embeddings=mp,
                           rope_embeddings=bool(rope), **kw)
 
@@ -19,7 +21,8 @@ def make_engine(spec, sd, dtype=torch.float32, max_batch=2, max_ctx=128, max_enc
                         ffn_dim=spec.ffn_dim, num_codebooks=spec.num_codebooks, vocab_size=spec.vocab_size,
                         max_positions=spec.max_position_embeddings, rope=spec.rope_embeddings, rope_theta=spec.rope_theta,
                         pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id, bos_token_id=spec.bos_token_id, dtype=dtype,
-                        max_batch=max_batch, max_ctx=max_ctx, max_enc=max_enc, max_prompt=max_prompt)
+                        max_batch=max_batch, max_ctx=max_ctx, max_enc=max_enc, max_prompt=max_prompt,
+                        num_kv_heads=spec.kv_heads, num_cross_kv_heads=spec.cross_kv_heads)
     eng.load_state_dict(sd)
     return eng
 

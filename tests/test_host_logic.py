@@ -100,8 +100,11 @@ def test_state_dict_uses_reference_names_and_round_trips(tmp_path):
 
 
 def test_unsupported_architectures_fail_loudly():
-    with pytest.raises(NotImplementedError, match="grouped-query"):
-        P.ParlerTTSForConditionalGeneration(_tiny_config(num_key_value_heads=1))
+    with pytest.raises(ValueError, match="divisible"):
+        P.ParlerTTSForConditionalGeneration(_tiny_config(num_key_value_heads=3))
+    m = P.ParlerTTSForConditionalGeneration(_tiny_config(num_key_value_heads=1))  # grouped-query attention is supported: K/V rows shrink
+    sd = m.decoder.state_dict()
+    assert sd["model.decoder.layers.0.self_attn.k_proj.weight"].shape[0] == 64 and sd["model.decoder.layers.0.self_attn.q_proj.weight"].shape[0] == 128
     with pytest.raises(NotImplementedError, match="gelu"):
         P.ParlerTTSForConditionalGeneration(_tiny_config(activation_function="relu"))
 

@@ -32,7 +32,7 @@ def _teacher_forced(eng, g, spec, sample_first=False):
     return outs
 
 
-@pytest.mark.parametrize("variant", ["sin", "rope"])
+@pytest.mark.parametrize("variant", ["sin", "rope", "gqa"])
 def test_fp32_logits_match_reference_golden(variant):
     g = np.load(os.path.join(GOLD, f"decoder_{variant}.npz"))
     spec = spec_from_gold(g["spec"])
@@ -45,7 +45,7 @@ def test_fp32_logits_match_reference_golden(variant):
         assert d < 2e-5, (s, float(d))
 
 
-@pytest.mark.parametrize("variant", ["sin", "rope"])
+@pytest.mark.parametrize("variant", ["sin", "rope", "gqa"])
 def test_bf16_logits_match_quantised_oracle(variant):
     g = np.load(os.path.join(GOLD, f"decoder_{variant}.npz"))
     spec = spec_from_gold(g["spec"])
@@ -187,6 +187,39 @@ def test_prefill_block_gemm_path(dtype):
     err = (eng.logits().cpu() - ref.step_logits[0]).abs().max()
     assert err < (1e-2 if quant else 2e-5), float(err)
     if not quant and ref.min_margin > 1e-4:
+        assert torch.equal(eng.generate_ids(enc, enc_mask, prompt, prompt_mask).cpu(), ref.sequences)
+
+
+@pytest.mark.parametrize("bsz", [3, 12])
+def test_grouped_query_attention_free_running(bsz):
+    """Grouped-query attention (repeat_kv modeling:280-289; K/V projections with fewer heads :449-452): 4 query heads on 2 self /
+    1 cross K/V heads, RoPE, ragged masks. bsz 3: fused cross block + fused-prologue GEMMs; bsz 12: prep / split-K / plain
+    cross-attention path and the block-GEMM prefill. First-step logits and free-running greedy ids vs the oracle (itself pinned
+    against the reference's GQA forward, tests/golden/decoder_gqa.npz)."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=256, hidden_size=256, num_attention_heads=4, ffn_dim=512,
+                          rope_embeddings=True, num_key_value_heads=2, num_cross_attention_key_value_heads=1)
+    sd = DO.make_decoder_weights(spec, seed=5)
+    g = torch.Generator().manual_seed(bsz)
+    N, P = 21, 23
+    enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
+    prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
+    enc_mask = torch.ones(bsz, N, dtype=torch.long)
+    prompt_mask = torch.ones(bsz, P, dtype=torch.long)
+    for b in range(bsz):
+        enc_mask[b, N - 2 * (b % 4):] = 0 if b % 4 else 1
+        prompt_mask[b, : b % 3] = 0
+    enc = enc * enc_mask[..., None]
+    gp = DO.GenParams(max_length=24, min_new_tokens=23)
+    ref = DO.sample_loop(DO.DecoderOracle(spec, sd), enc, enc_mask, prompt, prompt_mask, gp, keep_logits=True)
+    eng = make_engine(spec, sd, torch.float32, max_batch=bsz, max_ctx=64, max_enc=32, max_prompt=32)
+    eng.set_gen_params(max_length=24, min_new_tokens=23)
+    eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
+    assert (eng.logits().cpu() - ref.step_logits[0]).abs().max() < 2e-5
+    for s in range(1, 8):  # teacher-forced decode steps on the oracle's own ids: logits comparable whatever the arg-max margins
+        eng.push_tokens(ref.sequences[:, s])
+        eng.step_forward()
+        assert (eng.logits().cpu() - ref.step_logits[s]).abs().max() < 2e-5, s
+    if ref.min_margin > 1e-4:
         assert torch.equal(eng.generate_ids(enc, enc_mask, prompt, prompt_mask).cpu(), ref.sequences)
 
 

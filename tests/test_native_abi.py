@@ -27,18 +27,18 @@ def test_exports_every_declared_symbol():
     assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ptts_abi_version() == N.ABI_VERSION == 2
+    assert lib.ptts_abi_version() == N.ABI_VERSION == 3
 
 
 def test_invalid_config_is_value_error_not_crash():
     N, lib = _lib()
-    cfg = N.PttsConfig(1000, 2, 16, 256, 9, 1088, 256, 0, 10000.0, 1024, 1024, 1025, N.PTTS_BF16, 1, 64, 16, 8, 0)  # 1000 % 16 != 0
+    cfg = N.PttsConfig(1000, 2, 16, 256, 9, 1088, 256, 0, 10000.0, 1024, 1024, 1025, N.PTTS_BF16, 1, 64, 16, 8, 0, 0, 0)  # 1000 % 16 != 0
     h = C.c_void_p()
     rc = lib.ptts_engine_create(C.byref(cfg), C.byref(h))
     assert rc == N.PTTS_E_INVALID
     with pytest.raises(ValueError, match="hidden_size"):
         N.check(rc, "ptts_engine_create")
-    cfg = N.PttsConfig(1024, 2, 8, 256, 9, 1088, 256, 0, 10000.0, 1024, 1024, 1025, N.PTTS_BF16, 1, 64, 16, 8, 0)  # head_dim 128
+    cfg = N.PttsConfig(1024, 2, 8, 256, 9, 1088, 256, 0, 10000.0, 1024, 1024, 1025, N.PTTS_BF16, 1, 64, 16, 8, 0, 0, 0)  # head_dim 128
     rc = lib.ptts_engine_create(C.byref(cfg), C.byref(h))
     with pytest.raises(NotImplementedError, match="head_dim"):
         N.check(rc)

@@ -12,7 +12,7 @@ from oracle import dac_oracle as DA
 from oracle import decoder_oracle as DO
 
 
-@pytest.mark.parametrize("variant", ["sin", "rope"])
+@pytest.mark.parametrize("variant", ["sin", "rope", "gqa"])
 @pytest.mark.parametrize("attn", ["sdpa", "eager"])
 def test_decoder_logits_match_reference(variant, attn):
     g = np.load(os.path.join(GOLD, f"decoder_{variant}.npz"))
