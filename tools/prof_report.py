@@ -12,3 +12,7 @@ last = k[-196:]
 span = (last[-1][2] - last[0][1]) / 1e3
 busy = sum(x[2] - x[1] for x in last) / 1e3
 print(f"last 196 dispatches (~1 decode step): span {span:.1f} us, sum of kernel durations {busy:.1f} us")
+if len(sys.argv) > 3:  # decode steps in the trace: per-step sum over the kernels that run in every step (calls >= steps)
+    steps = int(sys.argv[3])
+    per = sum(r[9] for r in rows if r[5] >= steps) / steps / 1e3
+    print(f"decode-step kernels (calls >= {steps}): sum of durations per step = {per:.1f} us (profiled: each dispatch carries ~0.9 us of tracing overhead)")
