@@ -145,3 +145,86 @@ def test_voice_prompt_delay_round_trip_and_reference_undelay_quirk():
     keep_ref = (m_ref != bos) & (m_ref != pad)
     assert keep_ref.sum(1).tolist() == [L - K - k for k in range(K)]  # codebook k: k codes short
     assert not torch.equal(out[keep_ref].reshape(1, K, -1)[0, 1, :T], codes[1])
+
+
+class _FakeCodec:
+    """CPU stand-in for DACModel.decode with a finite, symmetric receptive field (3 latent frames each side, like a short
+    conv stack): sample n of frame t depends on frames t-3..t+3 and on every codebook. Lets the streamer's host logic
+    (un-delay, special-id filter, halo windows, stride trimming) be tested without a GPU."""
+
+    hop = 32
+    decoder_rates = (4, 2, 2, 2)
+
+    class config:
+        sampling_rate, frame_rate, codebook_size, num_codebooks = 32 * 86, 86, 1024, 9
+
+    device = torch.device("cpu")
+
+    def decode(self, audio_codes, audio_scales=None):
+        codes = audio_codes[0].double()  # [B, K, T]
+        B, K, T = codes.shape
+        w = torch.linspace(0.3, 1.0, K, dtype=torch.float64)[None, :, None]
+        lat = (codes * w).sum(1) / 1024.0  # [B, T]
+        pad = torch.nn.functional.pad(lat, (3, 3))
+        taps = torch.tensor([0.05, -0.1, 0.3, 1.0, 0.25, -0.15, 0.07], dtype=torch.float64)
+        sm = sum(taps[i] * pad[:, i: i + T] for i in range(7))  # [B, T]
+        phase = torch.arange(self.hop, dtype=torch.float64) / self.hop
+        wav = (sm[:, :, None] * torch.cos(2 * torch.pi * phase)[None, None] + 0.1 * pad[:, 2: 2 + T, None] * phase[None, None]).reshape(B, 1, T * self.hop)
+
+        class Out:
+            audio_values = wav.float()
+
+        return Out()
+
+
+def test_streamer_incremental_equals_full_redecode_on_cpu():
+    """ParlerTTSStreamer (streamer.py:66-131): the chunks emitted with the O(n) halo-window decode are the chunks of the
+    reference's full re-decode every `play_steps`, incl. the stride trimming, a frame dropped for a special id and the tail."""
+    import types
+    from parler_tts_amd.streamer import ParlerTTSStreamer, receptive_halo_frames
+
+    assert receptive_halo_frames((8, 8, 4, 2)) == 13  # documented halo of the 44 kHz decoder
+    K = 9
+    gc = types.SimpleNamespace(bos_token_id=1025, pad_token_id=1024, decoder_start_token_id=1025)
+    model = types.SimpleNamespace(decoder=types.SimpleNamespace(num_codebooks=K), audio_encoder=_FakeCodec(), generation_config=gc,
+                                  device=torch.device("cpu"), use_audio_scales=False, use_4dim_audio_codes=True)
+    g = torch.Generator().manual_seed(0)
+    L = 70
+    raw = torch.randint(0, 1024, (K, L), generator=g)
+    raw[3, 40] = 1030  # one special id mid-stream: that frame is dropped by both variants
+    chunks = {}
+    for inc in (False, True):
+        s = ParlerTTSStreamer(model, play_steps=10, incremental=inc)
+        s.halo_frames = 3 + 1 if inc else s.halo_frames  # the fake codec's receptive field
+        first = P.build_delay_pattern_mask(torch.full((K, 1), 1025), 1025, 1025, L, K)[0]
+        s.put(first)
+        for j in range(1, L):
+            s.put(raw[:, j])
+        s.end()
+        out = []
+        for c in s:
+            out.append(c)
+        chunks[inc] = out
+    assert len(chunks[True]) == len(chunks[False]) and len(chunks[True]) >= 7
+    for a, b in zip(chunks[True], chunks[False]):
+        assert a.shape == b.shape and np.allclose(a, b, atol=1e-6), (a.shape, b.shape)
+    total = np.concatenate(chunks[True])
+    assert total.shape[0] > 0 and total.shape[0] % 32 == 0
+    with pytest.raises(ValueError, match="batch size 1"):
+        ParlerTTSStreamer(model, play_steps=10).put(torch.zeros(2 * K, dtype=torch.long))
+
+
+def test_host_side_tables_and_weight_norm_match_the_oracle():
+    from oracle import dac_oracle as DA
+    from parler_tts_amd.engine import fold_weight_norm, rope_tables
+    from parler_tts_amd.synthetic import random_dac_state_dict
+
+    c1, s1 = rope_tables(64, 10000.0, 300)
+    c2, s2 = DO.rope_tables(64, 10000.0, 300)
+    assert torch.equal(c1, c2) and torch.equal(s1, s2)
+    for fmt in ("legacy", "parametrized"):
+        sd = DA.make_dac_weights(DA.DAC_TINY, 7, fmt, with_encoder=True)
+        a, b = fold_weight_norm(sd), DA.fold_weight_norm(sd)
+        assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    sd = random_dac_state_dict(latent_dim=64, decoder_dim=256, rates=(4, 2, 2, 2))
+    assert set(fold_weight_norm(sd)) == set(DA.fold_weight_norm(DA.make_dac_weights(DA.DAC_TINY, 1)))  # same tensor names as the oracle's decoder
