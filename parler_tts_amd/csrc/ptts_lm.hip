@@ -726,7 +726,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   return PTTS_OK;
 }
 
-// The decode step (195 kernel nodes for Mini-v1) is captured ONCE per batch size on the engine's private stream
+// The decode step (170 kernel nodes for Mini-v1 at batch <= 8) is captured ONCE per batch size on the engine's private stream
 // (capture records, it does not execute; the legacy NULL stream cannot be captured) and replayed into the caller's.
 static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   auto it = e->graphs.find(e->B);

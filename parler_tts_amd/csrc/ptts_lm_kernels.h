@@ -65,7 +65,7 @@ __global__ void convert_kernel(const ST* __restrict__ src, DT* __restrict__ dst,
 // HBM-bound at decode (every weight byte is read exactly once per step); MFMA is used because it
 // reduces over k in-register (no cross-lane shuffle tree) and makes batch <= 32 free, not for FLOPs.
 //   PRO_PLAIN : x fp32 [M][K]
-//   PRO_LN    : x = LayerNorm(h) (two-pass fp32 stats per row, eps 1e-5, affine)   modeling:1020,:1040,:1059,:1632
+//   PRO_LN    : x = LayerNorm(h) (fp32 stats per row in one shifted pass, eps 1e-5, affine)   modeling:1020,:1040,:1059,:1632
 //   PRO_ATTN  : x = softmax-combine of split-KV partials written by attn_kernel (S splits)
 //   PRO_COPY  : x already normalised / combined by rows_prep_kernel, in the engine dtype (M > 8: do it once, not per workgroup)
 //   EPI_STORE : out = acc            EPI_GELU: out = gelu_erf(acc) (:1060)
