@@ -81,7 +81,7 @@ def reference_forward(m, cache, ids, enc, enc_mask, prompt, prompt_mask, past_le
     return out.logits
 
 
-def gen_decoder(ref, variant: str):
+def gen_decoder(ref, variant: str, save: bool = True):
     from transformers.cache_utils import DynamicCache, EncoderDecoderCache
 
     rope = variant == "rope"
@@ -118,6 +118,8 @@ def gen_decoder(ref, variant: str):
             worst = max(worst, float((a[:, -1] - b[:, -1]).abs().max()))
     print(f"[decoder/{variant}] oracle vs reference ParlerTTSForCausalLM: max|Δlogit| = {worst:.3e}")
     assert worst < 2e-6, worst
+    if not save:
+        return worst
     np.savez_compressed(
         os.path.join(GOLD, f"decoder_{variant}.npz"),
         spec=np.array([spec.hidden_size, spec.num_hidden_layers, spec.num_attention_heads, spec.ffn_dim,
