@@ -76,6 +76,32 @@ class DACModel(torch.nn.Module):
     def state_dict(self, *args, prefix: str = "", **kwargs):
         return {prefix + k: v for k, v in self._weights.items()}
 
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **kwargs):
+        """config.json + model.safetensors under the reference wrapper's key names (``model.*``; helpers/push_to_hub_scripts/push_dac_to_hub.py:19-26)."""
+        import os
+
+        from safetensors.torch import save_file
+
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self._weights.items()}, os.path.join(save_directory, "model.safetensors"),
+                  metadata={"format": "pt"})
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args, config: Optional[DACConfig] = None, **kwargs):
+        import os
+
+        from safetensors.torch import load_file
+
+        path = pretrained_model_name_or_path
+        if not os.path.isdir(path):
+            from huggingface_hub import snapshot_download  # needs network / a local HF cache
+
+            path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors"])
+        m = cls(config or DACConfig.from_pretrained(path), **kwargs)
+        m.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
+        return m
+
     def _get_engine(self, batch: int, frames: int, need_encoder: bool = False) -> DacEngine:
         dev = self.device
         if dev.type != "cuda":

@@ -128,6 +128,38 @@ class ParlerTTSForCausalLM(nn.Module):
     def build_delay_pattern_mask(self, input_ids, bos_token_id, pad_token_id, max_length):
         return build_delay_pattern_mask(input_ids, bos_token_id, pad_token_id, max_length, self.num_codebooks)
 
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **kwargs):
+        """config.json + model.safetensors with the reference's decoder key names (helpers/model_init_scripts/init_model_600M.py:46-47)."""
+        from safetensors.torch import save_file
+
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(save_directory, "model.safetensors"),
+                  metadata={"format": "pt"})
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *model_args, config=None, **kwargs):
+        """A decoder directory written by ``save_pretrained`` - or a full Parler-TTS checkpoint, whose ``decoder.*`` tensors are taken
+        (:2654-2666 accepts both)."""
+        from safetensors.torch import load_file
+
+        path = pretrained_model_name_or_path
+        if config is None:
+            with open(os.path.join(path, "config.json")) as fh:
+                d = json.load(fh)
+            config = ParlerTTSConfig.from_dict(d).decoder if "decoder" in d else ParlerTTSDecoderConfig.from_dict(d)
+        if isinstance(config, ParlerTTSConfig):
+            config = config.decoder
+        m = cls(config, init_weights=False)
+        sd = load_file(os.path.join(path, "model.safetensors"))
+        if any(k.startswith("decoder.") for k in sd):
+            sd = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        missing = [k for k in missing if "rotary_emb" not in k]
+        if missing:
+            raise RuntimeError(f"decoder checkpoint {path} lacks {missing[:5]}")
+        return m
+
     @staticmethod
     def apply_delay_pattern_mask(input_ids, decoder_pad_token_mask):
         return apply_delay_pattern_mask(input_ids, decoder_pad_token_mask)
@@ -218,6 +250,34 @@ class ParlerTTSForConditionalGeneration(nn.Module):
     def get_audio_encoder(self):
         return self.audio_encoder
 
+    def get_encoder(self):
+        return self.get_text_encoder()
+
+    def get_decoder(self):
+        return self.decoder
+
+    def get_input_embeddings(self):
+        return self.text_encoder.get_input_embeddings()
+
+    def get_output_embeddings(self):
+        return self.decoder.lm_heads
+
+    def set_output_embeddings(self, new_embeddings):
+        self.decoder.lm_heads = new_embeddings
+        self._engine = None
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("the training forward (:2695-2880) is outside this inference implementation; call .generate()")
+
+    def prepare_decoder_input_ids_from_labels(self, labels: torch.Tensor):
+        """shift_tokens_right over [bsz, seq, codebooks] labels, transposed to [bsz, codebooks, seq] (:3196-3199, :187-202)."""
+        d = self.config.decoder
+        labels = labels.transpose(1, 2)
+        shifted = labels.new_zeros(labels.shape)
+        shifted[..., 1:] = labels[..., :-1].clone()
+        shifted[..., 0] = d.bos_token_id
+        return shifted.masked_fill(shifted == -100, d.pad_token_id)
+
     def freeze_encoders(self, freeze_text_encoder=True):
         pass  # inference-only implementation: nothing is trainable
 
@@ -278,6 +338,40 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if torch_dtype is not None:
             model.to(dtype=torch_dtype)
         return model
+
+    @classmethod
+    def from_sub_models_pretrained(cls, text_encoder_pretrained_model_name_or_path: Optional[str] = None,
+                                   audio_encoder_pretrained_model_name_or_path: Optional[str] = None,
+                                   decoder_pretrained_model_name_or_path: Optional[str] = None, *model_args, **kwargs):
+        """Composes a model from three sub-model checkpoints (:2490-2691; used by helpers/model_init_scripts/*.py). Keyword
+        arguments prefixed ``text_encoder_`` / ``audio_encoder_`` / ``decoder_`` go to the respective loader (``*_model`` passes
+        an instantiated module, ``*_config`` a config); the rest updates the composite config (e.g. ``vocab_size``,
+        ``prompt_cross_attention``)."""
+        split = {"text_encoder": {}, "audio_encoder": {}, "decoder": {}}
+        for k in list(kwargs):
+            for pre in split:
+                if k.startswith(pre + "_"):
+                    split[pre][k[len(pre) + 1:]] = kwargs.pop(k)
+                    break
+        text_encoder = split["text_encoder"].pop("model", None)
+        if text_encoder is None:
+            if text_encoder_pretrained_model_name_or_path is None:
+                raise ValueError("If `text_encoder_model` is not defined as an argument, a `text_encoder_pretrained_model_name_or_path` has to be defined.")
+            from transformers import AutoModelForTextEncoding
+
+            text_encoder = AutoModelForTextEncoding.from_pretrained(text_encoder_pretrained_model_name_or_path, *model_args, **split["text_encoder"])
+        audio_encoder = split["audio_encoder"].pop("model", None)
+        if audio_encoder is None:
+            if audio_encoder_pretrained_model_name_or_path is None:
+                raise ValueError("If `audio_encoder_model` is not defined as an argument, an `audio_encoder_pretrained_model_name_or_path` has to be defined.")
+            audio_encoder = DACModel.from_pretrained(audio_encoder_pretrained_model_name_or_path, **split["audio_encoder"])
+        decoder = split["decoder"].pop("model", None)
+        if decoder is None:
+            if decoder_pretrained_model_name_or_path is None:
+                raise ValueError("If `decoder_model` is not defined as an argument, a `decoder_pretrained_model_name_or_path` has to be defined.")
+            decoder = ParlerTTSForCausalLM.from_pretrained(decoder_pretrained_model_name_or_path, **split["decoder"])
+        config = ParlerTTSConfig.from_sub_models_config(text_encoder.config, audio_encoder.config, decoder.config, **kwargs)
+        return cls(text_encoder=text_encoder, audio_encoder=audio_encoder, decoder=decoder, config=config)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         audio = {k[len("audio_encoder."):]: v for k, v in state_dict.items() if k.startswith("audio_encoder.")}

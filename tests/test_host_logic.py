@@ -228,3 +228,41 @@ def test_host_side_tables_and_weight_norm_match_the_oracle():
         assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
     sd = random_dac_state_dict(latent_dim=64, decoder_dim=256, rates=(4, 2, 2, 2))
     assert set(fold_weight_norm(sd)) == set(DA.fold_weight_norm(DA.make_dac_weights(DA.DAC_TINY, 1)))  # same tensor names as the oracle's decoder
+
+
+def test_from_sub_models_pretrained_round_trip(tmp_path):
+    """helpers/model_init_scripts/init_model_600M.py workflow: decoder.save_pretrained -> from_sub_models_pretrained(text encoder dir,
+    audio encoder dir, decoder dir, vocab_size=...) -> save_pretrained -> from_pretrained; same tensors under the reference's names."""
+    from transformers import T5Config, T5EncoderModel
+
+    from oracle import dac_oracle as DA
+
+    t5 = T5EncoderModel(T5Config(vocab_size=128, d_model=128, d_kv=32, d_ff=256, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")).eval()
+    t5.save_pretrained(str(tmp_path / "t5"))
+    dac = P.DACModel(P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2], encoder_dim=16))
+    dac.load_state_dict({"model." + k: v for k, v in DA.make_dac_weights(DA.DAC_TINY, 4321, "parametrized", with_encoder=True).items()})
+    dac.save_pretrained(str(tmp_path / "dac"))
+    dec_cfg = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=256, num_hidden_layers=2, ffn_dim=256, num_attention_heads=2,
+                                       hidden_size=128, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025)
+    dec = P.ParlerTTSForCausalLM(dec_cfg)
+    dec.save_pretrained(str(tmp_path / "decoder"))
+    m = P.ParlerTTSForConditionalGeneration.from_sub_models_pretrained(
+        text_encoder_pretrained_model_name_or_path=str(tmp_path / "t5"), audio_encoder_pretrained_model_name_or_path=str(tmp_path / "dac"),
+        decoder_pretrained_model_name_or_path=str(tmp_path / "decoder"), vocab_size=128)
+    assert m.config.vocab_size == 128 and m.config.decoder.num_codebooks == 9 and m.config.audio_encoder.encoder_dim == 16
+    for k, v in dec.state_dict().items():
+        assert torch.equal(m.decoder.state_dict()[k], v), k
+    assert torch.equal(m.audio_encoder.state_dict()["model.decoder.model.0.bias"], dac.state_dict()["model.decoder.model.0.bias"])
+    assert m.get_decoder() is m.decoder and m.get_encoder() is m.text_encoder and m.get_input_embeddings() is m.text_encoder.get_input_embeddings()
+    m.save_pretrained(str(tmp_path / "full"))
+    m2 = P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path / "full"))
+    a, b = m.state_dict(), m2.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a if not k.endswith("_dummy"))
+    d2 = P.ParlerTTSForCausalLM.from_pretrained(str(tmp_path / "full"))  # a full checkpoint also serves as a decoder source (:2654-2666)
+    assert torch.equal(d2.state_dict()["lm_heads.3.weight"], dec.state_dict()["lm_heads.3.weight"])
+    with pytest.raises(ValueError, match="decoder_pretrained_model_name_or_path"):
+        P.ParlerTTSForConditionalGeneration.from_sub_models_pretrained(text_encoder_model=t5, audio_encoder_model=dac)
+    labels = torch.tensor([[[5, 6], [7, -100], [9, 10]]])  # [bsz, seq, codebooks]
+    assert m.prepare_decoder_input_ids_from_labels(labels).tolist() == [[[1025, 5, 7], [1025, 6, 1024]]]
+    with pytest.raises(NotImplementedError, match="generate"):
+        m(input_ids=torch.zeros(1, 2, dtype=torch.long))
