@@ -779,7 +779,7 @@ extern "C" int ptts_state(ptts_engine* e, int32_t* cur_len, int32_t* all_finishe
   PTTS_HIP(hipStreamSynchronize(st));
   if (cur_len) *cur_len = hp[0];
   int any = 0;
-  for (int i = 0; i < n; ++i) any |= hp[1 + i];
+  for (int i = 0; i < n; ++i) any |= hp[1 + i] > 0;  // 1 = still generating, -(t + 1) = finished at step t
   if (all_finished) *all_finished = any ? 0 : 1;
   return PTTS_OK;
 }

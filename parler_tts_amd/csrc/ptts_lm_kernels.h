@@ -1194,7 +1194,7 @@ struct TailArgs {
   long long* ids;
   int ids_ld;
   int* cur_len;        // [B]
-  int* unfinished;     // [B*K]
+  int* unfinished;     // [B*K]: 1 = still generating; -(t + 1) = finished at step (column) t
   int* has_eos;        // [B*K]
   int* first_unf;      // [B] local codebook index
   const DevGen* gen;
@@ -1272,10 +1272,15 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // ---- t = 0: every load that does not depend on another load goes in flight together (the step's critical path ends
   // here: lengths / flags / parameters / this wave's logits row are ONE round trip, the embedding rows a second one)
-  int any_local = 0;
-  for (int i = tid; i < a.B * a.K; i += blockDim.x) any_local |= a.unfinished[i];
   const DevGen g = *a.gen;
   const int t = a.cur_len[b];  // column the new token is written to; t-1 new tokens generated so far
+  // "has the reference loop already exited?" = every row finished BEFORE this step. Rows that finish during this very launch
+  // (other workgroups, stamp -(t + 1)) still count as active here, so the answer does not depend on workgroup timing.
+  int any_local = 0;
+  for (int i = tid; i < a.B * a.K; i += blockDim.x) {
+    const int v = a.unfinished[i];
+    any_local |= (v > 0) | (v <= -(t + 1));
+  }
   const int fu0 = a.first_unf[b];
   const int t_prefix = a.dims->T_prefix;
   const int he = lane < a.K ? a.has_eos[b * a.K + lane] : 0;  // every wave: the K EOS flags of this utterance
@@ -1287,7 +1292,7 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) lg[i] = (lane + 64 * i < a.V) ? sc0[lane + 64 * i] : -INFINITY;
   }
-  const int unf0 = k0 < a.K ? a.unfinished[b * a.K + k0] : 0;
+  const int unf0 = k0 < a.K ? (a.unfinished[b * a.K + k0] > 0) : 0;
   if (!__syncthreads_or(any_local)) return;  // every row of every utterance finished: the reference loop has exited (no-op step)
 
   int fu = fu0;
@@ -1318,12 +1323,12 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
       const float cand = (best == wbest) ? (float)bi : 3.0e9f;  // vocabulary indices are exact in fp32
       const int widx = (int)(-wave_max(-cand));
       if (lane == 0) {
-        const int unf = k == k0 ? unf0 : a.unfinished[row];
+        const int unf = k == k0 ? unf0 : (a.unfinished[row] > 0);
         const int nxt = unf ? widx : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
         a.ids[(size_t)row * a.ids_ld + t] = nxt;
         s_tok[k] = nxt;
         if (nxt == a.eos) a.has_eos[row] = 1;
-        if ((nxt == a.eos) || (t + 1 >= g.max_length)) a.unfinished[row] = 0;  // EosTokenCriteria | MaxLengthCriteria
+        if (unf && ((nxt == a.eos) || (t + 1 >= g.max_length))) a.unfinished[row] = -(t + 1);  // EosTokenCriteria | MaxLengthCriteria
       }
     }
     __syncthreads();
@@ -1389,13 +1394,13 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
       tok = s_pick;
     }
     if (tid == 0) {
-      const int unf = a.unfinished[row];
+      const int unf = a.unfinished[row] > 0;
       const int nxt = unf ? tok : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
       a.ids[(size_t)row * a.ids_ld + t] = nxt;
       s_tok[k] = nxt;
       if (nxt == a.eos) a.has_eos[row] = 1;
       const bool done = (nxt == a.eos) || (t + 1 >= g.max_length);  // EosTokenCriteria | MaxLengthCriteria
-      if (done) a.unfinished[row] = 0;
+      if (done && unf) a.unfinished[row] = -(t + 1);
     }
     __syncthreads();
   }
@@ -1413,7 +1418,7 @@ __global__ void push_tokens_kernel(const long long* tokens, const int* finished,
   const long long tk = tokens[row];
   ids[(size_t)row * ids_ld + t] = tk;
   if (tk == eos) has_eos[row] = 1;
-  if (finished && finished[row]) unfinished[row] = 0;
+  if (finished && finished[row] && unfinished[row] > 0) unfinished[row] = -(t + 1);
 }
 __global__ void bump_len_kernel(int* cur_len, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
