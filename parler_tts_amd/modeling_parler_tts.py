@@ -330,10 +330,15 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         from safetensors.torch import load_file
 
         index = os.path.join(path, "model.safetensors.index.json")
-        files = sorted(set(json.load(open(index))["weight_map"].values())) if os.path.exists(index) else ["model.safetensors"]
         sd: Dict[str, torch.Tensor] = {}
-        for fn in files:
-            sd.update(load_file(os.path.join(path, fn)))
+        if os.path.exists(index) or os.path.exists(os.path.join(path, "model.safetensors")):
+            files = sorted(set(json.load(open(index))["weight_map"].values())) if os.path.exists(index) else ["model.safetensors"]
+            for fn in files:
+                sd.update(load_file(os.path.join(path, fn)))
+        elif os.path.exists(os.path.join(path, "pytorch_model.bin")):  # legacy torch.save checkpoints (tensors only)
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"no model.safetensors[.index.json] or pytorch_model.bin under {path}")
         model.load_state_dict(sd)
         if torch_dtype is not None:
             model.to(dtype=torch_dtype)

@@ -258,6 +258,20 @@ def test_from_sub_models_pretrained_round_trip(tmp_path):
     m2 = P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path / "full"))
     a, b = m.state_dict(), m2.state_dict()
     assert all(torch.equal(a[k], b[k]) for k in a if not k.endswith("_dummy"))
+    import shutil
+
+    legacy = tmp_path / "legacy"  # torch.save checkpoint of the same tensors
+    legacy.mkdir()
+    shutil.copy(tmp_path / "full" / "config.json", legacy / "config.json")
+    from safetensors.torch import load_file
+
+    torch.save(load_file(str(tmp_path / "full" / "model.safetensors")), str(legacy / "pytorch_model.bin"))
+    m3 = P.ParlerTTSForConditionalGeneration.from_pretrained(str(legacy))
+    assert all(torch.equal(a[k], m3.state_dict()[k]) for k in a if not k.endswith("_dummy"))
+    (tmp_path / "empty").mkdir()
+    shutil.copy(tmp_path / "full" / "config.json", tmp_path / "empty" / "config.json")
+    with pytest.raises(FileNotFoundError, match="pytorch_model.bin"):
+        P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path / "empty"))
     d2 = P.ParlerTTSForCausalLM.from_pretrained(str(tmp_path / "full"))  # a full checkpoint also serves as a decoder source (:2654-2666)
     assert torch.equal(d2.state_dict()["lm_heads.3.weight"], dec.state_dict()["lm_heads.3.weight"])
     with pytest.raises(ValueError, match="decoder_pretrained_model_name_or_path"):
