@@ -177,3 +177,34 @@ def test_voice_prompt_glue_prefix_survives_and_lengths_count_from_given_columns(
     assert torch.equal(a, b)
     with pytest.raises(ValueError, match="no room"):
         m.generate(decoder_input_ids=prefix, input_ids=desc, prompt_input_ids=prompt_ids, max_length=7)
+
+
+def test_masks_encoder_outputs_and_num_return_sequences_glue():
+    """Padded description / prompt masks travel to the engine untouched, `encoder_outputs` bypasses the text encoder, and
+    `num_return_sequences` repeats every utterance (repeat_interleave, :3556-3561) - all host logic."""
+    m, spec, sd, dac = _model()
+    g = torch.Generator().manual_seed(5)
+    desc, prompt_ids = torch.randint(3, 128, (2, 9), generator=g), torch.randint(3, 128, (2, 6), generator=g)
+    dmask = torch.ones(2, 9, dtype=torch.long); dmask[1, 6:] = 0
+    pmask = torch.ones(2, 6, dtype=torch.long); pmask[0, :2] = 0
+    kw = dict(prompt_input_ids=prompt_ids, prompt_attention_mask=pmask, do_sample=False, max_new_tokens=24, min_new_tokens=24)
+    a = m.generate(input_ids=desc, attention_mask=dmask, **kw)
+    enc = m._encode_description(desc, dmask)
+    b = m.generate(encoder_outputs=(enc,), attention_mask=dmask, **kw)  # tuple form of BaseModelOutput
+    assert a.shape == (2, 32 * 16) and torch.equal(a, b)
+    # oracle pipeline with the same masks
+    prompt = m.embed_prompts(prompt_ids).float()
+    gp = DO.GenParams(max_length=25, min_new_tokens=24)
+    tr = DO.sample_loop(DO.DecoderOracle(spec, sd), enc.float(), dmask, prompt, pmask, gp)
+    codes = DO.undelay(tr.sequences, spec, 25)
+    for bb in range(2):
+        assert torch.allclose(a[bb], dac.decode(DO.valid_frames(codes[bb])[None])[0, 0], atol=1e-4)
+    # num_return_sequences: every utterance repeated in place (greedy needs sampling mode in GenerationConfig: top_k=1 keeps it deterministic
+    # on the manual path, where torch.multinomial over a one-hot distribution has a single outcome)
+    from transformers import LogitsProcessorList
+
+    c = m.generate(input_ids=desc, attention_mask=dmask, num_return_sequences=2, do_sample=True, top_k=1,
+                   logits_processor=LogitsProcessorList([P.ParlerTTSLogitsProcessor(1024, 9, 4, "cpu")]),
+                   prompt_input_ids=prompt_ids, prompt_attention_mask=pmask, max_new_tokens=24, min_new_tokens=24)
+    assert c.shape == (4, 32 * 16)
+    assert torch.allclose(c[0], a[0], atol=1e-4) and torch.allclose(c[1], a[0], atol=1e-4) and torch.allclose(c[2], a[1], atol=1e-4) and torch.allclose(c[3], a[1], atol=1e-4)
