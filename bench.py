@@ -35,25 +35,36 @@ AUDIO_S = FRAMES * 512 / 44100.0       # 9.985 s per utterance
 N_DESC, N_PROMPT = 64, 32
 
 
-def mini_config():
+def model_config(which: str = "mini"):
+    """Decoder shapes of the two released sizes; text encoder = google/flan-t5-large (training/README.md:91), so Large-v1
+    (hidden 1536) carries the 1024 -> 1536 `enc_to_dec_proj` (modeling:2388-2392)."""
     import parler_tts_amd as P
     from transformers import T5Config
 
     t5 = T5Config(vocab_size=32128, d_model=1024, d_kv=64, d_ff=2816, num_layers=24, num_heads=16, feed_forward_proj="gated-gelu",
-                  tie_word_embeddings=False)  # google/flan-t5-large encoder shape (training/README.md:91)
-    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=4096, num_hidden_layers=24, ffn_dim=4096,
-                                   num_attention_heads=16, hidden_size=1024, num_codebooks=9, pad_token_id=1024, eos_token_id=1024,
-                                   bos_token_id=1025)  # helpers/model_init_scripts/init_model_600M.py:27-44
+                  tie_word_embeddings=False)
+    if which == "large":  # helpers/model_init_scripts/init_large_model.py:25-43
+        dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=4096, num_hidden_layers=30, ffn_dim=6144,
+                                       num_attention_heads=24, num_key_value_heads=24, hidden_size=1536, num_codebooks=9, pad_token_id=1024,
+                                       eos_token_id=1024, bos_token_id=1025)
+    else:  # helpers/model_init_scripts/init_model_600M.py:27-44
+        dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=4096, num_hidden_layers=24, ffn_dim=4096,
+                                       num_attention_heads=16, hidden_size=1024, num_codebooks=9, pad_token_id=1024, eos_token_id=1024,
+                                       bos_token_id=1025)
     return P.ParlerTTSConfig.from_sub_models_config(t5, P.DACConfig(), dec, vocab_size=32128)
 
 
-def build_model(rank: int, world: int, device: torch.device, dtype: torch.dtype):
+def mini_config():
+    return model_config("mini")
+
+
+def build_model(rank: int, world: int, device: torch.device, dtype: torch.dtype, which: str = "mini"):
     """Rank 0 draws the synthetic weights (seed 1234); other ranks allocate and receive them by RCCL broadcast."""
     import parler_tts_amd as P
     from parler_tts_amd.synthetic import random_dac_state_dict
 
     torch.manual_seed(1234)
-    model = P.ParlerTTSForConditionalGeneration(mini_config())
+    model = P.ParlerTTSForConditionalGeneration(model_config(which))
     # A trained checkpoint never emits the 64 padding ids >= codebook_size (vocab 1088 = 1024 + 64); random LM heads would,
     # and generate() (like the reference :3627-3636) drops every frame containing one. Zero those rows so each
     # utterance decodes exactly FRAMES frames (the arithmetic per step is unchanged).
@@ -90,18 +101,9 @@ def hip_event_timer():
     return hip
 
 
-def measure_decode_roofline(model, bs: int, device) -> dict:
-    """HIP events (on the stream the graph is launched on) around 400 replays of the captured decode step at
-    mid-context. Algorithmic bytes per step = W_step*2 + B*2*layers*H*(Lc+N)*2 + B*(K*H*2 + K*V*4)."""
+def _timed_replays(eng, n: int) -> float:
+    """seconds per decode-step launch: HIP events on the stream the graph is launched on, around n replays."""
     hip = hip_event_timer()
-    desc, prompt = synthetic_batch(bs, 0, device)
-    enc = model._encode_description(desc, None).float()
-    pr = model.embed_prompts(prompt).float()
-    eng = model._get_engine(bs, N_DESC, N_PROMPT, NEW_TOKENS + 1)
-    eng.set_gen_params(max_length=NEW_TOKENS + 1, min_new_tokens=NEW_TOKENS)
-    eng.prefill(enc, None, pr, None, sample=True)
-    n_warm, n = 230, 400
-    eng.decode_steps(n_warm)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     e0, e1 = C.c_void_p(), C.c_void_p()
     hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
@@ -111,24 +113,58 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
     hip.hipEventSynchronize(e1)
     ms = C.c_float()
     hip.hipEventElapsedTime(C.byref(ms), e0, e1)
-    step_s = ms.value / 1e3 / n
+    return ms.value / 1e3 / n
+
+
+def _prefilled_engine(model, bs: int, device, **gen):
+    desc, prompt = synthetic_batch(bs, 0, device)
+    enc = model._encode_description(desc, None).float()
+    pr = model.embed_prompts(prompt).float()
+    eng = model._get_engine(bs, N_DESC, N_PROMPT, NEW_TOKENS + 1)
+    eng.set_gen_params(max_length=NEW_TOKENS + 1, min_new_tokens=NEW_TOKENS, **gen)
+    eng.prefill(enc, None, pr, None, sample=True)
+    return eng
+
+
+def measure_decode_roofline(model, bs: int, device) -> dict:
+    """HIP events (on the stream the graph is launched on) around 400 replays of the captured decode step at
+    mid-context. Algorithmic bytes per step = W_step*s + B*2*layers*H*(Lc+N)*s + B*(K*H*s + K*V*4)."""
+    eng = _prefilled_engine(model, bs, device)
+    n_warm, n = 230, 400
+    eng.decode_steps(n_warm)
+    step_s = _timed_replays(eng, n)
     d = model.config.decoder
     H, L, F, V, Kc = d.hidden_size, d.num_hidden_layers, d.ffn_dim, d.vocab_size, d.num_codebooks
-    w_step = L * (4 * H * H + 2 * H * H + 2 * H * F) + Kc * V * H  # 362.3 M for Mini-v1
+    w_step = L * (4 * H * H + 2 * H * H + 2 * H * F) + Kc * V * H  # 362.3 M for Mini-v1, 1005.9 M for Large-v1
     lc = N_PROMPT + 1 + n_warm + n // 2  # mean self-KV length over the timed replays
     es = 2 if model.dtype == torch.bfloat16 else 4
     bytes_step = w_step * es + bs * 2 * L * H * (lc + N_DESC) * es + bs * (Kc * H * es + Kc * V * 4)
     achieved = bytes_step / step_s / 1e9
-    traffic, tnote = None, "PMC pass not available"
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_step_bs1.json")
-    if bs == 1 and es == 2 and os.path.exists(pmc):  # committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE summary (separate passes)
+    traffic, tnote = None, "PMC pass not available for this configuration"
+    pmc = os.path.join(ROOT, "profiles", f"r02_pmc_step_bs{bs}.json")
+    if es == 2 and H == 1024 and os.path.exists(pmc):  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
         j = json.load(open(pmc))
         traffic = int(j["traffic_bytes_per_step"])
-        tnote = f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~735 MB)"
+        tnote = f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~{j.get('algorithmic_mb', '?')} MB)"
+    nodes = (8 * L + 2) if bs == 1 else ((7 * L + 2) if bs <= 8 else None)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
             "traffic": traffic, "traffic_note": tnote,
-            "kernel": "decode-step hipGraph (170 kernel nodes at bs<=8: 24 x 7 per layer + LM heads + sampler/embed tail; one hipGraphLaunch per generated frame)",
-            "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
+            "kernel": "decode-step hipGraph: one hipGraphLaunch per generated frame" + (f" ({nodes} kernel nodes)" if nodes else "")
+                      + (": bs=1 runs 8 row-per-wave GEMV / attention nodes per layer + LM heads + sampler/embed tail" if bs == 1 else ""),
+            "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "context": lc,
+            "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
+
+
+def measure_sampling_step(model, bs: int, device) -> dict:
+    """The same captured step with the sampler tail drawing (temperature 1.0, top_k 50, top_p 0.9) instead of taking the arg-max."""
+    out = {}
+    for name, gen in (("greedy", {}), ("sample_topk50", dict(do_sample=True, temperature=1.0, top_k=50, seed=1)),
+                      ("sample_topk50_topp0.9", dict(do_sample=True, temperature=0.9, top_k=50, top_p=0.9, seed=1))):
+        eng = _prefilled_engine(model, bs, device, **gen)
+        eng.decode_steps(100)
+        out[name + "_us_per_step"] = round(_timed_replays(eng, 300) * 1e6, 1)
+    out["ratio_sampling_over_greedy"] = round(out["sample_topk50_topp0.9_us_per_step"] / out["greedy_us_per_step"], 3)
+    return out
 
 
 def measure_ttft(model, bs: int, device, reps: int = 20) -> float:
@@ -152,9 +188,12 @@ def measure_ttft(model, bs: int, device, reps: int = 20) -> float:
 
 
 def cpu_baseline(budget_s: float = 20.0) -> dict:
-    """The oracle (CPU restatement of the reference path, kind 'port') on the host cores: Mini-v1 shapes, fp32,
-    greedy, bs=1, same synthetic input shapes; bounded sample: prefill + as many cached decode steps as fit the
-    budget, plus DAC decode of the frames produced, extrapolated per frame."""
+    """The oracle (CPU restatement of the reference path, kind 'port') on the host cores: Mini-v1 shapes, fp32, greedy,
+    bs=1, same synthetic input shapes. EVERYTHING reported is timed: prefill of P+1 positions + S cached decode passes
+    (as many as fit the budget) + DAC decode of the S+1-8 frames those passes complete; value = that audio / that time.
+    No extrapolation to 868 passes (so the prefill weighs ~5 % more than in the full run, and the context stays short:
+    both favour neither side by more than a few per cent). profiles/r02_cpu_baseline_calibration.txt holds the ratio of
+    this port to the reference's own ParlerTTSForCausalLM timed on the same host."""
     from oracle import dac_oracle as DA
     from oracle import decoder_oracle as DO
 
@@ -168,9 +207,8 @@ def cpu_baseline(budget_s: float = 20.0) -> dict:
     prompt = torch.randn(1, N_PROMPT, spec.hidden_size, generator=g) * 0.02
     ids = torch.full((9, 1), spec.bos_token_id, dtype=torch.long)
     with torch.no_grad():
-        # bs=1 decode is GEMV-sized: more threads than memory channels only adds synchronisation cost (256 threads on
-        # this class of host are ~600x SLOWER than 16). Sweep a few counts on 2 cached steps each and keep the fastest;
-        # `cores` reports the threads actually used.
+        # bs=1 decode is GEMV-sized: more threads than memory channels only adds synchronisation cost. Sweep a few thread
+        # counts on 2 cached steps each (untimed warm-up) and keep the fastest; `cores` reports the threads actually used.
         orc.forward(ids, enc, None, prompt, None)
         best, cores = None, 1
         for nt in sorted({c for c in (4, 8, 16, 32, 64) if c <= ncpu} | {min(ncpu, 8)}):
@@ -183,28 +221,48 @@ def cpu_baseline(budget_s: float = 20.0) -> dict:
             if best is None or dt < best:
                 best, cores = dt, nt
         torch.set_num_threads(cores)
+        dac = DA.DacOracle(DA.DAC_44KHZ, DA.make_dac_weights(DA.DAC_44KHZ, seed=4321))
+        dac.decode(torch.randint(0, 1024, (1, 9, 4), generator=g))  # warm-up
         orc.reset()
         t0 = time.perf_counter()
         logits = orc.forward(ids, enc, None, prompt, None)
         t_prefill = time.perf_counter() - t0
         steps, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < budget_s * 0.7 and steps < NEW_TOKENS - 1:
+        while time.perf_counter() - t1 < budget_s * 0.6 and steps < NEW_TOKENS - 1:
             nxt = logits[:, -1].argmax(-1, keepdim=True).clamp(max=1023)
             logits = orc.forward(nxt)
             steps += 1
-        t_step = (time.perf_counter() - t1) / max(steps, 1)
-        dac = DA.DacOracle(DA.DAC_44KHZ, DA.make_dac_weights(DA.DAC_44KHZ, seed=4321))
-        Tdac = 43
-        codes = torch.randint(0, 1024, (1, 9, Tdac), generator=g)
+        t_steps = time.perf_counter() - t1
+        frames = max(1, steps + 1 - (K_CODEBOOKS - 1))  # passes - (K - 1): the delay pattern's tail produces no audio
+        codes = torch.randint(0, 1024, (1, 9, frames), generator=g)
         t2 = time.perf_counter()
         dac.decode(codes)
-        t_dac_frame = (time.perf_counter() - t2) / Tdac
-    total = t_prefill + (NEW_TOKENS - 1) * t_step + FRAMES * t_dac_frame
-    return {"value": round(AUDIO_S / total, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle/ fp32 Mini-v1 bs=1: prefill of {N_PROMPT + 1} positions ({t_prefill:.2f}s) + {steps} cached decode steps "
-                      f"({t_step * 1e3:.1f} ms/step) + DAC decode of {Tdac} frames ({t_dac_frame * 1e3:.1f} ms/frame), extrapolated to "
-                      f"{NEW_TOKENS} passes / {FRAMES} frames; T5 encoder excluded",
-            "ms_per_decode_step": round(t_step * 1e3, 2)}
+        t_dac = time.perf_counter() - t2
+    total = t_prefill + t_steps + t_dac
+    audio = frames * 512 / 44100.0
+    return {"value": round(audio / total, 4), "unit": "audio-seconds/sec", "cores": cores, "host_cores": ncpu, "kind": "port",
+            "sample": f"oracle/ fp32 Mini-v1 bs=1, all timed: prefill of {N_PROMPT + 1} positions ({t_prefill:.2f} s) + {steps} cached decode passes "
+                      f"({t_steps / max(steps, 1) * 1e3:.1f} ms each) + DAC decode of the {frames} frames they complete ({t_dac:.2f} s) = {audio:.2f} s of audio in "
+                      f"{total:.1f} s on {cores} threads (thread count swept, host has {ncpu}); T5 encoder excluded",
+            "ms_per_decode_step": round(t_steps / max(steps, 1) * 1e3, 2)}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU over RCCL), relay
+    rank 0's JSON line. Equivalent to `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`."""
+    import socket
+    import subprocess
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PTTS_BENCH_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -212,27 +270,37 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bs", type=int, default=1, help="utterances per GPU per step (configs[1]: 1; configs[2]: 32)")
+    ap.add_argument("--bs", type=int, default=1, help="utterances per GPU per step (configs[1]: 1; configs[2]: 32; configs[3]: --model large --bs 1)")
+    ap.add_argument("--model", default="mini", choices=["mini", "large"], help="parler-tts-mini-v1 (BASELINE metric) or parler-tts-large-v1 shapes")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--sample", action="store_true", help="do_sample=True (temperature 1.0, top_k 50: the reference's default generation mode) instead of greedy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bs=32 / TTFT side measurements")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    if local >= ndev and not os.environ.get("PTTS_BENCH_SHARE_GPU"):
+        raise SystemExit(f"rank {rank} wants GPU {local} but only {ndev} visible (set PTTS_BENCH_SHARE_GPU=1 for a functional run of N ranks on fewer GPUs)")
+    dev_index = local % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        backend = os.environ.get("PTTS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for functional runs of ranks sharing one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
 
@@ -243,9 +311,11 @@ def main():
 
         dist.barrier()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = build_model(rank, world, device, dtype)
+    model = build_model(rank, world, device, dtype, args.model)
     desc, prompt = synthetic_batch(args.bs, rank, device)
     gen_kw = dict(input_ids=desc, prompt_input_ids=prompt, do_sample=False, max_new_tokens=NEW_TOKENS, min_new_tokens=NEW_TOKENS)
+    if args.sample:
+        gen_kw.update(do_sample=True, temperature=1.0, top_k=50)
 
     def barrier():
         if world > 1:
@@ -263,31 +333,36 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert wav.shape == (args.bs, FRAMES * 512), wav.shape
+    n_ranks = world
     if world > 1:
         import torch.distributed as dist
 
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    value = world * args.bs * args.steps * AUDIO_S / elapsed
+        n_ranks = dist.get_world_size()  # the ranks the process group actually holds
+    value = n_ranks * args.bs * args.steps * AUDIO_S / elapsed
 
     out = None
+    mname = "parler-tts-mini-v1" if args.model == "mini" else "parler-tts-large-v1"
     if rank == 0:
         out = {
             "metric": "audio-seconds/sec (whole node) + p50 time-to-first-token, Mini-v1 bs=1/32", "value": round(value, 3),
-            "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "audio-seconds/sec", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic (random-init weights at parler-tts-mini-v1 shapes, seeded token ids)",
-            "config": {"workload": f"parler-tts-mini-v1 {args.dtype} bs={args.bs}/GPU greedy, {N_DESC} description + {N_PROMPT} prompt tokens, "
-                                   f"{FRAMES} frames = {AUDIO_S:.3f} s audio/utterance ({NEW_TOKENS} decoder passes, hipGraph decode, DAC on-GPU)",
-                       "global_batch": world * args.bs, "frames": FRAMES, "parallelism": f"utterance-sharded x{world}, weights broadcast once"},
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": f"synthetic (random-init weights at {mname} shapes, seeded token ids)",
+            "config": {"workload": f"{mname} {args.dtype} bs={args.bs}/GPU {'sampling (T=1, top_k=50)' if args.sample else 'greedy'}, {N_DESC} description + "
+                                   f"{N_PROMPT} prompt tokens, {FRAMES} frames = {AUDIO_S:.3f} s audio/utterance ({NEW_TOKENS} decoder passes, hipGraph decode, DAC on-GPU)",
+                       "global_batch": n_ranks * args.bs, "frames": FRAMES, "parallelism": f"utterance-sharded x{n_ranks}, weights broadcast once"},
         }
+        if world > 1 and ndev < world:
+            out["config"]["note"] = f"functional run: {world} ranks share {ndev} GPU(s), backend {os.environ.get('PTTS_DIST_BACKEND', 'nccl')}; not a scaling measurement"
         if not args.no_extras:
             out["roofline"] = measure_decode_roofline(model, args.bs, device)
             out["ttft_p50_ms"] = round(measure_ttft(model, args.bs, device), 2)
         else:
             out["roofline"] = None
-    if rank == 0 and world == 1 and not args.no_extras and args.bs != 32:
+    if rank == 0 and world == 1 and not args.no_extras and args.bs != 32 and args.model == "mini":
         # side measurement of BASELINE configs[2] (bs=32, same model): one warm-up + one timed generate()
         try:
             d32, p32 = synthetic_batch(32, 0, device)
@@ -299,9 +374,15 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out["bs32"] = {"value": round(32 * AUDIO_S / dt, 2), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1),
-                           "ttft_p50_ms": round(measure_ttft(model, 32, device, reps=7), 2)}
+                           "ttft_p50_ms": round(measure_ttft(model, 32, device, reps=7), 2),
+                           "roofline": measure_decode_roofline(model, 32, device)}
         except Exception as e:  # side measurement must never break the contract line
             out["bs32"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_extras and not args.sample and args.model == "mini":
+        try:  # the reference's default generation mode (do_sample=True, init_model_600M.py:57-63): step time beside greedy
+            out["sampling"] = measure_sampling_step(model, args.bs, device)
+        except Exception as e:
+            out["sampling"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -455,11 +455,29 @@ def sample_loop(model: DecoderOracle, enc: torch.Tensor, enc_mask: Optional[torc
     return tr
 
 
+def teacher_forced_logits(model: DecoderOracle, enc: torch.Tensor, enc_mask: Optional[torch.Tensor], prompt: Optional[torch.Tensor],
+                          prompt_mask: Optional[torch.Tensor], seq: torch.Tensor, max_length: int, n_pass: Optional[int] = None) -> List[torch.Tensor]:
+    """Raw fp32 logits [B·K, V] of passes 0..n_pass-1 when the model is fed the GIVEN raw ids ``seq`` [B·K, >= n_pass] (delay
+    pattern applied as in the loop, :2909): lets a test judge every choice of another implementation against this model's own
+    scores at the same history, independently of earlier near-tie flips."""
+    spec = model.spec
+    K = spec.num_codebooks
+    model.reset()
+    _, pattern = build_delay_pattern_mask(seq[:, :1], spec.bos_token_id, spec.pad_token_id, max_length, K)
+    n_pass = seq.shape[1] - 1 if n_pass is None else n_pass
+    outs: List[torch.Tensor] = []
+    for s in range(n_pass):
+        fed = apply_delay_pattern_mask(seq[:, : s + 1], pattern)
+        logits = model.forward(fed, enc, enc_mask, prompt, prompt_mask) if s == 0 else model.forward(fed[:, -1:])
+        outs.append(logits[:, -1, :].float())
+    return outs
+
+
 def undelay(seq: torch.Tensor, spec: DecoderSpec, max_length: int, decoder_input_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """generate() post-processing :3585-3597 → codes [B, K, Lout-K] (may still contain ids >= codebook_size). With a voice
     prompt (``decoder_input_ids``) the pattern applied to the raw ids is the one built over the prefix (:3523-3530, :3586);
-    the un-delay mask is the BOS/PAD triangle pair (the reference rebuilds it from already-delayed ids, :3589-3594, which
-    misaligns codebooks k >= 1 — not reproduced)."""
+    the un-delay keep-mask is the BOS/PAD triangle pair of the BOS column (identical to the reference's mask built from the
+    un-delayed `input_ids`, :3589-3596: audio codes are never BOS/PAD)."""
     K = spec.num_codebooks
     bos, pad = spec.bos_token_id, spec.pad_token_id
     bsz = seq.shape[0] // K

@@ -30,6 +30,22 @@ int ptts_fail(int code, const char* fmt, ...);
     if (_r != PTTS_OK) return _r; \
   } while (0)
 
+// Every C-ABI entry point runs on the engine's device and restores the caller's current device on return (the engine
+// may live on cuda:N while torch's current device is another one).
+struct PttsDeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit PttsDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = prev == dev || hipSetDevice(dev) == hipSuccess;
+    if (prev == dev) prev = -1;  // nothing to restore
+  }
+  ~PttsDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define PTTS_DEVICE(dev)            \
+  PttsDeviceGuard _ptts_dg(dev);    \
+  if (!_ptts_dg.ok) return ptts_fail(PTTS_E_HIP, "hipSetDevice(%d) failed (%s:%d)", (int)(dev), __FILE__, __LINE__)
+
 // ---- bf16 <-> f32 (round-to-nearest-even, identical to torch's .to(bfloat16)) -------------------------
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   uint32_t u;
@@ -43,8 +59,12 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// two fp32 -> packed bf16 pair with ONE v_cvt_pk_bf16_f32 (gfx950; round-to-nearest-even like f32_to_bf16 above)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // element traits of the engine dtype

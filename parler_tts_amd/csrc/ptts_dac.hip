@@ -421,7 +421,7 @@ struct ptts_dac {
 
 extern "C" void ptts_dac_destroy(ptts_dac* d) {
   if (!d) return;
-  hipSetDevice(d->cfg.device);
+  PttsDeviceGuard _dg(d->cfg.device);
   hipDeviceSynchronize();
   for (void* p : d->allocs) hipFree(p);
   if (d->own_stream) hipStreamDestroy(d->own_stream);
@@ -443,7 +443,7 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
                "bf16-operand mode needs latent_dim and every decoder width to be multiples of 32");
   PTTS_CHECK(c.max_batch >= 1 && c.max_frames >= 1, PTTS_E_INVALID, "bad capacities");
   for (int i = 0; i < c.num_rates; ++i) PTTS_CHECK(c.rates[i] >= 2 && c.rates[i] <= 8 && c.rates[i] % 2 == 0, PTTS_E_UNSUPPORTED, "decoder rate %d unsupported (need an even stride in [2, 8])", c.rates[i]);
-  PTTS_HIP(hipSetDevice(c.device));
+  PTTS_DEVICE(c.device);
   ptts_dac* d = new ptts_dac();
   d->cfg = c;
   int rc = PTTS_OK;
@@ -567,7 +567,7 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
 
 extern "C" int ptts_dac_load_weight(ptts_dac* d, const char* name_c, const float* dev_ptr, const int64_t* shape, int32_t ndim, void* stream) {
   PTTS_CHECK(d && name_c && dev_ptr && shape, PTTS_E_INVALID, "null argument");
-  PTTS_HIP(hipSetDevice(d->cfg.device));
+  PTTS_DEVICE(d->cfg.device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = legacy default stream
   const ptts_dac_config& c = d->cfg;
   const std::string name(name_c);
@@ -713,7 +713,7 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
   const ptts_dac_config& c = d->cfg;
   PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds dac max_batch %d", B, c.max_batch);
   PTTS_CHECK(T >= 1 && T <= c.max_frames, PTTS_E_CAPACITY, "frames %d exceed dac max_frames %d", T, c.max_frames);
-  PTTS_HIP(hipSetDevice(c.device));
+  PTTS_DEVICE(c.device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);  // NULL = legacy default stream
   if (!d->table_ready) {
     for (int i = 0; i < c.num_codebooks; ++i) {
@@ -763,7 +763,7 @@ extern "C" int ptts_dac_encode(ptts_dac* d, const float* wave_dev, int64_t* code
   const int T = L / d->hop;
   PTTS_CHECK(T <= c.max_frames, PTTS_E_CAPACITY, "frames %d exceed dac max_frames %d", T, c.max_frames);
   const int nq = n_quantizers <= 0 || n_quantizers > c.num_codebooks ? c.num_codebooks : n_quantizers;
-  PTTS_HIP(hipSetDevice(c.device));
+  PTTS_DEVICE(c.device);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!d->vq_ready) {  // contiguous [K][...] copies for the search kernel + the normalised codebooks
     for (int i = 0; i < c.num_codebooks; ++i) {

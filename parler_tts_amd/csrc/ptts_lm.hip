@@ -9,6 +9,7 @@
 
 #include "ptts_common.h"
 #include "ptts_lm_kernels.h"
+#include "ptts_gemv_kernels.h"
 
 thread_local std::string g_ptts_err;
 int ptts_fail(int code, const char* fmt, ...) {
@@ -29,6 +30,8 @@ struct LayerW {
   void *qkv = nullptr, *o = nullptr, *cq = nullptr, *ckv = nullptr, *co = nullptr, *fc1 = nullptr, *fc2 = nullptr;
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
   void *k_self = nullptr, *v_self = nullptr, *k_cross = nullptr, *v_cross = nullptr;
+  // row-major [N][K] copies in the engine dtype for the single-utterance GEMV step (ptts_gemv_kernels.h); null = path off
+  void *qkv_rm = nullptr, *o_rm = nullptr, *cq_rm = nullptr, *co_rm = nullptr, *fc1_rm = nullptr, *fc2_rm = nullptr;
 };
 
 }  // namespace
@@ -45,6 +48,8 @@ struct ptts_engine {
   float *rope_cos = nullptr, *rope_sin = nullptr;
   float *lnf_g = nullptr, *lnf_b = nullptr;
   void* heads = nullptr;  // [K*V][H] packed
+  void* heads_rm = nullptr;  // [K*V][H] row-major (GEMV step)
+  bool use_gemv = false;     // M == 1 decode step on the row-per-wave GEMV kernels
   std::set<std::string> loaded, required;
   // scratch
   float *h = nullptr, *qkv = nullptr, *qc = nullptr, *part = nullptr, *stats = nullptr, *ffn = nullptr, *logits = nullptr;
@@ -56,6 +61,7 @@ struct ptts_engine {
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
+  int cross_waves = 4; // waves per cross-attention workgroup on the GEMV step: one 8-deep batch of row groups per wave covers max_enc
   // state
   long long* ids = nullptr;
   int ids_ld = 0;
@@ -202,7 +208,9 @@ int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of 
 template <typename WT>
 int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
   const dim3 grid(a.S, a.nheads, B * a.Q);
-  if (waves == 8) hipLaunchKernelGGL((attn_kernel<WT, 8>), grid, dim3(512), 0, st, a);
+  if (waves == 1) hipLaunchKernelGGL((attn_kernel<WT, 1>), grid, dim3(64), 0, st, a);
+  else if (waves == 2) hipLaunchKernelGGL((attn_kernel<WT, 2>), grid, dim3(128), 0, st, a);
+  else if (waves == 8) hipLaunchKernelGGL((attn_kernel<WT, 8>), grid, dim3(512), 0, st, a);
   else if (waves == 16) hipLaunchKernelGGL((attn_kernel<WT, 16>), grid, dim3(1024), 0, st, a);
   else hipLaunchKernelGGL((attn_kernel<WT, 4>), grid, dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
@@ -215,6 +223,75 @@ int launch_prep(GemmArgs a, void* dst, hipStream_t st) {
   a.invK = 1.0f / (float)a.K;
   hipLaunchKernelGGL((rows_prep_kernel<WT, PRO>), dim3((a.M + 3) / 4), dim3(256), 0, st, a, reinterpret_cast<WT*>(dst));
   return PTTS_OK;
+}
+
+// ---- single-utterance GEMV step (ptts_gemv_kernels.h) -------------------------------------------------------
+// rows per wave: enough that N / R waves is ~1024 (4 per CU), bounded by the loads a wave keeps in flight (R * NCH <= 40)
+inline bool gemv_nch_ok(int nch) { return nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8 || nch == 12 || nch == 16 || nch == 24; }
+inline bool gemv_k_ok(int K, size_t es) { return ((size_t)K * es) % 1024 == 0 && gemv_nch_ok((int)((size_t)K * es / 1024)); }
+inline int gemv_pick_rows(int N, int nch, int rcap) {
+  static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
+  const int want = (N + 1023) / 1024;
+  const int maxr = std::min(rcap, std::max(1, 40 / nch));
+  int r = 1;
+  for (int s : sup)
+    if (s <= maxr) { r = s; if (s >= want) break; }
+  return r;
+}
+
+template <typename WT, int PRO, int EPI, int S, int RCAP, int NCH, int R>
+int gemv_launch_inst(const GemvArgs& a, hipStream_t st) {
+  if constexpr (R * NCH <= 40 && R <= RCAP && (PRO == GV_COPY || NCH * Elem<WT>::EPL <= 32)) {
+    const int waves = (a.N + R - 1) / R;
+    const dim3 grid((waves + 3) / 4), block(PRO == GV_COPY ? 256 : 320);
+    const size_t sh = PRO == GV_COPY ? 0 : (size_t)a.K * sizeof(WT);
+    hipLaunchKernelGGL((gemv_kernel<WT, NCH, R, PRO, EPI, S>), grid, block, sh, st, a);
+    return PTTS_OK;
+  } else {
+    return ptts_fail(PTTS_E_UNSUPPORTED, "gemv: no instance for %d chunks x %d rows", NCH, R);
+  }
+}
+template <typename WT, int PRO, int EPI, int S, int RCAP, int NCH>
+int gemv_launch_nch(const GemvArgs& a, hipStream_t st) {
+  switch (gemv_pick_rows(a.N, NCH, RCAP)) {
+    case 1: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 1>(a, st);
+    case 2: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 2>(a, st);
+    case 3: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 3>(a, st);
+    case 4: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 4>(a, st);
+    case 5: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 5>(a, st);
+    case 6: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 6>(a, st);
+    case 8: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 8>(a, st);
+    default: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 10>(a, st);
+  }
+}
+// RCAP bounds the rows per wave that get instantiated for this (prologue, epilogue) pair
+template <typename WT, int PRO, int EPI, int S, int RCAP>
+int gemv_launch(GemvArgs a, hipStream_t st) {
+  a.invK = 1.0f / (float)a.K;
+  int rc;
+  switch ((int)((size_t)a.K * sizeof(WT) / 1024)) {
+    case 1: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 1>(a, st); break;
+    case 2: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 2>(a, st); break;
+    case 3: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 3>(a, st); break;
+    case 4: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 4>(a, st); break;
+    case 6: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 6>(a, st); break;
+    case 8: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 8>(a, st); break;
+    case 12: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 12>(a, st); break;
+    case 16: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 16>(a, st); break;
+    case 24: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 24>(a, st); break;
+    default: return ptts_fail(PTTS_E_UNSUPPORTED, "gemv: K=%d unsupported", a.K);
+  }
+  PTTS_TRY(rc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemv launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+template <typename WT>
+int gemv_attn_out(GemvArgs a, int S, hipStream_t st) {  // split-KV combine + out_proj + residual
+  if (S == 2) return gemv_launch<WT, GV_ATTN, GV_RESID, 2, 2>(a, st);
+  if (S == 4) return gemv_launch<WT, GV_ATTN, GV_RESID, 4, 2>(a, st);
+  if (S == 8) return gemv_launch<WT, GV_ATTN, GV_RESID, 8, 2>(a, st);
+  return ptts_fail(PTTS_E_UNSUPPORTED, "gemv: %d KV splits", S);
 }
 
 // LN -> GEMM and split-KV-combine -> GEMM: fused prologue at M <= 8 rows, prep kernel + copy staging above (the
@@ -259,6 +336,70 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     ea.H = H; ea.K = c.num_codebooks; ea.V1 = c.vocab_size + 1; ea.bos = c.bos_token_id; ea.pad = c.pad_token_id;
     ea.prefill = prefill ? 1 : 0;
     hipLaunchKernelGGL((embed_kernel<WT>), dim3(Q, B), dim3(256), 0, st, ea);
+  }
+  if (e->use_gemv && !prefill && M == 1) {
+    // single utterance: 8 row-per-wave GEMV / attention nodes per layer, every weight matrix spread over all CUs
+    const float* rc = c.rope ? e->rope_cos : nullptr;
+    const float* rs = c.rope ? e->rope_sin : nullptr;
+    for (int l = 0; l < c.num_layers; ++l) {
+      const LayerW& w = e->L[l];
+      {  // LN1 + fused QKV projection (:1020-1021, :848-850)
+        GemvArgs g = {};
+        g.W = w.qkv_rm; g.x = e->h; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.out = e->qkv; g.N = QKV; g.K = H;
+        PTTS_TRY((gemv_launch<WT, GV_LN, GV_STORE, 1, 10>(g, st)));
+      }
+      {  // causal self-attention over the KV arena, fused RoPE + append
+        AttnArgs a = {};
+        a.q = e->qkv; a.q_ld = QKV; a.knew = e->qkv + H; a.vnew = e->qkv + H + Hkv; a.kv_ld = QKV;
+        a.kv_heads = nkv; a.n_rep = nh / nkv;
+        a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.cur_len = e->cur_len; a.dims = e->dims;
+        a.mask = e->prompt_mask; a.mask_ld = e->max_prompt; a.cos = rc; a.sin = rs;
+        a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = 1; a.nheads = nh; a.H = H; a.cross = 0;
+        a.fused_append = 1; a.scale = scale;
+        a.direct_out = e->S_self == 1 ? e->xw : nullptr;
+        PTTS_TRY((launch_attn<WT>(a, 1, st, e->attn_waves)));
+      }
+      {  // [combine splits] + out_proj + residual (:1034)
+        GemvArgs g = {};
+        g.W = w.o_rm; g.out = e->h; g.N = H; g.K = H;
+        if (e->S_self == 1) { g.xw = e->xw; PTTS_TRY((gemv_launch<WT, GV_COPY, GV_RESID, 1, 2>(g, st))); }
+        else { g.part = e->part; g.stats = e->stats; g.nheads = nh; PTTS_TRY((gemv_attn_out<WT>(g, e->S_self, st))); }
+      }
+      {  // LN2 + cross q projection (:1040, :855)
+        GemvArgs g = {};
+        g.W = w.cq_rm; g.x = e->h; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.out = e->qc; g.N = H; g.K = H;
+        PTTS_TRY((gemv_launch<WT, GV_LN, GV_STORE, 1, 10>(g, st)));
+      }
+      {  // cross-attention against the static description K/V: one workgroup per head, softmax finished in the kernel
+        AttnArgs a = {};
+        a.q = e->qc; a.q_ld = H; a.kcache = w.k_cross; a.vcache = w.v_cross; a.cap = c.max_enc;
+        a.cur_len = e->cur_len; a.dims = e->dims; a.mask = e->enc_mask; a.mask_ld = c.max_enc;
+        a.cos = rc; a.sin = rs;  // quirk: q rotated, keys not (:858 vs :880)
+        a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = 1; a.nheads = nh; a.H = H; a.cross = 1;
+        a.kv_heads = nkc; a.n_rep = nh / nkc; a.fused_append = 0; a.scale = scale; a.direct_out = e->xw;
+        PTTS_TRY((launch_attn<WT>(a, 1, st, e->cross_waves)));
+      }
+      {  // cross out_proj + residual (:1052)
+        GemvArgs g = {};
+        g.W = w.co_rm; g.xw = e->xw; g.out = e->h; g.N = H; g.K = H;
+        PTTS_TRY((gemv_launch<WT, GV_COPY, GV_RESID, 1, 2>(g, st)));
+      }
+      {  // LN3 + fc1 + GELU (engine dtype), fc2 + residual (:1059-1064)
+        GemvArgs g = {};
+        g.W = w.fc1_rm; g.x = e->h; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.out = reinterpret_cast<float*>(e->xw2); g.N = F; g.K = H;
+        PTTS_TRY((gemv_launch<WT, GV_LN, GV_GELU_WT, 1, 10>(g, st)));
+        GemvArgs g2 = {};
+        g2.W = w.fc2_rm; g2.xw = e->xw2; g2.out = e->h; g2.N = H; g2.K = F;
+        PTTS_TRY((gemv_launch<WT, GV_COPY, GV_RESID, 1, 2>(g2, st)));
+      }
+    }
+    GemvArgs g = {};  // final LayerNorm + all K LM heads (:1632, :1917-1960)
+    g.W = e->heads_rm; g.x = e->h; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.out = e->logits;
+    g.N = c.num_codebooks * c.vocab_size; g.K = H;
+    PTTS_TRY((gemv_launch<WT, GV_LN, GV_STORE, 1, 10>(g, st)));
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "forward launch failed: %s", hipGetErrorString(err));
+    return PTTS_OK;
   }
   bool fc2_pending = false;
   for (int l = 0; l < c.num_layers; ++l) {
@@ -382,8 +523,8 @@ int launch_tail(ptts_engine* e, hipStream_t st, bool embed_next) {
   t.logits = e->logits; t.ids = e->ids; t.ids_ld = e->ids_ld; t.cur_len = e->cur_len; t.unfinished = e->unfinished;
   t.has_eos = e->has_eos; t.first_unf = e->first_unf; t.gen = e->gen; t.sort_buf = e->sort_buf;
   t.B = e->B; t.K = e->cfg.num_codebooks; t.V = e->cfg.vocab_size; t.eos = e->cfg.eos_token_id; t.pad = e->cfg.pad_token_id;
-  // greedy: one wave per codebook row; the sampling path sorts block-wide
-  const int nw = e->gp.do_sample ? 4 : std::min(std::max(e->cfg.num_codebooks, 4), 16);
+  // one wave per codebook row (greedy arg-max or the sort-free sampler), at least 4 waves for the embedding of the next column
+  const int nw = std::min(std::max(e->cfg.num_codebooks, 4), 16);
   hipLaunchKernelGGL(tail_kernel, dim3(e->B), dim3(nw * 64), 0, st, t);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "tail launch failed: %s", hipGetErrorString(err));
@@ -425,6 +566,13 @@ int pack_dispatch(ptts_engine* e, void* dst, const void* src, int src_dtype, int
   return e->cfg.dtype == PTTS_BF16 ? pack_into<bf16_t>(dst, src, src_dtype, N, K, row0, st) : pack_into<float>(dst, src, src_dtype, N, K, row0, st);
 }
 
+// row-major copy (rows [row0, row0 + N) of a [*, K] matrix) in the engine dtype for the GEMV step
+int rowmajor_dispatch(ptts_engine* e, void* dst, const void* src, int src_dtype, int N, int K, int row0, hipStream_t st) {
+  const size_t off = (size_t)row0 * K, n = (size_t)N * K;
+  if (e->cfg.dtype == PTTS_BF16) return convert_into<bf16_t>(reinterpret_cast<bf16_t*>(dst) + off, src, src_dtype, n, st);
+  return convert_into<float>(reinterpret_cast<float*>(dst) + off, src, src_dtype, n, st);
+}
+
 // NULL is the legacy default stream (what torch.cuda.current_stream() is on ROCm unless the caller switched): pass through.
 hipStream_t pick_stream(ptts_engine*, void* s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -444,7 +592,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   PTTS_CHECK(c.max_batch >= 1 && c.max_ctx >= 2 && c.max_enc >= 1 && c.max_prompt >= 1 && c.max_prompt <= c.max_ctx, PTTS_E_INVALID, "bad capacities");
   const int nkv_ = c.num_kv_heads > 0 ? c.num_kv_heads : c.num_heads, nkc_ = c.num_cross_kv_heads > 0 ? c.num_cross_kv_heads : nkv_;
   PTTS_CHECK(c.num_heads % nkv_ == 0 && c.num_heads % nkc_ == 0, PTTS_E_INVALID, "num_heads %d not divisible by the K/V head counts %d / %d", c.num_heads, nkv_, nkc_);
-  PTTS_HIP(hipSetDevice(c.device));
+  PTTS_DEVICE(c.device);
   ptts_engine* e = new ptts_engine();
   e->cfg = c;
   e->nkv = nkv_; e->nkc = nkc_;
@@ -456,6 +604,8 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size, nh = c.num_heads;
   const size_t es = e->esize;
   e->L.resize(c.num_layers);
+  // single-utterance decode step on the row-per-wave GEMV kernels: shapes whose rows are whole 1 KiB chunks
+  e->use_gemv = gemv_k_ok(H, es) && gemv_k_ok(F, es) && H <= 2048 && !(getenv("PTTS_NO_GEMV") && atoi(getenv("PTTS_NO_GEMV")));
 #define A(expr) if ((rc = (expr)) != PTTS_OK) return fail(rc)
   for (int l = 0; l < c.num_layers; ++l) {
     LayerW& w = e->L[l];
@@ -466,6 +616,11 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->alloc_bytes(&w.co, (size_t)H * H * es));
     A(e->alloc_bytes(&w.fc1, (size_t)F * H * es));
     A(e->alloc_bytes(&w.fc2, (size_t)F * H * es));
+    if (e->use_gemv) {
+      A(e->alloc_bytes(&w.qkv_rm, (size_t)(H + 2 * e->nkv * 64) * H * es)); A(e->alloc_bytes(&w.o_rm, (size_t)H * H * es));
+      A(e->alloc_bytes(&w.cq_rm, (size_t)H * H * es)); A(e->alloc_bytes(&w.co_rm, (size_t)H * H * es));
+      A(e->alloc_bytes(&w.fc1_rm, (size_t)F * H * es)); A(e->alloc_bytes(&w.fc2_rm, (size_t)F * H * es));
+    }
     A(e->alloc(&w.ln1_g, H)); A(e->alloc(&w.ln1_b, H)); A(e->alloc(&w.ln2_g, H)); A(e->alloc(&w.ln2_b, H));
     A(e->alloc(&w.ln3_g, H)); A(e->alloc(&w.ln3_b, H));
     const size_t kvs = (size_t)c.max_batch * e->nkv * c.max_ctx * 64 * es, kvc = (size_t)c.max_batch * e->nkc * c.max_enc * 64 * es;
@@ -483,6 +638,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   }
   A(e->alloc_bytes(&e->embed, (size_t)K * (V + 1) * H * es));
   A(e->alloc_bytes(&e->heads, (size_t)K * V * H * es));
+  if (e->use_gemv) A(e->alloc_bytes(&e->heads_rm, (size_t)K * V * H * es));
   A(e->alloc(&e->lnf_g, H)); A(e->alloc(&e->lnf_b, H));
   e->required.insert("model.decoder.layer_norm.weight");
   e->required.insert("model.decoder.layer_norm.bias");
@@ -492,7 +648,9 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
     snprintf(nm, sizeof nm, "lm_heads.%d.weight", k); e->required.insert(nm);
   }
   if (c.rope) {
-    A(e->alloc(&e->rope_cos, (size_t)c.max_positions * 64)); A(e->alloc(&e->rope_sin, (size_t)c.max_positions * 64));
+    // RoPE is computed for any position in the reference (:373-406): tables cover the whole KV capacity, not max_positions
+    const size_t rope_rows = (size_t)std::max(c.max_positions, c.max_ctx);
+    A(e->alloc(&e->rope_cos, rope_rows * 64)); A(e->alloc(&e->rope_sin, rope_rows * 64));
     e->required.insert("rope_cos"); e->required.insert("rope_sin");
   } else {
     A(e->alloc(&e->pos_table, (size_t)c.max_positions * H));
@@ -508,6 +666,13 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
     e->S_cross = 1;
     if (const char* ev = getenv("PTTS_ATTN_SPLITS")) e->S_self = std::max(1, std::min(8, atoi(ev)));  // tuning knobs (tools/)
     if (const char* ev = getenv("PTTS_ATTN_WAVES")) e->attn_waves = atoi(ev) == 16 ? 16 : (atoi(ev) == 8 ? 8 : 4);
+    {
+      const int rows_per_wave = (c.dtype == PTTS_BF16 ? 8 : 4) * 8;  // RPI row groups x 8 loads in flight
+      const int need = (c.max_enc + rows_per_wave - 1) / rows_per_wave;
+      e->cross_waves = need <= 1 ? 1 : (need <= 2 ? 2 : 4);
+      if (const char* ev = getenv("PTTS_CROSS_WAVES")) e->cross_waves = atoi(ev) == 1 ? 1 : (atoi(ev) == 2 ? 2 : 4);
+    }
+    if (e->use_gemv) while (e->S_self & (e->S_self - 1)) --e->S_self;  // the GEMV combine prologue is instantiated for 2 / 4 / 8 splits
   }
   const size_t rows = (size_t)c.max_batch * e->max_prompt;
   const size_t enc_rows = (size_t)c.max_batch * c.max_enc;
@@ -540,7 +705,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
 
 extern "C" void ptts_engine_destroy(ptts_engine* e) {
   if (!e) return;
-  hipSetDevice(e->cfg.device);
+  PttsDeviceGuard _dg(e->cfg.device);
   hipDeviceSynchronize();
   for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
   for (void* p : e->allocs) hipFree(p);
@@ -553,7 +718,7 @@ extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* 
                                 int32_t ndim, void* stream) {
   PTTS_CHECK(e && name_c && dev_ptr && shape, PTTS_E_INVALID, "null argument");
   PTTS_CHECK(src_dtype == PTTS_F32 || src_dtype == PTTS_BF16, PTTS_E_INVALID, "src_dtype must be f32 or bf16");
-  PTTS_HIP(hipSetDevice(e->cfg.device));
+  PTTS_DEVICE(e->cfg.device);
   hipStream_t st = pick_stream(e, stream);
   const ptts_config& c = e->cfg;
   const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size;
@@ -569,16 +734,17 @@ extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* 
     PTTS_CHECK(l >= 0 && l < c.num_layers, PTTS_E_INVALID, "%s: layer index out of range", name_c);
     LayerW& w = e->L[l];
     const std::string t(tail);
-    struct { const char* n; void* dst; int N, Kd, row0; } mats[] = {
-        {"self_attn.q_proj.weight", w.qkv, H, H, 0},       {"self_attn.k_proj.weight", w.qkv, e->nkv * 64, H, H},
-        {"self_attn.v_proj.weight", w.qkv, e->nkv * 64, H, H + e->nkv * 64}, {"self_attn.out_proj.weight", w.o, H, H, 0},
-        {"encoder_attn.q_proj.weight", w.cq, H, H, 0},     {"encoder_attn.k_proj.weight", w.ckv, e->nkc * 64, H, 0},
-        {"encoder_attn.v_proj.weight", w.ckv, e->nkc * 64, H, e->nkc * 64}, {"encoder_attn.out_proj.weight", w.co, H, H, 0},
-        {"fc1.weight", w.fc1, F, H, 0},                    {"fc2.weight", w.fc2, H, F, 0}};
+    struct { const char* n; void* dst; void* rm; int N, Kd, row0; } mats[] = {
+        {"self_attn.q_proj.weight", w.qkv, w.qkv_rm, H, H, 0},       {"self_attn.k_proj.weight", w.qkv, w.qkv_rm, e->nkv * 64, H, H},
+        {"self_attn.v_proj.weight", w.qkv, w.qkv_rm, e->nkv * 64, H, H + e->nkv * 64}, {"self_attn.out_proj.weight", w.o, w.o_rm, H, H, 0},
+        {"encoder_attn.q_proj.weight", w.cq, w.cq_rm, H, H, 0},     {"encoder_attn.k_proj.weight", w.ckv, nullptr, e->nkc * 64, H, 0},
+        {"encoder_attn.v_proj.weight", w.ckv, nullptr, e->nkc * 64, H, e->nkc * 64}, {"encoder_attn.out_proj.weight", w.co, w.co_rm, H, H, 0},
+        {"fc1.weight", w.fc1, w.fc1_rm, F, H, 0},                    {"fc2.weight", w.fc2, w.fc2_rm, H, F, 0}};
     for (auto& m : mats)
       if (t == m.n) {
         PTTS_TRY(want(m.N, m.Kd));
         PTTS_TRY(pack_dispatch(e, m.dst, dev_ptr, src_dtype, m.N, m.Kd, m.row0, st));
+        if (m.rm) PTTS_TRY(rowmajor_dispatch(e, m.rm, dev_ptr, src_dtype, m.N, m.Kd, m.row0, st));
         e->loaded.insert(name);
         return PTTS_OK;
       }
@@ -608,12 +774,14 @@ extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* 
     PTTS_CHECK(k >= 0 && k < K, PTTS_E_INVALID, "%s: codebook index out of range", name_c);
     PTTS_TRY(want(V, H));
     PTTS_TRY(pack_dispatch(e, e->heads, dev_ptr, src_dtype, V, H, k * V, st));
+    if (e->heads_rm) PTTS_TRY(rowmajor_dispatch(e, e->heads_rm, dev_ptr, src_dtype, V, H, k * V, st));
     e->loaded.insert(name);
     return PTTS_OK;
   }
   if (name == "lm_heads.weight") {  // use_fused_lm_heads :1834-1840
     PTTS_TRY(want((int64_t)K * V, H));
     PTTS_TRY(pack_dispatch(e, e->heads, dev_ptr, src_dtype, K * V, H, 0, st));
+    if (e->heads_rm) PTTS_TRY(rowmajor_dispatch(e, e->heads_rm, dev_ptr, src_dtype, K * V, H, 0, st));
     for (int i = 0; i < K; ++i) { char nm[64]; snprintf(nm, sizeof nm, "lm_heads.%d.weight", i); e->loaded.insert(nm); }
     return PTTS_OK;
   }
@@ -632,7 +800,8 @@ extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* 
   }
   if (name == "rope_cos" || name == "rope_sin") {  // fp32 tables as ParlerTTSRotaryEmbedding.forward computes them (:373-406)
     PTTS_CHECK(c.rope, PTTS_E_INVALID, "%s given but rope_embeddings is off", name_c);
-    PTTS_CHECK(ndim == 2 && shape[1] == 64 && shape[0] >= 1 && shape[0] <= c.max_positions, PTTS_E_INVALID, "%s: expected [<=%d, 64]", name_c, c.max_positions);
+    const int rope_rows = std::max(c.max_positions, c.max_ctx);
+    PTTS_CHECK(ndim == 2 && shape[1] == 64 && shape[0] >= c.max_ctx && shape[0] <= rope_rows, PTTS_E_INVALID, "%s: expected [%d..%d, 64] (one row per KV position)", name_c, c.max_ctx, rope_rows);
     PTTS_TRY(convert_into<float>(name == "rope_cos" ? e->rope_cos : e->rope_sin, dev_ptr, src_dtype, (size_t)shape[0] * 64, st));
     e->loaded.insert(name);
     return PTTS_OK;
@@ -667,7 +836,7 @@ extern "C" int ptts_set_audio_prefix(ptts_engine* e, const int64_t* codes_dev, i
   PTTS_CHECK(T >= 0 && (T == 0 || codes_dev), PTTS_E_INVALID, "bad audio prefix");
   PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds engine max_batch %d", B, c.max_batch);
   PTTS_CHECK(T + 2 <= c.max_ctx, PTTS_E_CAPACITY, "voice prompt of %d frames exceeds engine max_ctx %d", T, c.max_ctx);
-  PTTS_HIP(hipSetDevice(c.device));
+  PTTS_DEVICE(c.device);
   if (T > 0)
     PTTS_HIP(hipMemcpy2DAsync(e->prefix, (size_t)c.max_ctx * 8, codes_dev, (size_t)T * 8, (size_t)T * 8, (size_t)B * c.num_codebooks,
                               hipMemcpyDeviceToDevice, pick_stream(e, stream)));
@@ -687,7 +856,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   PTTS_CHECK(e->pending_T + 2 <= e->gp.max_length, PTTS_E_INVALID, "voice prompt of %d frames leaves no room below max_length %d", e->pending_T, e->gp.max_length);
   PTTS_CHECK(P + e->gp.max_length <= c.max_ctx, PTTS_E_CAPACITY, "P + max_length = %d exceeds engine max_ctx %d", P + e->gp.max_length, c.max_ctx);
   PTTS_CHECK(P + e->gp.max_length <= c.max_positions || c.rope, PTTS_E_CAPACITY, "P + max_length = %d exceeds max_position_embeddings %d", P + e->gp.max_length, c.max_positions);
-  PTTS_HIP(hipSetDevice(c.device));
+  PTTS_DEVICE(c.device);
   hipStream_t st = pick_stream(e, stream);
   const int H = c.hidden_size, K = c.num_codebooks;
   e->B = B; e->N = N; e->P = P;
@@ -753,7 +922,7 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
   PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
   PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_decode_steps called before ptts_prefill");
   PTTS_CHECK(n_steps >= 0, PTTS_E_INVALID, "n_steps < 0");
-  PTTS_HIP(hipSetDevice(e->cfg.device));
+  PTTS_DEVICE(e->cfg.device);
   hipStream_t st = pick_stream(e, stream);
   hipGraphExec_t ex = nullptr;
   PTTS_TRY(get_graph(e, &ex));
@@ -770,7 +939,7 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
 extern "C" int ptts_state(ptts_engine* e, int32_t* cur_len, int32_t* all_finished, void* stream) {
   PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
   PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_state called before ptts_prefill");
-  PTTS_HIP(hipSetDevice(e->cfg.device));
+  PTTS_DEVICE(e->cfg.device);
   hipStream_t st = pick_stream(e, stream);
   const int n = e->B * e->cfg.num_codebooks;
   int* hp = e->host_pinned;
@@ -794,7 +963,7 @@ extern "C" int ptts_ids(ptts_engine* e, int64_t** ids_dev, int32_t* row_stride) 
 extern "C" int ptts_step_forward(ptts_engine* e, void* stream) {
   PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
   PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_step_forward called before ptts_prefill");
-  PTTS_HIP(hipSetDevice(e->cfg.device));
+  PTTS_DEVICE(e->cfg.device);
   return forward_dispatch(e, false, pick_stream(e, stream));
 }
 
@@ -807,7 +976,7 @@ extern "C" int ptts_logits(ptts_engine* e, float** logits_dev) {
 extern "C" int ptts_push_tokens(ptts_engine* e, const int64_t* tokens_dev, const int32_t* finished_dev, void* stream) {
   PTTS_CHECK(e && tokens_dev, PTTS_E_INVALID, "null argument");
   PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_push_tokens called before ptts_prefill");
-  PTTS_HIP(hipSetDevice(e->cfg.device));
+  PTTS_DEVICE(e->cfg.device);
   hipStream_t st = pick_stream(e, stream);
   const int n = e->B * e->cfg.num_codebooks;
   hipLaunchKernelGGL(push_tokens_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const long long*)tokens_dev, finished_dev, e->ids,

@@ -1217,58 +1217,159 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 
 #define PTTS_SORT_N 2048
 
-// block-wide bitonic sort (descending by value, ascending index on ties) of n <= PTTS_SORT_N entries in LDS
-__device__ inline void bitonic_sort_desc(float* val, int* idx, int nthreads, int tid) {
-  for (int k = 2; k <= PTTS_SORT_N; k <<= 1) {
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      for (int i = tid; i < PTTS_SORT_N; i += nthreads) {
-        const int ixj = i ^ jj;
-        if (ixj > i) {
-          const bool up = (i & k) == 0;  // "up" segments sorted descending
-          const float a = val[i], b = val[ixj];
-          const int ia = idx[i], ib = idx[ixj];
-          const bool a_before_b = (a > b) || (a == b && ia < ib);
-          if (up ? !a_before_b : a_before_b) { val[i] = b; val[ixj] = a; idx[i] = ib; idx[ixj] = ia; }
-        }
-      }
-      __syncthreads();
+// ---- sort-free sampling, one wave per codebook row ------------------------------------------------------------------
+// monotone key of a float (larger value <=> larger unsigned key); -inf is the smallest key of any valid entry
+__device__ __forceinline__ unsigned f32_key(float x) {
+  const unsigned b = __float_as_uint(x);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+// TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> multinomial for ONE row held by one wave
+// (lane l owns entries l, l + 64, ...; NV per lane). No sort: both warpers keep a PREFIX of the descending order, i.e. a
+// threshold on the value, found by a 32-step radix search whose predicate is one wave reduction:
+//   top-k: largest key T with count(key >= T) >= k      (keeps ties at the k-th value, as `scores < topk[..., -1]` does)
+//   top-p: smallest key L with sum_{key > L} p < top_p  (sorted ascending, HF removes cumsum <= 1 - top_p: a token stays iff
+//          the mass strictly above it is < top_p; the arg-max always stays)
+// The draw walks the kept entries in lane-major order (any fixed order gives the same distribution; torch.multinomial's
+// own stream cannot be matched, parity is statistical: tests/test_lm_gpu.py chi-square + support checks).
+template <int NV>
+__device__ __forceinline__ int wave_sample_row(const float (&lg)[NV], int V, int lane, const DevGen& g, bool eos_blocked, int eos, float u01) {
+  const int nv = (V + 63) >> 6;
+  float x[NV];
+  unsigned key[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = lane + 64 * i;
+    float xv = -INFINITY;
+    if (i < nv && v < V) {
+      xv = lg[i];
+      xv = (eos_blocked && v == eos) ? -INFINITY : xv / g.temperature;  // processors first (-inf stays -inf), then scores / T
+    }
+    x[i] = xv;
+    key[i] = (i < nv && v < V) ? f32_key(xv) : 0u;  // key 0 < key(-inf): padding never counts
+  }
+  if (g.top_k > 0 && g.top_k < V) {
+    unsigned T = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned cand = T | (1u << bit);
+      float c = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (i < nv) c += key[i] >= cand ? 1.f : 0.f;
+      if (wave_sum(c) >= (float)g.top_k) T = cand;  // counts <= 2048 are exact in fp32
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (i < nv && key[i] < T) x[i] = -INFINITY;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i < nv) mx = fmaxf(mx, x[i]);
+  mx = wave_max(mx);
+  float e[NV], ls = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    e[i] = (i < nv && x[i] != -INFINITY) ? expf(x[i] - mx) : 0.f;
+    ls += e[i];
+  }
+  float tot = wave_sum(ls);
+  if (g.top_p < 1.0f) {
+    const float thr = g.top_p * tot;
+    unsigned L = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned test = L | ((1u << bit) - 1u);
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (i < nv) m += key[i] > test ? e[i] : 0.f;
+      if (!(wave_sum(m) < thr)) L |= 1u << bit;
+    }
+    ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (i < nv && key[i] < L) e[i] = 0.f;
+      ls += e[i];
+    }
+    tot = wave_sum(ls);
+  }
+  // inverse CDF over the kept entries in lane-major order
+  const float target = u01 * tot;
+  float incl = ls;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  const unsigned long long has = __ballot(ls > 0.f);
+  const unsigned long long hit = __ballot(ls > 0.f && incl >= target);
+  const int sel = hit ? (int)__builtin_ctzll(hit) : (has ? 63 - (int)__builtin_clzll(has) : 0);
+  float run = incl - ls;
+  int pick = -1, last = 0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i < nv && e[i] > 0.f) {
+      run += e[i];
+      last = lane + 64 * i;
+      if (pick < 0 && run >= target) pick = last;
     }
   }
+  if (pick < 0) pick = last;
+  return __shfl(pick, sel);
 }
 
 // Embedding of the token column just produced (column t, fed at position P + t) for the next decode step:
 // the delay pattern is applied exactly as embed_kernel / apply_delay_pattern_mask do (modeling:205-276, :1433).
-__device__ __forceinline__ void tail_embed_next(const TailArgs& a, int b, int t, const int* s_tok, int tid) {
-  if (!a.tables) return;
-  const DevDims dd = *a.dims;
-  const int max_length = dd.max_length, P = dd.P;
-  float* out = a.h + (size_t)b * a.H;
+// One thread owns 4 consecutive features; the K table rows (+ the position row) are ONE batch of independent loads
+// (the rolled k loop of round 1 was K sequential cold round trips: most of the 14 us the tail took).
+template <int KB>  // codebooks per batch of loads
+__device__ __forceinline__ void tail_embed_rows(const TailArgs& a, const DevDims& dd, int b, int t, const int* s_tok, int d, float (&acc)[4]) {
   const bf16_t* tb16 = reinterpret_cast<const bf16_t*>(a.tables);
   const float* tb32 = reinterpret_cast<const float*>(a.tables);
-  for (int d = tid; d < a.H; d += blockDim.x) {
-    float acc = 0.f;
-    for (int k = 0; k < a.K; ++k) {
+  for (int k0 = 0; k0 < a.K; k0 += KB) {
+    uint2 r16[KB];
+    float4 r32[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int k = min(k0 + u, a.K - 1);
       int tok = s_tok[k];
-      if (max_length >= 2 * a.K - 1) {
+      if (dd.max_length >= 2 * a.K - 1) {
         if (t <= k) tok = a.bos;
-        else if (t - k >= max_length - a.K + 1) tok = a.pad;
+        else if (t - k >= dd.max_length - a.K + 1) tok = a.pad;
         else if (t - k - 1 < dd.T_prefix) tok = (int)dd.prefix[(size_t)(b * a.K + k) * dd.prefix_ld + (t - k - 1)];  // voice prompt
       }
       const size_t off = ((size_t)k * (a.V + 1) + tok) * a.H + d;
-      acc += a.bf16_tables ? bf16_to_f32(tb16[off]) : tb32[off];
+      if (a.bf16_tables) r16[u] = *reinterpret_cast<const uint2*>(tb16 + off);
+      else r32[u] = *reinterpret_cast<const float4*>(tb32 + off);
     }
-    if (a.pos_table) acc += a.pos_table[(size_t)(P + t) * a.H + d];
-    out[d] = acc;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {  // sum([...]) order :1433
+      if (k0 + u < a.K) {
+        if (a.bf16_tables) {
+          acc[0] += __uint_as_float(r16[u].x << 16); acc[1] += __uint_as_float(r16[u].x & 0xffff0000u);
+          acc[2] += __uint_as_float(r16[u].y << 16); acc[3] += __uint_as_float(r16[u].y & 0xffff0000u);
+        } else {
+          acc[0] += r32[u].x; acc[1] += r32[u].y; acc[2] += r32[u].z; acc[3] += r32[u].w;
+        }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void tail_embed_next(const TailArgs& a, const DevDims& dd, int b, int t, const int* s_tok, int tid) {
+  if (!a.tables) return;
+  float* out = a.h + (size_t)b * a.H;
+  for (int d = tid * 4; d < a.H; d += blockDim.x * 4) {  // H % 4 == 0 (hidden_size % 32 == 0 is checked at create)
+    float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.pos_table) pos = *reinterpret_cast<const float4*>(a.pos_table + (size_t)(dd.P + t) * a.H + d);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.K <= 9) tail_embed_rows<9>(a, dd, b, t, s_tok, d, acc);
+    else tail_embed_rows<16>(a, dd, b, t, s_tok, d, acc);
+    *reinterpret_cast<float4*>(out + d) = make_float4(acc[0] + pos.x, acc[1] + pos.y, acc[2] + pos.z, acc[3] + pos.w);
   }
 }
 
 __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
   __shared__ int s_tok[32];
-  __shared__ float s_val[PTTS_SORT_N];
-  __shared__ int s_idx[PTTS_SORT_N];
-  __shared__ float s_red[8];
-  __shared__ int s_redi[8];
-  __shared__ int s_pick;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // ---- t = 0: every load that does not depend on another load goes in flight together (the step's critical path ends
   // here: lengths / flags / parameters / this wave's logits row are ONE round trip, the embedding rows a second one)
@@ -1282,7 +1383,8 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
     any_local |= (v > 0) | (v <= -(t + 1));
   }
   const int fu0 = a.first_unf[b];
-  const int t_prefix = a.dims->T_prefix;
+  const DevDims dd = *a.dims;  // the embedding of the next column needs P / max_length / the voice-prompt prefix: fetched now, not after the argmax
+  const int t_prefix = dd.T_prefix;
   const int he = lane < a.K ? a.has_eos[b * a.K + lane] : 0;  // every wave: the K EOS flags of this utterance
   constexpr int NV = PTTS_SORT_N / 64;                         // logits per lane (vocab <= PTTS_SORT_N)
   float lg[NV];
@@ -1300,16 +1402,18 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
   if (tid == 0) a.first_unf[b] = fu;
   const bool block_eos_all = (t - 1 - t_prefix) < g.min_new_tokens;  // new tokens = columns after the (1 + T_prefix) given ones
 
-  if (!g.do_sample) {
-    // greedy: one wave per codebook row, no workgroup barriers. torch.argmax semantics: first index on ties.
-    for (int k = w; k < a.K; k += (int)(blockDim.x >> 6)) {
-      const int row = b * a.K + k;
-      if (k != k0) {
-        const float* sc = a.logits + (size_t)row * a.V;
+  // one wave per codebook row, no workgroup barrier until every row has its token. greedy: torch.argmax semantics (first
+  // index on ties); do_sample: the warpers + multinomial on the same wave (wave_sample_row)
+  for (int k = w; k < a.K; k += (int)(blockDim.x >> 6)) {
+    const int row = b * a.K + k;
+    if (k != k0) {
+      const float* sc = a.logits + (size_t)row * a.V;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) lg[i] = (lane + 64 * i < a.V) ? sc[lane + 64 * i] : -INFINITY;
-      }
-      const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
+      for (int i = 0; i < NV; ++i) lg[i] = (lane + 64 * i < a.V) ? sc[lane + 64 * i] : -INFINITY;
+    }
+    const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
+    int widx;
+    if (!g.do_sample) {
       float best = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll
@@ -1321,91 +1425,24 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
       }
       const float wbest = wave_max(best);
       const float cand = (best == wbest) ? (float)bi : 3.0e9f;  // vocabulary indices are exact in fp32
-      const int widx = (int)(-wave_max(-cand));
-      if (lane == 0) {
-        const int unf = k == k0 ? unf0 : (a.unfinished[row] > 0);
-        const int nxt = unf ? widx : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
-        a.ids[(size_t)row * a.ids_ld + t] = nxt;
-        s_tok[k] = nxt;
-        if (nxt == a.eos) a.has_eos[row] = 1;
-        if (unf && ((nxt == a.eos) || (t + 1 >= g.max_length))) a.unfinished[row] = -(t + 1);  // EosTokenCriteria | MaxLengthCriteria
-      }
+      widx = (int)(-wave_max(-cand));
+    } else {
+      const unsigned long long hsh = splitmix64(g.seed ^ splitmix64(((unsigned long long)t << 32) ^ (unsigned long long)row));
+      const float u = (float)((hsh >> 40) + 0.5) * (1.0f / 16777216.0f);  // (0,1)
+      widx = wave_sample_row<NV>(lg, a.V, lane, g, eos_blocked, a.eos, u);
     }
-    __syncthreads();
-    if (tid == 0) a.cur_len[b] = t + 1;
-    tail_embed_next(a, b, t, s_tok, tid);
-    return;
-  }
-
-  for (int k = 0; k < a.K; ++k) {
-    const int row = b * a.K + k;
-    const float* sc = a.logits + (size_t)row * a.V;
-    const bool eos_blocked = block_eos_all || (g.use_eos_gate && k > fu);
-    int tok;
-    {
-      const float invT = 1.0f / g.temperature;
-      for (int v = tid; v < PTTS_SORT_N; v += blockDim.x) {
-        float x = -INFINITY;
-        if (v < a.V) {
-          x = sc[v];
-          if (eos_blocked && v == a.eos) x = -INFINITY;
-          else x *= invT;
-        }
-        s_val[v] = x;
-        s_idx[v] = v;
-      }
-      __syncthreads();
-      bitonic_sort_desc(s_val, s_idx, blockDim.x, tid);
-      if (tid == 0) {
-        // top-k: keep values >= k-th largest (TopKLogitsWarper keeps ties); top-p: keep while exclusive prefix < p
-        int n = a.V;
-        if (g.top_k > 0 && g.top_k < a.V) {
-          const float kth = s_val[g.top_k - 1];
-          n = g.top_k;
-          while (n < a.V && s_val[n] >= kth) ++n;
-        }
-        while (n > 1 && s_val[n - 1] == -INFINITY) --n;
-        const float mx = s_val[0];
-        float tot = 0.f;
-        for (int i = 0; i < n; ++i) tot += expf(s_val[i] - mx);
-        if (g.top_p < 1.0f) {
-          float run = 0.f;
-          int keep = 0;
-          for (int i = 0; i < n; ++i) {
-            if (i > 0 && run / tot >= g.top_p) break;
-            run += expf(s_val[i] - mx);
-            keep = i + 1;
-          }
-          n = keep;
-          tot = run;
-        }
-        const unsigned long long hsh = splitmix64(g.seed ^ splitmix64(((unsigned long long)t << 32) ^ (unsigned long long)row));
-        const float u = (float)((hsh >> 40) + 0.5) * (1.0f / 16777216.0f);  // (0,1)
-        const float target = u * tot;
-        float run = 0.f;
-        int pick = s_idx[n - 1];
-        for (int i = 0; i < n; ++i) {
-          run += expf(s_val[i] - mx);
-          if (run >= target) { pick = s_idx[i]; break; }
-        }
-        s_pick = pick;
-      }
-      __syncthreads();
-      tok = s_pick;
-    }
-    if (tid == 0) {
-      const int unf = a.unfinished[row] > 0;
-      const int nxt = unf ? tok : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
+    if (lane == 0) {
+      const int unf = k == k0 ? unf0 : (a.unfinished[row] > 0);
+      const int nxt = unf ? widx : a.pad;  // next_tokens * unfinished + pad * (1 - unfinished)
       a.ids[(size_t)row * a.ids_ld + t] = nxt;
       s_tok[k] = nxt;
       if (nxt == a.eos) a.has_eos[row] = 1;
-      const bool done = (nxt == a.eos) || (t + 1 >= g.max_length);  // EosTokenCriteria | MaxLengthCriteria
-      if (done && unf) a.unfinished[row] = -(t + 1);
+      if (unf && ((nxt == a.eos) || (t + 1 >= g.max_length))) a.unfinished[row] = -(t + 1);  // EosTokenCriteria | MaxLengthCriteria
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (tid == 0) a.cur_len[b] = t + 1;
-  tail_embed_next(a, b, t, s_tok, tid);
+  tail_embed_next(a, dd, b, t, s_tok, tid);
 }
 
 // manual path: append caller-chosen tokens (user LogitsProcessorList / StoppingCriteria ran on the host side)

@@ -27,9 +27,11 @@ def shard_batch(tensors: Sequence[torch.Tensor], rank: int, world: int) -> List[
     return [t[lo:hi] if t is not None else None for t in tensors]
 
 
-def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_bytes: int = 256 << 20, group=None) -> int:
-    """In-place broadcast of many tensors in few, large messages (per-link bound point-to-point xGMI: a handful of
-    256 MiB buckets, not thousands of small ones). Returns the number of collectives issued."""
+def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_bytes: int = 64 << 20, group=None) -> int:
+    """In-place broadcast of many tensors in few, large messages (per-link bound point-to-point xGMI: large messages, not
+    thousands of small ones). A tensor of at least ``bucket_bytes / 4`` is broadcast IN PLACE (no staging copy: the big
+    weight matrices never exist twice); smaller ones are coalesced into staging buckets of at most ``bucket_bytes``
+    (the only transient memory). Returns the number of collectives issued."""
     import torch.distributed as dist
 
     calls = 0
@@ -52,16 +54,21 @@ def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_byte
         bucket, size = [], 0
 
     for t in tensors:
-        bucket.append(t)
-        size += t.numel() * t.element_size()
-        if size >= bucket_bytes:
+        nbytes = t.numel() * t.element_size()
+        if nbytes * 4 >= bucket_bytes and t.is_contiguous():
+            dist.broadcast(t, src=src, group=group)
+            calls += 1
+            continue
+        if bucket and size + nbytes > bucket_bytes:
             flush()
+        bucket.append(t)
+        size += nbytes
     if bucket:
         flush()
     return calls
 
 
-def broadcast_model_weights(model, src: int = 0, bucket_bytes: int = 256 << 20) -> int:
+def broadcast_model_weights(model, src: int = 0, bucket_bytes: int = 64 << 20) -> int:
     """Weights of a ParlerTTSForConditionalGeneration (incl. the DAC wrapper's tensors) from rank ``src`` to all."""
     dev = model.device
     model.audio_encoder._weights = {k: v.to(dev) for k, v in model.audio_encoder._weights.items()}

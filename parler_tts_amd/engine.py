@@ -12,8 +12,10 @@ import torch
 from . import _native as N
 
 
-def _stream_ptr(stream: Optional["torch.cuda.Stream"] = None) -> C.c_void_p:
-    s = stream if stream is not None else torch.cuda.current_stream()
+def _stream_ptr(stream: Optional["torch.cuda.Stream"] = None, device=None) -> C.c_void_p:
+    """Handle of the CURRENT stream of `device` (the engine's device, not torch's current device: a stream belongs to
+    the device it was created on)."""
+    s = stream if stream is not None else torch.cuda.current_stream(device)
     return C.c_void_p(s.cuda_stream)
 
 
@@ -74,10 +76,10 @@ class DecoderEngine:
             t = t.float()
         t = t.to(self.device).contiguous()
         dt = N.PTTS_BF16 if t.dtype == torch.bfloat16 else N.PTTS_F32
-        N.check(self.lib.ptts_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, _shape_arr(t), t.dim(), _stream_ptr()),
+        N.check(self.lib.ptts_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, _shape_arr(t), t.dim(), _stream_ptr(device=self.device)),
                 f"ptts_load_weight({name})")
         # the engine re-packs asynchronously on the current stream; keep `t` alive until then
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
         """Accepts the reference's decoder state-dict names, optionally under `prefix`
@@ -91,7 +93,7 @@ class DecoderEngine:
                     continue
                 self.load_weight(name, v)
         if self.rope:
-            cos, sin = rope_tables(self.H // self.cfg.num_heads, self.rope_theta, self.max_positions)
+            cos, sin = rope_tables(self.H // self.cfg.num_heads, self.rope_theta, max(self.max_positions, self.cfg.max_ctx))  # RoPE has no position limit (:373-406)
             self.load_weight("rope_cos", cos)
             self.load_weight("rope_sin", sin)
         N.check(self.lib.ptts_weights_ready(self._h), "ptts_weights_ready")
@@ -124,28 +126,28 @@ class DecoderEngine:
             pm = prompt_mask.to(self.device, torch.int32).contiguous()
             keep.append(pm)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
-        N.check(self.lib.ptts_prefill(self._h, ptr(enc), ptr(em), ptr(pr), ptr(pm), B, Nn, P, int(sample), _stream_ptr()), "ptts_prefill")
+        N.check(self.lib.ptts_prefill(self._h, ptr(enc), ptr(em), ptr(pr), ptr(pm), B, Nn, P, int(sample), _stream_ptr(device=self.device)), "ptts_prefill")
         self.B, self.P = B, P
         self._keep = keep  # inputs are consumed asynchronously by the enqueued kernels
 
     def set_audio_prefix(self, codes: Optional[torch.Tensor]):
         """Voice prompt for the NEXT ``prefill``: un-delayed audio codes int64 [B, K, T] (or [B*K, T]); ``None`` clears it."""
         if codes is None or codes.shape[-1] == 0:
-            N.check(self.lib.ptts_set_audio_prefix(self._h, C.c_void_p(), 1, 0, _stream_ptr()), "ptts_set_audio_prefix")
+            N.check(self.lib.ptts_set_audio_prefix(self._h, C.c_void_p(), 1, 0, _stream_ptr(device=self.device)), "ptts_set_audio_prefix")
             return
         codes = codes.to(self.device, torch.int64).reshape(-1, codes.shape[-1]).contiguous()
         if codes.shape[0] % self.K:
             raise ValueError(f"audio prefix rows {codes.shape[0]} not a multiple of num_codebooks {self.K}")
-        N.check(self.lib.ptts_set_audio_prefix(self._h, C.c_void_p(codes.data_ptr()), codes.shape[0] // self.K, codes.shape[1], _stream_ptr()),
+        N.check(self.lib.ptts_set_audio_prefix(self._h, C.c_void_p(codes.data_ptr()), codes.shape[0] // self.K, codes.shape[1], _stream_ptr(device=self.device)),
                 "ptts_set_audio_prefix")
         self._keep_prefix = codes
 
     def decode_steps(self, n: int):
-        N.check(self.lib.ptts_decode_steps(self._h, int(n), _stream_ptr()), "ptts_decode_steps")
+        N.check(self.lib.ptts_decode_steps(self._h, int(n), _stream_ptr(device=self.device)), "ptts_decode_steps")
 
     def state(self) -> Tuple[int, bool]:
         cur, fin = C.c_int32(), C.c_int32()
-        N.check(self.lib.ptts_state(self._h, C.byref(cur), C.byref(fin), _stream_ptr()), "ptts_state")
+        N.check(self.lib.ptts_state(self._h, C.byref(cur), C.byref(fin), _stream_ptr(device=self.device)), "ptts_state")
         return cur.value, bool(fin.value)
 
     def _copy_out(self, ptr: int, shape, dtype, row_stride: Optional[int] = None) -> torch.Tensor:
@@ -154,10 +156,10 @@ class DecoderEngine:
         esz = out.element_size()
         hip = N.hip_runtime()
         if row_stride is None or row_stride == shape[-1]:
-            rc = hip.hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(out.numel() * esz), 3, _stream_ptr())
+            rc = hip.hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(out.numel() * esz), 3, _stream_ptr(device=self.device))
         else:
             rc = hip.hipMemcpy2DAsync(C.c_void_p(out.data_ptr()), C.c_size_t(shape[-1] * esz), C.c_void_p(ptr), C.c_size_t(row_stride * esz),
-                                      C.c_size_t(shape[-1] * esz), C.c_size_t(shape[0]), 3, _stream_ptr())
+                                      C.c_size_t(shape[-1] * esz), C.c_size_t(shape[0]), 3, _stream_ptr(device=self.device))
         if rc != 0:
             raise N.NativeLibraryError(f"hipMemcpy(D2D) failed with code {rc}")
         return out
@@ -170,7 +172,7 @@ class DecoderEngine:
         return self._copy_out(p.value, (self.B * self.K, cur), torch.int64, row_stride=ld.value)
 
     def step_forward(self):
-        N.check(self.lib.ptts_step_forward(self._h, _stream_ptr()), "ptts_step_forward")
+        N.check(self.lib.ptts_step_forward(self._h, _stream_ptr(device=self.device)), "ptts_step_forward")
 
     def logits(self) -> torch.Tensor:
         """fp32 [B*K, V] logits of the last forward (a copy)."""
@@ -182,7 +184,7 @@ class DecoderEngine:
         tk = tokens.to(self.device, torch.int64).contiguous()
         fn = finished.to(self.device, torch.int32).contiguous() if finished is not None else None
         N.check(self.lib.ptts_push_tokens(self._h, C.c_void_p(tk.data_ptr()), C.c_void_p(fn.data_ptr()) if fn is not None else C.c_void_p(),
-                                          _stream_ptr()), "ptts_push_tokens")
+                                          _stream_ptr(device=self.device)), "ptts_push_tokens")
         self._keep2 = (tk, fn)
 
     def generate_ids(self, enc, enc_mask, prompt, prompt_mask, poll_every: int = 64, audio_prefix: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -251,9 +253,9 @@ class DacEngine:
             t = t.detach().to(self.device, torch.float32).contiguous()
             if name.endswith(".alpha"):
                 t = t.reshape(-1).contiguous()
-            N.check(self.lib.ptts_dac_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), _shape_arr(t), t.dim(), _stream_ptr()),
+            N.check(self.lib.ptts_dac_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), _shape_arr(t), t.dim(), _stream_ptr(device=self.device)),
                     f"ptts_dac_load_weight({name})")
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
         N.check(self.lib.ptts_dac_weights_ready(self._h), "ptts_dac_weights_ready")
 
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
@@ -263,7 +265,7 @@ class DacEngine:
         codes = codes.to(self.device, torch.int64).contiguous()
         B, _, T = codes.shape
         out = torch.empty(B, 1, self.hop * T, dtype=torch.float32, device=self.device)
-        N.check(self.lib.ptts_dac_decode(self._h, C.c_void_p(codes.data_ptr()), C.c_void_p(out.data_ptr()), B, T, _stream_ptr()), "ptts_dac_decode")
+        N.check(self.lib.ptts_dac_decode(self._h, C.c_void_p(codes.data_ptr()), C.c_void_p(out.data_ptr()), B, T, _stream_ptr(device=self.device)), "ptts_dac_decode")
         self._keep = codes
         return out
 
@@ -280,7 +282,7 @@ class DacEngine:
             raise ValueError(f"waveform length {L} is not a positive multiple of the hop {self.hop} (apply the preprocess padding)")
         nq = self.K if n_quantizers is None else max(1, min(int(n_quantizers), self.K))
         codes = torch.empty(B, nq, L // self.hop, dtype=torch.int64, device=self.device)
-        N.check(self.lib.ptts_dac_encode(self._h, C.c_void_p(wave.data_ptr()), C.c_void_p(codes.data_ptr()), B, L, nq, _stream_ptr()), "ptts_dac_encode")
+        N.check(self.lib.ptts_dac_encode(self._h, C.c_void_p(wave.data_ptr()), C.c_void_p(codes.data_ptr()), B, L, nq, _stream_ptr(device=self.device)), "ptts_dac_encode")
         self._keep = wave
         return codes
 
@@ -289,7 +291,7 @@ class DacEngine:
         p = C.c_void_p()
         N.check(self.lib.ptts_dac_debug_latents(self._h, C.byref(p)), "ptts_dac_debug_latents")
         out = torch.empty(B, T, self.latent_dim, dtype=torch.float32, device=self.device)
-        rc = N.hip_runtime().hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(p.value), C.c_size_t(out.numel() * 4), 3, _stream_ptr())
+        rc = N.hip_runtime().hipMemcpyAsync(C.c_void_p(out.data_ptr()), C.c_void_p(p.value), C.c_size_t(out.numel() * 4), 3, _stream_ptr(device=self.device))
         if rc != 0:
             raise N.NativeLibraryError(f"hipMemcpy(D2D) failed with code {rc}")
         return out.transpose(1, 2).contiguous()

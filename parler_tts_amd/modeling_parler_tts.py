@@ -22,6 +22,7 @@ from torch import nn
 from .configuration_parler_tts import DACConfig, ParlerTTSConfig, ParlerTTSDecoderConfig
 from .dac_wrapper import DACModel
 from .engine import DecoderEngine
+from .logits_processors import ParlerTTSLogitsProcessor
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -316,10 +317,15 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         reference's key names. ``attn_implementation`` is accepted for drop-in compatibility and ignored: the
         whole attention registry (:933-937) is replaced by the HIP attention kernel."""
         path = pretrained_model_name_or_path
+        if torch_dtype is not None and torch_dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError(f"torch_dtype={torch_dtype}: the HIP engine implements float32 (parity) and bfloat16 (throughput)")
         if not os.path.isdir(path):
             from huggingface_hub import snapshot_download  # needs network / a local HF cache
 
-            path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors"])
+            hub_kw = {k: kwargs[k] for k in ("revision", "cache_dir", "token", "local_files_only") if kwargs.get(k) is not None}
+            path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors"], **hub_kw)
+            if not any(f.endswith(".safetensors") for f in os.listdir(path)):  # legacy repos ship pytorch_model.bin only
+                path = snapshot_download(pretrained_model_name_or_path, allow_patterns=["*.json", "*.bin"], **hub_kw)
         cfg = config or ParlerTTSConfig.from_pretrained(path)
         model = cls(cfg)
         gpath = os.path.join(path, "generation_config.json")
@@ -589,9 +595,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if streamer is not None:
             streamer.end()
         # --- un-delay (:3585-3597) and decode (:3600-3647) -------------------------------------------------------------
-        # With a voice prompt the reference re-builds the un-delay mask from the ALREADY delayed ids (:3589-3594), which
-        # drops the first k prompt codes of codebook k and misaligns the rows; the mask here is the one
-        # that inverts the delay pattern: BOS triangle + PAD triangle, independent of the prompt.
+        # The reference rebuilds the mask from the un-delayed `input_ids` (:3589-3594); only its BOS / PAD triangles are
+        # tested (:3596), and audio codes are never BOS / PAD, so the BOS column alone gives the identical keep-mask.
         output_ids = apply_delay_pattern_mask(output_ids, pattern)
         _, m2 = build_delay_pattern_mask(bos_col, bos, pad, output_ids.shape[1], K)
         keep = (m2 != bos) & (m2 != pad)
@@ -647,6 +652,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         seq = given_ids.clone()  # BOS column (+ the delayed voice-prompt columns)
         given = seq.shape[-1]
         unfinished = torch.ones(B * K, dtype=torch.long, device=dev)
+        if processors is None:  # :3418: the default LogitsProcessorList([ParlerTTSLogitsProcessor]) whenever none is passed,
+            processors = [ParlerTTSLogitsProcessor(eos, K, B, dev)]  # with or without user stopping criteria
         while True:
             scores = eng.logits().float()
             if min_new > 0 and (seq.shape[-1] - given) < min_new:
