@@ -13,8 +13,15 @@ against outputs of the *reference's own classes* run in the build container
   * delay-pattern helpers and ``ParlerTTSLogitsProcessor`` are pinned bit-exactly against
     modeling_parler_tts.py:205-276 and logits_processors.py:6-53;
   * the sampling loop restates transformers==4.46.1 ``GenerationMixin._sample`` (setup.py:21 pins
-    it; the package source is NOT under /root/reference and 4.46.1 is not installed, so that part
-    is "parity unpinned" beyond its reference call sites modeling_parler_tts.py:3412-3572).
+    it; the package source is NOT under /root/reference and 4.46.1 is not installed). It is pinned
+    against the transformers release that IS installed (5.x): ``oracle/hf_sample_shim.py`` lets the
+    installed ``GenerationMixin._sample`` + ``_get_logits_processor`` + ``_get_stopping_criteria``
+    drive this module's forward, and ``tests/test_sample_loop_vs_transformers.py`` requires identical
+    token ids (greedy, EOS gate / min_new_tokens / finished-row padding / early stop) and identical
+    processed scores + seeded draws under temperature / top-k / top-p. The per-step core of `_sample`
+    and the processor order [built-ins incl. MinNewTokens] + [custom list] + [warpers] are unchanged
+    between 4.46 and 5.x as far as the reference's call sites (modeling_parler_tts.py:3412-3572) can
+    tell; a 4.46.1 wheel has never been available offline, so THAT exact version stays unverified.
 
 All line numbers below are ``/root/reference/parler_tts/modeling_parler_tts.py`` unless noted.
 """
@@ -387,13 +394,14 @@ class GenParams:
 class GenTrace:
     sequences: torch.Tensor  # raw ids [B·K, Lout]
     step_logits: List[torch.Tensor] = field(default_factory=list)  # fp32 [B·K, V] before processors
+    step_scores: List[torch.Tensor] = field(default_factory=list)  # fp32 [B·K, V] after processors + warpers (what the selection sees)
     min_margin: float = float("inf")  # min top-2 margin over unfinished rows (greedy tie-safety)
 
 
 def sample_loop(model: DecoderOracle, enc: torch.Tensor, enc_mask: Optional[torch.Tensor],
                 prompt: Optional[torch.Tensor], prompt_mask: Optional[torch.Tensor], gp: GenParams,
                 generator: Optional[torch.Generator] = None, keep_logits: bool = False,
-                decoder_input_ids: Optional[torch.Tensor] = None) -> GenTrace:
+                decoder_input_ids: Optional[torch.Tensor] = None, keep_scores: bool = False) -> GenTrace:
     """``decoder_input_ids`` [bsz*K, T]: un-delayed audio codes of a voice prompt (modeling:3136-3194); the BOS column is
     prepended (:3017-3018), the delay pattern built over the prefix (:3523-3530) and the first forward runs over all given
     columns at once, as the reference does."""
@@ -437,8 +445,12 @@ def sample_loop(model: DecoderOracle, enc: torch.Tensor, enc_mask: Optional[torc
                 rm = cp <= (1 - gp.top_p)
                 rm[..., -1:] = False
                 scores = scores.masked_fill(rm.scatter(1, si, rm), -math.inf)
+            if keep_scores:
+                tr.step_scores.append(scores.clone())
             nxt = torch.multinomial(F.softmax(scores, dim=-1), 1, generator=generator).squeeze(1)
         else:
+            if keep_scores:
+                tr.step_scores.append(scores.clone())
             top2 = torch.topk(scores, 2, dim=-1)[0]
             m = (top2[:, 0] - top2[:, 1])[unfinished.bool()]
             if m.numel():

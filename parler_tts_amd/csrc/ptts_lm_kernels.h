@@ -607,21 +607,29 @@ __device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* o
   float4 v[NF4], g[NF4], bt[NF4];
 #pragma unroll
   for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
-  if (a.part) {  // pending split-K partials of the previous fc2: h += sum_s part[s] in fixed order, written back
-    for (int sp = 0; sp < a.S; ++sp) {
-      float4 u[NF4];
-#pragma unroll
-      for (int i = 0; i < NF4; ++i) u[i] = *reinterpret_cast<const float4*>(a.part + ((size_t)sp * a.M + m) * a.K + (lane + 64 * i) * 4);
-#pragma unroll
-      for (int i = 0; i < NF4; ++i) { v[i].x += u[i].x; v[i].y += u[i].y; v[i].z += u[i].z; v[i].w += u[i].w; }
-    }
-#pragma unroll
-    for (int i = 0; i < NF4; ++i) *reinterpret_cast<float4*>(xr + (lane + 64 * i) * 4) = v[i];
-  }
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
     bt[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+  }
+  if (a.part) {  // pending split-K partials of the previous fc2: h += sum_s part[s] in fixed order, written back
+    constexpr int SB = 4;  // partial rows in flight per batch (the rolled loop was one cold round trip per split)
+    for (int s0 = 0; s0 < a.S; s0 += SB) {
+      float4 u[SB][NF4];
+#pragma unroll
+      for (int sp = 0; sp < SB; ++sp)
+#pragma unroll
+        for (int i = 0; i < NF4; ++i)
+          u[sp][i] = *reinterpret_cast<const float4*>(a.part + ((size_t)min(s0 + sp, a.S - 1) * a.M + m) * a.K + (lane + 64 * i) * 4);
+#pragma unroll
+      for (int sp = 0; sp < SB; ++sp)
+        if (s0 + sp < a.S) {
+#pragma unroll
+          for (int i = 0; i < NF4; ++i) { v[i].x += u[sp][i].x; v[i].y += u[sp][i].y; v[i].z += u[sp][i].z; v[i].w += u[sp][i].w; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) *reinterpret_cast<float4*>(xr + (lane + 64 * i) * 4) = v[i];
   }
   const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
   float s1 = 0.f, s2 = 0.f;
