@@ -187,6 +187,37 @@ def measure_ttft(model, bs: int, device, reps: int = 20) -> float:
     return ts[len(ts) // 2] * 1e3
 
 
+def measure_ttfa(model, device, reps: int = 9, play_steps_in_s: float = 0.5) -> dict:
+    """p50 time-to-first-audio (INFERENCE.md:3 "under 500 ms"): wall time from calling generate(streamer=...) in a thread
+    (INFERENCE.md:130-148: play_steps = frame_rate * 0.5 s = 43 columns) to the first non-empty audio chunk in the queue:
+    T5 + prefill + 42 graph replays + un-delay + chunked DAC decode of the 34 complete frames, minus the stride."""
+    import threading
+
+    import parler_tts_amd as P
+
+    desc, prompt = synthetic_batch(1, 0, device)
+    play_steps = int(model.audio_encoder.config.frame_rate * play_steps_in_s)
+    kw = dict(input_ids=desc, prompt_input_ids=prompt, do_sample=False, max_new_tokens=3 * play_steps, min_new_tokens=3 * play_steps)
+    ts, first_len = [], 0
+    for i in range(reps + 2):
+        streamer = P.ParlerTTSStreamer(model, device=device, play_steps=play_steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = threading.Thread(target=model.generate, kwargs=dict(streamer=streamer, **kw))
+        th.start()
+        t_first = None
+        for chunk in streamer:
+            if t_first is None and chunk.shape[0] > 0:
+                t_first = time.perf_counter() - t0
+                first_len = int(chunk.shape[0])
+        th.join()
+        if i >= 2 and t_first is not None:
+            ts.append(t_first)
+    ts.sort()
+    return {"ttfa_p50_ms": round(ts[len(ts) // 2] * 1e3, 2), "play_steps": play_steps, "first_chunk_samples": first_len,
+            "first_chunk_audio_ms": round(first_len / model.audio_encoder.config.sampling_rate * 1e3, 1)}
+
+
 def cpu_baseline(budget_s: float = 20.0) -> dict:
     """The oracle (CPU restatement of the reference path, kind 'port') on the host cores: Mini-v1 shapes, fp32, greedy,
     bs=1, same synthetic input shapes. EVERYTHING reported is timed: prefill of P+1 positions + S cached decode passes
@@ -378,6 +409,11 @@ def main():
                            "roofline": measure_decode_roofline(model, 32, device)}
         except Exception as e:  # side measurement must never break the contract line
             out["bs32"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_extras and args.bs == 1:
+        try:
+            out["streaming"] = measure_ttfa(model, device)
+        except Exception as e:
+            out["streaming"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_extras and not args.sample and args.model == "mini":
         try:  # the reference's default generation mode (do_sample=True, init_model_600M.py:57-63): step time beside greedy
             out["sampling"] = measure_sampling_step(model, args.bs, device)

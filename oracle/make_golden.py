@@ -13,6 +13,7 @@ What is frozen (all inputs are seeded; weights are regenerated from seeds by the
   delay_kat.npz          build_delay_pattern_mask / apply_delay_pattern_mask known answers.
   eosgate_kat.npz        ParlerTTSLogitsProcessor known answers over a scripted id history.
   dac_tiny.npz           DAC decode restatement outputs (cross-checked against the transformers DacModel port).
+  streamer_ref.npz       audio chunks emitted by the reference ParlerTTSStreamer on a scripted token stream (oracle DAC as codec).
 """
 from __future__ import annotations
 
@@ -340,6 +341,50 @@ def gen_dac_encode():
                         codes=codes.numpy(), margin=margin.numpy())
 
 
+@torch.no_grad()
+def gen_streamer(ref):
+    """The REFERENCE's own ``ParlerTTSStreamer`` (parler_tts/streamer.py:11-147) fed a scripted token stream, with the oracle
+    DAC (tiny stack) as ``audio_encoder`` and a reference ``ParlerTTSForCausalLM`` as ``decoder`` (for its delay-pattern
+    helpers): the chunks it emits - full re-decode of the cache every ``play_steps``, stride trimming, a frame dropped for a
+    special id, final flush - are frozen as the golden stream for ``parler_tts_amd.streamer`` (CPU and HIP codec)."""
+    import types
+
+    from parler_tts.streamer import ParlerTTSStreamer as RefStreamer
+
+    spec = DO.TINY
+    K, L, play_steps = spec.num_codebooks, 75, 20
+    dec = build_reference_lm(ref, spec, DO.make_decoder_weights(spec, seed=1234))
+    dsd = DA.make_dac_weights(DA.DAC_TINY, seed=4321)
+    dac = DA.DacOracle(DA.DAC_TINY, dsd)
+
+    class Codec:  # the three things the streamer touches: config, device, decode
+        config = types.SimpleNamespace(sampling_rate=DA.DAC_TINY.hop_length * 86, frame_rate=86, codebook_size=1024, num_codebooks=K)
+        device = torch.device("cpu")
+
+        def decode(self, audio_codes, audio_scales=None):
+            return types.SimpleNamespace(audio_values=dac.decode(audio_codes[0]))
+
+    gc = types.SimpleNamespace(bos_token_id=spec.bos_token_id, pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id,
+                               decoder_start_token_id=spec.bos_token_id)
+    model = types.SimpleNamespace(decoder=dec, audio_encoder=Codec(), generation_config=gc, device=torch.device("cpu"),
+                                  use_audio_scales=True, use_4dim_audio_codes=True)
+    g = torch.Generator().manual_seed(11)
+    raw = torch.randint(0, 1024, (K, L), generator=g)
+    raw[4, 47] = spec.eos_token_id  # EOS mid-stream: the reference switches to its sequential branch and drops that frame (:95-104)
+    st = RefStreamer(model, play_steps=play_steps)  # default stride (streamer.py:56-57)
+    first, _ = dec.build_delay_pattern_mask(torch.full((K, 1), spec.bos_token_id), bos_token_id=spec.bos_token_id,
+                                            pad_token_id=spec.pad_token_id, max_length=L)
+    st.put(first)
+    for j in range(1, L):
+        st.put(raw[:, j])
+    st.end()
+    chunks = [c for c in st]
+    assert len(chunks) >= 4 and sum(len(c) for c in chunks) > 0
+    print(f"[streamer] reference ParlerTTSStreamer: {len(chunks)} chunks, lengths {[len(c) for c in chunks]}, stride {st.stride}")
+    np.savez_compressed(os.path.join(GOLD, "streamer_ref.npz"), raw=raw.numpy(), play_steps=play_steps, stride=int(st.stride), L=L,
+                        dac_seed=4321, lengths=np.array([len(c) for c in chunks]), audio=np.concatenate(chunks).astype(np.float32))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -353,6 +398,7 @@ def main():
     gen_decoder(ref, "gqa")
     gen_dac()
     gen_dac_encode()
+    gen_streamer(ref)
     print("golden vectors written to", GOLD)
 
 

@@ -43,7 +43,7 @@ class PttsDacConfig(C.Structure):
     ]
 
 
-ABI_VERSION = 3  # PTTS_ABI_VERSION in include/ptts.h
+ABI_VERSION = 4  # PTTS_ABI_VERSION in include/ptts.h
 
 # every symbol include/ptts.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64P = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
@@ -69,6 +69,7 @@ SYMBOLS = {
     "ptts_dac_load_weight": (C.c_int, [_VP, C.c_char_p, _VP, _I64P, _I32, _VP]),
     "ptts_dac_weights_ready": (C.c_int, [_VP]),
     "ptts_dac_decode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
+    "ptts_dac_decode_chunk": (C.c_int, [_VP, _VP, C.c_int64, _I32, _I32, _I32, _VP, _I32, _VP]),
     "ptts_dac_encode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "ptts_dac_debug_latents": (C.c_int, [_VP, C.POINTER(_VP)]),
 }

@@ -151,14 +151,16 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 }
 
 // final Conv1d(C -> 1, k7, pad 3) + tanh; one thread per output sample, weights [7][C] in LDS.
+// samples [skip, T) of every utterance are written to out[b * out_ld + (t - skip)] (skip > 0: the halo frames of a chunk)
 __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                     float* __restrict__ out, int B, int T, int C, int ktaps) {
+                                     float* __restrict__ out, int B, int T, int C, int ktaps, int skip, long long out_ld) {
   extern __shared__ float sw[];
   for (int i = threadIdx.x; i < ktaps * C; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * T) return;
   const int b = (int)(idx / T), t = (int)(idx % T);
+  if (t < skip) return;
   float acc = bias[0];
   for (int tap = 0; tap < ktaps; ++tap) {
     const int ti = t + tap - ktaps / 2;
@@ -170,7 +172,7 @@ __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* _
       acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
     }
   }
-  out[idx] = tanhf(acc);
+  out[(size_t)b * out_ld + (t - skip)] = tanhf(acc);
 }
 
 // first encoder Conv1d(1 -> C, k7, pad 3) on the raw waveform: one thread per (sample, 4 channels); writes the raw
@@ -312,12 +314,13 @@ __global__ void rvq_table_kernel(const float* __restrict__ cb, const float* __re
 }
 
 // z[b][t][c] = sum_i table[i][codes[b][i][t]][c]   (sequential over i, like from_codes)
+// codes rows have stride `ld` frames and the window starts at frame `t0` (chunked / streaming decode reads a slice in place)
 __global__ void rvq_gather_kernel(const long long* __restrict__ codes, const float* __restrict__ table, void* __restrict__ z,
-                                  int K, int T, int ncodes, int latent, int z_bf16) {
+                                  int K, int T, int ncodes, int latent, int z_bf16, long long ld, int t0) {
   const int t = blockIdx.x, b = blockIdx.y;
   __shared__ int s_code[32];
   if (threadIdx.x < K) {
-    long long cde = codes[((size_t)b * K + threadIdx.x) * T + t];
+    long long cde = codes[((size_t)b * K + threadIdx.x) * ld + t0 + t];
     if (cde < 0) cde = 0;
     if (cde >= ncodes) cde = ncodes - 1;
     s_code[threadIdx.x] = (int)cde;
@@ -707,8 +710,9 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   return PTTS_OK;
 }
 
-extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream) {
-  PTTS_CHECK(d && codes_dev && wave_dev, PTTS_E_INVALID, "null argument");
+// decode the window [t0, t0 + T) of codes rows with stride `ld`; samples [skip, hop*T) of the window go to wave_dev rows of out_ld
+static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld, int t0, float* wave_dev, int skip, long long out_ld,
+                             int32_t B, int32_t T, void* stream) {
   PTTS_TRY(ptts_dac_weights_ready(d));
   const ptts_dac_config& c = d->cfg;
   PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds dac max_batch %d", B, c.max_batch);
@@ -725,7 +729,7 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
   }
   const bool bf = c.compute_dtype == PTTS_BF16;
   hipLaunchKernelGGL(rvq_gather_kernel, dim3(T, B), dim3(256), 0, st, (const long long*)codes_dev, d->table, (void*)d->bufZ, c.num_codebooks, T,
-                     c.codebook_size, c.latent_dim, bf ? 1 : 0);
+                     c.codebook_size, c.latent_dim, bf ? 1 : 0, ld, t0);
   float *cur = d->bufA0, *other = d->bufA1;
   int Tcur = T;
   size_t li = 0;
@@ -745,10 +749,29 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
   }
   const size_t n = (size_t)B * Tcur;
   hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)7 * d->out_C * 4, st, cur, d->out_w, d->out_b,
-                     wave_dev, B, Tcur, d->out_C, 7);
+                     wave_dev, B, Tcur, d->out_C, 7, skip, out_ld);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
+}
+
+extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream) {
+  PTTS_CHECK(d && codes_dev && wave_dev, PTTS_E_INVALID, "null argument");
+  return dac_decode_window(d, codes_dev, T, 0, wave_dev, 0, (long long)d->hop * T, B, T, stream);
+}
+
+// Streaming / chunked decode (parler_tts/streamer.py:66-131 re-decodes the WHOLE token cache every `play_steps`): samples of
+// frames [first_frame, first_frame + n_frames) of codes [B][K][codes_ld], computed from the window that starts `halo` frames
+// earlier (clamped at 0) and ends at first_frame + n_frames - exactly the samples a decode of frames [0, first_frame + n_frames)
+// yields there whenever `halo` covers the decoder's one-sided receptive field (13 frames for strides 8, 8, 4, 2).
+extern "C" int ptts_dac_decode_chunk(ptts_dac* d, const int64_t* codes_dev, int64_t codes_ld, int32_t first_frame, int32_t n_frames,
+                                     int32_t halo, float* wave_dev, int32_t B, void* stream) {
+  PTTS_CHECK(d && codes_dev && wave_dev, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(first_frame >= 0 && n_frames >= 1 && halo >= 0 && (int64_t)first_frame + n_frames <= codes_ld, PTTS_E_INVALID,
+             "bad chunk [%d, %d) of %lld frames (halo %d)", first_frame, first_frame + n_frames, (long long)codes_ld, halo);
+  const int w0 = first_frame > halo ? first_frame - halo : 0;
+  return dac_decode_window(d, codes_dev, codes_ld, w0, wave_dev, (first_frame - w0) * d->hop, (long long)d->hop * n_frames, B,
+                           first_frame + n_frames - w0, stream);
 }
 
 // DACModel.encode (dac_wrapper/modeling_dac.py:33-104) for one chunk: wave_dev float32 [B][L] with L a multiple of the hop

@@ -59,6 +59,8 @@ struct ptts_engine {
   long long* prefix = nullptr;         // voice-prompt codes [max_batch*K][max_ctx], valid for the next prefill when pending_T > 0
   int pending_T = 0;
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
+  float* lnstat = nullptr;             // strip statistics of the residual rows (EPI_RESID -> PRO_LNS), [max_batch][H/16][2]
+  bool use_lns = true;                 // 8 < batch <= 32 decode: LayerNorm fused into the consumer GEMM (no rows_prep node)
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
   int cross_waves = 4; // waves per cross-attention workgroup on the GEMV step: one 8-deep batch of row groups per wave covers max_enc
@@ -117,7 +119,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   const int wmax = (a.M > 16 ? GemmMaxThreads<PRO, 2>::value : GemmMaxThreads<PRO, 1>::value) / 64;  // MTP 2 and 8 share the 512-thread bound
   // FULL variant: every wave owns whole 8-fragment groups (and K % 256 == 0): straight-line kernel
   int W = 0;
-  const bool ln_ok = PRO != PRO_LN || a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 1536;  // ln_row<> instances
+  const bool ln_ok = (PRO != PRO_LN && PRO != PRO_LNS) || a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 1536;  // ln_row<> instances
   if (a.K % 256 == 0 && ln_ok)
     for (int w = wmax; w >= 2; --w)
       if (nfrag % (8 * w) == 0) { W = w; break; }
@@ -299,6 +301,11 @@ int gemv_attn_out(GemvArgs a, int S, hipStream_t st) {  // split-KV combine + ou
 template <typename WT, int PRO, int EPI>
 int gemm_with_prologue(ptts_engine* e, GemmArgs g, hipStream_t st) {
   if (g.M <= 8) return launch_gemm<WT, PRO, EPI>(g, st);
+  if constexpr (PRO == PRO_LN) {
+    // statistics came with the residual rows and all M normalised rows fit in LDS beside the reduction buffer
+    if (g.lnstat && g.M <= 32 && (size_t)g.M * ((size_t)g.K * sizeof(WT) + 16) + 16 * 1024 <= 159 * 1024 && (g.K == 1024 || g.K == 1536))
+      return launch_gemm<WT, PRO_LNS, EPI>(g, st);
+  }
   PTTS_TRY((launch_prep<WT, PRO>(g, e->xw, st)));
   g.x = reinterpret_cast<const float*>(e->xw);
   g.x_ld = g.K; g.x_row_mul = 1; g.x_row_off = 0;
@@ -402,6 +409,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     return PTTS_OK;
   }
   bool fc2_pending = false;
+  const bool lns = e->use_lns && !prefill && M > 8 && M <= 32;  // LayerNorm statistics carried by the producer GEMM (PRO_LNS)
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
     {  // LN1 + fused QKV projection
@@ -431,6 +439,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       GemmArgs g = {};
       g.W = w.o; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      if (lns) g.stats_out = e->lnstat;  // strip statistics of the new residual rows for LN2 (PRO_LNS)
       if (e->S_self == 1) {
         g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
         PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
@@ -457,6 +466,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       GemmArgs g = {};
       g.W = w.cq; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln2_g; g.beta = w.ln2_b;
       g.out = e->qc; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      if (lns) g.lnstat = e->lnstat;
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
     {  // cross-attention against the static description K/V
@@ -475,6 +485,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       GemmArgs g = {};
       g.W = w.co; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      if (lns) g.stats_out = e->lnstat;  // for LN3
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
     }
     {  // LN3 + fc1 + GELU, then fc2 + residual. Above 8 rows the GELU output is written in the engine dtype so fc2
@@ -486,6 +497,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       g2.W = w.fc2; g2.x_ld = F; g2.x_row_mul = 1; g2.out = e->h; g2.out_ld = H; g2.M = M; g2.N = H; g2.K = F;
       if (big) {
         g.out = reinterpret_cast<float*>(e->xw2);
+        if (lns) g.lnstat = e->lnstat;
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
         g2.x = reinterpret_cast<const float*>(e->xw2);
         if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F)) {
@@ -525,7 +537,9 @@ int launch_tail(ptts_engine* e, hipStream_t st, bool embed_next) {
   t.B = e->B; t.K = e->cfg.num_codebooks; t.V = e->cfg.vocab_size; t.eos = e->cfg.eos_token_id; t.pad = e->cfg.pad_token_id;
   // one wave per codebook row (greedy arg-max or the sort-free sampler), at least 4 waves for the embedding of the next column
   const int nw = std::min(std::max(e->cfg.num_codebooks, 4), 16);
-  hipLaunchKernelGGL(tail_kernel, dim3(e->B), dim3(nw * 64), 0, st, t);
+  if (t.V <= 512) hipLaunchKernelGGL(tail_kernel<8>, dim3(e->B), dim3(nw * 64), 0, st, t);
+  else if (t.V <= 1152) hipLaunchKernelGGL(tail_kernel<18>, dim3(e->B), dim3(nw * 64), 0, st, t);
+  else hipLaunchKernelGGL(tail_kernel<32>, dim3(e->B), dim3(nw * 64), 0, st, t);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "tail launch failed: %s", hipGetErrorString(err));
   return PTTS_OK;
@@ -687,6 +701,8 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc_bytes(&e->xw, rows * H * es));
   A(e->alloc_bytes(&e->xw2, std::max(rows * F, enc_rows * (size_t)H) * es));
   A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
+  A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
+  e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
   A(e->alloc(&e->prefix, (size_t)c.max_batch * K * c.max_ctx));
   e->ids_ld = c.max_ctx + 8;
   A(e->alloc(&e->ids, (size_t)c.max_batch * K * e->ids_ld));

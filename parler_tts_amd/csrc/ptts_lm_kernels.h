@@ -72,7 +72,12 @@ __global__ void convert_kernel(const ST* __restrict__ src, DT* __restrict__ dst,
 //   EPI_RESID : out += acc (residual stream, :1034/:1052/:1064)
 //   EPI_KV    : scatter into the cross-attention K/V cache [b][head][t][64] (:877-878, cached :872-875)
 // ------------------------------------------------------------------------------------------------------
-enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2, PRO_COPY = 3 };  // PRO_COPY: x already in the engine dtype (prep kernel)
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2, PRO_COPY = 3, PRO_LNS = 4 };  // PRO_COPY: x already in the engine dtype (prep kernel)
+// PRO_LNS (8 < M <= 32): LayerNorm whose row statistics come from the PRODUCER of the residual stream. The EPI_RESID GEMM
+// that wrote h also wrote, per (row, 16-column strip), the strip mean and the strip sum of squared deviations
+// (`stats_out`); the consumer combines the K/16 strip partials per row (Chan's pairwise update, exact and cancellation
+// free) with 3 DPP steps for 8 rows at once, so the per-workgroup prologue is loads + one fma per element: no reduction
+// over K, and the separate rows_prep_kernel node (25 % of the batch-32 step in round 1) disappears.
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3, EPI_GELU_WT = 4 };  // _WT: output in the engine dtype
 
 struct GemmArgs {
@@ -94,6 +99,8 @@ struct GemmArgs {
   int rows_per_pass;   // activation rows staged in LDS per pass (<= 16 * MTP)
   int frags_per_wave;  // FULL variant: K/KT/W, a multiple of 8
   float invK;          // 1 / K
+  const float* lnstat; // PRO_LNS: [M][K/16][2] = (strip mean, strip M2) of x, written by the producer GEMM
+  float* stats_out;    // EPI_RESID: [M][N/16][2] strip statistics of the updated residual rows, or null
   int ksplit;          // split-K over blockIdx.y (PRO_COPY only): weight fragments per split, 0 = off
   long long out_split_stride;  // elements between the partial outputs of two splits
 #ifdef PTTS_TIMING
@@ -258,6 +265,73 @@ __device__ __forceinline__ void ln_stage(const Args& a, int m0, int nrows, char*
   }
 }
 
+// PRO_LNS staging. Wave w owns rows w, w + W, ... (<= 8 of them). Statistics: lane (ri, g) = (lane >> 3, lane & 7) reads a
+// contiguous chunk of K/128 strip partials of row w + W*ri, folds them relative to the first strip's mean, and an 8-lane DPP
+// reduction finishes all 8 rows together. Rows are then normalised from registers into LDS exactly as PRO_LN does.
+template <typename WT, int NF4, typename Hook>
+__device__ __forceinline__ void lns_stage(const GemmArgs& a, int nrows, char* s_x, int row_bytes, int lane, int wave, int W, Hook&& first) {
+  constexpr int NS = NF4 * 16;        // producer strips per row (K == NF4 * 256)
+  constexpr int CH = NF4 * 2;         // strip partials per lane
+  const int ri = lane >> 3, gq = lane & 7;
+  const int srow = min(wave + W * ri, nrows - 1);
+  const float2* sp = reinterpret_cast<const float2*>(a.lnstat) + (size_t)srow * NS;
+  const float2 first_strip = sp[0];
+  float2 part[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) part[i] = sp[gq * CH + i];
+  // first batch of rows (RB * NF4 float4 per lane) in flight together with gamma / beta
+  constexpr int RB = 2;  // rows in flight per wave (4 spilled 10-25 registers at the 256 budget of a 512-thread workgroup)
+  float4 g[NF4], bt[NF4];
+  auto load_rows = [&](int i0, float4 (&v)[RB][NF4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int r = min(wave + W * (i0 + i), nrows - 1);
+      const float* xr = a.x + (size_t)(r * a.x_row_mul + a.x_row_off) * a.x_ld;
+#pragma unroll
+      for (int f = 0; f < NF4; ++f) v[i][f] = *reinterpret_cast<const float4*>(xr + (lane + 64 * f) * 4);
+    }
+  };
+  float4 v[RB][NF4];
+  load_rows(0, v);
+#pragma unroll
+  for (int f = 0; f < NF4; ++f) {
+    g[f] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * f) * 4);
+    bt[f] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * f) * 4);
+  }
+  first(2);  // rendezvous + this wave's first weight fragments, queued behind the activations
+  // ---- row statistics for the 8 row slots of this wave
+  const float c = first_strip.x;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const float d = part[i].x - c;
+    s1 += d;
+    s2 += part[i].y + 16.f * d * d;
+  }
+  s1 = group_reduce<OpSum, 8>(s1);
+  s2 = group_reduce<OpSum, 8>(s2);
+  const float dm = s1 / (float)NS;
+  const float mean_l = c + dm;
+  const float rstd_l = rsqrtf(fmaxf((s2 - 16.f * (float)NS * dm * dm) * a.invK, 0.f) + 1e-5f);
+  const int nslots = (nrows - wave + W - 1) / W;  // rows this wave really owns
+#pragma unroll 1
+  for (int i0 = 0; i0 < nslots; i0 += RB) {
+    if (i0 != 0) load_rows(i0, v);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      if (i0 + i < nslots) {
+        const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean_l), (i0 + i) * 8));
+        const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstd_l), (i0 + i) * 8));
+        char* row = s_x + (size_t)(wave + W * (i0 + i)) * row_bytes;
+#pragma unroll
+        for (int f = 0; f < NF4; ++f)
+          lds_store4<WT>(row, (lane + 64 * f) * 4, (v[i][f].x - mean) * rstd * g[f].x + bt[f].x, (v[i][f].y - mean) * rstd * g[f].y + bt[f].y,
+                         (v[i][f].z - mean) * rstd * g[f].z + bt[f].z, (v[i][f].w - mean) * rstd * g[f].w + bt[f].w);
+      }
+    }
+  }
+}
+
 // one (row, 4-column) element of the PLAIN / ATTN prologue
 template <int PRO>
 __device__ __forceinline__ float4 stage_elem(const GemmArgs& a, int m, int k) {
@@ -295,6 +369,9 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
       if (nf4 <= 1) ln_stage<WT, 1, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);
       else ln_stage<WT, LN_MAX_F4, false>(a, m0, nrows, s_x, row_bytes, lane, wave, W, first);
     }
+  } else if (PRO == PRO_LNS) {  // host guarantees K in {1024, 1536}, 8 < M <= 32, rows_per_pass == M, W >= 4
+    if (a.K == 1024) lns_stage<WT, 4>(a, nrows, s_x, row_bytes, lane, wave, W, first);
+    else lns_stage<WT, 6>(a, nrows, s_x, row_bytes, lane, wave, W, first);
   } else if (PRO == PRO_COPY) {
     first(2);
     // bulk copy of engine-dtype rows, 16 B per lane, 8 independent loads in flight per thread
@@ -486,6 +563,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
           float4 o = mt == wave ? resid_pre : *p;
           o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
           *p = o;
+          r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = o.w;  // the updated residual values, for the strip statistics below
         } else {  // EPI_KV: n in [0, 2H): first half K, second half V
           const int H = a.N >> 1;
           const int which = n >= H;
@@ -497,6 +575,17 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
 #pragma unroll
           for (int e = 0; e < 4; ++e) store_from_f32<WT>(base + e, r[e]);
         }
+      }
+      if (EPI == EPI_RESID && a.stats_out) {
+        // strip statistics of the updated residual rows for the consumer's PRO_LNS prologue: lane (q, j) holds 4 of the strip's
+        // 16 columns of row j; the other 12 sit in lanes j + 16 / 32 / 48 (two permlane-swap steps, every lane takes part)
+        float sm = (r[0] + r[1]) + (r[2] + r[3]);
+        sm = swap32_reduce<OpSum>(swap16_reduce<OpSum>(sm));
+        const float mean = sm * 0.0625f;
+        const float d0 = r[0] - mean, d1 = r[1] - mean, d2 = r[2] - mean, d3 = r[3] - mean;
+        float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        m2 = swap32_reduce<OpSum>(swap16_reduce<OpSum>(m2));
+        if (q == 0 && mloc < nrows) reinterpret_cast<float2*>(a.stats_out)[(size_t)m * (a.N >> 4) + strip] = make_float2(mean, m2);
       }
     }
     PTTS_STAMP(PTTS_DBG(a), 5);
@@ -1275,7 +1364,8 @@ __device__ __forceinline__ int wave_sample_row(const float (&lg)[NV], int V, int
   for (int i = 0; i < NV; ++i)
     if (i < nv) mx = fmaxf(mx, x[i]);
   mx = wave_max(mx);
-  float e[NV], ls = 0.f;
+  float (&e)[NV] = x;  // from here on x holds the softmax numerators (one array less live: the kernel must not spill)
+  float ls = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     e[i] = (i < nv && x[i] != -INFINITY) ? expf(x[i] - mx) : 0.f;
@@ -1330,13 +1420,14 @@ __device__ __forceinline__ int wave_sample_row(const float (&lg)[NV], int V, int
 // the delay pattern is applied exactly as embed_kernel / apply_delay_pattern_mask do (modeling:205-276, :1433).
 // One thread owns 4 consecutive features; the K table rows (+ the position row) are ONE batch of independent loads
 // (the rolled k loop of round 1 was K sequential cold round trips: most of the 14 us the tail took).
-template <int KB>  // codebooks per batch of loads
+template <int KB, bool BF16>  // codebooks per batch of loads; table dtype
 __device__ __forceinline__ void tail_embed_rows(const TailArgs& a, const DevDims& dd, int b, int t, const int* s_tok, int d, float (&acc)[4]) {
   const bf16_t* tb16 = reinterpret_cast<const bf16_t*>(a.tables);
   const float* tb32 = reinterpret_cast<const float*>(a.tables);
+#pragma unroll 1
   for (int k0 = 0; k0 < a.K; k0 += KB) {
-    uint2 r16[KB];
-    float4 r32[KB];
+    uint2 r16[BF16 ? KB : 1];
+    float4 r32[BF16 ? 1 : KB];
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
       const int k = min(k0 + u, a.K - 1);
@@ -1347,13 +1438,13 @@ __device__ __forceinline__ void tail_embed_rows(const TailArgs& a, const DevDims
         else if (t - k - 1 < dd.T_prefix) tok = (int)dd.prefix[(size_t)(b * a.K + k) * dd.prefix_ld + (t - k - 1)];  // voice prompt
       }
       const size_t off = ((size_t)k * (a.V + 1) + tok) * a.H + d;
-      if (a.bf16_tables) r16[u] = *reinterpret_cast<const uint2*>(tb16 + off);
+      if constexpr (BF16) r16[u] = *reinterpret_cast<const uint2*>(tb16 + off);
       else r32[u] = *reinterpret_cast<const float4*>(tb32 + off);
     }
 #pragma unroll
     for (int u = 0; u < KB; ++u) {  // sum([...]) order :1433
       if (k0 + u < a.K) {
-        if (a.bf16_tables) {
+        if constexpr (BF16) {
           acc[0] += __uint_as_float(r16[u].x << 16); acc[1] += __uint_as_float(r16[u].x & 0xffff0000u);
           acc[2] += __uint_as_float(r16[u].y << 16); acc[3] += __uint_as_float(r16[u].y & 0xffff0000u);
         } else {
@@ -1370,12 +1461,14 @@ __device__ __forceinline__ void tail_embed_next(const TailArgs& a, const DevDims
     float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.pos_table) pos = *reinterpret_cast<const float4*>(a.pos_table + (size_t)(dd.P + t) * a.H + d);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.K <= 9) tail_embed_rows<9>(a, dd, b, t, s_tok, d, acc);
-    else tail_embed_rows<16>(a, dd, b, t, s_tok, d, acc);
+    if (a.bf16_tables) tail_embed_rows<9, true>(a, dd, b, t, s_tok, d, acc);  // K = 9 (Mini / Large v1): one batch; more codebooks loop
+    else tail_embed_rows<9, false>(a, dd, b, t, s_tok, d, acc);
     *reinterpret_cast<float4*>(out + d) = make_float4(acc[0] + pos.x, acc[1] + pos.y, acc[2] + pos.z, acc[3] + pos.w);
   }
 }
 
+// NV = logits per lane: 8 (vocab <= 512), 18 (<= 1152: Mini / Large v1, vocab 1088) or 32 (<= 2048)
+template <int NV>
 __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
   __shared__ int s_tok[32];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1394,7 +1487,6 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
   const DevDims dd = *a.dims;  // the embedding of the next column needs P / max_length / the voice-prompt prefix: fetched now, not after the argmax
   const int t_prefix = dd.T_prefix;
   const int he = lane < a.K ? a.has_eos[b * a.K + lane] : 0;  // every wave: the K EOS flags of this utterance
-  constexpr int NV = PTTS_SORT_N / 64;                         // logits per lane (vocab <= PTTS_SORT_N)
   float lg[NV];
   const int k0 = w;  // greedy: wave w starts with codebook row w
   if (k0 < a.K) {

@@ -270,6 +270,21 @@ class DacEngine:
         return out
 
 
+    def decode_chunk(self, codes: torch.Tensor, first_frame: int, n_frames: int, halo: int) -> torch.Tensor:
+        """codes int64 [B, K, T] (contiguous, on the device; read in place) → samples of frames [first_frame, first_frame +
+        n_frames) as float32 [B, 1, hop*n_frames], decoded from the window that starts ``halo`` frames earlier
+        (``ptts_dac_decode_chunk``). Enqueued on the CURRENT stream of the engine's device, so a caller can run it on a side
+        stream while the decoder graph replays on the main one."""
+        if codes.dim() != 3 or codes.shape[1] != self.K:
+            raise ValueError(f"audio_codes must be [batch, {self.K}, frames], got {tuple(codes.shape)}")
+        codes = codes.to(self.device, torch.int64).contiguous()
+        B, _, T = codes.shape
+        out = torch.empty(B, 1, self.hop * n_frames, dtype=torch.float32, device=self.device)
+        N.check(self.lib.ptts_dac_decode_chunk(self._h, C.c_void_p(codes.data_ptr()), T, int(first_frame), int(n_frames), int(halo),
+                                               C.c_void_p(out.data_ptr()), B, _stream_ptr(device=self.device)), "ptts_dac_decode_chunk")
+        self._keep = codes
+        return out
+
     def encode(self, wave: torch.Tensor, n_quantizers: Optional[int] = None) -> torch.Tensor:
         """waveform float32 [B, 1, L] (L a multiple of the hop) → codes int64 [B, n_quantizers, L / hop]."""
         if self.encoder_dim <= 0:

@@ -624,22 +624,71 @@ class ParlerTTSForConditionalGeneration(nn.Module):
     # -- default path: the whole `_sample` loop runs on the device -------------------------------------------------------
     def _run_device_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, given: int = 1):
         eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)  # BOS column + voice-prompt columns, then the first sampled one
-        sent = given
-        chunk = int(getattr(streamer, "play_steps", 16) or 16) if streamer is not None else 64
         remaining = max_length - given - 1
-        done = False
-        while True:
-            if streamer is not None:  # forward finished columns in order (one put per column, like `_sample`)
+        if streamer is None:
+            done = False
+            while not done and remaining > 0:
+                n = min(64, remaining)
+                eng.decode_steps(n)
+                remaining -= n
+                _, done = eng.state()
+            return eng.ids()
+        # Streaming: the decoder graph runs AHEAD on the main stream while the finished columns of the previous chunk are
+        # forwarded to the streamer on a side stream (one put per column, like `_sample`; the streamer's un-delay + chunked DAC
+        # decode is enqueued on that side stream too), so the codec never stalls the token loop. Columns are written once, so
+        # reading them while later steps run is safe; steps after every row finished are device-side no-ops.
+        chunk = int(getattr(streamer, "play_steps", 16) or 16)
+        if self.device.type != "cuda":  # host-logic tests drive this loop with a stand-in engine: same protocol, no streams
+            sent, done = given, False
+            while True:
                 ids = eng.ids()
                 for j in range(sent, ids.shape[1]):
                     streamer.put(ids[:, j].cpu())
                 sent = ids.shape[1]
-            if done or remaining <= 0:
-                break
-            n = min(chunk, remaining)
-            eng.decode_steps(n)
-            remaining -= n
-            _, done = eng.state()
+                if done or remaining <= 0:
+                    return eng.ids()
+                n = min(chunk, remaining)
+                eng.decode_steps(n)
+                remaining -= n
+                _, done = eng.state()
+        main = torch.cuda.current_stream(self.device)
+        side = self.__dict__.get("_stream_side")
+        if side is None or side.device != self.device:
+            side = self.__dict__["_stream_side"] = torch.cuda.Stream(self.device)
+        sent = given
+        first = min(max(chunk - given - 1, 0), remaining)  # land exactly on the streamer's first `play_steps` boundary
+        pending = []                     # events of the chunks in flight (oldest first)
+
+        def launch(n):
+            nonlocal remaining
+            if n > 0:
+                eng.decode_steps(n)
+                remaining -= n
+            ev = torch.cuda.Event()
+            ev.record(main)
+            pending.append(ev)
+
+        launch(first)
+        launch(min(chunk, remaining))    # one chunk ahead
+        done = False
+        while pending:
+            pending.pop(0).synchronize()  # the oldest chunk in flight has finished; later ones keep the GPU busy meanwhile
+            with torch.cuda.stream(side):
+                ids = eng.ids()
+                for j in range(sent, ids.shape[1]):
+                    streamer.put(ids[:, j].cpu())
+                sent = ids.shape[1]
+                _, done = eng.state()
+            if not done and remaining > 0:
+                launch(min(chunk, remaining))
+            elif done:
+                remaining = 0
+        main.synchronize()
+        with torch.cuda.stream(side):
+            ids = eng.ids()
+            for j in range(sent, ids.shape[1]):
+                streamer.put(ids[:, j].cpu())
+        side.synchronize()
         return eng.ids()
 
     # -- user LogitsProcessorList / StoppingCriteria: forward on the HIP engine, selection in torch --------------------------

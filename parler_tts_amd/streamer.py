@@ -71,7 +71,11 @@ class ParlerTTSStreamer:
         n = codes.shape[-1]
         if n == 0:
             return np.zeros(0, dtype=np.float32)
-        w0 = max(0, start_sample // self.hop_length - self.halo_frames)
+        f0 = start_sample // self.hop_length
+        if hasattr(self.audio_encoder, "decode_chunk"):  # native chunk entry: reads the window in place (ptts_dac_decode_chunk)
+            out = self.audio_encoder.decode_chunk(codes[None, ...], f0, n - f0, self.halo_frames).audio_values
+            return out[0, 0, start_sample - f0 * self.hop_length:].cpu().float().numpy()
+        w0 = max(0, f0 - self.halo_frames)
         out = self.audio_encoder.decode(audio_codes=codes[:, :, w0:][None, ...], **self.audio_kwargs).audio_values
         return out[0, 0, max(0, start_sample - w0 * self.hop_length):].cpu().float().numpy()
 

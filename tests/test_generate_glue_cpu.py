@@ -115,6 +115,16 @@ def _model(eos_gain=None):
     m._get_engine = lambda B, N, Pp, L: eng
     dac = DA.DacOracle(DA.DAC_TINY, dsd)
     m.audio_encoder.decode = lambda audio_codes, audio_scales=None, **kw: types.SimpleNamespace(audio_values=dac.decode(audio_codes[0].cpu()))
+
+    def decode_chunk(audio_codes, first_frame, n_frames=None, halo=16):  # ptts_dac_decode_chunk semantics on the oracle codec
+        codes = audio_codes[0].cpu()
+        n_frames = codes.shape[-1] - first_frame if n_frames is None else n_frames
+        w0 = max(0, first_frame - halo)
+        wav = dac.decode(codes[:, :, w0: first_frame + n_frames])
+        hop = DA.DAC_TINY.hop_length
+        return types.SimpleNamespace(audio_values=wav[:, :, (first_frame - w0) * hop:])
+
+    m.audio_encoder.decode_chunk = decode_chunk
     return m, spec, sd, dac
 
 

@@ -208,6 +208,70 @@ def test_mini_width_two_layers_fp32_and_bf16():
         eng.close()
 
 
+def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64):
+    g = torch.Generator().manual_seed(seed)
+    enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
+    prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
+    enc_mask = prompt_mask = None
+    if masks:
+        enc_mask, prompt_mask = C.ragged_masks(bsz, N, P, enc_step=2)
+        enc_mask[0, N - 3:] = 0  # batch 1 must see padding too
+        prompt_mask[0, :2] = 0
+        enc = enc * enc_mask[..., None]
+    step_ids = torch.randint(0, 1024, (steps, bsz * spec.num_codebooks), generator=g)
+    orc = DO.DecoderOracle(spec, sd, precision=prec)
+    ref = [orc.forward(torch.full((bsz * 9, 1), 1025), enc, enc_mask, prompt, prompt_mask)[:, -1]]
+    for s in range(steps):
+        ref.append(orc.forward(step_ids[s][:, None])[:, -1])
+    eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=max_ctx, max_enc=max(N, 16), max_prompt=P + 1)
+    eng.set_gen_params(max_length=16)
+    eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
+    outs = [eng.logits().cpu()]
+    for s in range(steps):
+        eng.push_tokens(step_ids[s])
+        eng.step_forward()
+        outs.append(eng.logits().cpu())
+    eng.close()
+    return max(float((a - b).abs().max()) for a, b in zip(outs, ref))
+
+
+@pytest.mark.parametrize("rope", [False, True])
+@pytest.mark.parametrize("gqa", [False, True])
+def test_single_utterance_gemv_step_variants(rope, gqa):
+    """bs = 1 at Mini width runs the row-per-wave GEMV step (ptts_gemv_kernels.h): LayerNorm / split-KV-combine prologue waves,
+    COPY kernels, 1-wave cross-attention. Padded description + prompt masks, RoPE (q rotated, keys not, in the cross block),
+    grouped-query attention (N_qkv = 1536: 2 rows per wave), fp32 and bf16, 6 teacher-forced steps vs the oracle."""
+    kw = dict(num_hidden_layers=2, max_position_embeddings=512, rope_embeddings=rope)
+    if gqa:
+        kw.update(num_key_value_heads=4, num_cross_attention_key_value_heads=2)
+    spec = DO.DecoderSpec(**kw)
+    sd = DO.make_decoder_weights(spec, seed=41)
+    for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
+        err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=1, N=21, P=6, steps=6, masks=True, seed=8)
+        assert err < tol, (prec, err)
+
+
+def test_single_utterance_gemv_step_long_context_all_split_counts():
+    """GEMV step with the KV length growing through several row-group batches: max_ctx 1100 -> 4 KV splits (combine prologue
+    S = 4); max_ctx 300 -> 2 splits; fp32, 40 free-running columns compared by logits on the oracle's ids."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=2048)
+    sd = DO.make_decoder_weights(spec, seed=43)
+    for max_ctx in (300, 1100):
+        err = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=1, N=9, P=200, steps=40, masks=False, seed=3, max_ctx=max_ctx)
+        assert err < 5e-5, (max_ctx, err)
+
+
+@pytest.mark.parametrize("bsz", [12, 32])
+def test_mini_width_batch_12_and_32_producer_statistics_layernorm(bsz):
+    """8 < batch <= 32 at Mini width: LN2 / LN3 take their row statistics from the producing out_proj GEMM (EPI_RESID strip
+    partials -> PRO_LNS prologue, no rows_prep node), LN1 folds the split-K fc2 partials in the prep kernel. Ragged masks."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=47)
+    for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
+        err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=21, P=6, steps=4, masks=True, seed=bsz)
+        assert err < tol, (bsz, prec, err)
+
+
 def test_large_v1_width_two_layers_bf16_and_fp32_batch():
     """Large-v1 widths (H=1536, 24 heads, F=6144; init_large_model.py:25-43) with 2 layers, batch 1 and 12:
     6-float4 LayerNorm rows, 6 / 12-wave K splits, the prep-kernel (M > 8) path."""

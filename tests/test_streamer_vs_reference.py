@@ -1,0 +1,121 @@
+"""``parler_tts_amd.ParlerTTSStreamer`` against chunks emitted by the REFERENCE's own ``ParlerTTSStreamer``
+(parler_tts/streamer.py:11-147), frozen in tests/golden/streamer_ref.npz by oracle/make_golden.py::gen_streamer (reference
+class imported under the shims, oracle DAC as its codec, scripted token stream with an EOS id mid-stream). The reference
+re-decodes the whole token cache at every ``play_steps``; here the O(n) halo-window path (``ptts_dac_decode_chunk``) must emit
+the same chunks: same lengths, same samples."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from oracle import dac_oracle as DA
+from oracle import decoder_oracle as DO
+
+
+def _gold():
+    g = np.load(os.path.join(GOLD, "streamer_ref.npz"))
+    lengths = g["lengths"].tolist()
+    audio = g["audio"]
+    chunks, o = [], 0
+    for n in lengths:
+        chunks.append(audio[o: o + n])
+        o += n
+    return g, chunks
+
+
+def _feed(streamer, g):
+    import parler_tts_amd as P
+
+    K, L = 9, int(g["L"])
+    raw = torch.from_numpy(g["raw"])
+    first = P.build_delay_pattern_mask(torch.full((K, 1), 1025), 1025, 1024, L, K)[0]
+    streamer.put(first)
+    for j in range(1, L):
+        streamer.put(raw[:, j])
+    streamer.end()
+    return [c for c in streamer]
+
+
+def _gc():
+    return types.SimpleNamespace(bos_token_id=1025, pad_token_id=1024, eos_token_id=1024, decoder_start_token_id=1025)
+
+
+@pytest.mark.parametrize("incremental", [False, True])
+def test_streamer_chunks_equal_reference_streamer_cpu_codec(incremental):
+    from parler_tts_amd.streamer import ParlerTTSStreamer
+
+    g, want = _gold()
+    dac = DA.DacOracle(DA.DAC_TINY, DA.make_dac_weights(DA.DAC_TINY, seed=int(g["dac_seed"])))
+    hop = DA.DAC_TINY.hop_length
+
+    class Codec:
+        config = types.SimpleNamespace(sampling_rate=hop * 86, frame_rate=86, codebook_size=1024, num_codebooks=9)
+        device = torch.device("cpu")
+        decoder_rates = DA.DAC_TINY.decoder_rates
+
+        def decode(self, audio_codes, audio_scales=None):
+            return types.SimpleNamespace(audio_values=dac.decode(audio_codes[0]))
+
+        def decode_chunk(self, audio_codes, first_frame, n_frames=None, halo=16):  # ptts_dac_decode_chunk semantics
+            codes = audio_codes[0]
+            n_frames = codes.shape[-1] - first_frame if n_frames is None else n_frames
+            w0 = max(0, first_frame - halo)
+            wav = dac.decode(codes[:, :, w0: first_frame + n_frames])
+            return types.SimpleNamespace(audio_values=wav[:, :, (first_frame - w0) * hop:])
+
+    model = types.SimpleNamespace(decoder=types.SimpleNamespace(num_codebooks=9), audio_encoder=Codec(), generation_config=_gc(),
+                                  device=torch.device("cpu"), use_audio_scales=True, use_4dim_audio_codes=True)
+    st = ParlerTTSStreamer(model, play_steps=int(g["play_steps"]), incremental=incremental)
+    assert st.stride == int(g["stride"])
+    got = _feed(st, g)
+    assert [len(c) for c in got] == [len(c) for c in want]
+    for a, b in zip(got, want):
+        assert np.allclose(a, b, atol=2e-6), float(np.abs(a - b).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("incremental", [False, True])
+def test_streamer_chunks_equal_reference_streamer_hip_codec(incremental):
+    import cases as C
+    import parler_tts_amd as P
+
+    g, want = _gold()
+    m, *_ = C.tiny_model(seed=0)  # its DAC weights are DA.make_dac_weights(DAC_TINY, seed=4321): the codec of the golden stream
+    assert int(g["dac_seed"]) == 4321
+    m = m.to("cuda")
+    m.generation_config = _gc()
+    st = P.ParlerTTSStreamer(m, device="cuda", play_steps=int(g["play_steps"]), incremental=incremental)
+    assert st.stride == int(g["stride"])
+    got = _feed(st, g)
+    assert [len(c) for c in got] == [len(c) for c in want]
+    for a, b in zip(got, want):
+        assert np.allclose(a, b, atol=1e-4), float(np.abs(a - b).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec_name,T,first,n,halo", [("tiny", 50, 0, 50, 13), ("tiny", 50, 17, 20, 16), ("44k", 120, 60, 43, 13), ("44k", 120, 100, 20, 20)])
+def test_dac_decode_chunk_equals_full_decode_window(spec_name, T, first, n, halo):
+    """ptts_dac_decode_chunk: the samples of frames [first, first + n) from a window with `halo` frames of left context equal
+    the same samples of a decode of frames [0, first + n) (no right context in either: the streaming situation)."""
+    from parler_tts_amd.engine import DacEngine
+    from parler_tts_amd.synthetic import random_dac_state_dict
+
+    if spec_name == "tiny":
+        spec, dsd = DA.DAC_TINY, DA.make_dac_weights(DA.DAC_TINY, seed=4321)
+        dac = DacEngine(num_codebooks=spec.num_codebooks, codebook_size=spec.codebook_size, codebook_dim=spec.codebook_dim, latent_dim=spec.latent_dim,
+                        decoder_dim=spec.decoder_dim, rates=spec.decoder_rates, max_batch=2, max_frames=T)
+    else:
+        spec, dsd = DA.DAC_44KHZ, random_dac_state_dict(seed=4321)
+        dac = DacEngine(max_batch=2, max_frames=T)
+    dac.load_state_dict({k: v.cuda() for k, v in dsd.items()})
+    codes = torch.randint(0, 1024, (2, 9, T), generator=torch.Generator().manual_seed(3)).cuda()
+    hop = dac.hop
+    full = dac.decode(codes[:, :, : first + n].contiguous())[:, :, first * hop:]
+    chunk = dac.decode_chunk(codes, first, n, halo)
+    assert chunk.shape == full.shape == (2, 1, n * hop)
+    assert float((chunk - full).abs().max()) <= 1e-5, float((chunk - full).abs().max())
+    with pytest.raises(ValueError, match="bad chunk"):
+        dac.decode_chunk(codes, T - 3, 5, halo)
