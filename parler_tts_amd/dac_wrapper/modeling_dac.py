@@ -98,7 +98,8 @@ class DACModel(torch.nn.Module):
             from huggingface_hub import snapshot_download  # needs network / a local HF cache
 
             path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors"])
-        m = cls(config or DACConfig.from_pretrained(path), **kwargs)
+        own = {k: kwargs[k] for k in ("decoder_dim", "decoder_rates", "codebook_dim") if k in kwargs}  # the rest are hub / Auto* kwargs
+        m = cls(config or DACConfig.from_pretrained(path), **own)
         m.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
         return m
 

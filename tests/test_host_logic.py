@@ -279,3 +279,21 @@ def test_from_sub_models_pretrained_round_trip(tmp_path):
     assert m.prepare_decoder_input_ids_from_labels(labels).tolist() == [[[1025, 5, 7], [1025, 6, 1024]]]
     with pytest.raises(NotImplementedError, match="generate"):
         m(input_ids=torch.zeros(1, 2, dtype=torch.long))
+
+
+def test_dac_codec_is_registered_with_transformers_auto_classes(tmp_path):
+    """The reference's codec plug point (parler_tts/__init__.py:20-25): AutoConfig.register("dac_on_the_hub", DACConfig) and
+    AutoModel.register(DACConfig, DACModel): a DAC directory resolves to this package's config / codec through the Auto classes."""
+    from oracle import dac_oracle as DA
+    from transformers import AutoConfig, AutoModel
+
+    assert P.REGISTERED_WITH_TRANSFORMERS
+    cfg = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2], encoder_dim=16)
+    m = P.DACModel(cfg)
+    m.load_state_dict({"model." + k: v for k, v in DA.make_dac_weights(DA.DAC_TINY, seed=1).items()})
+    m.save_pretrained(str(tmp_path))
+    c2 = AutoConfig.from_pretrained(str(tmp_path))
+    assert c2.model_type == "dac_on_the_hub" and c2.latent_dim == 64 and c2.codebook_size == 1024 and c2.frame_rate == 86
+    m2 = AutoModel.from_pretrained(str(tmp_path))
+    assert isinstance(m2, P.DACModel) and m2.decoder_dim == 256 and tuple(m2.decoder_rates) == (4, 2, 2, 2)
+    assert set(m2.state_dict()) == set(m.state_dict())
