@@ -138,7 +138,8 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
     w_step = L * (4 * H * H + 2 * H * H + 2 * H * F) + Kc * V * H  # 362.3 M for Mini-v1, 1005.9 M for Large-v1
     lc = N_PROMPT + 1 + n_warm + n // 2  # mean self-KV length over the timed replays
     es = 2 if model.dtype == torch.bfloat16 else 4
-    bytes_step = w_step * es + bs * 2 * L * H * (lc + N_DESC) * es + bs * (Kc * H * es + Kc * V * 4)
+    ws = 1 if (getattr(model, "decoder_weights_fp8", False) and bs <= 4) else es  # e4m3 weights are streamed by the GEMV step (batch <= 4)
+    bytes_step = w_step * ws + bs * 2 * L * H * (lc + N_DESC) * es + bs * (Kc * H * es + Kc * V * 4)
     achieved = bytes_step / step_s / 1e9
     traffic, tnote = None, "PMC pass not available for this configuration"
     pmc = os.path.join(ROOT, "profiles", f"r02_pmc_step_bs{bs}.json")
@@ -303,7 +304,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bs", type=int, default=1, help="utterances per GPU per step (configs[1]: 1; configs[2]: 32; configs[3]: --model large --bs 1)")
     ap.add_argument("--model", default="mini", choices=["mini", "large"], help="parler-tts-mini-v1 (BASELINE metric) or parler-tts-large-v1 shapes")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8w"], help="fp8w: bf16 engine streaming OCP e4m3 weights in the decode step (BASELINE configs[4])")
     ap.add_argument("--sample", action="store_true", help="do_sample=True (temperature 1.0, top_k 50: the reference's default generation mode) instead of greedy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bs=32 / TTFT side measurements")
@@ -341,8 +342,10 @@ def main():
         import torch.distributed as dist
 
         dist.barrier()
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
     model = build_model(rank, world, device, dtype, args.model)
+    if args.dtype == "fp8w":
+        model.enable_fp8_weights()
     desc, prompt = synthetic_batch(args.bs, rank, device)
     gen_kw = dict(input_ids=desc, prompt_input_ids=prompt, do_sample=False, max_new_tokens=NEW_TOKENS, min_new_tokens=NEW_TOKENS)
     if args.sample:
@@ -381,7 +384,7 @@ def main():
             "metric": "audio-seconds/sec (whole node) + p50 time-to-first-token, Mini-v1 bs=1/32", "value": round(value, 3),
             "unit": "audio-seconds/sec", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": f"synthetic (random-init weights at {mname} shapes, seeded token ids)",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "fp8w": "bf16 activations + KV, e4m3 weights"}[args.dtype], "data": f"synthetic (random-init weights at {mname} shapes, seeded token ids)",
             "config": {"workload": f"{mname} {args.dtype} bs={args.bs}/GPU {'sampling (T=1, top_k=50)' if args.sample else 'greedy'}, {N_DESC} description + "
                                    f"{N_PROMPT} prompt tokens, {FRAMES} frames = {AUDIO_S:.3f} s audio/utterance ({NEW_TOKENS} decoder passes, hipGraph decode, DAC on-GPU)",
                        "global_batch": n_ranks * args.bs, "frames": FRAMES, "parallelism": f"utterance-sharded x{n_ranks}, weights broadcast once"},

@@ -61,6 +61,8 @@ typedef struct {
   int32_t device;        /* HIP device ordinal */
   int32_t num_kv_heads;       /* grouped-query attention, self (repeat_kv :280-289, :449-452): 0 = num_heads (Mini/Large v1) */
   int32_t num_cross_kv_heads; /* cross-attention K/V heads: 0 = num_kv_heads */
+  int32_t weights_fp8;        /* 1 (dtype PTTS_BF16 only): the decode step at batch <= 4 streams OCP e4m3 weights with one power-of-two
+                                 scale per output row (ptts_load_weight_fp8); every other path uses their exact bf16 dequantisation */
 } ptts_config;
 
 /* Generation parameters: the subset of GenerationConfig that generate() consumes (:3395-3552). */
@@ -92,6 +94,11 @@ void ptts_engine_destroy(ptts_engine* e);
  * load_state_dict via from_pretrained (:2469-2488). */
 int ptts_load_weight(ptts_engine* e, const char* name, const void* dev_ptr, int32_t src_dtype,
                      const int64_t* shape, int32_t ndim, void* stream);
+/* weights_fp8 engines (BASELINE configs[4]): e4m3 bytes q_dev uint8 [N, K] + scale_dev float32 [N] of one decode-step projection
+ * matrix (q/k/v/out_proj, encoder_attn q/out_proj, fc1, fc2, lm_heads.k), with W = q * scale[:, None] exactly equal to the tensor
+ * given to ptts_load_weight under the same name (power-of-two scales make the bf16 dequantisation exact). */
+int ptts_load_weight_fp8(ptts_engine* e, const char* name, const uint8_t* q_dev, const float* scale_dev, const int64_t* shape,
+                         int32_t ndim, void* stream);
 /* 0 when every tensor the config requires has been loaded, PTTS_E_MISSING (message lists names) otherwise. */
 int ptts_weights_ready(ptts_engine* e);
 

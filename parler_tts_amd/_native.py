@@ -25,6 +25,7 @@ class PttsConfig(C.Structure):
         ("rope_theta", C.c_float), ("pad_token_id", C.c_int32), ("eos_token_id", C.c_int32), ("bos_token_id", C.c_int32),
         ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_ctx", C.c_int32), ("max_enc", C.c_int32),
         ("max_prompt", C.c_int32), ("device", C.c_int32), ("num_kv_heads", C.c_int32), ("num_cross_kv_heads", C.c_int32),
+        ("weights_fp8", C.c_int32),
     ]
 
 
@@ -53,6 +54,7 @@ SYMBOLS = {
     "ptts_engine_create": (C.c_int, [C.POINTER(PttsConfig), C.POINTER(_VP)]),
     "ptts_engine_destroy": (None, [_VP]),
     "ptts_load_weight": (C.c_int, [_VP, C.c_char_p, _VP, _I32, _I64P, _I32, _VP]),
+    "ptts_load_weight_fp8": (C.c_int, [_VP, C.c_char_p, _VP, _VP, _I64P, _I32, _VP]),
     "ptts_weights_ready": (C.c_int, [_VP]),
     "ptts_set_gen_params": (C.c_int, [_VP, C.POINTER(PttsGenParams)]),
     "ptts_prefill": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),

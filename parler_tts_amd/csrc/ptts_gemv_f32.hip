@@ -1,0 +1,21 @@
+// GEMV step instances: fp32 parity engine (one utterance) + the mode dispatcher.
+#define GV_WT float
+#define GV_W8 false
+#define GV_FN ptts_gemv_launch_f32
+#include "ptts_gemv_launch.inc"
+
+int ptts_gemv_launch_bf16(int pro, int epi, int S, GemvArgs a, hipStream_t st);
+int ptts_gemv_launch_w8(int pro, int epi, int S, GemvArgs a, hipStream_t st);
+
+int ptts_gemv_launch(int mode, int pro, int epi, int S, GemvArgs a, hipStream_t st) {
+  if (mode == GV_BF16) return ptts_gemv_launch_bf16(pro, epi, S, a, st);
+  if (mode == GV_BF16_W8) return ptts_gemv_launch_w8(pro, epi, S, a, st);
+  return ptts_gemv_launch_f32(pro, epi, S, a, st);
+}
+
+bool ptts_gemv_k_ok(int K, int mode) {
+  const int epl = mode == GV_F32 ? 4 : 8;
+  if (K % (64 * epl)) return false;
+  const int nch = K / (64 * epl);
+  return nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8 || nch == 12 || nch == 16 || nch == 24;
+}

@@ -1,44 +1,36 @@
-// Single-utterance decode step (M == 1): row-per-wave GEMV kernels (gfx950 / CDNA4, wave64).
+// Decode step at batch 1..4: row-per-wave GEMV kernels (gfx950 / CDNA4, wave64).
 //
-// Why not the MFMA strip kernel at M == 1 (profiles/r01_bench_bs1_rocprof_summary.txt, r01_sync_and_chain_probes.txt):
+// Why not the MFMA strip kernel at these batch sizes (profiles/r01_bench_bs1_rocprof_summary.txt, r01_sync_and_chain_probes.txt):
 // a 16-row MFMA strip fixes the unit of work at 16 x K weights, so the N = 1024 projections ran on 64 workgroups
 // (32 KB per CU), fc2 on 64 x 128 KB and the fused cross block on 16 x 128 KB, while one CU pulls only ~25-50 GB/s:
 // the step was bound by the per-CU stream of the least parallel kernels plus two workgroup barriers and an LDS
 // cross-wave reduction per node. Here the unit of work is ONE weight row per wave:
-//   * weights row-major [N][K] in the engine dtype (a second copy beside the MFMA-packed one, made at load time);
-//     lane l of a wave reads 16 B chunks c*1 KiB + 16 l of each of its R rows: every wave-load is 1 KiB contiguous,
-//     all R x NCH loads of a wave are in flight before the first wait, N / R waves cover all 256 CUs evenly
-//     (1024 waves: 8 KB per CU for the N = 1024 projections, 32 KB for fc1 / fc2);
-//   * the dot product runs on the VALU (v_dot2c_f32_bf16 / v_fma_f32: an M = 1 product has no reuse for the matrix
-//     core to exploit), the k reduction is one DPP / permlane wave reduction per row: no LDS, no cross-wave step;
-//   * LayerNorm / split-KV combine is done ONCE per workgroup by a dedicated prologue wave that owns no weights
-//     (its VMEM queue holds only the 4 KB row + gamma/beta, so nothing it waits for sits behind a weight burst)
-//     and hands the normalised row to the 4 GEMV waves through LDS in the engine dtype: one barrier per kernel;
+//   * weights row-major [N][K] (a second copy beside the MFMA-packed one, made at load time) in the engine dtype or,
+//     in W8 mode, as OCP e4m3 bytes with one power-of-two scale per row; lane l of a wave reads chunk c*64 + l of each
+//     of its R rows (16 B = 8 bf16 / 4 fp32, or 8 B = 8 e4m3): every wave-load is contiguous, all R x NCH loads of a
+//     wave are in flight before the first wait, N / R waves cover all 256 CUs evenly;
+//   * the dot products run on the VALU (v_dot2c_f32_bf16 / v_fma_f32; W8: v_cvt_pk_f32_fp8 + v_fma_f32) for each of
+//     the M <= 4 utterances against the SAME weight registers, the k reduction is one DPP / permlane wave reduction
+//     per (utterance, row): no LDS, no cross-wave step;
+//   * LayerNorm / split-KV combine is done ONCE per workgroup by dedicated prologue waves (one per utterance) that own
+//     no weights (their VMEM queue holds only the row + gamma/beta, so nothing they wait for sits behind a weight
+//     burst) and hand the normalised rows to the 4 GEMV waves through LDS in the engine dtype: one barrier per kernel;
 //   * COPY prologue (activations already final, in the engine dtype): no LDS and no barrier at all.
 // Reference semantics: modeling_parler_tts.py:983-1074 (layer), :1917-1960 (heads); LayerNorm eps 1e-5 (:961).
 #pragma once
 #include "ptts_common.h"
-
-enum { GV_LN = 0, GV_ATTN = 1, GV_COPY = 2 };
-enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2 };
-
-struct GemvArgs {
-  const void* W;       // row-major [N][K], engine dtype
-  const float* x;      // GV_LN: residual-stream row, fp32 [K]
-  const void* xw;      // GV_COPY: activation row in the engine dtype [K]
-  const float* gamma;  // GV_LN
-  const float* beta;
-  const float* part;   // GV_ATTN: split-KV partials [S][K] (unnormalised) ...
-  const float* stats;  // ... and their (max, sumexp) per head [S][nheads][2]
-  float* out;          // GV_STORE / GV_RESID: fp32 [N]; GV_GELU_WT: engine dtype [N]
-  int N, K, nheads;
-  float invK;
-};
+#include "ptts_gemv.h"
 
 __device__ __forceinline__ float gv_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <typename WT> struct GvDot;
-template <> struct GvDot<bf16_t> {  // 8 bf16 x 8 bf16 -> fp32 (products of two bf16 are exact in fp32)
+template <typename DT> __device__ __forceinline__ void gv_store(DT* p, float v);
+template <> __device__ __forceinline__ void gv_store<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void gv_store<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// one activation chunk (16 B: 8 bf16 / 4 fp32) against one weight chunk
+template <typename WT, bool W8> struct GvDot;
+template <> struct GvDot<bf16_t, false> {  // 8 bf16 x 8 bf16 -> fp32 (products of two bf16 are exact in fp32)
+  typedef uint4 WV;
   typedef __attribute__((ext_vector_type(2))) __bf16 v2bf;
   static __device__ __forceinline__ float run(const uint4& w, const uint4& x, float acc) {
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, w.x), __builtin_bit_cast(v2bf, x.x), acc, false);
@@ -48,7 +40,8 @@ template <> struct GvDot<bf16_t> {  // 8 bf16 x 8 bf16 -> fp32 (products of two 
     return acc;
   }
 };
-template <> struct GvDot<float> {
+template <> struct GvDot<float, false> {
+  typedef uint4 WV;
   static __device__ __forceinline__ float run(const uint4& w, const uint4& x, float acc) {
     acc = fmaf(__uint_as_float(w.x), __uint_as_float(x.x), acc);
     acc = fmaf(__uint_as_float(w.y), __uint_as_float(x.y), acc);
@@ -57,6 +50,25 @@ template <> struct GvDot<float> {
     return acc;
   }
 };
+template <> struct GvDot<bf16_t, true> {  // 8 e4m3 weights (exact in fp32) x 8 bf16 activations (exact in fp32), fp32 fma chain
+  typedef uint2 WV;
+  static __device__ __forceinline__ float run(const uint2& w, const uint4& x, float acc) {
+    const auto w01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.x, false), w23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.x, true);
+    const auto w45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.y, false), w67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w.y, true);
+    acc = fmaf(w01[0], __uint_as_float(x.x << 16), acc); acc = fmaf(w01[1], __uint_as_float(x.x & 0xffff0000u), acc);
+    acc = fmaf(w23[0], __uint_as_float(x.y << 16), acc); acc = fmaf(w23[1], __uint_as_float(x.y & 0xffff0000u), acc);
+    acc = fmaf(w45[0], __uint_as_float(x.z << 16), acc); acc = fmaf(w45[1], __uint_as_float(x.z & 0xffff0000u), acc);
+    acc = fmaf(w67[0], __uint_as_float(x.w << 16), acc); acc = fmaf(w67[1], __uint_as_float(x.w & 0xffff0000u), acc);
+    return acc;
+  }
+};
+template <typename WV> __device__ __forceinline__ WV gv_ld_nt(const WV* p);
+template <> __device__ __forceinline__ uint4 gv_ld_nt<uint4>(const uint4* p) { return ld_nt16(p); }
+template <> __device__ __forceinline__ uint2 gv_ld_nt<uint2>(const uint2* p) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+  return make_uint2(v.x, v.y);
+}
 
 template <typename WT> __device__ __forceinline__ void gv_lds_store4(char* base, int k, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void gv_lds_store4<float>(char* base, int k, float a, float b, float c, float d) {
@@ -77,12 +89,12 @@ __device__ __forceinline__ void gv_pair_sum(float& s1, float& s2) {
   s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 32));
 }
 
-// prologue wave, LayerNorm: row held in registers (K == NF4 * 256), shifted one-pass mean / variance
+// prologue wave, LayerNorm of one row: row held in registers (K == NF4 * 256), shifted one-pass mean / variance
 template <typename WT, int NF4>
-__device__ __forceinline__ void gv_ln_wave(const GemvArgs& a, char* s_x, int lane) {
+__device__ __forceinline__ void gv_ln_wave(const GemvArgs& a, const float* xr, char* s_x, int lane) {
   float4 v[NF4], g[NF4], bt[NF4];
 #pragma unroll
-  for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(a.x + (lane + 64 * i) * 4);
+  for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
     g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
@@ -106,10 +118,10 @@ __device__ __forceinline__ void gv_ln_wave(const GemvArgs& a, char* s_x, int lan
                       (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
 }
 
-// prologue wave, split-KV combine of the attention partials (attn_kernel wrote unnormalised sums + (max, sumexp) per
+// prologue wave, split-KV combine of one row's attention partials (attn_kernel wrote unnormalised sums + (max, sumexp) per
 // split and head): every load of the wave is issued before the first exp
 template <typename WT, int NF4, int S>
-__device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, char* s_x, int lane) {
+__device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, const float* part, const float* stats, char* s_x, int lane) {
   float4 p[NF4][S];
   float2 st[NF4][S];
 #pragma unroll
@@ -117,8 +129,8 @@ __device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, char* s_x, int l
     const int k = (lane + 64 * i) * 4, head = k >> 6;
 #pragma unroll
     for (int sp = 0; sp < S; ++sp) {
-      st[i][sp] = *reinterpret_cast<const float2*>(a.stats + ((size_t)sp * a.nheads + head) * 2);
-      p[i][sp] = *reinterpret_cast<const float4*>(a.part + (size_t)sp * a.K + k);
+      st[i][sp] = *reinterpret_cast<const float2*>(stats + ((size_t)sp * a.nheads + head) * 2);
+      p[i][sp] = *reinterpret_cast<const float4*>(part + (size_t)sp * a.K + k);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first exp
@@ -140,64 +152,83 @@ __device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, char* s_x, int l
   }
 }
 
-// NCH = 16-byte chunks per lane per weight row (K * sizeof(WT) == NCH * 1024), R = rows per wave, S = KV splits (GV_ATTN).
-template <typename WT, int NCH, int R, int PRO, int EPI, int S>
-__global__ void __launch_bounds__(PRO == GV_COPY ? 256 : 320) gemv_kernel(GemvArgs a) {
+// NCH = chunks per lane per row (K = NCH * 64 * EPL), R = weight rows per wave, S = KV splits (GV_ATTN), MB = utterances the
+// instance is built for (1 or GV_MAX_ROWS; a.M <= MB of them are live), W8 = e4m3 weights + per-row scale.
+template <typename WT, int NCH, int R, int PRO, int EPI, int S, int MB, bool W8>
+__global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_kernel(GemvArgs a) {
   constexpr bool HASPRO = PRO != GV_COPY;
   constexpr int EPL = Elem<WT>::EPL;
-  constexpr int NF4 = NCH * EPL / 4;  // float4 per lane of the fp32 row (K / 256)
-  extern __shared__ __attribute__((aligned(16))) char s_x[];  // HASPRO: the prepared row, engine dtype [K]
+  constexpr int NF4 = NCH * EPL / 4;  // float4 per lane of one fp32 row (K / 256)
+  constexpr int NPW = HASPRO ? MB : 0;  // prologue waves
+  typedef typename GvDot<WT, W8>::WV WV;
+  extern __shared__ __attribute__((aligned(16))) char s_x[];  // HASPRO: the prepared rows, engine dtype [MB][K]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (HASPRO && wave == 0) {
+  const int row_bytes = a.K * (int)sizeof(WT);
+  if (HASPRO && wave < NPW) {
     __builtin_amdgcn_s_setprio(3);
-    if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, s_x, lane);
-    else gv_attn_wave<WT, NF4, S>(a, s_x, lane);
+    if (wave < a.M) {
+      if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * row_bytes, lane);
+      else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * row_bytes, lane);
+    }
     __syncthreads();
     return;
   }
-  const int gw = blockIdx.x * 4 + wave - (HASPRO ? 1 : 0);
+  const int gw = blockIdx.x * 4 + wave - NPW;
   const int r0 = gw * R;
-  // everything this wave will ever load goes in flight now: residual values, (COPY) its activation chunks, its weights
-  float res_pre = 0.f;
-  if (EPI == GV_RESID && lane < R && r0 + lane < a.N) res_pre = a.out[r0 + lane];
-  uint4 xv[NCH];
+  // everything this wave will ever load goes in flight now: residual values, row scales, (COPY) its activation chunks, its weights
+  const int em = lane / R, er = lane - em * R;            // epilogue role of this lane: (utterance, row) = (em, er)
+  const bool elive = lane < MB * R && em < a.M && r0 + er < a.N;
+  float res_pre = 0.f, wsc = 1.f;
+  if (EPI == GV_RESID && elive) res_pre = a.out[(size_t)em * a.out_ld + r0 + er];
+  if (W8 && elive) wsc = a.wscale[r0 + er];
+  uint4 xv[MB][NCH];
   if (!HASPRO) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) xv[c] = reinterpret_cast<const uint4*>(a.xw)[c * 64 + lane];
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        xv[m][c] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.xw) + (size_t)min(m, a.M - 1) * a.xw_ld)[c * 64 + lane];
   }
-  uint4 wv[R][NCH];
+  WV wv[R][NCH];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = min(r0 + r, a.N - 1);  // clamped rows are computed and dropped
-    const uint4* wp = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.W) + (size_t)row * a.K) + lane;
+    const WV* wp = reinterpret_cast<const WV*>(reinterpret_cast<const char*>(a.W) + (size_t)row * a.K * (W8 ? 1 : sizeof(WT))) + lane;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) wv[r][c] = ld_nt16(wp + c * 64);
+    for (int c = 0; c < NCH; ++c) wv[r][c] = gv_ld_nt<WV>(wp + c * 64);
   }
   if (HASPRO) {
     __builtin_amdgcn_sched_barrier(0);  // the weight loads stay above the barrier
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) xv[c] = *reinterpret_cast<const uint4*>(s_x + (size_t)(c * 64 + lane) * 16);
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) xv[m][c] = *reinterpret_cast<const uint4*>(s_x + (size_t)min(m, a.M - 1) * row_bytes + (size_t)(c * 64 + lane) * 16);
   }
-  float acc[R], acc2[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (c & 1) acc2[r] = GvDot<WT>::run(wv[r][c], xv[c], acc2[r]);
-      else acc[r] = GvDot<WT>::run(wv[r][c], xv[c], acc[r]);
-    }
   float v = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float t = wave_sum(acc[r] + acc2[r]);
-    v = lane == r ? t : v;
+  for (int m = 0; m < MB; ++m) {
+    float acc[R], acc2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (c & 1) acc2[r] = GvDot<WT, W8>::run(wv[r][c], xv[m][c], acc2[r]);
+        else acc[r] = GvDot<WT, W8>::run(wv[r][c], xv[m][c], acc[r]);
+      }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float t = wave_sum(acc[r] + acc2[r]);
+      v = lane == m * R + r ? t : v;
+    }
   }
-  if (lane < R && r0 + lane < a.N) {
-    if (EPI == GV_STORE) a.out[r0 + lane] = v;
-    else if (EPI == GV_RESID) a.out[r0 + lane] = res_pre + v;
-    else store_from_f32<WT>(reinterpret_cast<WT*>(a.out) + r0 + lane, gv_gelu_erf(v));
+  if (elive) {
+    if (W8) v *= wsc;
+    float* o = a.out + (size_t)em * a.out_ld + r0 + er;
+    if (EPI == GV_STORE) *o = v;
+    else if (EPI == GV_RESID) *o = res_pre + v;
+    else gv_store<WT>(reinterpret_cast<WT*>(a.out) + (size_t)em * a.out_ld + r0 + er, gv_gelu_erf(v));
   }
 }

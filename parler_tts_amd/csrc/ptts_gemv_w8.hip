@@ -1,0 +1,6 @@
+// GEMV step instances: bf16 engine with OCP e4m3 weights (one power-of-two scale per output row), batch 1 and 2..4.
+#define GV_WT bf16_t
+#define GV_W8 true
+#define GV_MULTI 1
+#define GV_FN ptts_gemv_launch_w8
+#include "ptts_gemv_launch.inc"

@@ -9,7 +9,7 @@
 
 #include "ptts_common.h"
 #include "ptts_lm_kernels.h"
-#include "ptts_gemv_kernels.h"
+#include "ptts_gemv.h"
 
 thread_local std::string g_ptts_err;
 int ptts_fail(int code, const char* fmt, ...) {
@@ -32,6 +32,8 @@ struct LayerW {
   void *k_self = nullptr, *v_self = nullptr, *k_cross = nullptr, *v_cross = nullptr;
   // row-major [N][K] copies in the engine dtype for the single-utterance GEMV step (ptts_gemv_kernels.h); null = path off
   void *qkv_rm = nullptr, *o_rm = nullptr, *cq_rm = nullptr, *co_rm = nullptr, *fc1_rm = nullptr, *fc2_rm = nullptr;
+  // weights_fp8: the row-major copies hold OCP e4m3 bytes, one power-of-two scale per output row
+  float *qkv_sc = nullptr, *o_sc = nullptr, *cq_sc = nullptr, *co_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
 };
 
 }  // namespace
@@ -49,7 +51,11 @@ struct ptts_engine {
   float *lnf_g = nullptr, *lnf_b = nullptr;
   void* heads = nullptr;  // [K*V][H] packed
   void* heads_rm = nullptr;  // [K*V][H] row-major (GEMV step)
-  bool use_gemv = false;     // M == 1 decode step on the row-per-wave GEMV kernels
+  float* heads_sc = nullptr;
+  bool use_gemv = false;     // decode step at batch <= gemv_rows on the row-per-wave GEMV kernels
+  int gemv_rows = 1;         // 1 (fp32 parity engine) or GV_MAX_ROWS
+  bool w8 = false;           // cfg.weights_fp8: e4m3 row-major weights for the GEMV step (the MFMA paths use the exact bf16 dequantisation)
+  std::set<std::string> loaded_fp8, required_fp8;
   std::set<std::string> loaded, required;
   // scratch
   float *h = nullptr, *qkv = nullptr, *qc = nullptr, *part = nullptr, *stats = nullptr, *ffn = nullptr, *logits = nullptr;
@@ -227,75 +233,6 @@ int launch_prep(GemmArgs a, void* dst, hipStream_t st) {
   return PTTS_OK;
 }
 
-// ---- single-utterance GEMV step (ptts_gemv_kernels.h) -------------------------------------------------------
-// rows per wave: enough that N / R waves is ~1024 (4 per CU), bounded by the loads a wave keeps in flight (R * NCH <= 40)
-inline bool gemv_nch_ok(int nch) { return nch == 1 || nch == 2 || nch == 3 || nch == 4 || nch == 6 || nch == 8 || nch == 12 || nch == 16 || nch == 24; }
-inline bool gemv_k_ok(int K, size_t es) { return ((size_t)K * es) % 1024 == 0 && gemv_nch_ok((int)((size_t)K * es / 1024)); }
-inline int gemv_pick_rows(int N, int nch, int rcap) {
-  static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
-  const int want = (N + 1023) / 1024;
-  const int maxr = std::min(rcap, std::max(1, 40 / nch));
-  int r = 1;
-  for (int s : sup)
-    if (s <= maxr) { r = s; if (s >= want) break; }
-  return r;
-}
-
-template <typename WT, int PRO, int EPI, int S, int RCAP, int NCH, int R>
-int gemv_launch_inst(const GemvArgs& a, hipStream_t st) {
-  if constexpr (R * NCH <= 40 && R <= RCAP && (PRO == GV_COPY || NCH * Elem<WT>::EPL <= 32)) {
-    const int waves = (a.N + R - 1) / R;
-    const dim3 grid((waves + 3) / 4), block(PRO == GV_COPY ? 256 : 320);
-    const size_t sh = PRO == GV_COPY ? 0 : (size_t)a.K * sizeof(WT);
-    hipLaunchKernelGGL((gemv_kernel<WT, NCH, R, PRO, EPI, S>), grid, block, sh, st, a);
-    return PTTS_OK;
-  } else {
-    return ptts_fail(PTTS_E_UNSUPPORTED, "gemv: no instance for %d chunks x %d rows", NCH, R);
-  }
-}
-template <typename WT, int PRO, int EPI, int S, int RCAP, int NCH>
-int gemv_launch_nch(const GemvArgs& a, hipStream_t st) {
-  switch (gemv_pick_rows(a.N, NCH, RCAP)) {
-    case 1: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 1>(a, st);
-    case 2: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 2>(a, st);
-    case 3: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 3>(a, st);
-    case 4: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 4>(a, st);
-    case 5: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 5>(a, st);
-    case 6: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 6>(a, st);
-    case 8: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 8>(a, st);
-    default: return gemv_launch_inst<WT, PRO, EPI, S, RCAP, NCH, 10>(a, st);
-  }
-}
-// RCAP bounds the rows per wave that get instantiated for this (prologue, epilogue) pair
-template <typename WT, int PRO, int EPI, int S, int RCAP>
-int gemv_launch(GemvArgs a, hipStream_t st) {
-  a.invK = 1.0f / (float)a.K;
-  int rc;
-  switch ((int)((size_t)a.K * sizeof(WT) / 1024)) {
-    case 1: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 1>(a, st); break;
-    case 2: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 2>(a, st); break;
-    case 3: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 3>(a, st); break;
-    case 4: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 4>(a, st); break;
-    case 6: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 6>(a, st); break;
-    case 8: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 8>(a, st); break;
-    case 12: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 12>(a, st); break;
-    case 16: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 16>(a, st); break;
-    case 24: rc = gemv_launch_nch<WT, PRO, EPI, S, RCAP, 24>(a, st); break;
-    default: return ptts_fail(PTTS_E_UNSUPPORTED, "gemv: K=%d unsupported", a.K);
-  }
-  PTTS_TRY(rc);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemv launch failed: %s", hipGetErrorString(e));
-  return PTTS_OK;
-}
-template <typename WT>
-int gemv_attn_out(GemvArgs a, int S, hipStream_t st) {  // split-KV combine + out_proj + residual
-  if (S == 2) return gemv_launch<WT, GV_ATTN, GV_RESID, 2, 2>(a, st);
-  if (S == 4) return gemv_launch<WT, GV_ATTN, GV_RESID, 4, 2>(a, st);
-  if (S == 8) return gemv_launch<WT, GV_ATTN, GV_RESID, 8, 2>(a, st);
-  return ptts_fail(PTTS_E_UNSUPPORTED, "gemv: %d KV splits", S);
-}
-
 // LN -> GEMM and split-KV-combine -> GEMM: fused prologue at M <= 8 rows, prep kernel + copy staging above (the
 // redundant per-workgroup prologue is 88 % of the GEMM at M = 32: tools/phase_probe, profiles/).
 template <typename WT, int PRO, int EPI>
@@ -344,16 +281,24 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     ea.prefill = prefill ? 1 : 0;
     hipLaunchKernelGGL((embed_kernel<WT>), dim3(Q, B), dim3(256), 0, st, ea);
   }
-  if (e->use_gemv && !prefill && M == 1) {
-    // single utterance: 8 row-per-wave GEMV / attention nodes per layer, every weight matrix spread over all CUs
+  if (e->use_gemv && !prefill && M <= e->gemv_rows) {
+    // batch 1..4: 8 row-per-wave GEMV / attention nodes per layer, every weight matrix spread over all CUs and read once
     const float* rc = c.rope ? e->rope_cos : nullptr;
     const float* rs = c.rope ? e->rope_sin : nullptr;
+    const int mode = c.dtype == PTTS_F32 ? GV_F32 : (e->w8 ? GV_BF16_W8 : GV_BF16);
+    auto gv = [&](int pro, int epi, int S, GemvArgs g, const char* what) -> int {
+      g.M = M;
+      const int rc_ = ptts_gemv_launch(mode, pro, epi, S, g, st);
+      if (rc_ == -1) return ptts_fail(PTTS_E_UNSUPPORTED, "gemv: no instance for %s (N=%d K=%d M=%d)", what, g.N, g.K, M);
+      if (rc_ != 0) return ptts_fail(PTTS_E_HIP, "gemv launch failed (%s)", what);
+      return PTTS_OK;
+    };
     for (int l = 0; l < c.num_layers; ++l) {
       const LayerW& w = e->L[l];
       {  // LN1 + fused QKV projection (:1020-1021, :848-850)
         GemvArgs g = {};
-        g.W = w.qkv_rm; g.x = e->h; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.out = e->qkv; g.N = QKV; g.K = H;
-        PTTS_TRY((gemv_launch<WT, GV_LN, GV_STORE, 1, 10>(g, st)));
+        g.W = w.qkv_rm; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.out = e->qkv; g.out_ld = QKV; g.N = QKV; g.K = H;
+        PTTS_TRY(gv(GV_LN, GV_STORE, 1, g, "LN1+QKV"));
       }
       {  // causal self-attention over the KV arena, fused RoPE + append
         AttnArgs a = {};
@@ -364,18 +309,18 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = 1; a.nheads = nh; a.H = H; a.cross = 0;
         a.fused_append = 1; a.scale = scale;
         a.direct_out = e->S_self == 1 ? e->xw : nullptr;
-        PTTS_TRY((launch_attn<WT>(a, 1, st, e->attn_waves)));
+        PTTS_TRY((launch_attn<WT>(a, B, st, e->attn_waves)));
       }
       {  // [combine splits] + out_proj + residual (:1034)
         GemvArgs g = {};
-        g.W = w.o_rm; g.out = e->h; g.N = H; g.K = H;
-        if (e->S_self == 1) { g.xw = e->xw; PTTS_TRY((gemv_launch<WT, GV_COPY, GV_RESID, 1, 2>(g, st))); }
-        else { g.part = e->part; g.stats = e->stats; g.nheads = nh; PTTS_TRY((gemv_attn_out<WT>(g, e->S_self, st))); }
+        g.W = w.o_rm; g.wscale = w.o_sc; g.out = e->h; g.out_ld = H; g.N = H; g.K = H;
+        if (e->S_self == 1) { g.xw = e->xw; g.xw_ld = H; PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g, "out_proj")); }
+        else { g.part = e->part; g.stats = e->stats; g.nheads = nh; PTTS_TRY(gv(GV_ATTN, GV_RESID, e->S_self, g, "combine+out_proj")); }
       }
       {  // LN2 + cross q projection (:1040, :855)
         GemvArgs g = {};
-        g.W = w.cq_rm; g.x = e->h; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.out = e->qc; g.N = H; g.K = H;
-        PTTS_TRY((gemv_launch<WT, GV_LN, GV_STORE, 1, 10>(g, st)));
+        g.W = w.cq_rm; g.wscale = w.cq_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.out = e->qc; g.out_ld = H; g.N = H; g.K = H;
+        PTTS_TRY(gv(GV_LN, GV_STORE, 1, g, "LN2+cross q"));
       }
       {  // cross-attention against the static description K/V: one workgroup per head, softmax finished in the kernel
         AttnArgs a = {};
@@ -384,26 +329,27 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         a.cos = rc; a.sin = rs;  // quirk: q rotated, keys not (:858 vs :880)
         a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = 1; a.nheads = nh; a.H = H; a.cross = 1;
         a.kv_heads = nkc; a.n_rep = nh / nkc; a.fused_append = 0; a.scale = scale; a.direct_out = e->xw;
-        PTTS_TRY((launch_attn<WT>(a, 1, st, e->cross_waves)));
+        PTTS_TRY((launch_attn<WT>(a, B, st, e->cross_waves)));
       }
       {  // cross out_proj + residual (:1052)
         GemvArgs g = {};
-        g.W = w.co_rm; g.xw = e->xw; g.out = e->h; g.N = H; g.K = H;
-        PTTS_TRY((gemv_launch<WT, GV_COPY, GV_RESID, 1, 2>(g, st)));
+        g.W = w.co_rm; g.wscale = w.co_sc; g.xw = e->xw; g.xw_ld = H; g.out = e->h; g.out_ld = H; g.N = H; g.K = H;
+        PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g, "cross out_proj"));
       }
       {  // LN3 + fc1 + GELU (engine dtype), fc2 + residual (:1059-1064)
         GemvArgs g = {};
-        g.W = w.fc1_rm; g.x = e->h; g.gamma = w.ln3_g; g.beta = w.ln3_b; g.out = reinterpret_cast<float*>(e->xw2); g.N = F; g.K = H;
-        PTTS_TRY((gemv_launch<WT, GV_LN, GV_GELU_WT, 1, 10>(g, st)));
+        g.W = w.fc1_rm; g.wscale = w.fc1_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln3_g; g.beta = w.ln3_b;
+        g.out = reinterpret_cast<float*>(e->xw2); g.out_ld = F; g.N = F; g.K = H;
+        PTTS_TRY(gv(GV_LN, GV_GELU_WT, 1, g, "LN3+fc1"));
         GemvArgs g2 = {};
-        g2.W = w.fc2_rm; g2.xw = e->xw2; g2.out = e->h; g2.N = H; g2.K = F;
-        PTTS_TRY((gemv_launch<WT, GV_COPY, GV_RESID, 1, 2>(g2, st)));
+        g2.W = w.fc2_rm; g2.wscale = w.fc2_sc; g2.xw = e->xw2; g2.xw_ld = F; g2.out = e->h; g2.out_ld = H; g2.N = H; g2.K = F;
+        PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g2, "fc2"));
       }
     }
     GemvArgs g = {};  // final LayerNorm + all K LM heads (:1632, :1917-1960)
-    g.W = e->heads_rm; g.x = e->h; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.out = e->logits;
-    g.N = c.num_codebooks * c.vocab_size; g.K = H;
-    PTTS_TRY((gemv_launch<WT, GV_LN, GV_STORE, 1, 10>(g, st)));
+    g.W = e->heads_rm; g.wscale = e->heads_sc; g.x = e->h; g.x_ld = H; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.out = e->logits;
+    g.out_ld = c.num_codebooks * c.vocab_size; g.N = c.num_codebooks * c.vocab_size; g.K = H;
+    PTTS_TRY(gv(GV_LN, GV_STORE, 1, g, "final LN + LM heads"));
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "forward launch failed: %s", hipGetErrorString(err));
     return PTTS_OK;
@@ -619,7 +565,15 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   const size_t es = e->esize;
   e->L.resize(c.num_layers);
   // single-utterance decode step on the row-per-wave GEMV kernels: shapes whose rows are whole 1 KiB chunks
-  e->use_gemv = gemv_k_ok(H, es) && gemv_k_ok(F, es) && H <= 2048 && !(getenv("PTTS_NO_GEMV") && atoi(getenv("PTTS_NO_GEMV")));
+  const int gmode = c.dtype == PTTS_F32 ? GV_F32 : GV_BF16;
+  e->use_gemv = ptts_gemv_k_ok(H, gmode) && ptts_gemv_k_ok(F, gmode) && H <= 2048 && !(getenv("PTTS_NO_GEMV") && atoi(getenv("PTTS_NO_GEMV")));
+  e->gemv_rows = c.dtype == PTTS_F32 ? 1 : GV_MAX_ROWS;
+  if (const char* ev = getenv("PTTS_GEMV_ROWS")) e->gemv_rows = std::max(1, std::min(e->gemv_rows, atoi(ev)));  // A/B knob (tools/)
+  e->w8 = c.weights_fp8 != 0;
+  if (e->w8 && (c.dtype != PTTS_BF16 || !e->use_gemv)) {
+    ptts_engine_destroy(e);
+    return ptts_fail(PTTS_E_UNSUPPORTED, "weights_fp8 needs the bf16 engine and GEMV-step shapes (hidden / ffn multiples of 512, hidden <= 2048)");
+  }
 #define A(expr) if ((rc = (expr)) != PTTS_OK) return fail(rc)
   for (int l = 0; l < c.num_layers; ++l) {
     LayerW& w = e->L[l];
@@ -631,9 +585,18 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
     A(e->alloc_bytes(&w.fc1, (size_t)F * H * es));
     A(e->alloc_bytes(&w.fc2, (size_t)F * H * es));
     if (e->use_gemv) {
-      A(e->alloc_bytes(&w.qkv_rm, (size_t)(H + 2 * e->nkv * 64) * H * es)); A(e->alloc_bytes(&w.o_rm, (size_t)H * H * es));
-      A(e->alloc_bytes(&w.cq_rm, (size_t)H * H * es)); A(e->alloc_bytes(&w.co_rm, (size_t)H * H * es));
-      A(e->alloc_bytes(&w.fc1_rm, (size_t)F * H * es)); A(e->alloc_bytes(&w.fc2_rm, (size_t)F * H * es));
+      const size_t res = e->w8 ? 1 : es;  // row-major element size: e4m3 bytes or the engine dtype
+      const int nq = H + 2 * e->nkv * 64;
+      A(e->alloc_bytes(&w.qkv_rm, (size_t)nq * H * res)); A(e->alloc_bytes(&w.o_rm, (size_t)H * H * res));
+      A(e->alloc_bytes(&w.cq_rm, (size_t)H * H * res)); A(e->alloc_bytes(&w.co_rm, (size_t)H * H * res));
+      A(e->alloc_bytes(&w.fc1_rm, (size_t)F * H * res)); A(e->alloc_bytes(&w.fc2_rm, (size_t)F * H * res));
+      if (e->w8) {
+        A(e->alloc(&w.qkv_sc, nq)); A(e->alloc(&w.o_sc, H)); A(e->alloc(&w.cq_sc, H)); A(e->alloc(&w.co_sc, H));
+        A(e->alloc(&w.fc1_sc, F)); A(e->alloc(&w.fc2_sc, H));
+        const char* qm[] = {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "encoder_attn.q_proj",
+                            "encoder_attn.out_proj", "fc1", "fc2"};
+        for (const char* m : qm) { char nm[160]; snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.weight", l, m); e->required_fp8.insert(nm); }
+      }
     }
     A(e->alloc(&w.ln1_g, H)); A(e->alloc(&w.ln1_b, H)); A(e->alloc(&w.ln2_g, H)); A(e->alloc(&w.ln2_b, H));
     A(e->alloc(&w.ln3_g, H)); A(e->alloc(&w.ln3_b, H));
@@ -652,7 +615,11 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   }
   A(e->alloc_bytes(&e->embed, (size_t)K * (V + 1) * H * es));
   A(e->alloc_bytes(&e->heads, (size_t)K * V * H * es));
-  if (e->use_gemv) A(e->alloc_bytes(&e->heads_rm, (size_t)K * V * H * es));
+  if (e->use_gemv) A(e->alloc_bytes(&e->heads_rm, (size_t)K * V * H * (e->w8 ? 1 : es)));
+  if (e->w8) {
+    A(e->alloc(&e->heads_sc, (size_t)K * V));
+    for (int k = 0; k < K; ++k) { char nm[96]; snprintf(nm, sizeof nm, "lm_heads.%d.weight", k); e->required_fp8.insert(nm); }
+  }
   A(e->alloc(&e->lnf_g, H)); A(e->alloc(&e->lnf_b, H));
   e->required.insert("model.decoder.layer_norm.weight");
   e->required.insert("model.decoder.layer_norm.bias");
@@ -760,7 +727,7 @@ extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* 
       if (t == m.n) {
         PTTS_TRY(want(m.N, m.Kd));
         PTTS_TRY(pack_dispatch(e, m.dst, dev_ptr, src_dtype, m.N, m.Kd, m.row0, st));
-        if (m.rm) PTTS_TRY(rowmajor_dispatch(e, m.rm, dev_ptr, src_dtype, m.N, m.Kd, m.row0, st));
+        if (m.rm && !e->w8) PTTS_TRY(rowmajor_dispatch(e, m.rm, dev_ptr, src_dtype, m.N, m.Kd, m.row0, st));
         e->loaded.insert(name);
         return PTTS_OK;
       }
@@ -790,14 +757,14 @@ extern "C" int ptts_load_weight(ptts_engine* e, const char* name_c, const void* 
     PTTS_CHECK(k >= 0 && k < K, PTTS_E_INVALID, "%s: codebook index out of range", name_c);
     PTTS_TRY(want(V, H));
     PTTS_TRY(pack_dispatch(e, e->heads, dev_ptr, src_dtype, V, H, k * V, st));
-    if (e->heads_rm) PTTS_TRY(rowmajor_dispatch(e, e->heads_rm, dev_ptr, src_dtype, V, H, k * V, st));
+    if (e->heads_rm && !e->w8) PTTS_TRY(rowmajor_dispatch(e, e->heads_rm, dev_ptr, src_dtype, V, H, k * V, st));
     e->loaded.insert(name);
     return PTTS_OK;
   }
   if (name == "lm_heads.weight") {  // use_fused_lm_heads :1834-1840
     PTTS_TRY(want((int64_t)K * V, H));
     PTTS_TRY(pack_dispatch(e, e->heads, dev_ptr, src_dtype, K * V, H, 0, st));
-    if (e->heads_rm) PTTS_TRY(rowmajor_dispatch(e, e->heads_rm, dev_ptr, src_dtype, K * V, H, 0, st));
+    if (e->heads_rm && !e->w8) PTTS_TRY(rowmajor_dispatch(e, e->heads_rm, dev_ptr, src_dtype, K * V, H, 0, st));
     for (int i = 0; i < K; ++i) { char nm[64]; snprintf(nm, sizeof nm, "lm_heads.%d.weight", i); e->loaded.insert(nm); }
     return PTTS_OK;
   }
@@ -832,6 +799,47 @@ extern "C" int ptts_weights_ready(ptts_engine* e) {
   for (const auto& r : e->required)
     if (!e->loaded.count(r)) { if (n++ < 8) missing += (missing.empty() ? "" : ", ") + r; }
   if (n) return ptts_fail(PTTS_E_MISSING, "%d tensors not loaded: %s%s", n, missing.c_str(), n > 8 ? ", ..." : "");
+  for (const auto& r : e->required_fp8)
+    if (!e->loaded_fp8.count(r)) { if (n++ < 8) missing += (missing.empty() ? "" : ", ") + r; }
+  if (n) return ptts_fail(PTTS_E_MISSING, "%d e4m3 weight copies not loaded (ptts_load_weight_fp8): %s%s", n, missing.c_str(), n > 8 ? ", ..." : "");
+  return PTTS_OK;
+}
+
+// weights_fp8 engines: the OCP e4m3 bytes + per-row power-of-two scales of one projection matrix, quantised by the caller
+// (parler_tts_amd/quant.py) from the SAME tensor whose exact bf16 dequantisation went through ptts_load_weight.
+extern "C" int ptts_load_weight_fp8(ptts_engine* e, const char* name_c, const uint8_t* q_dev, const float* scale_dev, const int64_t* shape,
+                                    int32_t ndim, void* stream) {
+  PTTS_CHECK(e && name_c && q_dev && scale_dev && shape, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(e->w8, PTTS_E_INVALID, "ptts_load_weight_fp8 on an engine created without weights_fp8");
+  PTTS_CHECK(ndim == 2, PTTS_E_INVALID, "%s: expected a matrix", name_c);
+  PTTS_DEVICE(e->cfg.device);
+  hipStream_t st = pick_stream(e, stream);
+  const ptts_config& c = e->cfg;
+  const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size;
+  uint8_t* dst = nullptr;
+  float* sc = nullptr;
+  int N = 0, Kd = 0, row0 = 0, l = -1, k = -1;
+  char tail[128] = {0};
+  if (sscanf(name_c, "model.decoder.layers.%d.%127s", &l, tail) == 2) {
+    PTTS_CHECK(l >= 0 && l < c.num_layers, PTTS_E_INVALID, "%s: layer index out of range", name_c);
+    LayerW& w = e->L[l];
+    const std::string t(tail);
+    struct { const char* n; void* rm; float* sc; int N, Kd, row0; } mats[] = {
+        {"self_attn.q_proj.weight", w.qkv_rm, w.qkv_sc, H, H, 0}, {"self_attn.k_proj.weight", w.qkv_rm, w.qkv_sc, e->nkv * 64, H, H},
+        {"self_attn.v_proj.weight", w.qkv_rm, w.qkv_sc, e->nkv * 64, H, H + e->nkv * 64}, {"self_attn.out_proj.weight", w.o_rm, w.o_sc, H, H, 0},
+        {"encoder_attn.q_proj.weight", w.cq_rm, w.cq_sc, H, H, 0}, {"encoder_attn.out_proj.weight", w.co_rm, w.co_sc, H, H, 0},
+        {"fc1.weight", w.fc1_rm, w.fc1_sc, F, H, 0}, {"fc2.weight", w.fc2_rm, w.fc2_sc, H, F, 0}};
+    for (auto& m : mats)
+      if (t == m.n) { dst = (uint8_t*)m.rm; sc = m.sc; N = m.N; Kd = m.Kd; row0 = m.row0; }
+  } else if (sscanf(name_c, "lm_heads.%d.weight", &k) == 1) {
+    PTTS_CHECK(k >= 0 && k < K, PTTS_E_INVALID, "%s: codebook index out of range", name_c);
+    dst = (uint8_t*)e->heads_rm; sc = e->heads_sc; N = V; Kd = H; row0 = k * V;
+  }
+  PTTS_CHECK(dst && sc, PTTS_E_INVALID, "%s has no e4m3 copy (only the decode-step projection matrices do)", name_c);
+  PTTS_CHECK(shape[0] == N && shape[1] == Kd, PTTS_E_INVALID, "%s: expected shape [%d, %d]", name_c, N, Kd);
+  PTTS_HIP(hipMemcpyAsync(dst + (size_t)row0 * Kd, q_dev, (size_t)N * Kd, hipMemcpyDeviceToDevice, st));
+  PTTS_HIP(hipMemcpyAsync(sc + row0, scale_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+  e->loaded_fp8.insert(name_c);
   return PTTS_OK;
 }
 

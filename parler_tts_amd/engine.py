@@ -10,6 +10,7 @@ from typing import Dict, Iterable, Optional, Tuple
 import torch
 
 from . import _native as N
+from .quant import is_fp8_matrix
 
 
 def _stream_ptr(stream: Optional["torch.cuda.Stream"] = None, device=None) -> C.c_void_p:
@@ -40,7 +41,8 @@ class DecoderEngine:
                  vocab_size: int, max_positions: int, rope: bool = False, rope_theta: float = 10000.0,
                  pad_token_id: int = 1024, eos_token_id: int = 1024, bos_token_id: int = 1025,
                  dtype: torch.dtype = torch.bfloat16, max_batch: int = 1, max_ctx: int = 2700, max_enc: int = 256,
-                 max_prompt: int = 128, device: Optional[torch.device] = None, num_kv_heads: int = 0, num_cross_kv_heads: int = 0):
+                 max_prompt: int = 128, device: Optional[torch.device] = None, num_kv_heads: int = 0, num_cross_kv_heads: int = 0,
+                 weights_fp8: bool = False):
         if not torch.cuda.is_available():
             raise N.NativeLibraryError("DecoderEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = N.load_library()
@@ -53,7 +55,10 @@ class DecoderEngine:
         self.cfg = N.PttsConfig(hidden_size, num_layers, num_heads, ffn_dim, num_codebooks, vocab_size, max_positions, int(rope),
                                 float(rope_theta), pad_token_id, eos_token_id, bos_token_id,
                                 N.PTTS_BF16 if dtype == torch.bfloat16 else N.PTTS_F32, max_batch, max_ctx, max_enc, max_prompt,
-                                self.device.index or 0, int(num_kv_heads or 0), int(num_cross_kv_heads or 0))
+                                self.device.index or 0, int(num_kv_heads or 0), int(num_cross_kv_heads or 0), int(bool(weights_fp8)))
+        self.weights_fp8 = bool(weights_fp8)
+        if self.weights_fp8 and dtype != torch.bfloat16:
+            raise ValueError("weights_fp8 needs the bfloat16 engine (e4m3 weights, bf16 activations)")
         self._h = C.c_void_p()
         N.check(self.lib.ptts_engine_create(C.byref(self.cfg), C.byref(self._h)), "ptts_engine_create")
         self.B = 0
@@ -81,6 +86,18 @@ class DecoderEngine:
         # the engine re-packs asynchronously on the current stream; keep `t` alive until then
         torch.cuda.current_stream(self.device).synchronize()
 
+    def load_weight_fp8(self, name: str, tensor: torch.Tensor):
+        """weights_fp8 engines: quantise one projection matrix (``quant.quantize_rows_e4m3``), hand the exact dequantisation to
+        the ordinary loader (MFMA-packed bf16 copy for prefill / batch > 4) and the e4m3 bytes + row scales to the GEMV step."""
+        from .quant import quantize_rows_e4m3
+
+        q, scale, deq = quantize_rows_e4m3(tensor.detach().to(self.device))
+        self.load_weight(name, deq)
+        q, scale = q.contiguous(), scale.contiguous()
+        N.check(self.lib.ptts_load_weight_fp8(self._h, name.encode(), C.c_void_p(q.data_ptr()), C.c_void_p(scale.data_ptr()), _shape_arr(q), 2,
+                                              _stream_ptr(device=self.device)), f"ptts_load_weight_fp8({name})")
+        torch.cuda.current_stream(self.device).synchronize()
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
         """Accepts the reference's decoder state-dict names, optionally under `prefix`
         (e.g. ``"decoder."`` for a ParlerTTSForConditionalGeneration checkpoint)."""
@@ -91,7 +108,13 @@ class DecoderEngine:
             if name.startswith("model.decoder.") or name.startswith("lm_heads."):
                 if "rotary_emb" in name:
                     continue
-                self.load_weight(name, v)
+                if self.weights_fp8 and name == "lm_heads.weight":  # fused heads (:1834-1840): quantise per codebook slice
+                    for k in range(self.K):
+                        self.load_weight_fp8(f"lm_heads.{k}.weight", v[k * self.V:(k + 1) * self.V])
+                elif self.weights_fp8 and is_fp8_matrix(name):
+                    self.load_weight_fp8(name, v)
+                else:
+                    self.load_weight(name, v)
         if self.rope:
             cos, sin = rope_tables(self.H // self.cfg.num_heads, self.rope_theta, max(self.max_positions, self.cfg.max_ctx))  # RoPE has no position limit (:373-406)
             self.load_weight("rope_cos", cos)

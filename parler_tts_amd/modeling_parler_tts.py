@@ -401,6 +401,15 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     # -- engine ------------------------------------------------------------------------------------------------
+    def enable_fp8_weights(self, enabled: bool = True):
+        """Weight-only OCP e4m3 storage for the decoder's projection matrices (BASELINE configs[4]): the decode step at batch
+        <= 4 streams 1-byte weights with one power-of-two scale per output row; the model must be in bfloat16. Not a reference
+        feature (the reference has no quantised mode): outputs are those of the quantised model, checked against the oracle
+        evaluating the SAME quantised weights (oracle/fp8_oracle.py)."""
+        self.decoder_weights_fp8 = bool(enabled)
+        self._engine = None
+        return self
+
     def _get_engine(self, B: int, N: int, P: int, max_length: int) -> DecoderEngine:
         dev, dt = self.device, self.dtype
         if dev.type != "cuda":
@@ -408,7 +417,10 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if dt not in (torch.float32, torch.bfloat16):
             raise NotImplementedError(f"model dtype {dt}: the HIP engine implements float32 (parity) and bfloat16 (throughput)")
         e = self._engine
-        need = (dev, dt)
+        fp8 = bool(getattr(self, "decoder_weights_fp8", False))
+        if fp8 and dt != torch.bfloat16:
+            raise NotImplementedError("decoder_weights_fp8 needs the model in bfloat16 (e4m3 weights, bf16 activations)")
+        need = (dev, dt, fp8)
         if e is None or self._engine_key != need or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 or e.cfg.max_ctx < P + max_length:
             if e is not None:
                 e.close()
@@ -418,7 +430,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                               rope=d.rope_embeddings, rope_theta=d.rope_theta, pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id,
                               bos_token_id=d.bos_token_id, dtype=dt, max_batch=B, max_ctx=max(P + max_length, 64), max_enc=max(N, 16),
                               max_prompt=max(P + 1, 8), device=dev, num_kv_heads=d.num_key_value_heads,
-                              num_cross_kv_heads=d.num_cross_attention_key_value_heads)
+                              num_cross_kv_heads=d.num_cross_attention_key_value_heads, weights_fp8=fp8)
             e.load_state_dict(self.decoder.state_dict())
             self._engine, self._engine_key = e, need
         return e

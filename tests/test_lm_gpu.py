@@ -208,7 +208,7 @@ def test_mini_width_two_layers_fp32_and_bf16():
         eng.close()
 
 
-def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64):
+def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64, weights_fp8=False, oracle_sd=None):
     g = torch.Generator().manual_seed(seed)
     enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
     prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
@@ -219,11 +219,11 @@ def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, se
         prompt_mask[0, :2] = 0
         enc = enc * enc_mask[..., None]
     step_ids = torch.randint(0, 1024, (steps, bsz * spec.num_codebooks), generator=g)
-    orc = DO.DecoderOracle(spec, sd, precision=prec)
+    orc = DO.DecoderOracle(spec, oracle_sd if oracle_sd is not None else sd, precision=prec)
     ref = [orc.forward(torch.full((bsz * 9, 1), 1025), enc, enc_mask, prompt, prompt_mask)[:, -1]]
     for s in range(steps):
         ref.append(orc.forward(step_ids[s][:, None])[:, -1])
-    eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=max_ctx, max_enc=max(N, 16), max_prompt=P + 1)
+    eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=max_ctx, max_enc=max(N, 16), max_prompt=P + 1, weights_fp8=weights_fp8)
     eng.set_gen_params(max_length=16)
     eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
     outs = [eng.logits().cpu()]
@@ -259,6 +259,41 @@ def test_single_utterance_gemv_step_long_context_all_split_counts():
     for max_ctx in (300, 1100):
         err = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=1, N=9, P=200, steps=40, masks=False, seed=3, max_ctx=max_ctx)
         assert err < 5e-5, (max_ctx, err)
+
+
+@pytest.mark.parametrize("bsz", [2, 3, 4])
+def test_gemv_step_batch_2_to_4(bsz):
+    """Batch 2..4 on the bf16 engine runs the GEMV step with every weight row read once for all utterances (MB = 4 instances:
+    one prologue wave per utterance, M dot products per weight chunk); the fp32 parity engine keeps the MFMA strip path there.
+    Ragged masks per utterance, 5 teacher-forced steps vs the oracle."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=53)
+    for dtype, prec, tol in ((torch.bfloat16, "bf16", 2e-2), (torch.float32, "fp32", 5e-5)):
+        err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=21, P=6, steps=5, masks=True, seed=10 + bsz)
+        assert err < tol, (bsz, prec, err)
+
+
+@pytest.mark.parametrize("width,bsz", [("mini", 1), ("mini", 3), ("mini", 12), ("large", 1), ("large", 4)])
+def test_fp8_weight_mode_matches_the_quantised_oracle(width, bsz):
+    """weights_fp8 (BASELINE configs[4]): the engine quantises the projection matrices itself (e4m3, power-of-two row scales);
+    the oracle evaluates the SAME quantised model (oracle/fp8_oracle.py, hand-rounded e4m3) with its bf16 arithmetic. Batch 1 /
+    3 / 4: GEMV step streaming the 1-byte weights (v_cvt_pk_f32_fp8 + fma); batch 12: MFMA strips on the exact bf16
+    dequantisation. Same tolerance as the bf16 mode: the two sides differ by summation order only."""
+    from oracle import fp8_oracle as FO
+
+    kw = dict(num_hidden_layers=2, max_position_embeddings=512)
+    if width == "large":
+        kw.update(hidden_size=1536, num_attention_heads=24, ffn_dim=6144)
+    spec = DO.DecoderSpec(**kw)
+    sd = DO.make_decoder_weights(spec, seed=59)
+    qsd = FO.quantize_decoder_weights(sd)
+    err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=6, steps=4, masks=True, seed=20 + bsz,
+                                    weights_fp8=True, oracle_sd=qsd)
+    assert err < 2e-2, (width, bsz, err)
+    # and quantisation really happened: the un-quantised bf16 model is measurably different from the fp8 one
+    err_unq = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=6, steps=1, masks=True, seed=20 + bsz,
+                                        weights_fp8=True, oracle_sd=None)
+    assert err_unq > err
 
 
 @pytest.mark.parametrize("bsz", [12, 32])
