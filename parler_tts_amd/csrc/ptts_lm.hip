@@ -64,6 +64,7 @@ struct ptts_engine {
   int nkv = 0, nkc = 0;                // self / cross K/V heads (== num_heads unless grouped-query attention)
   long long* prefix = nullptr;         // voice-prompt codes [max_batch*K][max_ctx], valid for the next prefill when pending_T > 0
   int pending_T = 0;
+  int prefill_T = 0;                   // voice-prompt columns folded into the current prefill pass (batched multi-column prefill)
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   float* lnstat = nullptr;             // strip statistics of the residual rows (EPI_RESID -> PRO_LNS), [max_batch][H/16][2]
   bool use_lns = true;                 // 8 < batch <= 32 decode: LayerNorm fused into the consumer GEMM (no rows_prep node)
@@ -255,7 +256,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   const ptts_config& c = e->cfg;
   const int H = c.hidden_size, F = c.ffn_dim, nh = c.num_heads, B = e->B;
   const int nkv = e->nkv, nkc = e->nkc, Hkv = nkv * 64, QKV = H + 2 * Hkv;  // grouped-query attention: fewer K/V heads
-  const int Q = prefill ? e->P + 1 : 1;
+  const int Q = prefill ? e->P + 1 + e->prefill_T : 1;  // prompt positions + BOS column [+ the voice-prompt columns, run in the same pass]
   const int M = B * Q;
   const bool big = M > 8;
   const float scale = 1.0f / sqrtf((float)(H / nh));
@@ -903,12 +904,22 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   // stage inputs: encoder states -> qc (consumed by the cross K/V projection), prompt embeddings -> ffn
   PTTS_HIP(hipMemcpyAsync(e->qc, enc_dev, (size_t)B * N * H * 4, hipMemcpyDeviceToDevice, st));
   if (P > 0) PTTS_HIP(hipMemcpyAsync(e->ffn, prompt_dev, (size_t)B * P * H * 4, hipMemcpyDeviceToDevice, st));
-  PTTS_TRY(forward_dispatch(e, true, st));
-  // voice prompt (ptts_set_audio_prefix): the T given code columns are teacher-forced one position at a time through the
-  // decode path - the same numbers as the reference's single multi-column forward (causal attention over the same cache)
+  // voice prompt (ptts_set_audio_prefix): the reference runs BOS + the T given code columns in ONE multi-column forward
+  // (:3136-3194, causal attention); so does this prefill whenever the row capacity (max_prompt) holds P + 1 + T positions
+  // per utterance. Otherwise the T columns are teacher-forced one position at a time through the decode path (same numbers:
+  // causal attention over the same cache).
   const int T = e->pending_T;
   e->pending_T = 0;
-  for (int j = 1; j <= T; ++j) {
+  const bool batched = T > 0 && P + 1 + T <= e->max_prompt && !(getenv("PTTS_NO_BATCHED_PREFIX") && atoi(getenv("PTTS_NO_BATCHED_PREFIX")));
+  if (batched) {
+    hipLaunchKernelGGL(push_prefix_all_kernel, dim3((B * K * T + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, T, B, K, c.bos_token_id);
+    e->prefill_T = T;
+  }
+  const int rc_fwd = forward_dispatch(e, true, st);
+  e->prefill_T = 0;
+  PTTS_TRY(rc_fwd);
+  if (batched) hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, T + 1);
+  for (int j = 1; j <= (batched ? 0 : T); ++j) {
     hipLaunchKernelGGL(push_prefix_col_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, j, B, K, c.bos_token_id);
     hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, j + 1);
     PTTS_TRY(forward_dispatch(e, false, st, true));

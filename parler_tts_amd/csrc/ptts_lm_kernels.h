@@ -1259,8 +1259,8 @@ __global__ void embed_kernel(EmbedArgs a) {
   const int b = blockIdx.y;
   const int P = a.dims->P;
   const int qi = blockIdx.x;
-  const int Q = a.prefill ? P + 1 : 1;
-  const int j = a.prefill ? 0 : a.cur_len[b] - 1;      // token column
+  const int Q = a.prefill ? (int)gridDim.x : 1;        // prefill: P prompt positions + the given decoder columns (BOS [+ voice-prompt prefix])
+  const int j = a.prefill ? max(qi - P, 0) : a.cur_len[b] - 1;  // token column
   const int pos = a.prefill ? qi : P + j;              // absolute position (padded prompt ids still count, :1470)
   float* out = a.h + ((size_t)b * Q + qi) * a.H;
   const WT* tab = reinterpret_cast<const WT*>(a.tables);
@@ -1567,6 +1567,14 @@ __global__ void push_prefix_col_kernel(long long* ids, int ids_ld, const DevDims
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= B * K) return;
   const int k = row % K;
+  const DevDims dd = *dims;
+  ids[(size_t)row * ids_ld + j] = j <= k ? (long long)bos : dd.prefix[(size_t)row * dd.prefix_ld + (j - k - 1)];
+}
+// all T voice-prompt columns of the raw ids at once (batched multi-column prefill)
+__global__ void push_prefix_all_kernel(long long* ids, int ids_ld, const DevDims* dims, int T, int B, int K, int bos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * K * T) return;
+  const int row = i / T, j = 1 + i % T, k = row % K;
   const DevDims dd = *dims;
   ids[(size_t)row * ids_ld + j] = j <= k ? (long long)bos : dd.prefix[(size_t)row * dd.prefix_ld + (j - k - 1)];
 }

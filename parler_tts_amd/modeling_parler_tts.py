@@ -410,7 +410,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         self._engine = None
         return self
 
-    def _get_engine(self, B: int, N: int, P: int, max_length: int) -> DecoderEngine:
+    def _get_engine(self, B: int, N: int, P: int, max_length: int, T: int = 0) -> DecoderEngine:
+        """T = voice-prompt frames: the prefill runs the P prompt positions, the BOS column and the T given columns in one pass."""
         dev, dt = self.device, self.dtype
         if dev.type != "cuda":
             raise RuntimeError("generate() runs on the HIP engine only: move the model to a cuda device first (there is no CPU fallback)")
@@ -421,7 +422,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if fp8 and dt != torch.bfloat16:
             raise NotImplementedError("decoder_weights_fp8 needs the model in bfloat16 (e4m3 weights, bf16 activations)")
         need = (dev, dt, fp8)
-        if e is None or self._engine_key != need or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 or e.cfg.max_ctx < P + max_length:
+        if e is None or self._engine_key != need or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 + T or e.cfg.max_ctx < P + max_length:
             if e is not None:
                 e.close()
             d = self.config.decoder
@@ -429,7 +430,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                               num_codebooks=d.num_codebooks, vocab_size=d.vocab_size, max_positions=d.max_position_embeddings,
                               rope=d.rope_embeddings, rope_theta=d.rope_theta, pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id,
                               bos_token_id=d.bos_token_id, dtype=dt, max_batch=B, max_ctx=max(P + max_length, 64), max_enc=max(N, 16),
-                              max_prompt=max(P + 1, 8), device=dev, num_kv_heads=d.num_key_value_heads,
+                              max_prompt=max(P + 1 + T, 8), device=dev, num_kv_heads=d.num_key_value_heads,
                               num_cross_kv_heads=d.num_cross_attention_key_value_heads, weights_fp8=fp8)
             e.load_state_dict(self.decoder.state_dict())
             self._engine, self._engine_key = e, need
@@ -585,7 +586,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             raise ValueError(f"Input length of decoder_input_ids is {T0 + 1}, but `max_length` is set to {max_length}: no room for a generated token")
         if max_length < 2:
             raise ValueError("`max_length` / `max_new_tokens` leave no room for a generated token")
-        eng = self._get_engine(B, N, P, max_length)
+        eng = self._get_engine(B, N, P, max_length, T0)
         do_sample = bool(gc.do_sample)
         manual = (logits_processor is not None and len(logits_processor) > 0) or (stopping_criteria is not None and len(stopping_criteria) > 0)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0  # follows torch.manual_seed()

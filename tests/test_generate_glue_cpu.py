@@ -112,7 +112,7 @@ def _model(eos_gain=None):
     m.decoder.load_state_dict(sd, strict=False)
     dsd = DA.make_dac_weights(DA.DAC_TINY, seed=4321)
     eng = OracleEngine(spec, sd)
-    m._get_engine = lambda B, N, Pp, L: eng
+    m._get_engine = lambda B, N, Pp, L, T=0: eng
     dac = DA.DacOracle(DA.DAC_TINY, dsd)
     m.audio_encoder.decode = lambda audio_codes, audio_scales=None, **kw: types.SimpleNamespace(audio_values=dac.decode(audio_codes[0].cpu()))
 

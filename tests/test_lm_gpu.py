@@ -102,6 +102,31 @@ def test_voice_prompt_prefix_continuation_ids_bit_exact(seed):
     assert torch.equal(eng.generate_ids(enc, None, prompt, None).cpu(), ref0.sequences)
 
 
+@pytest.mark.parametrize("batched", [True, False])
+def test_voice_prompt_batched_multi_column_prefill(batched):
+    """The T voice-prompt columns run in the SAME prefill pass as the prompt + BOS column when the engine's row capacity holds
+    P + 1 + T positions (what generate() allocates), as the reference's single multi-column forward does (:3136-3194); with a
+    smaller capacity they are teacher-forced one position at a time. Both must give the oracle's ids (2 utterances, ragged
+    prompt mask, EOS paths)."""
+    spec, sd, enc, prompt, pre, gp = C.voice_lm_case(C.VOICE_LM_SEEDS[0])
+    T = pre.shape[-1]
+    ref = DO.sample_loop(DO.DecoderOracle(spec, sd), enc, None, prompt, None, gp, decoder_input_ids=pre)
+    assert ref.min_margin >= C.MARGIN
+    P = prompt.shape[1]
+    eng = make_engine(spec, sd, torch.float32, max_batch=1, max_prompt=(P + 1 + T) if batched else (P + 1))
+    eng.set_gen_params(max_length=gp.max_length, min_new_tokens=gp.min_new_tokens)
+    ids = eng.generate_ids(enc, None, prompt, None, poll_every=5, audio_prefix=pre[None]).cpu()
+    assert torch.equal(ids, ref.sequences)
+    # first-step logits of the continuation (position P + 1 + T) vs the oracle's multi-column forward
+    eng.set_audio_prefix(pre[None])
+    eng.prefill(enc, None, prompt, None, sample=False)
+    orc = DO.DecoderOracle(spec, sd)
+    seq0 = torch.cat([torch.full((spec.num_codebooks, 1), spec.bos_token_id), pre], 1)
+    delayed, pattern = DO.build_delay_pattern_mask(seq0, spec.bos_token_id, spec.pad_token_id, gp.max_length, spec.num_codebooks)
+    lg = orc.forward(DO.apply_delay_pattern_mask(delayed, pattern), enc, None, prompt, None)[:, -1]
+    assert (eng.logits().cpu() - lg).abs().max() < 2e-5
+
+
 def test_early_stop_when_all_rows_hit_eos():
     """Every codebook emits EOS as soon as the gate lets it: the loop must end after min_new + K steps, not at
     max_length. All non-EOS LM-head rows are zero, so blocked rows see an all-equal score vector: also checks the
