@@ -143,7 +143,7 @@ __device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, const float* par
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int sp = 0; sp < S; ++sp) {
-      const float w = (st[i][sp].x == -INFINITY) ? 0.f : __expf(st[i][sp].x - mx);
+      const float w = (st[i][sp].x == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[i][sp].x - mx);  // statistics are in log2 units (attn_kernel)
       den += w * st[i][sp].y;
       o.x += w * p[i][sp].x; o.y += w * p[i][sp].y; o.z += w * p[i][sp].z; o.w += w * p[i][sp].w;
     }
@@ -163,12 +163,12 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
   typedef typename GvDot<WT, W8>::WV WV;
   extern __shared__ __attribute__((aligned(16))) char s_x[];  // HASPRO: the prepared rows, engine dtype [MB][K]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row_bytes = a.K * (int)sizeof(WT);
-  if (HASPRO && wave < NPW) {
+  constexpr int ROW_BYTES = NCH * 64 * 16;  // K * sizeof(WT), from the template: no kernel argument is read before the branch below,
+  if (HASPRO && wave < NPW) {             // so each kind of wave fetches its arguments in ONE scalar round trip (two cost ~0.12 us per node)
     __builtin_amdgcn_s_setprio(3);
-    if (wave < a.M) {
-      if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * row_bytes, lane);
-      else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * row_bytes, lane);
+    if (MB == 1 || wave < a.M) {
+      if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * ROW_BYTES, lane);
+      else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
     }
     __syncthreads();
     return;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
   const int r0 = gw * R;
   // everything this wave will ever load goes in flight now: residual values, row scales, (COPY) its activation chunks, its weights
   const int em = lane / R, er = lane - em * R;            // epilogue role of this lane: (utterance, row) = (em, er)
-  const bool elive = lane < MB * R && em < a.M && r0 + er < a.N;
+  const bool elive = lane < MB * R && (MB == 1 || em < a.M) && r0 + er < a.N;
   float res_pre = 0.f, wsc = 1.f;
   if (EPI == GV_RESID && elive) res_pre = a.out[(size_t)em * a.out_ld + r0 + er];
   if (W8 && elive) wsc = a.wscale[r0 + er];
@@ -187,13 +187,13 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
-        xv[m][c] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.xw) + (size_t)min(m, a.M - 1) * a.xw_ld)[c * 64 + lane];
+        xv[m][c] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.xw) + (size_t)(MB == 1 ? 0 : min(m, a.M - 1)) * a.xw_ld)[c * 64 + lane];
   }
   WV wv[R][NCH];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = min(r0 + r, a.N - 1);  // clamped rows are computed and dropped
-    const WV* wp = reinterpret_cast<const WV*>(reinterpret_cast<const char*>(a.W) + (size_t)row * a.K * (W8 ? 1 : sizeof(WT))) + lane;
+    const WV* wp = reinterpret_cast<const WV*>(reinterpret_cast<const char*>(a.W) + (size_t)((unsigned)row * (unsigned)(ROW_BYTES / (W8 ? (int)sizeof(WT) : 1)))) + lane;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) wv[r][c] = gv_ld_nt<WV>(wp + c * 64);
   }
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) xv[m][c] = *reinterpret_cast<const uint4*>(s_x + (size_t)min(m, a.M - 1) * row_bytes + (size_t)(c * 64 + lane) * 16);
+      for (int c = 0; c < NCH; ++c) xv[m][c] = *reinterpret_cast<const uint4*>(s_x + (size_t)(MB == 1 ? 0 : min(m, a.M - 1)) * ROW_BYTES + (size_t)(c * 64 + lane) * 16);
   }
   float v = 0.f;
 #pragma unroll

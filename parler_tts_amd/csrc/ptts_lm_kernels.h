@@ -344,7 +344,7 @@ __device__ __forceinline__ float4 stage_elem(const GemmArgs& a, int m, int k) {
     float4 o = make_float4(0, 0, 0, 0);
     for (int sp = 0; sp < a.S; ++sp) {
       const float ms = st[(size_t)sp * a.nheads * 2], ls = st[(size_t)sp * a.nheads * 2 + 1];
-      const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mx);
+      const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - mx);  // statistics are in log2 units (attn_kernel)
       den += w * ls;
       const float4 t = *reinterpret_cast<const float4*>(a.part + ((size_t)m * a.S + sp) * a.K + k);
       o.x += w * t.x; o.y += w * t.y; o.z += w * t.z; o.w += w * t.w;
@@ -933,8 +933,12 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       reinterpret_cast<uint4*>(Vc + (size_t)pos * 64)[c] = vnew_p;
     }
   }
+  // softmax in base 2: log2(e) is folded into the query scale, every exponential is ONE v_exp_f32 (expf is a ~15-instruction
+  // sequence, 11 of them per lane sat on this kernel's dependent chain); the (max, sumexp) statistics handed to the split-KV
+  // combine are therefore in log2 units too (stage_elem<PRO_ATTN>, gv_attn_wave)
+  const float qscale = a.scale * 1.44269504088896340736f;
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) qv[e] *= a.scale;
+  for (int e = 0; e < EPL; ++e) qv[e] *= qscale;
 
   const int G = (L + RPI - 1) / RPI;
   float m_run = -INFINITY, l_run = 0.f, o[EPL];
@@ -971,13 +975,13 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     bm = across_groups_reduce<OpMax, LPR>(bm);
     const float m_new = fmaxf(m_run, bm);
     if (m_new == -INFINITY) continue;  // wave-uniform: nothing visible yet
-    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
     l_run *= alpha;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] *= alpha;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float p = ok[u] ? expf(sc[u] - m_new) : 0.f;
+      const float p = ok[u] ? __builtin_amdgcn_exp2f(sc[u] - m_new) : 0.f;
       float vx[EPL];
       unpack16(vf[u], vx, WT());
       l_run += p;
@@ -1003,7 +1007,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     float ov = 0.f, lv = 0.f;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      const float wgt = (s_ml[i][0] == -INFINITY) ? 0.f : expf(s_ml[i][0] - M);
+      const float wgt = (s_ml[i][0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s_ml[i][0] - M);
       ov += wgt * s_o[i][tid];
       lv += wgt * s_ml[i][1];
     }
