@@ -99,10 +99,15 @@ def test_streamer_chunks_equal_reference_streamer_hip_codec(incremental):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec_name,T,first,n,halo", [("tiny", 50, 0, 50, 13), ("tiny", 50, 17, 20, 16), ("44k", 120, 60, 43, 13), ("44k", 120, 100, 20, 20)])
+@pytest.mark.parametrize("spec_name,T,first,n,halo", [("tiny", 50, 0, 50, 26), ("tiny", 60, 35, 25, 26), ("44k", 120, 60, 43, 13), ("44k", 120, 100, 20, 20)])
 def test_dac_decode_chunk_equals_full_decode_window(spec_name, T, first, n, halo):
     """ptts_dac_decode_chunk: the samples of frames [first, first + n) from a window with `halo` frames of left context equal
-    the same samples of a decode of frames [0, first + n) (no right context in either: the streaming situation)."""
+    the same samples of a decode of frames [0, first + n) (no right context in either: the streaming situation). The halo is
+    the decoder's one-sided receptive field in latent frames (streamer.receptive_halo_frames): 13 for the 44.1 kHz stack
+    (strides 8, 8, 4, 2), 26 for the tiny test stack (strides 4, 2, 2, 2: smaller strides, wider field in frames)."""
+    from parler_tts_amd.streamer import receptive_halo_frames
+
+    assert receptive_halo_frames((8, 8, 4, 2)) == 13 and receptive_halo_frames((4, 2, 2, 2)) == 26
     from parler_tts_amd.engine import DacEngine
     from parler_tts_amd.synthetic import random_dac_state_dict
 
