@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { GV_LN = 0, GV_ATTN = 1, GV_COPY = 2 };
+enum { GV_LN = 0, GV_ATTN = 1, GV_COPY = 2, GV_SOFTMAX = 3 };  // SOFTMAX: per-head softmax of folded cross-attention scores (ptts_lm_kernels.h: xfold)
 enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2 };
 enum { GV_F32 = 0, GV_BF16 = 1, GV_BF16_W8 = 2 };  // engine dtype of activations / weights; W8 = OCP e4m3 weights, bf16 activations
 
@@ -18,6 +18,9 @@ struct GemvArgs {
   const float* beta;
   const float* part;    // GV_ATTN: split-KV partials [M][S][K] (unnormalised) ...
   const float* stats;   // ... and their (max, sumexp) per head [M][S][nheads][2]
+  const int* mask;      // GV_SOFTMAX: description padding mask int32 [>= NE] (1 = keep) or null; x = scores fp32 [heads][NE]
+  const int* n_valid;   // GV_SOFTMAX: device-resident description length N (positions >= N carry no key)
+  int ne;               // GV_SOFTMAX: positions per head in the folded layout (32 or 64)
   float* out;           // GV_STORE / GV_RESID: fp32 [M][out_ld]; GV_GELU_WT: engine dtype [M][out_ld]
   int x_ld, xw_ld, out_ld;
   int M, N, K, nheads;

@@ -152,6 +152,37 @@ __device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, const float* par
   }
 }
 
+// prologue wave, folded cross-attention (static description K/V folded into the projections at prefill: scores = M x, out = U p):
+// per-head softmax of the K = heads * NE base-2 scores. A head's NE scores sit in NE/4 consecutive lanes of one float4 slot
+// (16 lanes for NE = 64, 8 for NE = 32): max and sum are DPP reductions inside that lane group. Masked / absent positions get 0.
+template <typename WT, int NF4>
+__device__ __forceinline__ void gv_softmax_wave(const GemvArgs& a, char* s_x, int lane) {
+  float4 sc[NF4];
+  int4 mk[NF4];
+  const int nv = *a.n_valid;
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int k = (lane + 64 * i) * 4;
+    sc[i] = *reinterpret_cast<const float4*>(a.x + k);
+    mk[i] = a.mask ? *reinterpret_cast<const int4*>(a.mask + (k & (a.ne - 1))) : make_int4(1, 1, 1, 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int n = ((lane + 64 * i) * 4) & (a.ne - 1);
+    const bool v0 = n < nv && mk[i].x != 0, v1 = n + 1 < nv && mk[i].y != 0, v2 = n + 2 < nv && mk[i].z != 0, v3 = n + 3 < nv && mk[i].w != 0;
+    const float s0 = v0 ? sc[i].x : -INFINITY, s1 = v1 ? sc[i].y : -INFINITY, s2 = v2 ? sc[i].z : -INFINITY, s3 = v3 ? sc[i].w : -INFINITY;
+    float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+    mx = a.ne == 64 ? group_reduce<OpMax, 16>(mx) : group_reduce<OpMax, 8>(mx);
+    const float e0 = v0 ? __builtin_amdgcn_exp2f(s0 - mx) : 0.f, e1 = v1 ? __builtin_amdgcn_exp2f(s1 - mx) : 0.f;
+    const float e2 = v2 ? __builtin_amdgcn_exp2f(s2 - mx) : 0.f, e3 = v3 ? __builtin_amdgcn_exp2f(s3 - mx) : 0.f;
+    float sm = (e0 + e1) + (e2 + e3);
+    sm = a.ne == 64 ? group_reduce<OpSum, 16>(sm) : group_reduce<OpSum, 8>(sm);
+    const float inv = sm > 0.f ? 1.0f / sm : 0.f;
+    gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, e0 * inv, e1 * inv, e2 * inv, e3 * inv);
+  }
+}
+
 // NCH = chunks per lane per row (K = NCH * 64 * EPL), R = weight rows per wave, S = KV splits (GV_ATTN), MB = utterances the
 // instance is built for (1 or GV_MAX_ROWS; a.M <= MB of them are live), W8 = e4m3 weights + per-row scale.
 template <typename WT, int NCH, int R, int PRO, int EPI, int S, int MB, bool W8>
@@ -168,6 +199,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
     __builtin_amdgcn_s_setprio(3);
     if (MB == 1 || wave < a.M) {
       if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * ROW_BYTES, lane);
+      else if (PRO == GV_SOFTMAX) gv_softmax_wave<WT, NF4>(a, s_x, lane);  // single utterance only
       else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
     }
     __syncthreads();

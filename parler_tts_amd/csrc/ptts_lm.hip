@@ -34,6 +34,7 @@ struct LayerW {
   void *qkv_rm = nullptr, *o_rm = nullptr, *cq_rm = nullptr, *co_rm = nullptr, *fc1_rm = nullptr, *fc2_rm = nullptr;
   // weights_fp8: the row-major copies hold OCP e4m3 bytes, one power-of-two scale per output row
   float *qkv_sc = nullptr, *o_sc = nullptr, *cq_sc = nullptr, *co_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
+  void *xM = nullptr, *xU = nullptr;  // folded cross-attention of the current single utterance: M [heads*NE][H], U [H][heads*NE] (engine dtype)
 };
 
 }  // namespace
@@ -54,6 +55,8 @@ struct ptts_engine {
   float* heads_sc = nullptr;
   bool use_gemv = false;     // decode step at batch <= gemv_rows on the row-per-wave GEMV kernels
   int gemv_rows = 1;         // 1 (fp32 parity engine) or GV_MAX_ROWS
+  int xfold_ne = 0;          // > 0: static cross-attention folding available (positions per head in the folded layout)
+  bool xfold_valid = false;  // the folded matrices of the CURRENT call are in place (single utterance)
   bool w8 = false;           // cfg.weights_fp8: e4m3 row-major weights for the GEMV step (the MFMA paths use the exact bf16 dequantisation)
   std::set<std::string> loaded_fp8, required_fp8;
   std::set<std::string> loaded, required;
@@ -83,7 +86,7 @@ struct ptts_engine {
   int B = 0, N = 0, P = 0;
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
-  std::map<int, hipGraphExec_t> graphs;  // key: batch size
+  std::map<int, hipGraphExec_t> graphs;  // key: 2 * batch size + folded-cross-block flag
   int* host_pinned = nullptr;
 
   template <typename T> int alloc(T** p, size_t n) {
@@ -318,6 +321,17 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         if (e->S_self == 1) { g.xw = e->xw; g.xw_ld = H; PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g, "out_proj")); }
         else { g.part = e->part; g.stats = e->stats; g.nheads = nh; PTTS_TRY(gv(GV_ATTN, GV_RESID, e->S_self, g, "combine+out_proj")); }
       }
+      if (e->xfold_valid && M == 1) {
+        // folded cross block (xfold_*_kernel at prefill): LN2 + (K Wq) x -> base-2 scores; per-head softmax + (Wo V^T) p + residual
+        const int K2 = nh * e->xfold_ne, gm = c.dtype == PTTS_F32 ? GV_F32 : GV_BF16;  // M / U are in the engine dtype, never e4m3
+        GemvArgs g = {};
+        g.W = w.xM; g.x = e->h; g.x_ld = H; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.out = e->qc; g.out_ld = K2; g.N = K2; g.K = H; g.M = 1;
+        if (ptts_gemv_launch(gm, GV_LN, GV_STORE, 1, g, st) != 0) return ptts_fail(PTTS_E_HIP, "gemv launch failed (LN2 + folded scores)");
+        GemvArgs g2 = {};
+        g2.W = w.xU; g2.x = e->qc; g2.mask = e->enc_mask; g2.n_valid = &e->dims->N; g2.ne = e->xfold_ne;
+        g2.out = e->h; g2.out_ld = H; g2.N = H; g2.K = K2; g2.M = 1;
+        if (ptts_gemv_launch(gm, GV_SOFTMAX, GV_RESID, 1, g2, st) != 0) return ptts_fail(PTTS_E_HIP, "gemv launch failed (softmax + folded out_proj)");
+      } else {
       {  // LN2 + cross q projection (:1040, :855)
         GemvArgs g = {};
         g.W = w.cq_rm; g.wscale = w.cq_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.out = e->qc; g.out_ld = H; g.N = H; g.K = H;
@@ -336,6 +350,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         GemvArgs g = {};
         g.W = w.co_rm; g.wscale = w.co_sc; g.xw = e->xw; g.xw_ld = H; g.out = e->h; g.out_ld = H; g.N = H; g.K = H;
         PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g, "cross out_proj"));
+      }
       }
       {  // LN3 + fc1 + GELU (engine dtype), fc2 + residual (:1059-1064)
         GemvArgs g = {};
@@ -492,6 +507,24 @@ int launch_tail(ptts_engine* e, hipStream_t st, bool embed_next) {
   return PTTS_OK;
 }
 
+// static cross-attention folding for the utterance just prefilled (xfold_*_kernel): 2 small GEMM-like kernels per layer
+template <typename WT, bool W8>
+int fold_cross(ptts_engine* e, hipStream_t st) {
+  const ptts_config& c = e->cfg;
+  const int H = c.hidden_size, nh = c.num_heads, NE = e->xfold_ne, n_rep = nh / e->nkc;
+  const float qscale = 1.44269504088896340736f / sqrtf((float)(H / nh));
+  for (int l = 0; l < c.num_layers; ++l) {
+    const LayerW& w = e->L[l];
+    hipLaunchKernelGGL((xfold_m_kernel<WT, W8>), dim3((H / 8 + 63) / 64, NE, nh), dim3(64), 0, st, w.cq_rm, w.cq_sc, w.k_cross,
+                       reinterpret_cast<WT*>(w.xM), H, NE, c.max_enc, n_rep, e->dims, qscale);
+    hipLaunchKernelGGL((xfold_u_kernel<WT, W8>), dim3((nh * NE + 63) / 64, H), dim3(64), 0, st, w.co_rm, w.co_sc, w.v_cross,
+                       reinterpret_cast<WT*>(w.xU), H, NE, nh, c.max_enc, n_rep, e->dims);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "cross-attention fold launch failed: %s", hipGetErrorString(err));
+  return PTTS_OK;
+}
+
 int forward_dispatch(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true) {
   return e->cfg.dtype == PTTS_BF16 ? forward<bf16_t>(e, prefill, st, with_embed) : forward<float>(e, prefill, st, with_embed);
 }
@@ -571,6 +604,10 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   e->gemv_rows = c.dtype == PTTS_F32 ? 1 : GV_MAX_ROWS;
   if (const char* ev = getenv("PTTS_GEMV_ROWS")) e->gemv_rows = std::max(1, std::min(e->gemv_rows, atoi(ev)));  // A/B knob (tools/)
   e->w8 = c.weights_fp8 != 0;
+  // static cross-attention folding: single utterance, sinusoidal positions (RoPE rotates the cross query by position), <= 64
+  // description tokens, full cross K/V heads not required (n_rep handled), folded widths must be GEMV shapes
+  if (e->use_gemv && !c.rope && c.max_enc <= 64 && ptts_gemv_k_ok(nh * 64, gmode) && !(getenv("PTTS_NO_XFOLD") && atoi(getenv("PTTS_NO_XFOLD"))))
+    e->xfold_ne = 64;
   if (e->w8 && (c.dtype != PTTS_BF16 || !e->use_gemv)) {
     ptts_engine_destroy(e);
     return ptts_fail(PTTS_E_UNSUPPORTED, "weights_fp8 needs the bf16 engine and GEMV-step shapes (hidden / ffn multiples of 512, hidden <= 2048)");
@@ -591,6 +628,9 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
       A(e->alloc_bytes(&w.qkv_rm, (size_t)nq * H * res)); A(e->alloc_bytes(&w.o_rm, (size_t)H * H * res));
       A(e->alloc_bytes(&w.cq_rm, (size_t)H * H * res)); A(e->alloc_bytes(&w.co_rm, (size_t)H * H * res));
       A(e->alloc_bytes(&w.fc1_rm, (size_t)F * H * res)); A(e->alloc_bytes(&w.fc2_rm, (size_t)F * H * res));
+      if (e->xfold_ne) {
+        A(e->alloc_bytes(&w.xM, (size_t)nh * e->xfold_ne * H * es)); A(e->alloc_bytes(&w.xU, (size_t)nh * e->xfold_ne * H * es));
+      }
       if (e->w8) {
         A(e->alloc(&w.qkv_sc, nq)); A(e->alloc(&w.o_sc, H)); A(e->alloc(&w.cq_sc, H)); A(e->alloc(&w.co_sc, H));
         A(e->alloc(&w.fc1_sc, F)); A(e->alloc(&w.fc2_sc, H));
@@ -915,9 +955,16 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
     hipLaunchKernelGGL(push_prefix_all_kernel, dim3((B * K * T + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, T, B, K, c.bos_token_id);
     e->prefill_T = T;
   }
+  e->xfold_valid = false;  // the prefill itself (and anything before the fold below) runs the un-folded cross-attention
   const int rc_fwd = forward_dispatch(e, true, st);
   e->prefill_T = 0;
   PTTS_TRY(rc_fwd);
+  if (e->xfold_ne && B == 1) {
+    if (c.dtype == PTTS_F32) PTTS_TRY((fold_cross<float, false>(e, st)));
+    else if (e->w8) PTTS_TRY((fold_cross<bf16_t, true>(e, st)));
+    else PTTS_TRY((fold_cross<bf16_t, false>(e, st)));
+    e->xfold_valid = true;
+  }
   if (batched) hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, T + 1);
   for (int j = 1; j <= (batched ? 0 : T); ++j) {
     hipLaunchKernelGGL(push_prefix_col_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, j, B, K, c.bos_token_id);
@@ -933,7 +980,8 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
 // The decode step (170 kernel nodes for Mini-v1 at batch <= 8) is captured ONCE per batch size on the engine's private stream
 // (capture records, it does not execute; the legacy NULL stream cannot be captured) and replayed into the caller's.
 static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
-  auto it = e->graphs.find(e->B);
+  const int key = e->B * 2 + (e->xfold_valid ? 1 : 0);  // the node set of the step depends on the batch size and on the folded cross block
+  auto it = e->graphs.find(key);
   if (it != e->graphs.end()) { *out = it->second; return PTTS_OK; }
   hipGraph_t g = nullptr;
   hipStream_t st = e->own_stream;
@@ -948,7 +996,7 @@ static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
   if (ie != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-  e->graphs[e->B] = ex;
+  e->graphs[key] = ex;
   *out = ex;
   return PTTS_OK;
 }

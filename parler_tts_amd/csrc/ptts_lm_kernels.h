@@ -1213,6 +1213,73 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Static cross-attention folding (single utterance, sinusoidal positions, description <= 64 tokens).
+// The description K/V never change during a call (:872-875), so for one utterance both cross projections can absorb them once
+// at prefill:   scores_h = K_h (Wq_h x) = (K_h Wq_h) x = M_h x        out = Wo concat_h(V_h^T p_h) = sum_h (Wo_h V_h^T) p_h = U p
+// M [heads*NE][H] has exactly the size of Wq (NE = 64 = head_dim) and U [H][heads*NE] the size of Wo, so the decode step streams
+// the same bytes but the cross block becomes TWO GEMV nodes (LN2 + M x; per-head softmax + U p + residual) instead of three
+// (LN2 + q projection, attention kernel, out projection): one dependent ~3.6 us node less per layer. log2(e) / sqrt(d) is folded
+// into M (base-2 softmax). Exact algebra; in bf16 M and U are rounded once to bf16 (the reference rounds q and the context).
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, bool W8> struct RmRow {  // one row-major weight row as fp32: engine dtype, or e4m3 bytes * row scale
+  static __device__ __forceinline__ void ld8(const void* W, const float* sc, int row, int K, int k, float (&o)[8]) {
+    if constexpr (W8) {
+      const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(W) + (size_t)row * K + k);
+      const float s = sc[row];
+      const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+      const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+      o[0] = a[0] * s; o[1] = a[1] * s; o[2] = b[0] * s; o[3] = b[1] * s; o[4] = c[0] * s; o[5] = c[1] * s; o[6] = d[0] * s; o[7] = d[1] * s;
+    } else {
+      const WT* p = reinterpret_cast<const WT*>(W) + (size_t)row * K + k;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = Elem<WT>::ld(p + e);
+    }
+  }
+};
+
+// M[(h*NE + n)][k] = qscale * sum_d K[h/n_rep][n][d] * Wq[h*64 + d][k]; one thread = 8 consecutive k. grid (H/8/64, NE, heads), 64 threads
+template <typename WT, bool W8>
+__global__ void __launch_bounds__(64) xfold_m_kernel(const void* __restrict__ Wq, const float* __restrict__ wsc, const void* __restrict__ kcache,
+                                                     WT* __restrict__ M, int H, int NE, int cap, int n_rep, const DevDims* dims, float qscale) {
+  const int k = (blockIdx.x * 64 + threadIdx.x) * 8, n = blockIdx.y, h = blockIdx.z;
+  if (k >= H) return;
+  WT* out = M + ((size_t)h * NE + n) * H + k;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < dims->N) {
+    const WT* kr = reinterpret_cast<const WT*>(kcache) + ((size_t)(h / n_rep) * cap + n) * 64;
+    for (int d = 0; d < 64; ++d) {
+      const float kd = Elem<WT>::ld(kr + d);
+      float w[8];
+      RmRow<WT, W8>::ld8(Wq, wsc, h * 64 + d, H, k, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(kd, w[e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) store_from_f32<WT>(out + e, acc[e] * qscale);
+}
+
+// U[o][h*NE + n] = sum_d Wo[o][h*64 + d] * V[h/n_rep][n][d]; one thread = one (o, h, n). grid (NE*heads/64, H), 64 threads
+template <typename WT, bool W8>
+__global__ void __launch_bounds__(64) xfold_u_kernel(const void* __restrict__ Wo, const float* __restrict__ wsc, const void* __restrict__ vcache,
+                                                     WT* __restrict__ U, int H, int NE, int heads, int cap, int n_rep, const DevDims* dims) {
+  const int col = blockIdx.x * 64 + threadIdx.x, o = blockIdx.y;
+  if (col >= heads * NE) return;
+  const int h = col / NE, n = col - h * NE;
+  float acc = 0.f;
+  if (n < dims->N) {
+    const WT* vr = reinterpret_cast<const WT*>(vcache) + ((size_t)(h / n_rep) * cap + n) * 64;
+    for (int d0 = 0; d0 < 64; d0 += 8) {
+      float w[8];
+      RmRow<WT, W8>::ld8(Wo, wsc, o, H, h * 64 + d0, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf(w[e], Elem<WT>::ld(vr + d0 + e), acc);
+    }
+  }
+  store_from_f32<WT>(U + (size_t)o * heads * NE + col, acc);
+}
+
 // prefill: write all Q new K/V rows (RoPE on k) into the self cache.  grid (Q, heads, B), 64 threads
 template <typename WT>
 __global__ void kv_append_kernel(const float* __restrict__ knew, const float* __restrict__ vnew, int kv_ld, void* kcache,
