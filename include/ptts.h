@@ -170,13 +170,16 @@ int ptts_dac_weights_ready(ptts_dac* d);
 /* codes_dev int64 [B, K, T] -> wave_dev float32 [B, hop*T]  (hop = prod(rates)). */
 int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream);
 /* Streaming / chunked decode (parler_tts/streamer.py:66-131: `apply_delay_pattern_mask` there re-decodes the whole token
- * cache at every `play_steps`; SURVEY.md §8(b) `ptts_dac_decode_chunk`): samples of frames [first_frame, first_frame + n_frames)
- * of codes_dev int64 [B, K, codes_ld] -> wave_dev float32 [B, hop * n_frames], computed from the window that starts `halo`
- * frames earlier (clamped at frame 0) and ends with the chunk. With halo >= the decoder's one-sided receptive field
- * (13 frames for strides 8, 8, 4, 2) these are exactly the samples a decode of frames [0, first_frame + n_frames) has there,
- * at O(chunk) instead of O(cache). Enqueue it on a second stream to overlap with ptts_decode_steps. */
+ * cache at every `play_steps`; SURVEY.md §8(b) `ptts_dac_decode_chunk`): the window of frames [first_frame - halo (clamped at 0),
+ * first_frame + n_frames) of codes_dev int64 [B, K, codes_ld] is decoded and the samples of its frames [first_frame,
+ * first_frame + n_emit) are written to wave_dev float32 rows of stride wave_ld samples (n_emit <= 0: n_frames; wave_ld <= 0:
+ * hop * n_emit). With halo >= the decoder's one-sided receptive field (13 frames for strides 8, 8, 4, 2):
+ *   - n_emit == n_frames: exactly the samples a decode of frames [0, first_frame + n_frames) has there (the streamer's case:
+ *     nothing exists yet to the right);
+ *   - n_emit == n_frames - halo: exactly the samples of the FULL utterance decode (the frames kept back are the right halo),
+ *     which lets generate() decode finished frames chunk by chunk on a second stream while ptts_decode_steps keeps running. */
 int ptts_dac_decode_chunk(ptts_dac* d, const int64_t* codes_dev, int64_t codes_ld, int32_t first_frame, int32_t n_frames,
-                          int32_t halo, float* wave_dev, int32_t B, void* stream);
+                          int32_t halo, float* wave_dev, int64_t wave_ld, int32_t n_emit, int32_t B, void* stream);
 /* DACModel.encode for voice prompts (dac_wrapper/modeling_dac.py:33-104, used by modeling_parler_tts.py:3136-3194):
  * wave_dev float32 [B, L], L a multiple of the hop (the caller applies model.preprocess's right zero padding, :64)
  * -> codes_dev int64 [B, n_quantizers, L/hop]  (model.encode :95: encoder stack + residual VQ nearest-neighbour search).

@@ -71,7 +71,7 @@ SYMBOLS = {
     "ptts_dac_load_weight": (C.c_int, [_VP, C.c_char_p, _VP, _I64P, _I32, _VP]),
     "ptts_dac_weights_ready": (C.c_int, [_VP]),
     "ptts_dac_decode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
-    "ptts_dac_decode_chunk": (C.c_int, [_VP, _VP, C.c_int64, _I32, _I32, _I32, _VP, _I32, _VP]),
+    "ptts_dac_decode_chunk": (C.c_int, [_VP, _VP, C.c_int64, _I32, _I32, _I32, _VP, C.c_int64, _I32, _I32, _VP]),
     "ptts_dac_encode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "ptts_dac_debug_latents": (C.c_int, [_VP, C.POINTER(_VP)]),
 }

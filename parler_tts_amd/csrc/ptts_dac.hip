@@ -21,6 +21,8 @@
 #include <vector>
 #include <string.h>
 
+#include <algorithm>
+
 #include "ptts_common.h"
 
 namespace {
@@ -153,14 +155,14 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 // final Conv1d(C -> 1, k7, pad 3) + tanh; one thread per output sample, weights [7][C] in LDS.
 // samples [skip, T) of every utterance are written to out[b * out_ld + (t - skip)] (skip > 0: the halo frames of a chunk)
 __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                     float* __restrict__ out, int B, int T, int C, int ktaps, int skip, long long out_ld) {
+                                     float* __restrict__ out, int B, int T, int C, int ktaps, int skip, long long out_ld, int t_end) {
   extern __shared__ float sw[];
   for (int i = threadIdx.x; i < ktaps * C; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * T) return;
   const int b = (int)(idx / T), t = (int)(idx % T);
-  if (t < skip) return;
+  if (t < skip || t >= t_end) return;
   float acc = bias[0];
   for (int tap = 0; tap < ktaps; ++tap) {
     const int ti = t + tap - ktaps / 2;
@@ -712,7 +714,7 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
 
 // decode the window [t0, t0 + T) of codes rows with stride `ld`; samples [skip, hop*T) of the window go to wave_dev rows of out_ld
 static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld, int t0, float* wave_dev, int skip, long long out_ld,
-                             int32_t B, int32_t T, void* stream) {
+                             int32_t B, int32_t T, void* stream, int emit = -1) {
   PTTS_TRY(ptts_dac_weights_ready(d));
   const ptts_dac_config& c = d->cfg;
   PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds dac max_batch %d", B, c.max_batch);
@@ -749,7 +751,7 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
   }
   const size_t n = (size_t)B * Tcur;
   hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)7 * d->out_C * 4, st, cur, d->out_w, d->out_b,
-                     wave_dev, B, Tcur, d->out_C, 7, skip, out_ld);
+                     wave_dev, B, Tcur, d->out_C, 7, skip, out_ld, emit < 0 ? Tcur : std::min(Tcur, skip + emit));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
@@ -765,13 +767,16 @@ extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wav
 // earlier (clamped at 0) and ends at first_frame + n_frames - exactly the samples a decode of frames [0, first_frame + n_frames)
 // yields there whenever `halo` covers the decoder's one-sided receptive field (13 frames for strides 8, 8, 4, 2).
 extern "C" int ptts_dac_decode_chunk(ptts_dac* d, const int64_t* codes_dev, int64_t codes_ld, int32_t first_frame, int32_t n_frames,
-                                     int32_t halo, float* wave_dev, int32_t B, void* stream) {
+                                     int32_t halo, float* wave_dev, int64_t wave_ld, int32_t n_emit, int32_t B, void* stream) {
   PTTS_CHECK(d && codes_dev && wave_dev, PTTS_E_INVALID, "null argument");
   PTTS_CHECK(first_frame >= 0 && n_frames >= 1 && halo >= 0 && (int64_t)first_frame + n_frames <= codes_ld, PTTS_E_INVALID,
              "bad chunk [%d, %d) of %lld frames (halo %d)", first_frame, first_frame + n_frames, (long long)codes_ld, halo);
+  if (n_emit <= 0 || n_emit > n_frames) n_emit = n_frames;
+  if (wave_ld <= 0) wave_ld = (int64_t)d->hop * n_emit;
+  PTTS_CHECK(wave_ld >= (int64_t)d->hop * n_emit, PTTS_E_INVALID, "wave_ld %lld < %d emitted frames", (long long)wave_ld, n_emit);
   const int w0 = first_frame > halo ? first_frame - halo : 0;
-  return dac_decode_window(d, codes_dev, codes_ld, w0, wave_dev, (first_frame - w0) * d->hop, (long long)d->hop * n_frames, B,
-                           first_frame + n_frames - w0, stream);
+  return dac_decode_window(d, codes_dev, codes_ld, w0, wave_dev, (first_frame - w0) * d->hop, wave_ld, B, first_frame + n_frames - w0, stream,
+                           n_emit * d->hop);
 }
 
 // DACModel.encode (dac_wrapper/modeling_dac.py:33-104) for one chunk: wave_dev float32 [B][L] with L a multiple of the hop

@@ -178,15 +178,15 @@ class DACModel(torch.nn.Module):
         return DACDecoderOutput(out)
 
     @torch.no_grad()
-    def decode_chunk(self, audio_codes, first_frame: int, n_frames: Optional[int] = None, halo: int = 16):
+    def decode_chunk(self, audio_codes, first_frame: int, n_frames: Optional[int] = None, halo: int = 16, out=None, n_emit=None):
         """Streaming decode (not in the reference wrapper; its streamer re-decodes the whole cache, streamer.py:119-122):
         audio_codes [1, 1, num_codebooks, frames] → the samples of frames [first_frame, first_frame + n_frames) as
         [1, 1, hop*n_frames], computed from a window with ``halo`` frames of left context (``ptts_dac_decode_chunk``)."""
         codes = audio_codes[0]
         B, _, T = codes.shape
         n_frames = T - first_frame if n_frames is None else n_frames
-        eng = self._get_engine(B, min(T, n_frames + halo))
-        return DACDecoderOutput(eng.decode_chunk(codes, first_frame, n_frames, halo))
+        eng = self._get_engine(B, min(T, n_frames + halo))  # window = n_frames + halo frames
+        return DACDecoderOutput(eng.decode_chunk(codes, first_frame, n_frames, halo, out=out, n_emit=n_emit))
 
     def forward(self, tensor):
         raise ValueError("`DACModel.forward` not implemented yet")  # modeling_dac.py:144-145

@@ -293,20 +293,30 @@ class DacEngine:
         return out
 
 
-    def decode_chunk(self, codes: torch.Tensor, first_frame: int, n_frames: int, halo: int) -> torch.Tensor:
-        """codes int64 [B, K, T] (contiguous, on the device; read in place) → samples of frames [first_frame, first_frame +
-        n_frames) as float32 [B, 1, hop*n_frames], decoded from the window that starts ``halo`` frames earlier
-        (``ptts_dac_decode_chunk``). Enqueued on the CURRENT stream of the engine's device, so a caller can run it on a side
-        stream while the decoder graph replays on the main one."""
+    def decode_chunk(self, codes: torch.Tensor, first_frame: int, n_frames: int, halo: int, out: Optional[torch.Tensor] = None,
+                     n_emit: Optional[int] = None) -> torch.Tensor:
+        """codes int64 [B, K, T] (contiguous, on the device; read in place): decodes the window [first_frame - halo,
+        first_frame + n_frames) and returns the samples of frames [first_frame, first_frame + n_emit) (default: all n_frames) as
+        float32 [B, 1, hop*n_emit] (``ptts_dac_decode_chunk``). ``out``: a float32 [B, >= hop*(first_frame + n_emit)] waveform
+        buffer to write into at sample offset hop*first_frame instead (chunked decode of a whole utterance). Enqueued on the
+        CURRENT stream of the engine's device: a caller can run it on a side stream while the decoder graph replays."""
         if codes.dim() != 3 or codes.shape[1] != self.K:
             raise ValueError(f"audio_codes must be [batch, {self.K}, frames], got {tuple(codes.shape)}")
-        codes = codes.to(self.device, torch.int64).contiguous()
+        if codes.device != self.device or codes.dtype != torch.int64 or not codes.is_contiguous():
+            codes = codes.to(self.device, torch.int64).contiguous()
         B, _, T = codes.shape
-        out = torch.empty(B, 1, self.hop * n_frames, dtype=torch.float32, device=self.device)
+        n_emit = n_frames if n_emit is None else int(n_emit)
+        if out is None:
+            dst = torch.empty(B, 1, self.hop * n_emit, dtype=torch.float32, device=self.device)
+            ptr, ld = dst.data_ptr(), self.hop * n_emit
+        else:
+            if out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] != B or out.stride(1) != 1 or out.shape[1] < self.hop * (first_frame + n_emit):
+                raise ValueError("out must be a float32 [batch, samples] buffer covering the emitted frames")
+            dst, ptr, ld = out, out.data_ptr() + 4 * self.hop * first_frame, out.stride(0)
         N.check(self.lib.ptts_dac_decode_chunk(self._h, C.c_void_p(codes.data_ptr()), T, int(first_frame), int(n_frames), int(halo),
-                                               C.c_void_p(out.data_ptr()), B, _stream_ptr(device=self.device)), "ptts_dac_decode_chunk")
+                                               C.c_void_p(ptr), int(ld), int(n_emit), B, _stream_ptr(device=self.device)), "ptts_dac_decode_chunk")
         self._keep = codes
-        return out
+        return dst
 
     def encode(self, wave: torch.Tensor, n_quantizers: Optional[int] = None) -> torch.Tensor:
         """waveform float32 [B, 1, L] (L a multiple of the hop) → codes int64 [B, n_quantizers, L / hop]."""

@@ -600,7 +600,10 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if streamer is not None:
             streamer.put(delayed.cpu())  # :3533-3534
         eng.set_audio_prefix(prefix)
-        if not manual:
+        wav_pre = None
+        if not manual and streamer is None and dev.type == "cuda" and getattr(self, "overlap_codec", True) and max_length - K >= 96:
+            output_ids, wav_pre = self._run_device_loop_overlap(eng, enc, enc_mask, prompt, prompt_mask, max_length, delayed.shape[1])
+        elif not manual:
             output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, delayed.shape[1])
         else:
             output_ids = self._run_host_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, logits_processor,
@@ -617,7 +620,10 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         cb = self.audio_encoder.config.codebook_size
         bad = codes >= cb
         if not bool(bad.any()):
-            wav = self.audio_encoder.decode(audio_codes=codes[None], audio_scales=[None] * B).audio_values.squeeze(1)
+            if wav_pre is not None and wav_pre.shape == (B, codes.shape[-1] * self._codec_hop()):
+                wav = wav_pre  # decoded chunk by chunk on the side stream while the token loop ran (same samples as one full decode)
+            else:
+                wav = self.audio_encoder.decode(audio_codes=codes[None], audio_scales=[None] * B).audio_values.squeeze(1)
             lengths = [int(wav.shape[1])] * B
         else:  # per-sample: drop every column holding a special id, decode, zero-pad (:3627-3647)
             outs: List[torch.Tensor] = []
@@ -703,6 +709,83 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                 streamer.put(ids[:, j].cpu())
         side.synchronize()
         return eng.ids()
+
+    def _codec_hop(self) -> int:
+        return int(math.prod(getattr(self.audio_encoder, "decoder_rates", (8, 8, 4, 2))))
+
+    def _run_device_loop_overlap(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, given: int = 1):
+        """The default (non-streaming) loop with the codec overlapped (BASELINE configs[4] "streaming DAC decode"): the token
+        graph runs one chunk ahead on the main stream; on a side stream the frames completed by the previous chunk are
+        un-delayed and decoded with ``ptts_dac_decode_chunk`` straight into the final waveform, keeping one receptive field
+        of frames back as the right halo, so the samples are those of ONE full-utterance decode. Falls back (returns no
+        waveform) as soon as a special id (EOS / padding >= codebook_size) shows up: those runs need the reference's
+        per-sample column filter (:3627-3647) before decoding."""
+        from .streamer import receptive_halo_frames
+
+        dev = self.device
+        K = self.config.decoder.num_codebooks
+        ae = self.audio_encoder
+        hop, halo, cb = self._codec_hop(), receptive_halo_frames(getattr(ae, "decoder_rates", (8, 8, 4, 2))), ae.config.codebook_size
+        B, F = enc.shape[0], max_length - K
+        eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.get("_stream_side")
+        if side is None or side.device != dev:
+            side = self.__dict__["_stream_side"] = torch.cuda.Stream(dev)
+        wav = torch.empty(B, F * hop, dtype=torch.float32, device=dev)
+        codes = torch.zeros(B, K, F, dtype=torch.long, device=dev)
+        wav.record_stream(side)
+        codes.record_stream(side)
+        side.wait_stream(main)
+        remaining = max_length - given - 1
+        chunk, pending = 64, []
+        have = emitted = 0
+        ok, done = True, False
+
+        def launch(n):
+            nonlocal remaining
+            if n > 0:
+                eng.decode_steps(n)
+                remaining -= n
+            ev = torch.cuda.Event()
+            ev.record(main)
+            pending.append(ev)
+
+        def absorb(final: bool):
+            nonlocal have, emitted, ok, done
+            cur, done = eng.state()
+            if not ok:
+                return
+            ids = eng.ids().view(B, K, -1)
+            f_new = max(0, min(ids.shape[-1] - K, F))
+            if f_new > have:
+                for k in range(K):  # un-delay: the code of (codebook k, frame f) sits in column f + 1 + k
+                    codes[:, k, have:f_new] = ids[:, k, have + 1 + k: f_new + 1 + k]
+                if bool((codes[:, :, have:f_new] >= cb).any()):
+                    ok = False
+                    return
+                have = f_new
+            keep_back = 0 if (final and have == F) else halo
+            if have - keep_back > emitted:
+                ae.decode_chunk(codes[None], emitted, have - emitted, halo, out=wav, n_emit=have - keep_back - emitted)
+                emitted = have - keep_back
+
+        launch(min(chunk, remaining))
+        launch(min(chunk, remaining))  # one chunk ahead of the codec
+        while pending:
+            pending.pop(0).synchronize()
+            with torch.cuda.stream(side):
+                absorb(final=False)
+            if not done and remaining > 0:
+                launch(min(chunk, remaining))
+            elif done:
+                remaining = 0
+        main.synchronize()
+        with torch.cuda.stream(side):
+            absorb(final=True)
+        side.synchronize()
+        ids = eng.ids()
+        return ids, (wav if (ok and emitted == F and ids.shape[1] == max_length) else None)
 
     # -- user LogitsProcessorList / StoppingCriteria: forward on the HIP engine, selection in torch --------------------------
     def _run_host_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, processors, criteria, streamer, eos, pad,

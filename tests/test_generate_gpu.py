@@ -257,3 +257,32 @@ def test_bf16_model_tracks_the_quantised_oracle():
     wav_ref = DA.DacOracle(DA.DAC_TINY, dsd).decode(DO.valid_frames(codes[0])[None])[0, 0]
     assert wav_ref.shape[0] == b.shape[1]
     assert float((b[0].cpu() - wav_ref).pow(2).mean().sqrt()) <= 0.03 * float(wav_ref.pow(2).mean().sqrt())
+
+
+def test_codec_overlapped_with_the_token_loop_gives_the_full_decode():
+    """generate() without a streamer decodes finished frames chunk by chunk on a side stream while the token graph keeps
+    running (ptts_dac_decode_chunk with left + right halos): the waveform must be bit-identical to the one-shot decode after
+    the loop, and an EOS-terminated run (special ids -> per-sample column filter) must fall back to the sequential branch."""
+    ms, isd = C.GEN_FIXED_SEEDS[False]
+    m, spec, sd, dsd = _tiny_model(seed=ms)
+    m = m.to("cuda")
+    desc, prompt_ids, _ = C.gen_fixed_inputs(isd)
+    kw = dict(input_ids=desc.cuda().repeat(2, 1), prompt_input_ids=prompt_ids.cuda().repeat(2, 1), do_sample=False, max_new_tokens=200,
+              min_new_tokens=200)
+    m.overlap_codec = True
+    a = m.generate(**kw)
+    m.overlap_codec = False
+    b = m.generate(**kw)
+    assert a.shape == b.shape == (2, (201 - 9) * DA.DAC_TINY.hop_length)
+    assert torch.equal(a, b)
+    # EOS-heavy model: ids contain special tokens -> the overlapped loop must hand over to the filtered decode
+    m2, *_ = _tiny_model(seed=C.GEN_EOS_SEEDS[0], eos_gain=6.0)
+    m2 = m2.to("cuda")
+    d2, dm2, p2, pm2, _ = C.gen_eos_inputs(C.GEN_EOS_SEEDS[1])
+    kw2 = dict(input_ids=d2.cuda(), attention_mask=dm2.cuda(), prompt_input_ids=p2.cuda(), prompt_attention_mask=pm2.cuda(), do_sample=False,
+               max_new_tokens=150, min_new_tokens=10, return_dict_in_generate=True)
+    m2.overlap_codec = True
+    o1 = m2.generate(**kw2)
+    m2.overlap_codec = False
+    o2 = m2.generate(**kw2)
+    assert o1["audios_length"] == o2["audios_length"] and torch.equal(o1.sequences, o2.sequences)
