@@ -156,11 +156,27 @@ def test_streamer_thread_protocol():
     prompt_ids = torch.randint(3, 128, (1, 4), generator=g).cuda()
     kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=120, min_new_tokens=120)
     full = m.generate(**kw)[0].cpu().numpy()
-    streamer = P.ParlerTTSStreamer(m, device="cuda", play_steps=20, stride=8)
-    th = threading.Thread(target=m.generate, kwargs=dict(streamer=streamer, **kw))
-    th.start()
-    chunks = [c for c in streamer]
-    th.join()
+    def run(st):  # a generate() thread that dies must not leave the consumer blocked on the queue: record the error, end the stream
+        errs = []
+
+        def target():
+            try:
+                m.generate(streamer=st, **kw)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+                st.on_finalized_audio(np.zeros(0, dtype=np.float32), stream_end=True)
+
+        th = threading.Thread(target=target)
+        th.start()
+        out = [c for c in st]
+        th.join(timeout=120)
+        assert not th.is_alive(), "generate() thread still running"
+        if errs:
+            raise errs[0]
+        return out
+
+    streamer = P.ParlerTTSStreamer(m, device="cuda", play_steps=20, stride=8, timeout=120)
+    chunks = run(streamer)
     audio = np.concatenate(chunks)
     assert len(chunks) >= 3 and audio.shape == full.shape
     # the final flush decodes the complete token cache: its tail must equal the non-streamed waveform's tail
@@ -169,11 +185,8 @@ def test_streamer_thread_protocol():
     # incremental (halo-window) decoding emits exactly the chunks of the reference's full re-decode of the whole cache
     chunks_by_mode = []
     for inc in (True, False):
-        st = P.ParlerTTSStreamer(m, device="cuda", play_steps=20, stride=8, incremental=inc)
-        th = threading.Thread(target=m.generate, kwargs=dict(streamer=st, **kw))
-        th.start()
-        chunks_by_mode.append([c for c in st])
-        th.join()
+        st = P.ParlerTTSStreamer(m, device="cuda", play_steps=20, stride=8, incremental=inc, timeout=120)
+        chunks_by_mode.append(run(st))
     assert [len(c) for c in chunks_by_mode[0]] == [len(c) for c in chunks_by_mode[1]]
     for a_, b_ in zip(*chunks_by_mode):
         assert np.allclose(a_, b_, atol=1e-6)
