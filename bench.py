@@ -147,11 +147,12 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
         j = json.load(open(pmc))
         traffic = int(j["traffic_bytes_per_step"])
         tnote = f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~{j.get('algorithmic_mb', '?')} MB)"
-    nodes = (8 * L + 2) if bs == 1 else ((7 * L + 2) if bs <= 8 else None)
+    folded = bs == 1 and not getattr(d, "rope_embeddings", False) and N_DESC <= 64  # static cross-attention folding
+    nodes = ((7 if folded else 8) * L + 2) if bs <= 4 else ((7 * L + 2) if bs <= 8 else None)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
             "traffic": traffic, "traffic_note": tnote,
             "kernel": "decode-step hipGraph: one hipGraphLaunch per generated frame" + (f" ({nodes} kernel nodes)" if nodes else "")
-                      + (": bs=1 runs 8 row-per-wave GEMV / attention nodes per layer + LM heads + sampler/embed tail" if bs == 1 else ""),
+                      + (f": batch <= 4 runs {7 if folded else 8} row-per-wave GEMV / attention nodes per layer + LM heads + sampler/embed tail" if bs <= 4 else ""),
             "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "context": lc,
             "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
 
