@@ -601,7 +601,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             streamer.put(delayed.cpu())  # :3533-3534
         eng.set_audio_prefix(prefix)
         wav_pre = None
-        if not manual and streamer is None and dev.type == "cuda" and getattr(self, "overlap_codec", True) and max_length - K >= 96:
+        # opt-in (model.overlap_codec = True): on ONE GPU the overlap does not pay (bs=32: 1513 -> 1575 ms per generate(), the codec's
+        # MFMA kernels take CUs from the latency-bound token kernels; bs=1: the per-chunk polling costs what the 5.7 ms decode saves)
+        if not manual and streamer is None and dev.type == "cuda" and getattr(self, "overlap_codec", False) and max_length - K >= 96:
             output_ids, wav_pre = self._run_device_loop_overlap(eng, enc, enc_mask, prompt, prompt_mask, max_length, delayed.shape[1])
         elif not manual:
             output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, delayed.shape[1])
