@@ -44,6 +44,8 @@ struct ptts_engine {
   int max_prompt = 0;  // P + 1 rows capacity per utterance
   size_t esize = 4;
   hipStream_t own_stream = nullptr;
+  hipStream_t fold_stream = nullptr;   // cross-attention folding runs here, beside the rest of the prefill
+  hipEvent_t ev_kv = nullptr, ev_fold = nullptr;  // cross K/V cache written / folded matrices ready
   std::vector<void*> allocs;
   std::vector<LayerW> L;
   void* embed = nullptr;       // [K][V+1][H]
@@ -57,6 +59,7 @@ struct ptts_engine {
   int gemv_rows = 1;         // 1 (fp32 parity engine) or GV_MAX_ROWS
   int xfold_ne = 0;          // > 0: static cross-attention folding available (positions per head in the folded layout)
   bool xfold_valid = false;  // the folded matrices of the CURRENT call are in place (single utterance)
+  bool fold_pending = false; // the fold is still running on fold_stream: the caller's stream has not been made to wait for it yet
   bool w8 = false;           // cfg.weights_fp8: e4m3 row-major weights for the GEMV step (the MFMA paths use the exact bf16 dequantisation)
   std::set<std::string> loaded_fp8, required_fp8;
   std::set<std::string> loaded, required;
@@ -276,6 +279,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       g.kcache = e->L[l].k_cross; g.vcache = e->L[l].v_cross; g.kv_rows_per_b = e->N; g.kv_cap = c.max_enc; g.nheads = nkc;
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_KV>(g, st)));
     }
+    if (e->xfold_ne && B == 1) hipEventRecord(e->ev_kv, st);  // the fold (ptts_prefill) may start now, beside the layer stack
   }
   if (with_embed) {
     EmbedArgs ea = {};
@@ -440,7 +444,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.kv_heads = nkc; a.n_rep = nh / nkc;
       a.fused_append = 0; a.scale = scale;
       a.direct_out = e->xw;  // the description is short: never split, softmax finished in the attention kernel
-      PTTS_TRY((launch_attn<WT>(a, B, st)));
+      PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->cross_waves)));  // decode: as few waves as cover the description (no LDS combine at 1)
     }
     }
     {  // cross out_proj + residual, activations read straight from the attention output
@@ -595,6 +599,9 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   int rc = PTTS_OK;
   auto fail = [&](int r) { ptts_engine_destroy(e); return r; };
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate failed"));
+  if (hipStreamCreateWithFlags(&e->fold_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_kv, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_fold, hipEventDisableTiming) != hipSuccess)
+    return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate / hipEventCreate failed"));
   const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size, nh = c.num_heads;
   const size_t es = e->esize;
   e->L.resize(c.num_layers);
@@ -735,6 +742,9 @@ extern "C" void ptts_engine_destroy(ptts_engine* e) {
   for (void* p : e->allocs) hipFree(p);
   if (e->host_pinned) hipHostFree(e->host_pinned);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
+  if (e->fold_stream) hipStreamDestroy(e->fold_stream);
+  if (e->ev_kv) hipEventDestroy(e->ev_kv);
+  if (e->ev_fold) hipEventDestroy(e->ev_fold);
   delete e;
 }
 
@@ -960,10 +970,19 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   e->prefill_T = 0;
   PTTS_TRY(rc_fwd);
   if (e->xfold_ne && B == 1) {
-    if (c.dtype == PTTS_F32) PTTS_TRY((fold_cross<float, false>(e, st)));
-    else if (e->w8) PTTS_TRY((fold_cross<bf16_t, true>(e, st)));
-    else PTTS_TRY((fold_cross<bf16_t, false>(e, st)));
+    // the fold only needs the cross K/V cache (first kernels of the prefill): it runs on its own stream beside the layer stack,
+    // and what follows on the caller's stream (teacher-forced prefix columns, then every decode step) waits for it; the first
+    // token (tail below) does not, so time-to-first-token is unchanged by the fold
+    static const bool sync_fold = getenv("PTTS_FOLD_SYNC") && atoi(getenv("PTTS_FOLD_SYNC"));
+    hipStream_t fs = sync_fold ? st : e->fold_stream;
+    if (!sync_fold) PTTS_HIP(hipStreamWaitEvent(fs, e->ev_kv, 0));
+    if (c.dtype == PTTS_F32) PTTS_TRY((fold_cross<float, false>(e, fs)));
+    else if (e->w8) PTTS_TRY((fold_cross<bf16_t, true>(e, fs)));
+    else PTTS_TRY((fold_cross<bf16_t, false>(e, fs)));
+    if (!sync_fold) PTTS_HIP(hipEventRecord(e->ev_fold, fs));
     e->xfold_valid = true;
+    e->fold_pending = !sync_fold;
+    if (e->fold_pending && T > 0 && !batched) { PTTS_HIP(hipStreamWaitEvent(st, e->ev_fold, 0)); e->fold_pending = false; }
   }
   if (batched) hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, T + 1);
   for (int j = 1; j <= (batched ? 0 : T); ++j) {
@@ -972,6 +991,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
     PTTS_TRY(forward_dispatch(e, false, st, true));
   }
   if (sample) PTTS_TRY(launch_tail(e, st, true));  // also embeds the sampled column for the first decode step
+  if (e->fold_pending) { PTTS_HIP(hipStreamWaitEvent(st, e->ev_fold, 0)); e->fold_pending = false; }  // later work on st sees the folded matrices
   e->h_ready = sample != 0;
   e->prefilled = true;
   return PTTS_OK;
