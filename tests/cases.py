@@ -140,3 +140,30 @@ def gen_voice_inputs(input_seed):
     voice = 0.3 * torch.randn(1, 1, 32 * 6 - 5, generator=g)  # 6 frames after the preprocess padding
     codes = torch.randint(0, 1024, (9, 6), generator=g)       # a synthetic voice prompt given directly as decoder_input_ids
     return desc, prompt_ids, voice, codes, DO.GenParams(max_length=27, min_new_tokens=20)
+
+
+# ---- generate() at GEMV-step widths: tiny T5 (d_model 128) + enc_to_dec_proj + a 512-wide, 2-layer decoder + tiny DAC ------------------
+GEN_MID_SEEDS = (1, 103)  # (model seed, input seed): oracle margin 3.2e-3
+
+
+def mid_model(seed=1):
+    """hidden 512 (8 heads) / ffn 1024: the smallest shapes the row-per-wave GEMV step, the folded cross block and the e4m3 weight
+    mode are instantiated for; text encoder width 128 != decoder width, so `enc_to_dec_proj` (modeling:2388-2392) is on the path."""
+    import parler_tts_amd as P
+    from oracle import dac_oracle as DA
+    from transformers import T5Config
+
+    torch.manual_seed(seed)
+    t5 = T5Config(vocab_size=128, d_model=128, d_kv=32, d_ff=256, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")
+    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=256, num_hidden_layers=2, ffn_dim=1024, num_attention_heads=8,
+                                   hidden_size=512, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025)
+    dac = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2], encoder_dim=16)
+    m = P.ParlerTTSForConditionalGeneration(P.ParlerTTSConfig.from_sub_models_config(t5, dac, dec, vocab_size=128))
+    spec = DO.DecoderSpec(hidden_size=512, num_attention_heads=8, ffn_dim=1024, num_hidden_layers=2, max_position_embeddings=256)
+    sd = DO.make_decoder_weights(spec, seed=1234 + seed)
+    for k in range(9):
+        sd[f"lm_heads.{k}.weight"][1024:] = 0.0
+    m.decoder.load_state_dict(sd, strict=False)
+    dsd = DA.make_dac_weights(DA.DAC_TINY, seed=4321)
+    m.audio_encoder.load_state_dict({"model." + k: v for k, v in dsd.items()})
+    return m, spec, sd, dsd

@@ -299,3 +299,49 @@ def test_codec_overlapped_with_the_token_loop_gives_the_full_decode():
     m2.overlap_codec = False
     o2 = m2.generate(**kw2)
     assert o1["audios_length"] == o2["audios_length"] and torch.equal(o1.sequences, o2.sequences)
+
+
+def test_generate_at_gemv_widths_with_enc_to_dec_proj_matches_oracle():
+    """512-wide decoder behind a 128-wide text encoder: `enc_to_dec_proj` (:2388-2392) on the conditioning path, the single-
+    utterance GEMV step with the folded cross-attention block and the hipGraph replay inside generate(); fp32 waveform vs the
+    oracle pipeline (seed scanned: margin 3.2e-3)."""
+    ms, isd = C.GEN_MID_SEEDS
+    m, spec, sd, dsd = C.mid_model(ms)
+    assert hasattr(m, "enc_to_dec_proj")
+    m = m.to("cuda")
+    desc, prompt_ids, gp = C.gen_fixed_inputs(isd)
+    wav = m.generate(input_ids=desc.cuda(), prompt_input_ids=prompt_ids.cuda(), do_sample=False, max_new_tokens=30, min_new_tokens=30)
+    tr, wav_ref = _oracle_pipeline(m, spec, sd, dsd, desc, None, prompt_ids, None, gp)
+    assert tr.min_margin >= C.MARGIN
+    assert torch.equal(m._engine.ids().cpu(), tr.sequences)
+    assert float((wav[0].cpu() - wav_ref[0]).pow(2).mean().sqrt()) <= 1e-4
+
+
+def test_generate_with_fp8_weights_tracks_the_quantised_oracle():
+    """model.enable_fp8_weights() (BASELINE configs[4]): bf16 model, decode step streaming e4m3 weights. Every token the engine
+    chose must be (near-)optimal under the oracle that evaluates the SAME quantised model at the same history; switching the
+    mode off again restores the plain bf16 engine."""
+    from oracle import fp8_oracle as FO
+
+    ms, isd = C.GEN_MID_SEEDS
+    m, spec, sd, dsd = C.mid_model(ms)
+    desc, prompt_ids, gp = C.gen_fixed_inputs(isd)
+    m = m.to("cuda").to(dtype=torch.bfloat16).enable_fp8_weights()
+    b = m.generate(input_ids=desc.cuda(), prompt_input_ids=prompt_ids.cuda(), do_sample=False, max_new_tokens=30, min_new_tokens=30)
+    assert m._engine.weights_fp8 and torch.isfinite(b).all() and b.shape == (1, (31 - 9) * DA.DAC_TINY.hop_length)
+    ids = m._engine.ids().cpu()
+    enc = m._encode_description(desc.cuda(), None).float().cpu()
+    prompt = m.embed_prompts(prompt_ids.cuda()).float().cpu()
+    qsd = FO.quantize_decoder_weights(sd)
+    outs = DO.teacher_forced_logits(DO.DecoderOracle(spec, qsd, precision="bf16"), enc, None, prompt, None, ids, gp.max_length)
+    exact, total = 0, 0
+    for s_, lg in enumerate(outs):
+        lg = lg.clone()
+        lg[:, spec.eos_token_id] = -float("inf")
+        gap = lg.max(-1)[0] - lg.gather(1, ids[:, s_ + 1][:, None])[:, 0]
+        assert float(gap.max()) <= 3e-2, (s_, float(gap.max()))
+        exact += int((gap == 0).sum()); total += gap.numel()
+    assert exact >= 0.9 * total, (exact, total)
+    m.enable_fp8_weights(False)
+    m.generate(input_ids=desc.cuda(), prompt_input_ids=prompt_ids.cuda(), do_sample=False, max_new_tokens=12, min_new_tokens=12)
+    assert not m._engine.weights_fp8
