@@ -723,7 +723,8 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->ids, (size_t)c.max_batch * K * e->ids_ld));
   A(e->alloc(&e->cur_len, c.max_batch)); A(e->alloc(&e->unfinished, (size_t)c.max_batch * K));
   A(e->alloc(&e->has_eos, (size_t)c.max_batch * K)); A(e->alloc(&e->first_unf, c.max_batch));
-  A(e->alloc(&e->enc_mask, enc_rows)); A(e->alloc(&e->prompt_mask, rows));
+  A(e->alloc(&e->enc_mask, enc_rows + 64));  // + 64: the folded cross block reads the mask in int4 groups up to position 63 whatever max_enc is
+  A(e->alloc(&e->prompt_mask, rows));
   A(e->alloc(&e->dims, 1)); A(e->alloc(&e->gen, 1));
 #undef A
   if (hipHostMalloc((void**)&e->host_pinned, ((size_t)c.max_batch * K + 16) * 4) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipHostMalloc failed"));
@@ -973,7 +974,9 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
     // the fold only needs the cross K/V cache (first kernels of the prefill): it runs on its own stream beside the layer stack,
     // and what follows on the caller's stream (teacher-forced prefix columns, then every decode step) waits for it; the first
     // token (tail below) does not, so time-to-first-token is unchanged by the fold
-    static const bool sync_fold = getenv("PTTS_FOLD_SYNC") && atoi(getenv("PTTS_FOLD_SYNC"));
+    // (measured: run beside the prefill the fold did not shorten time-to-first-token (8.98 vs 8.44 ms) and the first streamed
+    // chunk came 23 ms later (61.5 vs 38 ms time-to-first-audio): the decode steps wait on the second queue. Default: same stream.)
+    static const bool sync_fold = !(getenv("PTTS_FOLD_ASYNC") && atoi(getenv("PTTS_FOLD_ASYNC")));
     hipStream_t fs = sync_fold ? st : e->fold_stream;
     if (!sync_fold) PTTS_HIP(hipStreamWaitEvent(fs, e->ev_kv, 0));
     if (c.dtype == PTTS_F32) PTTS_TRY((fold_cross<float, false>(e, fs)));
