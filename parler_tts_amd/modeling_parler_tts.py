@@ -191,6 +191,57 @@ def _default_generation_config(config: ParlerTTSConfig):
     return gc  # helpers/model_init_scripts/init_model_600M.py:57-63
 
 
+class _StepPump:
+    """Keeps the decoder graph enqueued at most `max_ahead` steps beyond the oldest chunk boundary still in flight, in pieces of
+    a few steps, polling that boundary's event between pieces. The look-ahead keeps the GPU busy while the host forwards the
+    finished chunk; it is bounded because (a) hipGraphLaunch blocks the calling thread once the hardware queue is full and
+    (b) HIP multiplexes streams onto a few hardware queues: when the side stream shares one with the main stream, its copies
+    and codec kernels run only after everything already enqueued there, so the first audio is late by the look-ahead."""
+
+    def __init__(self, eng, stream, first: int, chunk: int, remaining: int, piece: int = 4, max_ahead: int = 16):
+        self.eng, self.stream, self.chunk, self.piece, self.max_ahead = eng, stream, chunk, piece, max_ahead
+        self.remaining = remaining
+        self.cur_left = first        # steps still to enqueue before the next boundary; -1 = nothing left to enqueue
+        self.in_flight = []          # events of the boundaries enqueued and not yet observed (oldest first)
+        self.after = []              # steps enqueued after in_flight[i] (and before in_flight[i + 1])
+
+    def _enqueue_piece(self):
+        n = min(self.piece, self.cur_left)
+        if n > 0:
+            self.eng.decode_steps(n)
+            self.cur_left -= n
+            self.remaining -= n
+            if self.after:
+                self.after[-1] += n
+        if self.cur_left == 0:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.in_flight.append(ev)
+            self.after.append(0)
+            self.cur_left = min(self.chunk, self.remaining) if self.remaining > 0 else -1
+
+    def stop(self):
+        """every row finished: steps already enqueued are device-side no-ops, enqueue no more"""
+        self.cur_left, self.remaining = -1, 0
+
+    def wait_boundary(self) -> bool:
+        """True once the oldest boundary in flight has completed; False when nothing is in flight and nothing is left."""
+        while True:
+            if self.in_flight and self.in_flight[0].query():
+                break
+            if self.cur_left >= 0 and sum(self.after) < self.max_ahead:
+                self._enqueue_piece()
+                continue
+            if not self.in_flight:
+                return False
+            self.in_flight[0].synchronize()
+            break
+        self.in_flight.pop(0)
+        self.after.pop(0)
+        self.max_ahead = max(self.max_ahead, self.chunk)  # only the FIRST boundary is latency-critical: a full chunk ahead afterwards
+        return True
+
+
 class ParlerTTSForConditionalGeneration(nn.Module):
     config_class = ParlerTTSConfig
     base_model_prefix = "encoder_decoder"
@@ -675,40 +726,24 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         main = torch.cuda.current_stream(self.device)
         side = self.__dict__.get("_stream_side")
         if side is None or side.device != self.device:
-            side = self.__dict__["_stream_side"] = torch.cuda.Stream(self.device)
+            side = self.__dict__["_stream_side"] = torch.cuda.Stream(self.device, priority=-1)  # its own (high-priority) hardware queue
         sent = given
         first = min(max(chunk - given - 1, 0), remaining)  # land exactly on the streamer's first `play_steps` boundary
-        pending = []                     # events of the chunks in flight (oldest first)
-
-        def launch(n):
-            nonlocal remaining
-            if n > 0:
-                eng.decode_steps(n)
-                remaining -= n
-            ev = torch.cuda.Event()
-            ev.record(main)
-            pending.append(ev)
-
-        launch(first)
-        launch(min(chunk, remaining))    # one chunk ahead
-        done = False
-        while pending:
-            pending.pop(0).synchronize()  # the oldest chunk in flight has finished; later ones keep the GPU busy meanwhile
+        pump = _StepPump(eng, main, first, chunk, remaining)
+        while pump.wait_boundary():      # the oldest chunk in flight has finished; later steps keep the GPU busy meanwhile
             with torch.cuda.stream(side):
-                ids = eng.ids()
-                for j in range(sent, ids.shape[1]):
-                    streamer.put(ids[:, j].cpu())
-                sent = ids.shape[1]
+                cols = eng.ids()[:, sent:].cpu()  # one copy for the chunk, then one put per column like `_sample`
+                for j in range(cols.shape[1]):
+                    streamer.put(cols[:, j])
+                sent += cols.shape[1]
                 _, done = eng.state()
-            if not done and remaining > 0:
-                launch(min(chunk, remaining))
-            elif done:
-                remaining = 0
+            if done:
+                pump.stop()
         main.synchronize()
         with torch.cuda.stream(side):
-            ids = eng.ids()
-            for j in range(sent, ids.shape[1]):
-                streamer.put(ids[:, j].cpu())
+            cols = eng.ids()[:, sent:].cpu()
+            for j in range(cols.shape[1]):
+                streamer.put(cols[:, j])
         side.synchronize()
         return eng.ids()
 
@@ -733,25 +768,14 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         main = torch.cuda.current_stream(dev)
         side = self.__dict__.get("_stream_side")
         if side is None or side.device != dev:
-            side = self.__dict__["_stream_side"] = torch.cuda.Stream(dev)
+            side = self.__dict__["_stream_side"] = torch.cuda.Stream(dev, priority=-1)
         wav = torch.empty(B, F * hop, dtype=torch.float32, device=dev)
         codes = torch.zeros(B, K, F, dtype=torch.long, device=dev)
         wav.record_stream(side)
         codes.record_stream(side)
         side.wait_stream(main)
-        remaining = max_length - given - 1
-        chunk, pending = 64, []
         have = emitted = 0
         ok, done = True, False
-
-        def launch(n):
-            nonlocal remaining
-            if n > 0:
-                eng.decode_steps(n)
-                remaining -= n
-            ev = torch.cuda.Event()
-            ev.record(main)
-            pending.append(ev)
 
         def absorb(final: bool):
             nonlocal have, emitted, ok, done
@@ -772,16 +796,13 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                 ae.decode_chunk(codes[None], emitted, have - emitted, halo, out=wav, n_emit=have - keep_back - emitted)
                 emitted = have - keep_back
 
-        launch(min(chunk, remaining))
-        launch(min(chunk, remaining))  # one chunk ahead of the codec
-        while pending:
-            pending.pop(0).synchronize()
+        remaining = max_length - given - 1
+        pump = _StepPump(eng, main, min(64, remaining), 64, remaining, max_ahead=64)  # one chunk ahead of the codec
+        while pump.wait_boundary():
             with torch.cuda.stream(side):
                 absorb(final=False)
-            if not done and remaining > 0:
-                launch(min(chunk, remaining))
-            elif done:
-                remaining = 0
+            if done:
+                pump.stop()
         main.synchronize()
         with torch.cuda.stream(side):
             absorb(final=True)
