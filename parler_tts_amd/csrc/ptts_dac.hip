@@ -43,11 +43,16 @@ struct ConvArgs {
   int stride, Tn;      // input stride of a down-sampling conv (else 1); output frames per phase (Tin unless strided)
 };
 
+// FAST (bf16-operand mode, whose activations are rounded to bf16 anyway): v_sin_f32 on a*x / 2pi instead of the ~100-instruction
+// exact sinf - the Snake epilogue of the 42 M-element layers was ~100 us of VALU per layer (profiles/r02_dac_layers.txt).
+template <bool FAST>
 __device__ __forceinline__ float snake_f(float x, float al) {
+  float s;
 #ifdef PTTS_DAC_FAST_SIN
-  const float s = __sinf(al * x);
+  s = __sinf(al * x);
 #else
-  const float s = sinf(al * x);
+  if constexpr (FAST) s = __sinf(al * x);
+  else s = sinf(al * x);
 #endif
   return x + (1.0f / (al + 1e-9f)) * (s * s);
 }
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
     if (a.out_act) {
       const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
-      const float4 sv = make_float4(snake_f(v.x, al.x), snake_f(v.y, al.y), snake_f(v.z, al.z), snake_f(v.w, al.w));
+      const float4 sv = make_float4(snake_f<BF>(v.x, al.x), snake_f<BF>(v.y, al.y), snake_f<BF>(v.z, al.z), snake_f<BF>(v.w, al.w));
       if (BF && !a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
       else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
     }
@@ -152,29 +157,201 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   if (CS >= 8) { emit(acc[6 % CS][0], 6, 0); emit(acc[6 % CS][1], 6, 1); emit(acc[7 % CS][0], 7, 0); emit(acc[7 % CS][1], 7, 1); }
 }
 
-// final Conv1d(C -> 1, k7, pad 3) + tanh; one thread per output sample, weights [7][C] in LDS.
-// samples [skip, T) of every utterance are written to out[b * out_ld + (t - skip)] (skip > 0: the halo frames of a chunk)
+// LDS-tiled variant of the bf16-operand kernel for the stride-1 layers of the 44.1 kHz stack (k7 dilated convs, k1 convs,
+// the 2-tap phases of the transposed convs): the kernel above fetches every activation fragment from L1/L2 once per TAP and
+// every weight fragment once per WAVE (10 KB per wave per 256 MFMA cycles = 160 B/clk/CU asked of a 64 B/clk L1), and ran at
+// 10 % of the bf16 MFMA peak. Here a workgroup owns 128 consecutive frames x NW*CSW 16-channel strips:
+//   * the activation slab of one KCH-channel chunk ([128 + halo] rows x KCH bf16) is staged ONCE into LDS and read by all
+//     taps (7x fewer global reads) and all waves; rows are RS = KCH*2 + 32 bytes apart: RS/32 is odd, so the 16 lanes of each
+//     ds_read_b128 service group land on 16 distinct 16-byte bank slots for ANY row base (the tap offset tap*dil is arbitrary);
+//   * waves split the output strips (CSW each) and share the frames, so every wave's weight fragments are its own: CSW KB
+//     per wave per k-step from L2/L1 (24 B/clk/CU at CSW = 3), prefetched one k-step ahead in registers, also across chunks;
+//   * two LDS buffers: chunk c+1 is fetched into registers while chunk c computes and committed before the ONE barrier of
+//     the chunk; B fragments are read in two halves of 4 frame tiles, each half in flight under the other half's 12 MFMAs.
+// Per k-step and wave: 24 MFMAs 16x16x32 (384 cycles) against 8 ds_read_b128 + 3 global 16-B loads.
+template <int CSW, int NW, int KS, int MAXHALO>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_lds_kernel(ConvArgs a) {
+  constexpr int FT = 8, TF = FT * 16;
+  constexpr int KCH = 32 * KS;
+  constexpr int RS = KS * 64 + 32;
+  constexpr int SL = KS * 4;  // 16-byte slots per slab row
+  constexpr int NT = NW * 64;
+  constexpr int MAXROWS = TF + MAXHALO;
+  constexpr int NST = (MAXROWS * SL + NT - 1) / NT;  // staged 16-byte pieces per thread and chunk
+  __shared__ __attribute__((aligned(16))) unsigned char slab[2][MAXROWS * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int ntile = (a.Tn + TF - 1) / TF;
+  const int tile = blockIdx.x % ntile, ph = (blockIdx.x / ntile) % a.nphase, b = blockIdx.x / (ntile * a.nphase);
+  const int nstrips = a.Cout / 16;
+  const int strip0 = (blockIdx.y * NW + wave) * CSW;
+  const int cpt = a.Cin / 32, nk = a.ntaps * cpt;
+  const int nchunk = a.Cin / KCH;
+  const int NS = a.ntaps * KS;  // k-steps per chunk
+  const int t0 = tile * TF;
+  // slab row r holds input frame t0 + o0 + r; tap `tap` of output frame t0 + f reads row f + rel(tap)
+  const int o0 = a.transposed ? (ph + a.pad) / a.nphase - (a.ntaps - 1) : -a.pad;
+  const int halo = a.transposed ? a.ntaps - 1 : (a.ntaps - 1) * a.dil;
+  const int nslot = (TF + halo) * SL;
+  const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)b * a.Tin * a.Cin * 2;
+  const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)ph * nstrips + strip0) * nk * 64 + lane;
+  const int lrow = j * RS + q * 16;
+
+  f32x4 acc[CSW][FT];
+#pragma unroll
+  for (int s = 0; s < CSW; ++s)
+#pragma unroll
+    for (int f = 0; f < FT; ++f) acc[s][f] = f32x4{0, 0, 0, 0};
+
+  uint4 stg[NST];
+#define PTTS_SLAB_FETCH(C)                                                                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
+    const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL, ti_ = t0 + o0 + r_;                              \
+    stg[i_] = make_uint4(0, 0, 0, 0);                                                                                    \
+    if (idx_ < nslot && ti_ >= 0 && ti_ < a.Tin)                                                                          \
+      stg[i_] = *reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * a.Cin + (size_t)(C) * KCH) * 2 + sl_ * 16);            \
+  }
+#define PTTS_SLAB_COMMIT(BUF)                                                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
+    const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL;                                                  \
+    if (idx_ < nslot) *reinterpret_cast<uint4*>(&slab[BUF][r_ * RS + sl_ * 16]) = stg[i_];                                 \
+  }
+  // weight fragments of k-step (chunk C, step S): ks = tap * cpt + C * KS + kk
+#define PTTS_W_FETCH(WF, C, S)                                                                                          \
+  do {                                                                                                                  \
+    const int tap_ = (S) / KS, kk_ = (S) - tap_ * KS;                                                                     \
+    const float4* wp_ = Wp + (size_t)(tap_ * cpt + (C) * KS + kk_) * 64;                                                  \
+    _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_) WF[s_] = wp_[(size_t)s_ * nk * 64];                               \
+  } while (0)
+  // B fragments (4 frame tiles from F0) of step S out of buffer SB
+#define PTTS_B_FETCH(BV, SB, S, F0)                                                                                     \
+  do {                                                                                                                  \
+    const int tap_ = (S) / KS, kk_ = (S) - tap_ * KS;                                                                     \
+    const int rel_ = a.transposed ? (a.ntaps - 1 - tap_) : tap_ * a.dil;                                                  \
+    const unsigned char* sp_ = (SB) + (rel_ + (F0) * 16) * RS + kk_ * 64 + lrow;                                          \
+    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) BV[f_] = *reinterpret_cast<const uint4*>(sp_ + f_ * 16 * RS);       \
+  } while (0)
+
+  // One k-step: MFMAs of (chunk c, step st) with the weight fragments WC while WN receives those of the NEXT k-step (possibly the
+  // first of chunk c + 1). Two copies alternate W0 / W1 so that the prefetched registers are never copied (a copy makes the
+  // compiler wait for the loads it has just issued). The last step of a chunk commits the staged slab and holds the chunk's barrier.
+#define PTTS_MFMA_HALF(WC, BV, F0)                                                                                      \
+  _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_)                      \
+    acc[s_][(F0) + f_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WC[s_]), __builtin_bit_cast(bf16x8, BV[f_]), acc[s_][(F0) + f_], 0, 0, 0);
+#define PTTS_STEP(WC, WN)                                                                                               \
+  {                                                                                                                     \
+    const unsigned char* sb_ = slab[c & 1];                                                                               \
+    const bool more_ = c + 1 < nchunk, lastst_ = st + 1 == NS;                                                            \
+    const int nc_ = lastst_ ? c + 1 : c, ns_ = lastst_ ? 0 : st + 1;                                                      \
+    const bool next_ = nc_ < nchunk; /* the prefetch is unconditional (a valid re-fetch at the very end): a branch here */  \
+    if (st == 0 && more_) { PTTS_SLAB_FETCH(c + 1); } /* would merge into a conservative vmcnt on the MFMAs below */       \
+    PTTS_W_FETCH(WN, next_ ? nc_ : c, next_ ? ns_ : st);                                                                  \
+    PTTS_B_FETCH(bB, sb_, st, 4);                                                                                         \
+    PTTS_MFMA_HALF(WC, bA, 0)                                                                                             \
+    if (!lastst_) PTTS_B_FETCH(bA, sb_, st + 1, 0);                                                                       \
+    PTTS_MFMA_HALF(WC, bB, 4)                                                                                             \
+    if (lastst_) {                                                                                                        \
+      if (more_) { PTTS_SLAB_COMMIT((c + 1) & 1); }                                                                       \
+      __syncthreads();                                                                                                    \
+      if (more_) PTTS_B_FETCH(bA, slab[(c + 1) & 1], 0, 0);                                                               \
+      ++c;                                                                                                                \
+      st = 0;                                                                                                             \
+    } else {                                                                                                              \
+      ++st;                                                                                                               \
+    }                                                                                                                     \
+  }
+  float4 w0[CSW], w1[CSW];
+  uint4 bA[4], bB[4];
+  PTTS_W_FETCH(w0, 0, 0);
+  PTTS_SLAB_FETCH(0);
+  PTTS_SLAB_COMMIT(0);
+  __syncthreads();
+  PTTS_B_FETCH(bA, slab[0], 0, 0);
+  int c = 0, st = 0;
+  const int total = nchunk * NS;
+  for (int g = 0; g < total; g += 2) {
+    PTTS_STEP(w0, w1)
+    if (g + 1 < total) PTTS_STEP(w1, w0)
+  }
+#undef PTTS_STEP
+#undef PTTS_MFMA_HALF
+#undef PTTS_SLAB_FETCH
+#undef PTTS_SLAB_COMMIT
+#undef PTTS_W_FETCH
+#undef PTTS_B_FETCH
+  // epilogue: as conv_mfma_kernel (D[row = co_local = q*4 + r][col = frame j]); explicit (s, f) calls keep `acc` statically indexed
+  const int Tout = a.Tn * a.nphase;
+  auto emit = [&](const f32x4 av, const int s, const int f) {
+    const int jj = t0 + f * 16 + j;
+    if (jj >= a.Tn) return;
+    const int co = (strip0 + s) * 16 + q * 4;
+    const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
+    const size_t o = ((size_t)b * Tout + (size_t)jj * a.nphase + ph) * a.Cout + co;
+    float4 v = make_float4(av[0] + bs.x, av[1] + bs.y, av[2] + bs.z, av[3] + bs.w);
+    if (a.skip) {
+      const float4 sk = *reinterpret_cast<const float4*>(a.skip + o);
+      v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
+    }
+    if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
+    if (a.out_act) {
+      const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
+      const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+      if (!a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
+    }
+  };
+#define PTTS_EMIT_ROW(S)                                                                                                  \
+  if (CSW > (S)) {                                                                                                        \
+    emit(acc[(S) % CSW][0], S, 0); emit(acc[(S) % CSW][1], S, 1); emit(acc[(S) % CSW][2], S, 2); emit(acc[(S) % CSW][3], S, 3); \
+    emit(acc[(S) % CSW][4], S, 4); emit(acc[(S) % CSW][5], S, 5); emit(acc[(S) % CSW][6], S, 6); emit(acc[(S) % CSW][7], S, 7); \
+  }
+  PTTS_EMIT_ROW(0)
+  PTTS_EMIT_ROW(1)
+  PTTS_EMIT_ROW(2)
+  PTTS_EMIT_ROW(3)
+#undef PTTS_EMIT_ROW
+}
+
+// final Conv1d(C -> 1, k7, pad 3) + tanh; weights [7][C] in LDS. One thread per OS = 4 consecutive output samples: the 10 input rows
+// they touch are read once (60 float4 loads per sample instead of 168; the kernel was 187 us of the 860-frame decode, L1-bound on
+// the 7x re-read). Per sample the fma order is unchanged (bias, then tap 0..6 x channel 0..C-1), so the exact-f32 mode is bit-identical.
+// samples [skip, t_end) of every utterance are written to out[b * out_ld + (t - skip)] (skip > 0: the halo frames of a chunk)
+constexpr int OUT_OS = 4;
 __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                      float* __restrict__ out, int B, int T, int C, int ktaps, int skip, long long out_ld, int t_end) {
   extern __shared__ float sw[];
   for (int i = threadIdx.x; i < ktaps * C; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
+  const int TG = (T + OUT_OS - 1) / OUT_OS;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)B * T) return;
-  const int b = (int)(idx / T), t = (int)(idx % T);
-  if (t < skip || t >= t_end) return;
-  float acc = bias[0];
-  for (int tap = 0; tap < ktaps; ++tap) {
-    const int ti = t + tap - ktaps / 2;
+  if (idx >= (size_t)B * TG) return;
+  const int b = (int)(idx / TG), t0 = (int)(idx % TG) * OUT_OS;
+  if (t0 + OUT_OS <= skip || t0 >= t_end) return;
+  float acc[OUT_OS];
+#pragma unroll
+  for (int s = 0; s < OUT_OS; ++s) acc[s] = bias[0];
+  const int half = ktaps / 2;
+  for (int r = 0; r < OUT_OS + ktaps - 1; ++r) {  // input row t0 - half + r feeds sample s with tap r - s
+    const int ti = t0 - half + r;
     if (ti < 0 || ti >= T) continue;
     const float4* xr = reinterpret_cast<const float4*>(x + ((size_t)b * T + ti) * C);
-    const float4* wr = reinterpret_cast<const float4*>(sw + tap * C);
     for (int c4 = 0; c4 < C / 4; ++c4) {
-      const float4 xv = xr[c4], wv = wr[c4];
-      acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+      const float4 xv = xr[c4];
+#pragma unroll
+      for (int s = 0; s < OUT_OS; ++s) {
+        const int tap = r - s;
+        if (tap >= 0 && tap < ktaps) {
+          const float4 wv = reinterpret_cast<const float4*>(sw + tap * C)[c4];
+          acc[s] = fmaf(xv.x, wv.x, acc[s]); acc[s] = fmaf(xv.y, wv.y, acc[s]); acc[s] = fmaf(xv.z, wv.z, acc[s]); acc[s] = fmaf(xv.w, wv.w, acc[s]);
+        }
+      }
     }
   }
-  out[(size_t)b * out_ld + (t - skip)] = tanhf(acc);
+#pragma unroll
+  for (int s = 0; s < OUT_OS; ++s) {
+    const int t = t0 + s;
+    if (t < T && t >= skip && t < t_end) out[(size_t)b * out_ld + (t - skip)] = tanhf(acc[s]);
+  }
 }
 
 // first encoder Conv1d(1 -> C, k7, pad 3) on the raw waveform: one thread per (sample, 4 channels); writes the raw
@@ -202,7 +379,7 @@ __global__ void conv_in_kernel(const float* __restrict__ wave, const float* __re
   const size_t off = bt * C + c4 * 4;
   *reinterpret_cast<float4*>(out_raw + off) = make_float4(o[0], o[1], o[2], o[3]);
   const float4 al = *reinterpret_cast<const float4*>(alpha + c4 * 4);
-  *reinterpret_cast<float4*>(out_act + off) = make_float4(snake_f(o[0], al.x), snake_f(o[1], al.y), snake_f(o[2], al.z), snake_f(o[3], al.w));
+  *reinterpret_cast<float4*>(out_act + off) = make_float4(snake_f<false>(o[0], al.x), snake_f<false>(o[1], al.y), snake_f<false>(o[2], al.z), snake_f<false>(o[3], al.w));
 }
 
 // F.normalize(codebook) rows: c / max(||c||_2, 1e-12)
@@ -679,6 +856,33 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
     a.stride = 1; a.Tn = Tin;
   }
   const int nstrips = L.Cout / 16;
+  // LDS-tiled kernel where it wins (rocprof per layer, profiles/r02_dac_layers.txt): every k7 conv (2x the direct kernel) and the
+  // transposed convs into >= 192 channels. The k1 convs and the last transposed conv are bound by their epilogue traffic
+  // (residual read + two writes per element) and run as fast or faster on the direct kernel's 4-5 waves per SIMD than on this one's 2.
+  static const bool no_lds = getenv("PTTS_DAC_NO_LDS") != nullptr;
+  static const int lds_min_c = getenv("PTTS_DAC_LDS_MIN_C") ? atoi(getenv("PTTS_DAC_LDS_MIN_C")) : 96;
+  static const bool lds_small_taps = getenv("PTTS_DAC_LDS_K1") != nullptr;
+  const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c : (lds_small_taps || (a.transposed && L.Cout >= 192));
+  if (L.bf16 && !no_lds && lds_ok && a.stride == 1 && nstrips % 6 == 0) {
+    const int nw = nstrips % 12 == 0 ? 4 : 2;
+    const int halo = a.transposed ? a.ntaps - 1 : (a.ntaps - 1) * a.dil;
+    const dim3 grid((unsigned)(((a.Tn + 127) / 128) * a.nphase * B), (unsigned)(nstrips / (3 * nw)));
+    bool done = true;
+    if (a.ntaps > 2 && halo <= 54 && a.Cin % 32 == 0) {
+      if (nw == 4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 1, 54>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv_lds_kernel<3, 2, 1, 54>), grid, dim3(128), 0, st, a);
+    } else if (a.ntaps <= 2 && a.Cin % 96 == 0) {
+      if (nw == 4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 3, 2>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv_lds_kernel<3, 2, 3, 2>), grid, dim3(128), 0, st, a);
+    } else {
+      done = false;
+    }
+    if (done) {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "conv launch failed: %s", hipGetErrorString(e));
+      return PTTS_OK;
+    }
+  }
   // waves per workgroup: fewer (finer tiles) when the launch would otherwise put < ~6 workgroups on each CU, so the
   // 256 CUs finish together (324 four-wave workgroups on 256 CUs = 63 % balance; 1296 one-wave ones = 84 %+)
   static int forced_nw = getenv("PTTS_DAC_WAVES") ? atoi(getenv("PTTS_DAC_WAVES")) : 0;
@@ -749,7 +953,7 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
       PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st, last));
     }
   }
-  const size_t n = (size_t)B * Tcur;
+  const size_t n = (size_t)B * ((Tcur + OUT_OS - 1) / OUT_OS);
   hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)7 * d->out_C * 4, st, cur, d->out_w, d->out_b,
                      wave_dev, B, Tcur, d->out_C, 7, skip, out_ld, emit < 0 ? Tcur : std::min(Tcur, skip + emit));
   hipError_t e = hipGetLastError();
