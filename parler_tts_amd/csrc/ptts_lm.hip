@@ -89,6 +89,8 @@ struct ptts_engine {
   int B = 0, N = 0, P = 0;
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
+  int kv_ub = 0;         // host-side upper bound of the self-KV positions written so far (prefill + one per decode forward)
+  int kv_bound = 0;      // attention fetch bound of the next decode forward: kv_ub + 1 rounded up to 64, <= max_ctx
   std::map<int, hipGraphExec_t> graphs;  // key: 2 * batch size + folded-cross-block flag
   int* host_pinned = nullptr;
 
@@ -312,7 +314,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         AttnArgs a = {};
         a.q = e->qkv; a.q_ld = QKV; a.knew = e->qkv + H; a.vnew = e->qkv + H + Hkv; a.kv_ld = QKV;
         a.kv_heads = nkv; a.n_rep = nh / nkv;
-        a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.cur_len = e->cur_len; a.dims = e->dims;
+        a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.kv_bound = e->kv_bound; a.cur_len = e->cur_len; a.dims = e->dims;
         a.mask = e->prompt_mask; a.mask_ld = e->max_prompt; a.cos = rc; a.sin = rs;
         a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = 1; a.nheads = nh; a.H = H; a.cross = 0;
         a.fused_append = 1; a.scale = scale;
@@ -343,7 +345,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       }
       {  // cross-attention against the static description K/V: one workgroup per head, softmax finished in the kernel
         AttnArgs a = {};
-        a.q = e->qc; a.q_ld = H; a.kcache = w.k_cross; a.vcache = w.v_cross; a.cap = c.max_enc;
+        a.q = e->qc; a.q_ld = H; a.kcache = w.k_cross; a.vcache = w.v_cross; a.cap = c.max_enc; a.kv_bound = c.max_enc;
         a.cur_len = e->cur_len; a.dims = e->dims; a.mask = e->enc_mask; a.mask_ld = c.max_enc;
         a.cos = rc; a.sin = rs;  // quirk: q rotated, keys not (:858 vs :880)
         a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = 1; a.nheads = nh; a.H = H; a.cross = 1;
@@ -393,7 +395,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       AttnArgs a = {};
       a.q = e->qkv; a.q_ld = QKV; a.knew = e->qkv + H; a.vnew = e->qkv + H + Hkv; a.kv_ld = QKV;
       a.kv_heads = nkv; a.n_rep = nh / nkv;
-      a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims;
+      a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.kv_bound = prefill ? c.max_ctx : e->kv_bound; a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims;
       a.mask = e->prompt_mask; a.mask_ld = e->max_prompt;
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
       a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
@@ -437,7 +439,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     }
     {  // cross-attention against the static description K/V
       AttnArgs a = {};
-      a.q = e->qc; a.q_ld = H; a.kcache = w.k_cross; a.vcache = w.v_cross; a.cap = c.max_enc;
+      a.q = e->qc; a.q_ld = H; a.kcache = w.k_cross; a.vcache = w.v_cross; a.cap = c.max_enc; a.kv_bound = c.max_enc;
       a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims; a.mask = e->enc_mask; a.mask_ld = c.max_enc;
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;  // quirk: q rotated, keys not (:858 vs :880)
       a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 1;
@@ -531,6 +533,15 @@ int fold_cross(ptts_engine* e, hipStream_t st) {
 
 int forward_dispatch(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true) {
   return e->cfg.dtype == PTTS_BF16 ? forward<bf16_t>(e, prefill, st, with_embed) : forward<float>(e, prefill, st, with_embed);
+}
+
+// every decode forward appends one self-KV position: advance the host's bound before launching it (eagerly or as a graph)
+static const bool g_no_kv_bound = getenv("PTTS_NO_KV_BOUND") && atoi(getenv("PTTS_NO_KV_BOUND"));
+static int advance_kv(ptts_engine* e) {
+  e->kv_ub += 1;
+  const int cap = e->cfg.max_ctx;
+  e->kv_bound = g_no_kv_bound ? cap : std::min(cap, (e->kv_ub + 1 + 63) / 64 * 64);
+  return e->kv_bound;
 }
 
 bool ends_with(const std::string& s, const char* suf) {
@@ -970,6 +981,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   const int rc_fwd = forward_dispatch(e, true, st);
   e->prefill_T = 0;
   PTTS_TRY(rc_fwd);
+  e->kv_ub = P + 1 + (batched ? T : 0);  // self-KV positions written by this pass
   if (e->xfold_ne && B == 1) {
     // the fold only needs the cross K/V cache (first kernels of the prefill): it runs on its own stream beside the layer stack,
     // and what follows on the caller's stream (teacher-forced prefix columns, then every decode step) waits for it; the first
@@ -991,6 +1003,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   for (int j = 1; j <= (batched ? 0 : T); ++j) {
     hipLaunchKernelGGL(push_prefix_col_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, j, B, K, c.bos_token_id);
     hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, j + 1);
+    advance_kv(e);
     PTTS_TRY(forward_dispatch(e, false, st, true));
   }
   if (sample) PTTS_TRY(launch_tail(e, st, true));  // also embeds the sampled column for the first decode step
@@ -1003,7 +1016,9 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
 // The decode step (170 kernel nodes for Mini-v1 at batch <= 8) is captured ONCE per batch size on the engine's private stream
 // (capture records, it does not execute; the legacy NULL stream cannot be captured) and replayed into the caller's.
 static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
-  const int key = e->B * 2 + (e->xfold_valid ? 1 : 0);  // the node set of the step depends on the batch size and on the folded cross block
+  // the node set of the step depends on the batch size and on the folded cross block; the attention fetch bound (a kernel argument)
+  // on the 64-position bucket of the context
+  const int key = e->B * 2 + (e->xfold_valid ? 1 : 0) + 4096 * (e->kv_bound / 64);
   auto it = e->graphs.find(key);
   if (it != e->graphs.end()) { *out = it->second; return PTTS_OK; }
   hipGraph_t g = nullptr;
@@ -1030,15 +1045,19 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
   PTTS_CHECK(n_steps >= 0, PTTS_E_INVALID, "n_steps < 0");
   PTTS_DEVICE(e->cfg.device);
   hipStream_t st = pick_stream(e, stream);
-  hipGraphExec_t ex = nullptr;
-  PTTS_TRY(get_graph(e, &ex));
   if (n_steps > 0 && !e->h_ready) {  // previous column came from ptts_push_tokens / an un-sampled prefill: embed it once, eagerly
+    advance_kv(e);
     PTTS_TRY(forward_dispatch(e, false, st, true));
     PTTS_TRY(launch_tail(e, st, true));
     e->h_ready = true;
     --n_steps;
   }
-  for (int i = 0; i < n_steps; ++i) PTTS_HIP(hipGraphLaunch(ex, st));
+  for (int i = 0; i < n_steps; ++i) {
+    hipGraphExec_t ex = nullptr;
+    advance_kv(e);
+    PTTS_TRY(get_graph(e, &ex));  // cached per (batch, fold, 64-position bucket)
+    PTTS_HIP(hipGraphLaunch(ex, st));
+  }
   return PTTS_OK;
 }
 
@@ -1070,6 +1089,7 @@ extern "C" int ptts_step_forward(ptts_engine* e, void* stream) {
   PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
   PTTS_CHECK(e->prefilled, PTTS_E_INVALID, "ptts_step_forward called before ptts_prefill");
   PTTS_DEVICE(e->cfg.device);
+  advance_kv(e);
   return forward_dispatch(e, false, pick_stream(e, stream));
 }
 

@@ -809,6 +809,7 @@ struct AttnArgs {
   void* kcache;
   void* vcache;
   int cap;             // cache capacity in positions
+  int kv_bound;        // host-known upper bound of the valid length (<= cap): first-batch rows at or beyond it are not fetched
   const int* cur_len;  // decode: per-batch column count (position = P + cur_len[b] - 1); null in prefill
   const DevDims* dims;
   const int* mask;     // [B][mask_ld] int32 (1 = keep) or null
@@ -879,8 +880,10 @@ __device__ __forceinline__ void rope_apply(float (&x)[EPL], const float (&y)[EPL
 }
 
 // ONE dependent round trip per kernel: every global load of a wave's first batch (q chunk, new K/V row, 8 K + 8 V cache
-// rows, masks) is issued together with the loads of the device-resident lengths. Addresses are clamped by the cache
-// capacity (a kernel argument); validity against the lengths is applied when the data is used.
+// rows, masks) is issued together with the loads of the device-resident lengths. Addresses are clamped by kv_bound, a kernel
+// argument: the cache capacity, or - decode steps - the host's upper bound of the context rounded up to 64 (the step graph is
+// captured once per 64-position bucket), so the speculative batch does not fetch rows no utterance can have yet (PMC: 34 MB per
+// launch at batch 32 and context 57 against 7.5 MB of live cache); validity against the lengths is applied when the data is used.
 template <typename WT, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8;
@@ -913,7 +916,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int t = (wv + u * TW) * RPI + r;
-    const int tc = t < a.cap ? t : 0;
+    const int tc = t < a.kv_bound ? t : 0;
     kf[u] = Kb[(size_t)tc * LPR + c];
     vf[u] = Vb[(size_t)tc * LPR + c];
     mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
