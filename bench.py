@@ -146,9 +146,9 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
     if es == 2 and H == 1024 and os.path.exists(pmc):  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
         j = json.load(open(pmc))
         traffic = int(j["traffic_bytes_per_step"])
-        tnote = (f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~{j.get('algorithmic_mb', '?')} MB). Context-independent "
-                 "below 1024 positions: every weight matrix is fetched once and the attention kernel's first load batch (16 wave slots x 16 "
-                 "row groups = 4.0 MB per launch) is issued whatever the device-resident length is, so the figure also holds at the timed context")
+        tnote = (f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~{j.get('algorithmic_mb', '?')} MB). Every weight "
+                 "matrix is fetched once at any context; the attention fetches are bounded by the host's context bound rounded up to 64 positions, "
+                 "so the K/V part of the traffic grows with the context like the algorithmic term (bytes_per_launch is quoted at the timed context)")
     folded = bs == 1 and not getattr(d, "rope_embeddings", False) and N_DESC <= 64  # static cross-attention folding
     nodes = ((7 if folded else 8) * L + 2) if bs <= 4 else ((7 * L + 2) if bs <= 8 else None)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
