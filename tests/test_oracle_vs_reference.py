@@ -50,3 +50,79 @@ def test_delay_pattern_and_eos_gate_match_reference_live(ref):
         seq = torch.cat([seq, nxt[:, None]], dim=1)
         r = proc(seq, torch.zeros(bsz * K, V))
         assert torch.equal(r, gate(seq, torch.zeros(bsz * K, V))) and torch.equal(r, mine(seq, torch.zeros(bsz * K, V))), step
+
+
+@pytest.mark.parametrize("pca,desc_mask,prompt_mask", [(False, True, True), (False, False, False), (True, True, True), (True, True, False), (True, False, True)])
+def test_generate_conditioning_matches_reference_helpers_live(ref, pca, desc_mask, prompt_mask):
+    """what generate() hands to the engine's prefill (description states, their mask, prompt states, their mask)
+    against the reference's OWN `_prepare_text_encoder_kwargs_for_generation` (:3048-3097) and
+    `_prepare_prompt_kwargs_for_generation` (:3099-3134), called unbound on a stand-in `self` that shares this package's torch
+    modules (T5 encoder, enc_to_dec_proj, embed_prompts) and uses the reference's own sinusoidal positional embedding class:
+    enc_to_dec_proj (T5 width != decoder width), masked description positions zeroed, prompt_cross_attention concatenation with
+    positions and the synthesised all-ones masks."""
+    import types
+
+    from transformers import GenerationConfig, T5Config
+
+    import parler_tts_amd as P
+
+    M = ref.modeling_parler_tts
+    torch.manual_seed(3)
+    t5 = T5Config(vocab_size=128, d_model=96, d_kv=32, d_ff=256, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")
+    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=256, num_hidden_layers=2, ffn_dim=256, num_attention_heads=2,
+                                   hidden_size=128, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025)
+    cfg = P.ParlerTTSConfig.from_sub_models_config(t5, P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2]), dec,
+                                                   vocab_size=128, prompt_cross_attention=pca)
+    m = P.ParlerTTSForConditionalGeneration(cfg).eval()
+    assert hasattr(m, "enc_to_dec_proj")
+    g = torch.Generator().manual_seed(4)
+    B, N, Pn = 3, 7, 5
+    desc, prompt_ids = torch.randint(3, 128, (B, N), generator=g), torch.randint(3, 128, (B, Pn), generator=g)
+    dm = torch.ones(B, N, dtype=torch.long)
+    dm[1, 5:] = 0
+    dm[2, 3:] = 0
+    pm = torch.ones(B, Pn, dtype=torch.long)
+    pm[2, :2] = 0
+    dm, pm = (dm if desc_mask else None), (pm if prompt_mask else None)
+
+    captured = {}
+
+    class Stop(Exception):
+        pass
+
+    class Capture:
+        cfg = types.SimpleNamespace(max_batch=64, max_enc=4096, max_prompt=4096, max_ctx=1 << 20)
+
+        def set_gen_params(self, **kw):
+            pass
+
+        def set_audio_prefix(self, codes):
+            pass
+
+        def prefill(self, enc, enc_mask, prompt, prompt_mask, sample=True):
+            captured.update(enc=enc, enc_mask=enc_mask, prompt=prompt, prompt_mask=prompt_mask)
+            raise Stop()
+
+    m._get_engine = lambda *a, **k: Capture()
+    with pytest.raises(Stop):
+        m.generate(input_ids=desc, attention_mask=dm, prompt_input_ids=prompt_ids, prompt_attention_mask=pm, do_sample=False, max_new_tokens=4)
+
+    stub = types.SimpleNamespace(text_encoder=m.text_encoder, get_text_encoder=lambda: m.text_encoder, decoder=types.SimpleNamespace(config=types.SimpleNamespace(hidden_size=dec.hidden_size, cross_attention_hidden_size=None)),
+                                 enc_to_dec_proj=m.enc_to_dec_proj, embed_prompts=m.embed_prompts, prompt_cross_attention=pca, device=torch.device("cpu"),
+                                 embed_positions=M.ParlerTTSSinusoidalPositionalEmbedding(dec.max_position_embeddings, dec.hidden_size))
+    cls = M.ParlerTTSForConditionalGeneration
+    with torch.no_grad():
+        kw = {"attention_mask": dm, "prompt_attention_mask": pm}
+        kw = cls._prepare_text_encoder_kwargs_for_generation(stub, desc, kw, "input_ids", GenerationConfig())
+        kw = cls._prepare_prompt_kwargs_for_generation(stub, prompt_ids, kw)
+    want_enc = kw["encoder_outputs"].last_hidden_state
+
+    def same(a, b):
+        return (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape and torch.allclose(a.float(), b.float(), atol=1e-6))
+
+    assert same(captured["enc"], want_enc)
+    assert same(captured["enc_mask"], kw["attention_mask"])
+    assert same(captured["prompt"], kw.get("prompt_hidden_states"))
+    assert same(captured["prompt_mask"], kw.get("prompt_attention_mask"))
+    if pca:
+        assert captured["prompt"] is None and captured["enc"].shape[1] == N + Pn
