@@ -199,3 +199,82 @@ def test_decoder_start_columns_match_reference_helper_live(ref, given):
         assert eng.prefix is None
     else:
         assert torch.equal(eng.prefix.cpu(), codes[:K])
+
+
+@pytest.mark.parametrize("masks", [False, True])
+def test_generate_ids_equal_a_loop_of_the_reference_generate_time_functions_live(ref, masks):
+    """End to end without the reference's `generate()` (written against transformers 4.46's GenerationMixin, not runnable on the
+    installed 5.x): every model-specific step of it is the reference's OWN function, called unbound on a stand-in `self` -
+    `_prepare_text_encoder_kwargs_for_generation`, `_prepare_prompt_kwargs_for_generation`, `_prepare_decoder_input_ids_for_generation`,
+    `build_delay_pattern_mask`, `_get_initial_cache_position`, and per step `prepare_inputs_for_generation` (:2882-2986: delay mask,
+    last-column slicing, prompt dropped after step 0, decoder_attention_mask synthesised from the prompt mask, cache positions) ->
+    `ParlerTTSForConditionalGeneration.forward` (:2695-2880) -> the reference ParlerTTSForCausalLM with an EncoderDecoderCache ->
+    MinNewTokens + the reference `ParlerTTSLogitsProcessor`; only the third-party `_sample` skeleton (pinned separately against the
+    installed transformers) is restated. The ids must equal the ones `generate()` of this package produces on the same inputs
+    (host glue + oracle-backed engine; the HIP engine is pinned to the oracle by the -m gpu tests)."""
+    import math
+    import types
+
+    from transformers import GenerationConfig
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+    from transformers.modeling_outputs import BaseModelOutput  # noqa: F401  (what the reference helper wraps the states in)
+
+    import oracle.make_golden as mg
+    import test_generate_glue_cpu as G
+
+    M = ref.modeling_parler_tts
+    C = M.ParlerTTSForConditionalGeneration
+    m, spec, sd, dac = G._model(eos_gain=6.0)
+    K, bos, pad, eos = spec.num_codebooks, spec.bos_token_id, spec.pad_token_id, spec.eos_token_id
+    g = torch.Generator().manual_seed(21)
+    B, N, Pn, L, min_new = 2, 8, 5, 34, 3
+    desc, prompt_ids = torch.randint(3, 128, (B, N), generator=g), torch.randint(3, 128, (B, Pn), generator=g)
+    dm = pm = None
+    if masks:
+        dm = torch.ones(B, N, dtype=torch.long); dm[1, 5:] = 0
+        pm = torch.ones(B, Pn, dtype=torch.long); pm[1, :2] = 0  # left-padded prompt, like a batched tokenizer call
+    # --- this package ---------------------------------------------------------------------------------------------------------------
+    eng = m._get_engine(B, N, Pn, L)
+    m.generate(input_ids=desc, attention_mask=dm, prompt_input_ids=prompt_ids, prompt_attention_mask=pm, do_sample=False, max_length=L,
+               min_new_tokens=min_new)
+    mine = eng.full  # [B*K, columns]: the delayed ids of the whole run
+    # --- the reference's functions -------------------------------------------------------------------------------------------------
+    lm = mg.build_reference_lm(ref, spec, sd)
+    lm.config.cross_attention_hidden_size = None
+    stub = types.SimpleNamespace(
+        text_encoder=m.text_encoder, get_text_encoder=lambda: m.text_encoder, decoder=lm, embed_prompts=m.embed_prompts, prompt_cross_attention=False,
+        device=torch.device("cpu"), config=types.SimpleNamespace(use_return_dict=True, decoder=types.SimpleNamespace(audio_channels=1)),
+        generation_config=types.SimpleNamespace(bos_token_id=bos, pad_token_id=pad, max_length=L),
+        _get_decoder_start_token_id=lambda a, b: a if a is not None else b)
+    with torch.no_grad():
+        kw = {"attention_mask": dm, "prompt_attention_mask": pm}
+        kw = C._prepare_text_encoder_kwargs_for_generation(stub, desc, kw, "input_ids", GenerationConfig())
+        kw = C._prepare_prompt_kwargs_for_generation(stub, prompt_ids, kw)
+        ids, kw = C._prepare_decoder_input_ids_for_generation(stub, B, "input_ids", kw, decoder_start_token_id=bos, bos_token_id=bos,
+                                                              device=torch.device("cpu"))
+        seq, pattern = lm.build_delay_pattern_mask(ids, bos_token_id=bos, pad_token_id=pad, max_length=L)
+        kw["decoder_delay_pattern_mask"] = pattern
+        kw["past_key_values"] = EncoderDecoderCache(DynamicCache(), DynamicCache())
+        kw["use_cache"] = True
+        kw = C._get_initial_cache_position(stub, seq, kw)
+        assert kw["cache_position"].tolist() == list(range(Pn + 1))  # prompt positions + the BOS column
+        proc = M.ParlerTTSLogitsProcessor(eos, K, B, "cpu")
+        unfinished = torch.ones(B * K, dtype=torch.long)
+        while True:
+            inputs = C.prepare_inputs_for_generation(stub, seq, **kw)
+            out = C.forward(stub, **inputs, return_dict=True)
+            scores = out.logits[:, -1, :].clone().float()
+            if seq.shape[-1] - 1 < min_new:
+                scores[:, eos] = -math.inf
+            scores = proc(seq, scores)
+            nxt = torch.argmax(scores, dim=-1)
+            nxt = nxt * unfinished + pad * (1 - unfinished)
+            seq = torch.cat([seq, nxt[:, None]], dim=-1)
+            kw["past_key_values"] = out.past_key_values
+            kw["cache_position"] = kw["cache_position"][-1:] + 1  # GenerationMixin._update_model_kwargs_for_generation
+            unfinished = unfinished & ~((nxt == eos) | (seq.shape[-1] >= L)).long()
+            if unfinished.max() == 0:
+                break
+    assert seq.shape == mine.shape and seq.shape[1] > 12, (seq.shape, mine.shape)
+    assert torch.equal(seq, mine)
+    assert int((seq[:, 1:] == eos).any(dim=1).sum()) >= 2  # EOS really happened on some rows: the gate and the padding were exercised
