@@ -201,8 +201,36 @@ def test_decoder_start_columns_match_reference_helper_live(ref, given):
         assert torch.equal(eng.prefix.cpu(), codes[:K])
 
 
-@pytest.mark.parametrize("masks", [False, True])
-def test_generate_ids_equal_a_loop_of_the_reference_generate_time_functions_live(ref, masks):
+def _product_model_with_oracle_engine(pca: bool):
+    """tests/test_generate_glue_cpu.py::_model with a `prompt_cross_attention` switch: this package's model, oracle-backed engine."""
+    import types
+
+    from transformers import T5Config
+
+    import parler_tts_amd as P
+    import test_generate_glue_cpu as G
+    from oracle import dac_oracle as DA
+    from oracle import decoder_oracle as DO
+
+    torch.manual_seed(0)
+    t5 = T5Config(vocab_size=128, d_model=128, d_kv=32, d_ff=256, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")
+    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=256, num_hidden_layers=2, ffn_dim=256, num_attention_heads=2,
+                                   hidden_size=128, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025)
+    m = P.ParlerTTSForConditionalGeneration(P.ParlerTTSConfig.from_sub_models_config(
+        t5, P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2]), dec, vocab_size=128, prompt_cross_attention=pca)).eval()
+    spec, sd = DO.TINY, DO.make_decoder_weights(DO.TINY, seed=1237)
+    for k in range(9):
+        sd[f"lm_heads.{k}.weight"][1024] *= 6.0  # EOS reachable with random heads
+    m.decoder.load_state_dict(sd, strict=False)
+    eng = G.OracleEngine(spec, sd)
+    m._get_engine = lambda B, N, Pp, L, T=0: eng
+    dac = DA.DacOracle(DA.DAC_TINY, DA.make_dac_weights(DA.DAC_TINY, seed=4321))
+    m.audio_encoder.decode = lambda audio_codes, audio_scales=None, **kw: types.SimpleNamespace(audio_values=dac.decode(audio_codes[0].cpu()))
+    return m, spec, sd, eng
+
+
+@pytest.mark.parametrize("masks,pca,prefix", [(False, False, False), (True, False, False), (True, True, False), (False, True, False), (True, False, True)])
+def test_generate_ids_equal_a_loop_of_the_reference_generate_time_functions_live(ref, masks, pca, prefix):
     """End to end without the reference's `generate()` (written against transformers 4.46's GenerationMixin, not runnable on the
     installed 5.x): every model-specific step of it is the reference's OWN function, called unbound on a stand-in `self` -
     `_prepare_text_encoder_kwargs_for_generation`, `_prepare_prompt_kwargs_for_generation`, `_prepare_decoder_input_ids_for_generation`,
@@ -211,60 +239,66 @@ def test_generate_ids_equal_a_loop_of_the_reference_generate_time_functions_live
     `ParlerTTSForConditionalGeneration.forward` (:2695-2880) -> the reference ParlerTTSForCausalLM with an EncoderDecoderCache ->
     MinNewTokens + the reference `ParlerTTSLogitsProcessor`; only the third-party `_sample` skeleton (pinned separately against the
     installed transformers) is restated. The ids must equal the ones `generate()` of this package produces on the same inputs
-    (host glue + oracle-backed engine; the HIP engine is pinned to the oracle by the -m gpu tests)."""
+    (host glue + oracle-backed engine; the HIP engine is pinned to the oracle by the -m gpu tests). Variants: padded description +
+    left-padded prompt masks, `prompt_cross_attention`, and a voice-prompt prefix given as `decoder_input_ids` (multi-column first pass,
+    lengths counted from the given columns)."""
     import math
     import types
 
     from transformers import GenerationConfig
     from transformers.cache_utils import DynamicCache, EncoderDecoderCache
-    from transformers.modeling_outputs import BaseModelOutput  # noqa: F401  (what the reference helper wraps the states in)
 
     import oracle.make_golden as mg
-    import test_generate_glue_cpu as G
 
     M = ref.modeling_parler_tts
     C = M.ParlerTTSForConditionalGeneration
-    m, spec, sd, dac = G._model(eos_gain=6.0)
+    m, spec, sd, eng = _product_model_with_oracle_engine(pca)
     K, bos, pad, eos = spec.num_codebooks, spec.bos_token_id, spec.pad_token_id, spec.eos_token_id
-    g = torch.Generator().manual_seed(21)
-    B, N, Pn, L, min_new = 2, 8, 5, 34, 3
+    g = torch.Generator().manual_seed(21 + 2 * int(pca) + int(prefix))
+    B, N, Pn, T0, min_new = 2, 8, 5, (4 if prefix else 0), 3
+    L = 34 + T0
     desc, prompt_ids = torch.randint(3, 128, (B, N), generator=g), torch.randint(3, 128, (B, Pn), generator=g)
+    codes = torch.randint(0, 1024, (B * K, T0), generator=g) if prefix else None
     dm = pm = None
     if masks:
         dm = torch.ones(B, N, dtype=torch.long); dm[1, 5:] = 0
         pm = torch.ones(B, Pn, dtype=torch.long); pm[1, :2] = 0  # left-padded prompt, like a batched tokenizer call
     # --- this package ---------------------------------------------------------------------------------------------------------------
-    eng = m._get_engine(B, N, Pn, L)
-    m.generate(input_ids=desc, attention_mask=dm, prompt_input_ids=prompt_ids, prompt_attention_mask=pm, do_sample=False, max_length=L,
-               min_new_tokens=min_new)
+    m.generate(input_ids=desc, attention_mask=dm, prompt_input_ids=prompt_ids, prompt_attention_mask=pm, decoder_input_ids=codes, do_sample=False,
+               max_length=L, min_new_tokens=min_new)
     mine = eng.full  # [B*K, columns]: the delayed ids of the whole run
     # --- the reference's functions -------------------------------------------------------------------------------------------------
     lm = mg.build_reference_lm(ref, spec, sd)
     lm.config.cross_attention_hidden_size = None
     stub = types.SimpleNamespace(
-        text_encoder=m.text_encoder, get_text_encoder=lambda: m.text_encoder, decoder=lm, embed_prompts=m.embed_prompts, prompt_cross_attention=False,
+        text_encoder=m.text_encoder, get_text_encoder=lambda: m.text_encoder, decoder=lm, embed_prompts=m.embed_prompts, prompt_cross_attention=pca,
+        embed_positions=M.ParlerTTSSinusoidalPositionalEmbedding(256, spec.hidden_size),
         device=torch.device("cpu"), config=types.SimpleNamespace(use_return_dict=True, decoder=types.SimpleNamespace(audio_channels=1)),
         generation_config=types.SimpleNamespace(bos_token_id=bos, pad_token_id=pad, max_length=L),
         _get_decoder_start_token_id=lambda a, b: a if a is not None else b)
     with torch.no_grad():
         kw = {"attention_mask": dm, "prompt_attention_mask": pm}
+        if prefix:
+            kw["decoder_input_ids"] = codes.clone()
         kw = C._prepare_text_encoder_kwargs_for_generation(stub, desc, kw, "input_ids", GenerationConfig())
         kw = C._prepare_prompt_kwargs_for_generation(stub, prompt_ids, kw)
         ids, kw = C._prepare_decoder_input_ids_for_generation(stub, B, "input_ids", kw, decoder_start_token_id=bos, bos_token_id=bos,
                                                               device=torch.device("cpu"))
+        given = ids.shape[1]
+        assert given == 1 + T0
         seq, pattern = lm.build_delay_pattern_mask(ids, bos_token_id=bos, pad_token_id=pad, max_length=L)
         kw["decoder_delay_pattern_mask"] = pattern
         kw["past_key_values"] = EncoderDecoderCache(DynamicCache(), DynamicCache())
         kw["use_cache"] = True
         kw = C._get_initial_cache_position(stub, seq, kw)
-        assert kw["cache_position"].tolist() == list(range(Pn + 1))  # prompt positions + the BOS column
+        assert kw["cache_position"].tolist() == list(range((0 if pca else Pn) + given))  # prompt positions (unless cross-attended) + given columns
         proc = M.ParlerTTSLogitsProcessor(eos, K, B, "cpu")
         unfinished = torch.ones(B * K, dtype=torch.long)
         while True:
             inputs = C.prepare_inputs_for_generation(stub, seq, **kw)
             out = C.forward(stub, **inputs, return_dict=True)
             scores = out.logits[:, -1, :].clone().float()
-            if seq.shape[-1] - 1 < min_new:
+            if seq.shape[-1] - given < min_new:
                 scores[:, eos] = -math.inf
             scores = proc(seq, scores)
             nxt = torch.argmax(scores, dim=-1)
@@ -275,6 +309,6 @@ def test_generate_ids_equal_a_loop_of_the_reference_generate_time_functions_live
             unfinished = unfinished & ~((nxt == eos) | (seq.shape[-1] >= L)).long()
             if unfinished.max() == 0:
                 break
-    assert seq.shape == mine.shape and seq.shape[1] > 12, (seq.shape, mine.shape)
+    assert seq.shape == mine.shape and seq.shape[1] > given + 8, (seq.shape, mine.shape)
     assert torch.equal(seq, mine)
-    assert int((seq[:, 1:] == eos).any(dim=1).sum()) >= 2  # EOS really happened on some rows: the gate and the padding were exercised
+    assert int((seq[:, given:] == eos).any(dim=1).sum()) >= 2  # EOS really happened on some rows: the gate and the padding were exercised
