@@ -123,6 +123,14 @@ def test_bf16_operand_mode_full_size_44khz():
     d.load_state_dict(sd)
     r = _rel_rms(d.decode(codes.cuda()).cpu(), ref)
     assert r <= 3e-2, r
+    # batch > 1 through the LDS-tiled k7 / transposed-conv kernels (utterance index in blockIdx.x), each row against the oracle
+    codes3 = torch.randint(0, 1024, (3, 9, 20), generator=torch.Generator().manual_seed(5))
+    ref3 = DA.DacOracle(spec, sd).decode(codes3)
+    d3 = DacEngine(max_batch=3, max_frames=32, compute_dtype=torch.bfloat16)
+    d3.load_state_dict(sd)
+    out3 = d3.decode(codes3.cuda()).cpu()
+    for b in range(3):
+        assert _rel_rms(out3[b], ref3[b]) <= 3e-2, b
 
 
 def test_shift_equivariance_away_from_edges():
