@@ -312,3 +312,25 @@ def test_generate_ids_equal_a_loop_of_the_reference_generate_time_functions_live
     assert seq.shape == mine.shape and seq.shape[1] > given + 8, (seq.shape, mine.shape)
     assert torch.equal(seq, mine)
     assert int((seq[:, given:] == eos).any(dim=1).sum()) >= 2  # EOS really happened on some rows: the gate and the padding were exercised
+
+
+def test_delay_pattern_closed_form_equals_reference_function_property_live(ref):
+    """hypothesis: this package's closed-form build_delay_pattern_mask against the reference's loop-built one (modeling:214-276) over
+    random codebook counts, batch sizes, given columns and max lengths (the domain the reference's loop accepts, :241-243)."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    import parler_tts_amd as P
+
+    @settings(max_examples=120, deadline=None)
+    @given(K=st.integers(1, 9), bsz=st.integers(1, 3), seq_len=st.integers(1, 12), extra=st.integers(0, 30), seed=st.integers(0, 10_000))
+    def check(K, bsz, seq_len, extra, seed):
+        max_len = seq_len + extra
+        hypothesis.assume(max_len < 2 * K - 1 or max_len >= seq_len + K - 1)
+        ids = torch.randint(0, 1024, (bsz * K, seq_len), generator=torch.Generator().manual_seed(seed))
+        ids[:, 0] = 1025
+        a = ref.build_delay_pattern_mask(ids, 1025, 1024, max_len, K)
+        b = P.build_delay_pattern_mask(ids, 1025, 1024, max_len, K)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    check()
