@@ -334,3 +334,65 @@ def test_delay_pattern_closed_form_equals_reference_function_property_live(ref):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
     check()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_streamer_equals_reference_streamer_on_random_streams_live(ref, seed):
+    """The golden stream (tests/golden/streamer_ref.npz) generalised: random stream length, `play_steps`, explicit or default stride
+    and 0-2 special ids mid-stream; the REFERENCE's own ParlerTTSStreamer (full re-decode of the cache every `play_steps`,
+    streamer.py:66-131) and this package's incremental halo-window streamer, both over the oracle codec, must emit the same chunks."""
+    import types
+
+    import numpy as np
+    from parler_tts.streamer import ParlerTTSStreamer as RefStreamer
+
+    import oracle.make_golden as mg
+    from oracle import dac_oracle as DA
+    from oracle import decoder_oracle as DO
+    from parler_tts_amd.streamer import ParlerTTSStreamer
+
+    g = torch.Generator().manual_seed(100 + seed)
+    spec = DO.TINY
+    K = spec.num_codebooks
+    L = int(torch.randint(30, 70, (1,), generator=g))
+    play_steps = int(torch.randint(10, 24, (1,), generator=g))
+    stride = None if seed % 2 == 0 else int(torch.randint(0, 40, (1,), generator=g))
+    dec = mg.build_reference_lm(ref, spec, DO.make_decoder_weights(spec, seed=1234))
+    dac = DA.DacOracle(DA.DAC_TINY, DA.make_dac_weights(DA.DAC_TINY, seed=4321))
+    hop = DA.DAC_TINY.hop_length
+
+    class Codec:
+        config = types.SimpleNamespace(sampling_rate=hop * 86, frame_rate=86, codebook_size=1024, num_codebooks=K)
+        device = torch.device("cpu")
+        decoder_rates = DA.DAC_TINY.decoder_rates
+
+        def decode(self, audio_codes, audio_scales=None):
+            return types.SimpleNamespace(audio_values=dac.decode(audio_codes[0]))
+
+        def decode_chunk(self, audio_codes, first_frame, n_frames=None, halo=16):  # ptts_dac_decode_chunk semantics
+            codes = audio_codes[0]
+            n_frames = codes.shape[-1] - first_frame if n_frames is None else n_frames
+            w0 = max(0, first_frame - halo)
+            return types.SimpleNamespace(audio_values=dac.decode(codes[:, :, w0: first_frame + n_frames])[:, :, (first_frame - w0) * hop:])
+
+    gc = types.SimpleNamespace(bos_token_id=spec.bos_token_id, pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id,
+                               decoder_start_token_id=spec.bos_token_id)
+    raw = torch.randint(0, 1024, (K, L), generator=g)
+    for _ in range(seed % 3):  # special ids mid-stream: the frame that holds one is dropped (streamer.py:95-104)
+        raw[int(torch.randint(0, K, (1,), generator=g)), int(torch.randint(12, L - 1, (1,), generator=g))] = spec.eos_token_id
+    first, _ = dec.build_delay_pattern_mask(torch.full((K, 1), spec.bos_token_id), bos_token_id=spec.bos_token_id, pad_token_id=spec.pad_token_id,
+                                            max_length=L)
+    outs = []
+    for cls, decoder in ((RefStreamer, dec), (ParlerTTSStreamer, types.SimpleNamespace(num_codebooks=K))):
+        model = types.SimpleNamespace(decoder=decoder, audio_encoder=Codec(), generation_config=gc, device=torch.device("cpu"),
+                                      use_audio_scales=True, use_4dim_audio_codes=True)
+        st = cls(model, play_steps=play_steps, stride=stride)
+        st.put(first.clone())
+        for j in range(1, L):
+            st.put(raw[:, j])
+        st.end()
+        outs.append([np.asarray(c) for c in st])
+    want, got = outs
+    assert len(want) >= 2 and [len(c) for c in got] == [len(c) for c in want], ([len(c) for c in got], [len(c) for c in want])
+    for a, b in zip(got, want):  # window decode vs whole-cache decode on the CPU conv kernels: fp32 summation order differs at the 1e-6 level
+        assert np.allclose(a, b, atol=2e-5), float(np.abs(a - b).max())
