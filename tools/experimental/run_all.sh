@@ -7,7 +7,7 @@ set -u
 O=gpurun_out/r03a; mkdir -p $O
 S=$O/summary.txt; : > $S
 build() { python -c "import __graft_entry__ as g; g.build()" > $O/build_$1.log 2>&1 && echo "[$1] build ok" >> $S || { echo "[$1] BUILD FAILED" >> $S; tail -5 $O/build_$1.log >> $S; return 1; }; }
-step32() { env "$@" timeout 120 python tools/step_probe2.py 32 "$1" 2>&1 | grep step_probe2 >> $S; }
+step32() { local tag=$1; shift; env "$@" timeout 120 python tools/step_probe2.py 32 "$tag" 2>&1 | grep step_probe2 >> $S; }
 
 echo "## baseline (HEAD)" >> $S
 step32 baseline PTTS_NOOP=1
