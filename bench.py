@@ -126,6 +126,30 @@ def _prefilled_engine(model, bs: int, device, **gen):
     return eng
 
 
+NODE_FLOOR_US = 2.13  # a dependent, trivial kernel node inside a hipGraph on MI355X (profiles/r01_sync_and_chain_probes.txt, relay chain)
+
+
+def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool):
+    """Kernel nodes of the captured decode step (csrc/ptts_lm.hip forward<> + tail), by batch-size regime."""
+    if bs <= 4:   # GEMV step: LN1+QKV, attention, combine+out_proj, [LN2+Mx, softmax+Up | LN2+q, cross-attn, out_proj], LN3+fc1, fc2
+        return (7 if folded else 8) * layers + 2
+    if bs <= 8:   # MFMA strips with fused prologues + the fused LN2 / cross-q / cross-attention kernel
+        return 7 * layers + 2
+    if bs <= 32 and hidden in (1024, 1536):  # rows_prep(LN1), QKV, attention, out_proj, LNS+cross-q, cross-attn, out_proj, LNS+fc1, fc2
+        return 9 * layers + 3
+    return None
+
+
+def latency_model(nodes: int, us_per_launch: float) -> dict:
+    """The step is a chain of `nodes` dependent kernels; each costs at least one kernel boundary whatever it computes. The HBM
+    roofline says how far the step is from the byte floor, this says how far it is from the dependency floor of its own structure."""
+    floor = nodes * NODE_FLOOR_US
+    return {"nodes": nodes, "dependent_node_floor_us": NODE_FLOOR_US, "floor_us_per_launch": round(floor, 1),
+            "us_per_node": round(us_per_launch / nodes, 2), "frac_of_node_floor": round(floor / us_per_launch, 3),
+            "note": "floor = nodes x the measured cost of a dependent trivial kernel node in a hipGraph (profiles/r01_sync_and_chain_probes.txt); "
+                    "in-kernel grid barriers measured no cheaper at >= 128 workgroups (same file)"}
+
+
 def measure_decode_roofline(model, bs: int, device) -> dict:
     """HIP events (on the stream the graph is launched on) around 400 replays of the captured decode step at
     mid-context. Algorithmic bytes per step = W_step*s + B*2*layers*H*(Lc+N)*s + B*(K*H*s + K*V*4)."""
@@ -150,13 +174,20 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
                  "matrix is fetched once at any context; the attention fetches are bounded by the host's context bound rounded up to 64 positions, "
                  "so the K/V part of the traffic grows with the context like the algorithmic term (bytes_per_launch is quoted at the timed context)")
     folded = bs == 1 and not getattr(d, "rope_embeddings", False) and N_DESC <= 64  # static cross-attention folding
-    nodes = ((7 if folded else 8) * L + 2) if bs <= 4 else ((7 * L + 2) if bs <= 8 else None)
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
-            "traffic": traffic, "traffic_note": tnote,
-            "kernel": "decode-step hipGraph: one hipGraphLaunch per generated frame" + (f" ({nodes} kernel nodes)" if nodes else "")
-                      + (f": batch <= 4 runs {7 if folded else 8} row-per-wave GEMV / attention nodes per layer + LM heads + sampler/embed tail" if bs <= 4 else ""),
-            "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "context": lc,
-            "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
+    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+           "traffic": traffic, "traffic_note": tnote,
+           "kernel": "decode-step hipGraph: one hipGraphLaunch per generated frame",
+           "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "context": lc,
+           "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
+    try:  # side information only: must never break the contract line
+        nodes = step_graph_nodes(bs, L, H, folded)
+        if nodes:
+            out["kernel"] += f" ({nodes} kernel nodes)" + (f": batch <= 4 runs {7 if folded else 8} row-per-wave GEMV / attention nodes per layer + LM heads "
+                                                            "+ sampler/embed tail" if bs <= 4 else "")
+            out["latency_model"] = latency_model(nodes, step_s * 1e6)
+    except Exception:  # noqa: BLE001
+        pass
+    return out
 
 
 def measure_sampling_step(model, bs: int, device) -> dict:

@@ -1,0 +1,69 @@
+"""CPU: the arithmetic bench.py puts into the `roofline` object of its JSON line (algorithmic bytes per decode step of SURVEY.md
+§8(d), node count of the captured step, dependency floor), with the GPU parts (engine, HIP-event timing) replaced by stand-ins.
+A typo here would break the contract line on the GPU box, where nothing can be fixed any more."""
+import json
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+class _Eng:
+    def decode_steps(self, n):
+        self.n = getattr(self, "n", 0) + n
+
+
+def _model(which, dtype=torch.bfloat16, fp8=False):
+    cfg = bench.model_config(which)
+    m = types.SimpleNamespace(config=cfg, dtype=dtype, decoder_weights_fp8=fp8)
+    return m
+
+
+@pytest.mark.parametrize("which,bs,step_us,nodes", [("mini", 1, 617.6, 170), ("mini", 32, 1515.6, 219), ("mini", 8, 1330.0, 170), ("large", 1, 1030.0, 212)])
+def test_roofline_object_arithmetic(monkeypatch, which, bs, step_us, nodes):
+    monkeypatch.setattr(bench, "_prefilled_engine", lambda model, b, device, **gen: _Eng())
+    monkeypatch.setattr(bench, "_timed_replays", lambda eng, n: step_us * 1e-6)
+    r = bench.measure_decode_roofline(_model(which), bs, torch.device("cpu"))
+    json.dumps(r)  # serialisable
+    d = bench.model_config(which).decoder
+    H, L, F, V, K = d.hidden_size, d.num_hidden_layers, d.ffn_dim, d.vocab_size, d.num_codebooks
+    w_step = L * (6 * H * H + 2 * H * F) + K * V * H
+    assert w_step == (362_348_544 if which == "mini" else 1_005_944_832)  # 362.3 M / 1005.9 M weights streamed per step
+    lc = bench.N_PROMPT + 1 + 230 + 200
+    expect = w_step * 2 + bs * 2 * L * H * (lc + bench.N_DESC) * 2 + bs * (K * H * 2 + K * V * 4)
+    assert r["bytes_per_launch"] == expect and r["context"] == lc
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["achieved"] == pytest.approx(expect / (step_us * 1e-6) / 1e9, rel=1e-3)
+    assert r["frac"] == pytest.approx(r["achieved"] / 8000.0, abs=1e-4)
+    assert r["us_per_launch"] == pytest.approx(step_us, abs=0.06)
+    lm = r["latency_model"]
+    assert lm["nodes"] == nodes and lm["floor_us_per_launch"] == pytest.approx(nodes * bench.NODE_FLOOR_US, abs=0.06)
+    assert 0 < lm["frac_of_node_floor"] < 1 and lm["us_per_node"] == pytest.approx(step_us / nodes, abs=0.01)
+    if which == "mini" and bs in (1, 32):  # committed PMC pass of this configuration
+        assert isinstance(r["traffic"], int) and 0.9 < r["traffic"] / (w_step * 2) < 2.5
+    else:
+        assert r["traffic"] is None
+
+
+def test_roofline_counts_one_byte_weights_for_the_fp8_gemv_step(monkeypatch):
+    monkeypatch.setattr(bench, "_prefilled_engine", lambda model, b, device, **gen: _Eng())
+    monkeypatch.setattr(bench, "_timed_replays", lambda eng, n: 1e-3)
+    r8 = bench.measure_decode_roofline(_model("large", fp8=True), 4, torch.device("cpu"))
+    r16 = bench.measure_decode_roofline(_model("large"), 4, torch.device("cpu"))
+    assert r16["bytes_per_launch"] - r8["bytes_per_launch"] == 1_005_944_832  # e4m3 weights halve the weight term only
+    r8b = bench.measure_decode_roofline(_model("large", fp8=True), 12, torch.device("cpu"))  # batch > 4: MFMA path on the bf16 dequantisation
+    r16b = bench.measure_decode_roofline(_model("large"), 12, torch.device("cpu"))
+    assert r8b["bytes_per_launch"] == r16b["bytes_per_launch"]
+
+
+def test_step_graph_node_counts_follow_the_forward_structure():
+    assert bench.step_graph_nodes(1, 24, 1024, True) == 170 and bench.step_graph_nodes(1, 24, 1024, False) == 194
+    assert bench.step_graph_nodes(4, 30, 1536, False) == 242 and bench.step_graph_nodes(8, 24, 1024, False) == 170
+    assert bench.step_graph_nodes(32, 24, 1024, False) == 219 and bench.step_graph_nodes(32, 24, 512, False) is None
+    assert bench.step_graph_nodes(64, 24, 1024, False) is None
