@@ -79,3 +79,54 @@ def test_world_size_2_broadcast_and_sharding():
     rebuilt = torch.tensor(g0[0])[:5].tolist() + torch.tensor(g0[1])[:4].tolist()
     assert rebuilt == batch.tolist()
     assert t0 == t1 == 2.0
+
+
+def _model_worker(rank, world, port, q):
+    """what bench.py does at N > 1 (build_model): every rank constructs the model from ITS OWN random state, rank 0's weights win"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+
+    from cases import tiny_model
+    from parler_tts_amd.distributed import broadcast_model_weights
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, _, _, _ = tiny_model(seed=0)
+        if rank != 0:  # a replica that must be overwritten: different decoder / text-encoder / prompt-embedding / codec tensors
+            torch.manual_seed(999)
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(torch.randn_like(p) if p.is_floating_point() else 1)
+                m.audio_encoder._weights = {k: v + 1 for k, v in m.audio_encoder._weights.items()}
+        m._engine, m.audio_encoder._engine = "stale", "stale"  # packed copies of the old tensors must be dropped
+        n = broadcast_model_weights(m, src=0, bucket_bytes=1 << 20)
+        ref, _, _, _ = tiny_model(seed=0)  # rank 0's tensors, rebuilt locally from the same seed
+        same = all(torch.equal(a, b) for (_, a), (_, b) in zip(sorted(m.state_dict().items()), sorted(ref.state_dict().items())))
+        same_dac = all(torch.equal(m.audio_encoder._weights[k], v) for k, v in ref.audio_encoder._weights.items())
+        q.put((rank, n, same, same_dac, m._engine is None and m.audio_encoder._engine is None, len(list(m.parameters()))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_model_weight_broadcast():
+    """`broadcast_model_weights` on a whole ParlerTTSForConditionalGeneration (T5 + decoder holder + prompt embedding + DAC wrapper's
+    tensor dict): rank 1 ends with rank 0's tensors bit for bit, in few collectives, and the lazily packed engines are invalidated."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, same0, dac0, inv0, np0), (_, n1, same1, dac1, inv1, np1) = res
+    assert same0 and dac0, "rank 0's own weights changed"
+    assert same1 and dac1, "rank 1 did not receive rank 0's weights bit-exactly"
+    assert inv0 and inv1
+    assert n0 == n1 and n0 < np0, f"{n0} collectives for {np0} parameter tensors: small tensors must be coalesced"
