@@ -63,9 +63,11 @@ class OracleGenerationHost(torch.nn.Module, GenerationMixin):
 
 
 def hf_sample(oracle: DO.DecoderOracle, enc, enc_mask, prompt, prompt_mask, gp: DO.GenParams, eos_gate_factory=None,
-              decoder_input_ids: Optional[torch.Tensor] = None):
+              decoder_input_ids: Optional[torch.Tensor] = None, encoder_input_ids: Optional[torch.Tensor] = None, **config_extra):
     """Runs the installed transformers `_sample` the way the reference's generate() sets it up (:3395-3572).
-    Returns (sequences [B*K, Lout], processed scores per step)."""
+    Returns (sequences [B*K, Lout], processed scores per step). ``config_extra``: further GenerationConfig fields (repetition_penalty,
+    no_repeat_ngram_size, min_p, ...) that transformers' own `_get_logits_processor` turns into processors (:3540-3547);
+    ``encoder_input_ids``: the description token ids the reference passes there as `encoder_input_ids=inputs_tensor`."""
     spec = oracle.spec
     K = spec.num_codebooks
     bsz = enc.shape[0]
@@ -74,14 +76,14 @@ def hf_sample(oracle: DO.DecoderOracle, enc, enc_mask, prompt, prompt_mask, gp: 
     gc = GenerationConfig(do_sample=gp.do_sample, max_length=gp.max_length, min_new_tokens=gp.min_new_tokens or None,
                           temperature=gp.temperature if gp.do_sample else None, top_k=(gp.top_k or None) if gp.do_sample else None,
                           top_p=gp.top_p if gp.do_sample else None, pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id,
-                          bos_token_id=spec.bos_token_id, return_dict_in_generate=True, output_scores=True, use_cache=True)
+                          bos_token_id=spec.bos_token_id, return_dict_in_generate=True, output_scores=True, use_cache=True, **config_extra)
     host._prepare_special_tokens(gc, False, device=torch.device("cpu"))
     seq = torch.full((bsz * K, 1), spec.bos_token_id, dtype=torch.long)  # :3011-3014
     if decoder_input_ids is not None and decoder_input_ids.shape[-1] > 0:
         seq = torch.cat([seq, decoder_input_ids.long()], dim=-1)
     input_ids_length = seq.shape[-1]
     custom = LogitsProcessorList([eos_gate_factory(bsz)] if (gp.use_eos_gate and eos_gate_factory is not None) else [])  # :3418
-    processors = host._get_logits_processor(generation_config=gc, input_ids_seq_length=input_ids_length, encoder_input_ids=None,
+    processors = host._get_logits_processor(generation_config=gc, input_ids_seq_length=input_ids_length, encoder_input_ids=encoder_input_ids,
                                             prefix_allowed_tokens_fn=None, logits_processor=custom, device="cpu")  # :3412-3427
     criteria = host._get_stopping_criteria(generation_config=gc, stopping_criteria=StoppingCriteriaList())  # :3424-3427
     delayed, pattern = DO.build_delay_pattern_mask(seq, spec.bos_token_id, spec.pad_token_id, gp.max_length, K)  # :3523-3530

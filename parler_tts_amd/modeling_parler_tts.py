@@ -22,6 +22,7 @@ from torch import nn
 from .configuration_parler_tts import DACConfig, ParlerTTSConfig, ParlerTTSDecoderConfig
 from .dac_wrapper import DACModel
 from .engine import DecoderEngine
+from .generation_extras import active_extras, build_processors, build_stopping_criteria, check_generation_mode, check_model_kwargs
 from .logits_processors import ParlerTTSLogitsProcessor
 
 
@@ -582,15 +583,14 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         encoder_outputs = mk.pop("encoder_outputs", None)
         input_values = mk.pop("input_values", None)
         decoder_input_ids = mk.pop("decoder_input_ids", None)
+        check_model_kwargs(mk)  # unknown names raise like transformers' _validate_model_kwargs; forward arguments this path cannot honour raise too
         if mk.get("past_key_values") is not None and getattr(gc, "cache_implementation", None) is not None:
             raise ValueError("Passing both `cache_implementation` (used to initialize certain caches) and `past_key_values` (a "
                              "Cache object) is unsupported. Please use only one of the two.")
         if getattr(gc, "cache_implementation", None) == "quantized":
             raise ValueError("This model does not support the quantized cache. If you want your model to support quantized "
                              "cache, please open an issue on the Parler-TTS repository https://github.com/huggingface/parler-tts")
-        if (getattr(gc, "num_beams", 1) or 1) > 1 or (getattr(gc, "num_beam_groups", 1) or 1) > 1:
-            raise ValueError("Got incompatible mode for generation, should be one of greedy or sampling. "
-                             "Ensure that beam search is de-activated by setting `num_beams=1` and `num_beam_groups=1`.")
+        check_generation_mode(gc)  # greedy / sampling only (:3574-3578)
         dev = self.device
         d = self.config.decoder
         K = d.num_codebooks
@@ -663,6 +663,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             max_length = int(gc.max_new_tokens) + 1 + T0
         else:
             max_length = int(gc.max_length)
+        gc.max_length = max_length  # what _prepare_generated_length leaves in the config (ForcedEOS / length-penalty processors read it)
         min_new = int(gc.min_new_tokens or 0)
         if getattr(gc, "min_length", 0):
             min_new = max(min_new, int(gc.min_length) - 1 - T0)
@@ -672,6 +673,11 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             raise ValueError("`max_length` / `max_new_tokens` leave no room for a generated token")
         do_sample = bool(gc.do_sample)
         manual = (logits_processor is not None and len(logits_processor) > 0) or (stopping_criteria is not None and len(stopping_criteria) > 0)
+        # GenerationConfig options the device sampler does not implement (repetition / n-gram penalties, bad words, min-p, typical-p,
+        # max_time ...): the reference honours them through transformers' _get_logits_processor (:3540-3552); here they run the host
+        # loop with transformers' own processor objects (generation_extras.py). Nothing is silently ignored.
+        extras = active_extras(gc)
+        manual = manual or bool(extras)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0  # follows torch.manual_seed()
         n_split = self._decode_streams(B) if (not manual and streamer is None and not getattr(self, "overlap_codec", False)) else 1
         gen_kw = dict(max_length=max_length, min_new_tokens=min_new, do_sample=do_sample, temperature=float(gc.temperature or 1.0),
@@ -701,8 +707,15 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         elif not manual:
             output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, delayed.shape[1])
         else:
+            hf_list = None
+            if extras:
+                custom = logits_processor if logits_processor is not None else [ParlerTTSLogitsProcessor(eos, K, B, dev)]  # :3418
+                enc_ids = input_ids if (input_ids is not None and torch.is_tensor(input_ids) and input_ids.dim() == 2) else None
+                hf_list = build_processors(gc, delayed.shape[1], enc_ids, custom, dev, eos)
+                cfg_criteria, user_criteria = build_stopping_criteria(gc, stopping_criteria)
+                stopping_criteria = cfg_criteria + user_criteria
             output_ids = self._run_host_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, logits_processor,
-                                             stopping_criteria, streamer, eos, pad, delayed)
+                                             stopping_criteria, streamer, eos, pad, delayed, hf_list=hf_list)
         if streamer is not None:
             streamer.end()
         # --- un-delay (:3585-3597) and decode (:3600-3647) -------------------------------------------------------------
@@ -903,7 +916,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
 
     # -- user LogitsProcessorList / StoppingCriteria: forward on the HIP engine, selection in torch --------------------------
     def _run_host_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, min_new, gc, processors, criteria, streamer, eos, pad,
-                       given_ids):
+                       given_ids, hf_list=None):
+        """``hf_list``: the COMPLETE processor list of the call (config processors, custom / default list, warpers) built by
+        generation_extras.build_processors; when given it replaces the inline MinNewTokens / warper code below."""
         dev = self.device
         eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
         B = enc.shape[0]
@@ -915,21 +930,25 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             processors = [ParlerTTSLogitsProcessor(eos, K, B, dev)]  # with or without user stopping criteria
         while True:
             scores = eng.logits().float()
-            if min_new > 0 and (seq.shape[-1] - given) < min_new:
-                scores[:, eos] = -math.inf
-            for proc in (processors or []):
-                scores = proc(seq, scores)
+            if hf_list is not None:  # transformers' own processor objects in its order: config -> custom / default list -> warpers
+                scores = hf_list(seq, scores)
+            else:
+                if min_new > 0 and (seq.shape[-1] - given) < min_new:
+                    scores[:, eos] = -math.inf
+                for proc in (processors or []):
+                    scores = proc(seq, scores)
+                if gc.do_sample:
+                    if gc.temperature and gc.temperature != 1.0:
+                        scores = scores / gc.temperature
+                    if gc.top_k:
+                        kth = torch.topk(scores, min(int(gc.top_k), scores.shape[-1]))[0][..., -1, None]
+                        scores = scores.masked_fill(scores < kth, -math.inf)
+                    if gc.top_p is not None and gc.top_p < 1.0:
+                        sl, si = torch.sort(scores, descending=False)
+                        rm = sl.softmax(dim=-1).cumsum(dim=-1) <= (1 - gc.top_p)
+                        rm[..., -1:] = False
+                        scores = scores.masked_fill(rm.scatter(1, si, rm), -math.inf)
             if gc.do_sample:
-                if gc.temperature and gc.temperature != 1.0:
-                    scores = scores / gc.temperature
-                if gc.top_k:
-                    kth = torch.topk(scores, min(int(gc.top_k), scores.shape[-1]))[0][..., -1, None]
-                    scores = scores.masked_fill(scores < kth, -math.inf)
-                if gc.top_p is not None and gc.top_p < 1.0:
-                    sl, si = torch.sort(scores, descending=False)
-                    rm = sl.softmax(dim=-1).cumsum(dim=-1) <= (1 - gc.top_p)
-                    rm[..., -1:] = False
-                    scores = scores.masked_fill(rm.scatter(1, si, rm), -math.inf)
                 nxt = torch.multinomial(torch.softmax(scores, dim=-1), 1).squeeze(1)
             else:
                 nxt = torch.argmax(scores, dim=-1)

@@ -130,6 +130,30 @@ def test_stopping_criteria_only_keeps_the_default_eos_gate():
         assert float((b[i, :n].cpu() - wav_ref[i]).pow(2).mean().sqrt()) <= 1e-4
 
 
+def test_generation_config_processors_run_the_host_loop_on_the_hip_engine():
+    """GenerationConfig options the device sampler does not implement (repetition_penalty, no_repeat_ngram_size ...) switch generate() to
+    the host loop with transformers' own processor objects (generation_extras.py; the reference gets them from `_get_logits_processor`,
+    :3540-3547). Same HIP engine, same logits: the call must equal, bit for bit, the same processors handed in as a user list (a path the
+    tests above cover), and differ from the plain call. What the processors compute is pinned on CPU (tests/test_generation_extras_cpu.py)."""
+    import parler_tts_amd as P
+    from transformers.generation.logits_process import NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor
+
+    m, *_ = _tiny_model(seed=6, eos_gain=6.0)
+    m = m.to("cuda")
+    g = torch.Generator().manual_seed(5)
+    desc = torch.randint(3, 128, (2, 6), generator=g).cuda()
+    prompt_ids = torch.randint(3, 128, (2, 3), generator=g).cuda()
+    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=36, min_new_tokens=4)
+    plain = m.generate(**kw)
+    a = m.generate(repetition_penalty=1.4, no_repeat_ngram_size=2, **kw)
+    user = [RepetitionPenaltyLogitsProcessor(penalty=1.4), NoRepeatNGramLogitsProcessor(2), P.ParlerTTSLogitsProcessor(1024, 9, 2, "cuda")]
+    b = m.generate(logits_processor=user, **kw)
+    assert a.shape == b.shape and torch.equal(a, b)
+    assert a.shape != plain.shape or not torch.equal(a, plain)
+    with pytest.raises(NotImplementedError, match="guidance_scale"):
+        m.generate(guidance_scale=3.0, **kw)
+
+
 def test_sampling_is_seeded_and_in_range():
     m, *_ = _tiny_model(seed=4)
     m = m.to("cuda")
