@@ -183,6 +183,23 @@ class GenerateOutput(dict):
         self[k] = v
 
 
+def _single_device(device_map):
+    """``device_map`` forms that name ONE device (the whole model lives on one GPU: SURVEY.md §8(e), one process per GPU); a real
+    multi-device map has no meaning for this engine and is refused."""
+    if device_map is None:
+        return None
+    if isinstance(device_map, dict):
+        targets = set(device_map.values())
+        if len(targets) != 1:
+            raise NotImplementedError(f"device_map={device_map}: the HIP engines keep a whole model replica on one device (one process per GPU)")
+        device_map = targets.pop()
+    if device_map in ("auto", "balanced", "sequential"):
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if isinstance(device_map, int):
+        return torch.device("cuda", device_map)
+    return torch.device(device_map)
+
+
 def _default_generation_config(config: ParlerTTSConfig):
     from transformers import GenerationConfig
 
@@ -369,8 +386,18 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         reference's key names. ``attn_implementation`` is accepted for drop-in compatibility and ignored: the
         whole attention registry (:933-937) is replaced by the HIP attention kernel."""
         path = pretrained_model_name_or_path
+        if torch_dtype is None and kwargs.get("dtype") is not None:
+            torch_dtype = kwargs["dtype"]  # newer transformers releases spell it `dtype=`
+        if isinstance(torch_dtype, str):
+            torch_dtype = None if torch_dtype == "auto" else getattr(torch, torch_dtype)
         if torch_dtype is not None and torch_dtype not in (torch.float32, torch.bfloat16):
             raise NotImplementedError(f"torch_dtype={torch_dtype}: the HIP engine implements float32 (parity) and bfloat16 (throughput)")
+        device = _single_device(kwargs.get("device_map"))
+        # hub / loader plumbing that has no effect on a locally materialised state dict, everything else must be a config field or raises
+        loader_kw = {"dtype", "device_map", "revision", "cache_dir", "token", "local_files_only", "force_download", "resume_download", "proxies",
+                     "subfolder", "variant", "use_safetensors", "low_cpu_mem_usage", "trust_remote_code", "use_auth_token", "weights_only",
+                     "output_loading_info", "offload_folder", "offload_state_dict", "max_memory", "tp_plan"}
+        overrides = {k: v for k, v in kwargs.items() if k not in loader_kw}
         if not os.path.isdir(path):
             from huggingface_hub import snapshot_download  # needs network / a local HF cache
 
@@ -379,6 +406,10 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             if not any(f.endswith(".safetensors") for f in os.listdir(path)):  # legacy repos ship pytorch_model.bin only
                 path = snapshot_download(pretrained_model_name_or_path, allow_patterns=["*.json", "*.bin"], **hub_kw)
         cfg = config or ParlerTTSConfig.from_pretrained(path)
+        for k, v in overrides.items():  # transformers semantics: a kwarg naming a config attribute overrides it, any other is an error
+            if not hasattr(cfg, k):
+                raise TypeError(f"{cls.__name__}.from_pretrained() got an unexpected keyword argument '{k}'")
+            setattr(cfg, k, v)
         model = cls(cfg)
         gpath = os.path.join(path, "generation_config.json")
         if os.path.exists(gpath):
@@ -400,6 +431,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         model.load_state_dict(sd)
         if torch_dtype is not None:
             model.to(dtype=torch_dtype)
+        if device is not None:
+            model.to(device)
         return model
 
     @classmethod

@@ -97,6 +97,17 @@ def test_state_dict_uses_reference_names_and_round_trips(tmp_path):
     assert all(torch.equal(a[k], b[k]) for k in a if not k.endswith("_dummy"))
     assert "model.decoder.model.1.block.1.parametrizations.weight.original0" in m2.audio_encoder.state_dict()
     assert m2.generation_config.decoder_start_token_id == 1025 and m2.generation_config.max_length == 2580
+    # loader kwargs: `dtype=` alias, single-device `device_map`, config-field overrides; anything else is an error, not silently dropped
+    m3 = P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path), dtype="bfloat16", device_map={"": "cpu"}, low_cpu_mem_usage=True,
+                                                             attn_implementation="sdpa", vocab_size=m.config.vocab_size)
+    assert m3.dtype == torch.bfloat16 and m3.device.type == "cpu"
+    assert torch.equal(m3.state_dict()["embed_prompts.weight"], a["embed_prompts.weight"].to(torch.bfloat16))
+    with pytest.raises(TypeError, match="unexpected keyword argument 'torch_dtyp'"):
+        P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path), torch_dtyp=torch.bfloat16)
+    with pytest.raises(NotImplementedError, match="one device"):
+        P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path), device_map={"text_encoder": 0, "decoder": 1})
+    with pytest.raises(NotImplementedError, match="float16"):
+        P.ParlerTTSForConditionalGeneration.from_pretrained(str(tmp_path), torch_dtype=torch.float16)
 
 
 def test_unsupported_architectures_fail_loudly():
