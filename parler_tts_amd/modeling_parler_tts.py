@@ -711,6 +711,15 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         # loop with transformers' own processor objects (generation_extras.py). Nothing is silently ignored.
         extras = active_extras(gc)
         manual = manual or bool(extras)
+        # return_dict_in_generate + output_scores / output_logits: the reference returns `_sample`'s per-step tuples next to the waveform
+        # (:3648-3651 keeps the ModelOutput); they exist on the host loop only
+        as_dict = bool(getattr(gc, "return_dict_in_generate", False))
+        keep_scores = as_dict and bool(getattr(gc, "output_scores", False))
+        keep_logits = as_dict and bool(getattr(gc, "output_logits", False))
+        if as_dict and (getattr(gc, "output_attentions", False) or getattr(gc, "output_hidden_states", False)):
+            raise NotImplementedError("output_attentions / output_hidden_states: the HIP decoder does not materialise attention maps or per-layer states")
+        manual = manual or keep_scores or keep_logits
+        self._step_records = ([] if keep_scores else None, [] if keep_logits else None)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0  # follows torch.manual_seed()
         n_split = self._decode_streams(B) if (not manual and streamer is None and not getattr(self, "overlap_codec", False)) else 1
         gen_kw = dict(max_length=max_length, min_new_tokens=min_new, do_sample=do_sample, temperature=float(gc.temperature or 1.0),
@@ -777,8 +786,14 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                 outs.append(w)
             lengths = [int(w.shape[0]) for w in outs]
             wav = torch.nn.utils.rnn.pad_sequence(outs, batch_first=True, padding_value=0)
-        if getattr(gc, "return_dict_in_generate", False):
-            return GenerateOutput(sequences=wav, audios_length=lengths)
+        if as_dict:
+            out = GenerateOutput(sequences=wav, audios_length=lengths)
+            if keep_scores:
+                out["scores"] = tuple(self._step_records[0])
+            if keep_logits:
+                out["logits"] = tuple(self._step_records[1])
+            self._step_records = (None, None)
+            return out
         return wav
 
     # -- default path: the whole `_sample` loop runs on the device -------------------------------------------------------
@@ -963,6 +978,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             processors = [ParlerTTSLogitsProcessor(eos, K, B, dev)]  # with or without user stopping criteria
         while True:
             scores = eng.logits().float()
+            rec_scores, rec_logits = getattr(self, "_step_records", (None, None))
+            if rec_logits is not None:
+                rec_logits.append(scores.clone())
             if hf_list is not None:  # transformers' own processor objects in its order: config -> custom / default list -> warpers
                 scores = hf_list(seq, scores)
             else:
@@ -981,6 +999,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                         rm = sl.softmax(dim=-1).cumsum(dim=-1) <= (1 - gc.top_p)
                         rm[..., -1:] = False
                         scores = scores.masked_fill(rm.scatter(1, si, rm), -math.inf)
+            if rec_scores is not None:
+                rec_scores.append(scores)
             if gc.do_sample:
                 nxt = torch.multinomial(torch.softmax(scores, dim=-1), 1).squeeze(1)
             else:

@@ -124,3 +124,25 @@ def test_max_time_becomes_a_stopping_criterion_and_unsupported_options_raise():
     with pytest.raises(NotImplementedError, match="inputs_embeds"):
         m.generate(max_new_tokens=12, inputs_embeds=torch.zeros(1, 7, 128), **kw)
     m.generate(max_new_tokens=12, min_new_tokens=12, use_cache=True, padding_mask=None, **kw)  # accepted no-ops
+
+
+def test_output_scores_and_logits_are_the_per_step_tuples_of_transformers_sample():
+    """return_dict_in_generate + output_scores / output_logits: the reference hands back `_sample`'s ModelOutput with the waveform in
+    `.sequences` (:3648-3651), so `.scores` (processed) and `.logits` (raw) are there; here they come from the host loop."""
+    m, spec, sd, dac = _model(eos_gain=4.0)
+    g = torch.Generator().manual_seed(23)
+    desc, prompt_ids = torch.randint(3, 128, (2, 8), generator=g), torch.randint(3, 128, (2, 4), generator=g)
+    out = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_length=24, min_new_tokens=5, return_dict_in_generate=True,
+                     output_scores=True, output_logits=True)
+    enc = m._encode_description(desc, None).float()
+    prompt = m.embed_prompts(prompt_ids).float()
+    with torch.no_grad():
+        seq, scores, _ = HS.hf_sample(DO.DecoderOracle(spec, sd), enc, None, prompt, None, DO.GenParams(max_length=24, min_new_tokens=5), lambda b: _gate(spec, b))
+    assert len(out.scores) == len(scores) == len(out.logits) == seq.shape[1] - 1
+    for a, b, raw in zip(out.scores, scores, out.logits):
+        assert torch.equal(torch.isinf(a), torch.isinf(b)) and torch.allclose(a[~torch.isinf(a)], b[~torch.isinf(b)], atol=1e-6)
+        assert not torch.isinf(raw).any() and torch.allclose(raw[~torch.isinf(a)], a[~torch.isinf(a)], atol=1e-6)  # greedy: processing only masks
+    plain = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_length=24, min_new_tokens=5, return_dict_in_generate=True)
+    assert "scores" not in plain and torch.equal(plain.sequences, out.sequences)
+    with pytest.raises(NotImplementedError, match="output_attentions"):
+        m.generate(input_ids=desc, prompt_input_ids=prompt_ids, max_length=24, return_dict_in_generate=True, output_attentions=True)
