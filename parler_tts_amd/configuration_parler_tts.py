@@ -57,6 +57,7 @@ class ParlerTTSDecoderConfig(_Config):
     """Fields and defaults of the reference decoder config (configuration_parler_tts.py:111-172)."""
 
     model_type = "parler_tts_decoder"
+    keys_to_ignore_at_inference = ["past_key_values"]
 
     def __init__(self, vocab_size=2049, max_position_embeddings=2048, num_hidden_layers=24, ffn_dim=4096,
                  num_attention_heads=16, num_key_value_heads=None, num_cross_attention_key_value_heads=None, layerdrop=0.0,

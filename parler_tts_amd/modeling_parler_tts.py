@@ -166,8 +166,34 @@ class ParlerTTSForCausalLM(nn.Module):
     def apply_delay_pattern_mask(input_ids, decoder_pad_token_mask):
         return apply_delay_pattern_mask(input_ids, decoder_pad_token_mask)
 
+    # accessors of the reference class (:1845-1861); the modules they return are parameter holders with the reference's names
+    def get_input_embeddings(self):
+        return self.model.decoder.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.model.decoder.embed_tokens = value
+
+    def get_output_embeddings(self):
+        return self.lm_heads
+
+    def set_output_embeddings(self, new_embeddings):
+        self.lm_heads = new_embeddings
+
+    def get_decoder(self):
+        return self.model.decoder
+
+    def set_decoder(self, decoder):
+        self.model.decoder = decoder
+
     def forward(self, *args, **kwargs):
         raise NotImplementedError("the decoder forward runs inside the HIP engine; call ParlerTTSForConditionalGeneration.generate()")
+
+    def generate(self, *args, **kwargs):
+        """The reference's decoder-only ``generate`` (:2072-2300, inherited from MusicGen) cannot run there either: it calls
+        ``build_delay_pattern_mask(input_ids, pad_token_id=..., max_length=...)`` without the required ``bos_token_id`` (:2189-2193 vs the
+        signature at :2041-2043) and raises TypeError. Generation goes through the composite model."""
+        raise NotImplementedError("decoder-only generate() is dead code in the reference (TypeError at modeling_parler_tts.py:2189); "
+                                  "call ParlerTTSForConditionalGeneration.generate()")
 
 
 class GenerateOutput(dict):
