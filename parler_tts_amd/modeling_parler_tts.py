@@ -127,7 +127,10 @@ class ParlerTTSForCausalLM(nn.Module):
             for k in range(c.num_codebooks):
                 _set_param(self, f"lm_heads.{k}.weight", mk(c.vocab_size, H))
 
-    def build_delay_pattern_mask(self, input_ids, bos_token_id, pad_token_id, max_length):
+    def build_delay_pattern_mask(self, input_ids, bos_token_id, pad_token_id, max_length=None):
+        if max_length is None:  # :2068: the model's generation_config (a bare PreTrainedModel default: max_length 20)
+            gc = getattr(self, "generation_config", None)
+            max_length = int(gc.max_length) if gc is not None and getattr(gc, "max_length", None) is not None else 20
         return build_delay_pattern_mask(input_ids, bos_token_id, pad_token_id, max_length, self.num_codebooks)
 
     def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **kwargs):
