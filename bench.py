@@ -150,6 +150,50 @@ def latency_model(nodes: int, us_per_launch: float) -> dict:
                     "in-kernel grid barriers measured no cheaper at >= 128 workgroups (same file)"}
 
 
+def measure_traffic_live(bs: int, steps: int = 24, timeout_s: int = 90):
+    """`--live-pmc` (off by default until validated on the GPU box): HBM bytes per decode step measured during THIS run instead of read
+    from profiles/: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains) over
+    tools/prof_eager.py (the step's kernels launched eagerly: --pmc does not survive graph replays in this image), summarised by
+    tools/pmc_report2.py with the guide's gfx950 correction (FETCH_SIZE x2). Returns the report's dict or None (any failure, no
+    rocprofv3, already running under a profiler): the caller then falls back to the committed pass."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3")
+    if rp is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    tmp = tempfile.mkdtemp(prefix="ptts_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, PROF_B=str(bs), PROF_STEPS=str(steps), TMPDIR="/tmp")
+        dbs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            r = subprocess.run([rp, "--pmc", counter, "-d", out_dir, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "prof_eager.py")],
+                               cwd="/tmp", env=env, timeout=timeout_s, capture_output=True)
+            found = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not found:
+                return None
+            dbs[counter] = found[0]
+        out_json = os.path.join(tmp, "traffic.json")
+        context = N_PROMPT + 1 + steps  # self-KV positions when the eager run ends
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_report2.py"), dbs["FETCH_SIZE"], dbs["WRITE_SIZE"], str(min(16, steps - 1)),
+                            str(context), str(bs), out_json], timeout=60, capture_output=True)
+        if r.returncode != 0 or not os.path.exists(out_json):
+            return None
+        j = json.load(open(out_json))
+        j["source"] = "LIVE in this bench run: " + j.get("source", "")
+        return j
+    except Exception:  # noqa: BLE001 — a side measurement: never fatal
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+LIVE_PMC = False  # set by --live-pmc
+
+
 def measure_decode_roofline(model, bs: int, device) -> dict:
     """HIP events (on the stream the graph is launched on) around 400 replays of the captured decode step at
     mid-context. Algorithmic bytes per step = W_step*s + B*2*layers*H*(Lc+N)*s + B*(K*H*s + K*V*4)."""
@@ -167,8 +211,9 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
     achieved = bytes_step / step_s / 1e9
     traffic, tnote = None, "PMC pass not available for this configuration"
     pmc = os.path.join(ROOT, "profiles", f"r02_pmc_step_bs{bs}.json")
-    if es == 2 and H == 1024 and os.path.exists(pmc):  # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
-        j = json.load(open(pmc))
+    live = measure_traffic_live(bs) if (LIVE_PMC and es == 2 and H == 1024 and L == 24 and ws == 2) else None
+    if live is not None or (es == 2 and H == 1024 and os.path.exists(pmc)):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
+        j = live if live is not None else json.load(open(pmc))
         traffic = int(j["traffic_bytes_per_step"])
         tnote = (f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~{j.get('algorithmic_mb', '?')} MB). Every weight "
                  "matrix is fetched once at any context; the attention fetches are bounded by the host's context bound rounded up to 64 positions, "
@@ -342,7 +387,11 @@ def main():
     ap.add_argument("--sample", action="store_true", help="do_sample=True (temperature 1.0, top_k 50: the reference's default generation mode) instead of greedy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bs=32 / TTFT side measurements")
+    ap.add_argument("--live-pmc", action="store_true", help="measure roofline.traffic in this run (two rocprofv3 --pmc child passes, +~45 s) "
+                                                            "instead of reading the committed pass under profiles/")
     args = ap.parse_args()
+    global LIVE_PMC
+    LIVE_PMC = bool(args.live_pmc)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))

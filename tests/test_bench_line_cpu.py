@@ -67,3 +67,16 @@ def test_step_graph_node_counts_follow_the_forward_structure():
     assert bench.step_graph_nodes(4, 30, 1536, False) == 242 and bench.step_graph_nodes(8, 24, 1024, False) == 170
     assert bench.step_graph_nodes(32, 24, 1024, False) == 219 and bench.step_graph_nodes(32, 24, 512, False) is None
     assert bench.step_graph_nodes(64, 24, 1024, False) is None
+
+
+def test_live_pmc_result_replaces_the_committed_pass_and_failures_fall_back(monkeypatch):
+    monkeypatch.setattr(bench, "_prefilled_engine", lambda model, b, device, **gen: _Eng())
+    monkeypatch.setattr(bench, "_timed_replays", lambda eng, n: 6e-4)
+    monkeypatch.setattr(bench, "LIVE_PMC", True)
+    monkeypatch.setattr(bench, "measure_traffic_live", lambda bs, **k: {"traffic_bytes_per_step": 7.7e8, "context": 57, "algorithmic_mb": 736.6,
+                                                                       "source": "LIVE in this bench run: rocprofv3 --pmc ..."})
+    r = bench.measure_decode_roofline(_model("mini"), 1, torch.device("cpu"))
+    assert r["traffic"] == 770000000 and r["traffic_note"].startswith("LIVE in this bench run")
+    monkeypatch.setattr(bench, "measure_traffic_live", lambda bs, **k: None)  # rocprofv3 missing / child failed: the committed pass is quoted
+    r = bench.measure_decode_roofline(_model("mini"), 1, torch.device("cpu"))
+    assert isinstance(r["traffic"], int) and not r["traffic_note"].startswith("LIVE")
