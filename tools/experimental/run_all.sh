@@ -1,19 +1,21 @@
 #!/bin/bash
-# First GPU call of the next round: every parked experiment measured in ONE gpurun call (~6-8 GPU-minutes).
+# First GPU call of the next round: every parked experiment measured in ONE gpurun call (~5 GPU-minutes, no compilation on the box).
+#   bash tools/experimental/build_variants.sh                                   # here, on the CPU: one library per patch under parler_tts_amd/exp/
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/experimental/run_all.sh'
-# For each patch: apply -> build -> guarded parity tests -> probe -> revert. Results in gpurun_out/r03a/summary.txt.
-# The snapshot on the GPU box has no .git: `git apply` works on a plain directory.
+# Each variant: guarded parity tests (tools/experimental/test_experimental_gpu.py) -> probe, selected with PTTS_LIB. A variant whose
+# library is missing is skipped (build it first). Results in gpurun_out/r03a/summary.txt.
 set -u
 O=gpurun_out/r03a; mkdir -p $O
 S=$O/summary.txt; : > $S
-build() { python -c "import __graft_entry__ as g; g.build()" > $O/build_$1.log 2>&1 && echo "[$1] build ok" >> $S || { echo "[$1] BUILD FAILED" >> $S; tail -5 $O/build_$1.log >> $S; return 1; }; }
+E=parler_tts_amd/exp
 step32() { local tag=$1; shift; env "$@" timeout 120 python tools/step_probe2.py 32 "$tag" 2>&1 | grep step_probe2 >> $S; }
+tests() { local tag=$1 k=$2; shift 2; env "$@" timeout 400 python -m pytest tools/experimental/test_experimental_gpu.py -q -x -k "$k" > $O/pytest_$tag.log 2>&1; echo "[$tag] $(tail -1 $O/pytest_$tag.log)" >> $S; }
 
-echo "## baseline (HEAD)" >> $S
+echo "## baseline (HEAD library)" >> $S
 step32 baseline PTTS_NOOP=1
 timeout 200 python tools/dac_probe.py 2>&1 | grep "B=1 T=860\|B=32" >> $S
 
-echo "## PTTS_DECODE_STREAMS=2 (already in the tree): e2e generate() of 32 utterances, 860 frames" >> $S
+echo "## PTTS_DECODE_STREAMS (in the tree): e2e generate() of 32 utterances, 860 frames, 1 / 2 / 4 sub-batches" >> $S
 cat > $O/e2e32.py <<'PY'
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
@@ -30,25 +32,30 @@ for n in (1, 2, 4):
 PY
 timeout 300 python $O/e2e32.py 2>&1 | grep "e2e bs=32" >> $S
 
-for P in fc2_last_arriver xattn_groups; do
-  echo "## $P" >> $S
-  git apply tools/experimental/$P.patch || { echo "[$P] patch does not apply" >> $S; continue; }
-  if build $P; then
-    PTTS_TEST_EXPERIMENTAL=1 timeout 400 python -m pytest tests/test_lm_gpu.py -q -x -k "experimental or producer_statistics or batch_sizes" > $O/pytest_$P.log 2>&1; tail -1 $O/pytest_$P.log >> $S
-    if [ $P = fc2_last_arriver ]; then step32 $P PTTS_FC2_ARRIVE=1; else step32 $P PTTS_XATTN_GROUPS=1; fi
-  fi
-  git apply -R tools/experimental/$P.patch
+for V in fc2_last_arriver xattn_groups lm_batch32_both; do
+  echo "## $V" >> $S
+  L=$E/libptts_$V.so
+  [ -f $L ] || { echo "[$V] $L missing: run tools/experimental/build_variants.sh first" >> $S; continue; }
+  case $V in
+    fc2_last_arriver) K="arriver"; F="PTTS_FC2_ARRIVE=1";;
+    xattn_groups)     K="groups";  F="PTTS_XATTN_GROUPS=1";;
+    *)                K="together or arriver or groups"; F="PTTS_FC2_ARRIVE=1 PTTS_XATTN_GROUPS=1";;
+  esac
+  tests $V "$K" PTTS_LIB=$PWD/$L
+  step32 $V PTTS_LIB=$PWD/$L $F
 done
 
-echo "## both LM patches" >> $S
-git apply tools/experimental/lm_batch32_both.patch && build both && step32 both PTTS_FC2_ARRIVE=1 PTTS_XATTN_GROUPS=1
-git apply -R tools/experimental/lm_batch32_both.patch
-
 echo "## dac_fused_resunit" >> $S
-git apply tools/experimental/dac_fused_resunit.patch && build dacfuse && {
-  PTTS_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_dac_gpu.py -q -x -k "fused_residual or full_size" > $O/pytest_dacfuse.log 2>&1; tail -1 $O/pytest_dacfuse.log >> $S
-  PTTS_DAC_FUSE_RES=1 timeout 200 python tools/dac_probe.py 2>&1 | grep "B=1 T=860\|B=32" >> $S
-}
-git apply -R tools/experimental/dac_fused_resunit.patch
-build head   # leave the tree and the .so as they were
+L=$E/libptts_dac_fused_resunit.so
+if [ -f $L ]; then
+  tests dacfuse "fused_residual" PTTS_LIB=$PWD/$L
+  PTTS_LIB=$PWD/$L PTTS_DAC_FUSE_RES=1 timeout 200 python tools/dac_probe.py 2>&1 | grep "B=1 T=860\|B=32" >> $S
+else
+  echo "[dacfuse] $L missing" >> $S
+fi
+
+echo "## bench.py --live-pmc (roofline.traffic measured in the run)" >> $S
+timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --live-pmc 2>/dev/null | python -c "
+import json, sys
+j = json.loads(sys.stdin.readline()); r = j['roofline']; print('traffic', r['traffic'], '|', r['traffic_note'][:80])" >> $S 2>&1
 cat $S
