@@ -25,6 +25,7 @@ for V in fc2_last_arriver xattn_groups lm_batch32_both dac_fused_resunit; do
   rm -rf "$T"
   echo "built parler_tts_amd/exp/libptts_$V.so"
 done
+hipcc --offload-arch=gfx950 -O3 -w -std=c++17 -o tools/chain_probe32 tools/chain_probe32.hip && echo "built tools/chain_probe32"
 python - <<'PY'
 import ctypes, glob, os, torch  # noqa: F401  (torch first: one HIP runtime instance)
 for p in sorted(glob.glob("parler_tts_amd/exp/libptts_*.so")):
