@@ -64,3 +64,30 @@ def test_engines_refuse_to_run_without_gpu():
         DecoderEngine(hidden_size=128, num_layers=1, num_heads=2, ffn_dim=256, num_codebooks=9, vocab_size=1088, max_positions=64)
     with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
         DacEngine()
+
+
+def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_binding(tmp_path):
+    """include/ptts.h is the drop-in boundary: it must compile as C99 (no torch / C++ types in the signatures) and as C++, and the
+    struct layouts a C caller sees must be the ones parler_tts_amd/_native.py declares to ctypes (a silent mismatch would corrupt
+    every configuration field)."""
+    import shutil
+    import subprocess
+
+    N, lib = _lib()
+    inc = os.path.join(ROOT, "include")
+    gcc, gxx = shutil.which("gcc"), shutil.which("g++")
+    if gcc is None or gxx is None:
+        pytest.skip("no host compiler")
+    subprocess.check_call([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "ptts.h")])
+    subprocess.check_call([gxx, "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", os.path.join(inc, "ptts.h")])
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ptts.h"\n'
+                   'int main(void) {\n'
+                   '  printf("%d %zu %zu %zu %zu %zu %zu\\n", PTTS_ABI_VERSION, sizeof(ptts_config), sizeof(ptts_gen_params), sizeof(ptts_dac_config),\n'
+                   '         offsetof(ptts_config, rope_theta), offsetof(ptts_gen_params, seed), offsetof(ptts_dac_config, compute_dtype));\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert [int(x) for x in out] == [N.ABI_VERSION, C.sizeof(N.PttsConfig), C.sizeof(N.PttsGenParams), C.sizeof(N.PttsDacConfig),
+                                     N.PttsConfig.rope_theta.offset, N.PttsGenParams.seed.offset, N.PttsDacConfig.compute_dtype.offset]
