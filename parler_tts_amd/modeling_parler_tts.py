@@ -328,8 +328,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         self.use_audio_scales = True      # DACModel.decode takes `audio_scales` (:2416-2417)
         self.use_4dim_audio_codes = True  # model_type "dac_on_the_hub" (:2419-2422)
         self.generation_config = _default_generation_config(config)
-        self._engine: Optional[DecoderEngine] = None
-        self._engine_key = None
+        self._engine = None  # (property) drops every cached decoder engine
         for p in self.parameters():
             p.requires_grad_(False)
         self.eval()
@@ -531,24 +530,45 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             raise RuntimeError("generate() runs on the HIP engine only: move the model to a cuda device first (there is no CPU fallback)")
         if dt not in (torch.float32, torch.bfloat16):
             raise NotImplementedError(f"model dtype {dt}: the HIP engine implements float32 (parity) and bfloat16 (throughput)")
-        e = self._engine
         fp8 = bool(getattr(self, "decoder_weights_fp8", False))
         if fp8 and dt != torch.bfloat16:
             raise NotImplementedError("decoder_weights_fp8 needs the model in bfloat16 (e4m3 weights, bf16 activations)")
-        need = (dev, dt, fp8)
-        if e is None or self._engine_key != need or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 + T or e.cfg.max_ctx < P + max_length:
+        # One engine per batch-size class, capacities grow-only inside a class. The engine tunes itself to its max_batch at creation (KV
+        # splits of the self-attention, GEMV step up to 4 utterances vs MFMA strips), so a single-utterance call must not land on an engine
+        # sized for 32 (1 KV split instead of 4), and a server that alternates between a wide batch and a long single utterance must not
+        # re-pack ~1.5 GB of weights and re-capture the step graphs on every call. Two resident engines cost two packed weight copies.
+        key = (dev, dt, fp8, "small" if B <= 4 else "large")
+        engines = self.__dict__.setdefault("_engines", {})
+        e = engines.get(key)
+        if e is None or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 + T or e.cfg.max_ctx < P + max_length:
+            caps = dict(max_batch=B, max_ctx=max(P + max_length, 64), max_enc=max(N, 16), max_prompt=max(P + 1 + T, 8))
             if e is not None:
+                caps = {k: max(v, int(getattr(e.cfg, k))) for k, v in caps.items()}
                 e.close()
+            for k in [k for k in engines if k[:3] != key[:3]]:  # the model moved / changed dtype / weight format: stale engines go
+                engines.pop(k).close()
             d = self.config.decoder
             e = DecoderEngine(hidden_size=d.hidden_size, num_layers=d.num_hidden_layers, num_heads=d.num_attention_heads, ffn_dim=d.ffn_dim,
                               num_codebooks=d.num_codebooks, vocab_size=d.vocab_size, max_positions=d.max_position_embeddings,
                               rope=d.rope_embeddings, rope_theta=d.rope_theta, pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id,
-                              bos_token_id=d.bos_token_id, dtype=dt, max_batch=B, max_ctx=max(P + max_length, 64), max_enc=max(N, 16),
-                              max_prompt=max(P + 1 + T, 8), device=dev, num_kv_heads=d.num_key_value_heads,
-                              num_cross_kv_heads=d.num_cross_attention_key_value_heads, weights_fp8=fp8)
+                              bos_token_id=d.bos_token_id, dtype=dt, device=dev, num_kv_heads=d.num_key_value_heads,
+                              num_cross_kv_heads=d.num_cross_attention_key_value_heads, weights_fp8=fp8, **caps)
             e.load_state_dict(self.decoder.state_dict())
-            self._engine, self._engine_key = e, need
+            engines[key] = e
+        self.__dict__["_engine_last"] = e
         return e
+
+    @property
+    def _engine(self) -> Optional[DecoderEngine]:
+        """The decoder engine the last call ran on (tests read its ids); assigning ``None`` drops every cached engine (weights, device or
+        dtype changed: they re-pack lazily)."""
+        return self.__dict__.get("_engine_last")
+
+    @_engine.setter
+    def _engine(self, value):
+        if value is None:
+            self.__dict__["_engines"] = {}
+        self.__dict__["_engine_last"] = value
 
     def _get_split_engines(self, n: int, Bsub: int, N: int, P: int, max_length: int, T: int = 0) -> List[DecoderEngine]:
         """n engines of `Bsub` utterances each for the stream-split device loop (each holds its own packed weight copy)."""

@@ -308,3 +308,41 @@ def test_dac_codec_is_registered_with_transformers_auto_classes(tmp_path):
     m2 = AutoModel.from_pretrained(str(tmp_path))
     assert isinstance(m2, P.DACModel) and m2.decoder_dim == 256 and tuple(m2.decoder_rates) == (4, 2, 2, 2)
     assert set(m2.state_dict()) == set(m.state_dict())
+
+
+def test_decoder_engines_are_cached_per_batch_class_and_only_grow(monkeypatch):
+    """generate() keeps one HIP decoder engine per batch-size class (<= 4 utterances: GEMV step, 4 KV splits; wider: MFMA strips, no
+    split) with grow-only capacities: alternating a wide batch with a long single utterance re-creates nothing, a single-utterance call
+    never lands on an engine tuned for 32, and `model._engine = None` (weights / device / dtype changed) drops them all."""
+    import types
+
+    from parler_tts_amd import modeling_parler_tts as M
+
+    made = []
+
+    class FakeEngine:
+        def __init__(self, **kw):
+            self.cfg = types.SimpleNamespace(**{k: kw[k] for k in ("max_batch", "max_ctx", "max_enc", "max_prompt")})
+            self.closed = False
+            made.append(self)
+
+        def load_state_dict(self, sd):
+            self.loaded = len(sd)
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(M, "DecoderEngine", FakeEngine)
+    m = P.ParlerTTSForConditionalGeneration(_tiny_config())
+    monkeypatch.setattr(type(m), "device", property(lambda self: torch.device("cuda", 0)))
+    one = m._get_engine(1, 64, 32, 869)
+    wide = m._get_engine(32, 64, 32, 100)
+    assert m._get_engine(1, 64, 32, 869) is one and m._get_engine(20, 10, 5, 64) is wide and len(made) == 2  # alternating: nothing re-created
+    assert (one.cfg.max_batch, wide.cfg.max_batch) == (1, 32) and m._engine is wide                        # last used
+    grown = m._get_engine(2, 64, 40, 1200)  # same class, more capacity: re-created once with the maximum of old and new
+    assert one.closed and len(made) == 3 and vars(grown.cfg) == dict(max_batch=2, max_ctx=1240, max_enc=64, max_prompt=41)
+    assert m._get_engine(1, 16, 8, 64) is grown and m._get_engine(4, 64, 40, 1200) is not grown and len(made) == 4
+    m._engine = None
+    assert m._engine is None and m._get_engine(1, 16, 8, 64) not in made[:4] and len(made) == 5
+    m.enable_fp8_weights(False)  # any weight-format / placement change drops the cache as well
+    assert m._engine is None
