@@ -47,6 +47,7 @@ class DACModel(torch.nn.Module):
     DECODER_DIM = 1536
     DECODER_RATES = (8, 8, 4, 2)
     ENCODER_DIM = 64
+    MAX_GROWN_FRAME_UTTERANCES = 32 * 900  # grow-only engine capacities up to this batch x frames product (~30 GB of activations at 44.1 kHz)
 
     def __init__(self, config: DACConfig, decoder_dim: Optional[int] = None, decoder_rates=None, codebook_dim: Optional[int] = None):
         super().__init__()
@@ -123,9 +124,16 @@ class DACModel(torch.nn.Module):
             if need_encoder and not has_enc:
                 raise RuntimeError("DACModel.encode: the checkpoint holds no 'model.encoder.*' tensors")
             keep_enc = need_encoder or (e is not None and e.encoder_dim > 0)  # the encoder is built on first use only
+            nb, nf = max(batch, 1), max(frames, 64)
+            if e is not None and self._engine_dev == dev and e.compute_dtype == compute:
+                # capacities grow with the calls (a wide batch after a long utterance keeps room for both: no re-packing when a server
+                # alternates) as long as the activation buffers stay moderate: they scale with batch x frames, ~1 MB per frame-utterance
+                gb, gf = max(nb, e.max_batch), max(nf, e.max_frames)
+                if gb * gf <= self.MAX_GROWN_FRAME_UTTERANCES:
+                    nb, nf = gb, gf
             e = DacEngine(num_codebooks=c.num_codebooks, codebook_size=c.codebook_size, codebook_dim=self.codebook_dim,
                           latent_dim=c.latent_dim, decoder_dim=self.decoder_dim, rates=self.decoder_rates,
-                          max_batch=max(batch, 1), max_frames=max(frames, 64), device=dev,
+                          max_batch=nb, max_frames=nf, device=dev,
                           encoder_dim=self.encoder_dim if keep_enc else 0, compute_dtype=compute)
             e.load_state_dict({k[len("model."):]: v for k, v in self._weights.items()})
             self._engine, self._engine_dev = e, dev

@@ -346,3 +346,32 @@ def test_decoder_engines_are_cached_per_batch_class_and_only_grow(monkeypatch):
     assert m._engine is None and m._get_engine(1, 16, 8, 64) not in made[:4] and len(made) == 5
     m.enable_fp8_weights(False)  # any weight-format / placement change drops the cache as well
     assert m._engine is None
+
+
+def test_dac_engine_capacities_grow_within_a_memory_bound(monkeypatch):
+    from parler_tts_amd.dac_wrapper import modeling_dac as MD
+
+    made = []
+
+    class FakeDac:
+        def __init__(self, **kw):
+            self.max_batch, self.max_frames, self.encoder_dim, self.compute_dtype = kw["max_batch"], kw["max_frames"], kw["encoder_dim"], kw["compute_dtype"]
+            made.append(self)
+
+        def load_state_dict(self, sd):
+            pass
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(MD, "DacEngine", FakeDac)
+    from oracle import dac_oracle as DA
+
+    d = P.DACModel(P.DACConfig(latent_dim=64), decoder_dim=256, decoder_rates=[4, 2, 2, 2])
+    d.load_state_dict({"model." + k: v for k, v in DA.make_dac_weights(DA.DAC_TINY, 1).items()})
+    monkeypatch.setattr(type(d), "device", property(lambda self: torch.device("cuda", 0)))
+    a = d._get_engine(1, 2580)
+    b = d._get_engine(8, 860)       # 8 x 2580 = 20640 frame-utterances: inside the bound, the engine keeps room for both shapes
+    assert (b.max_batch, b.max_frames) == (8, 2580) and d._get_engine(1, 2580) is b and d._get_engine(8, 860) is b and len(made) == 2
+    c = d._get_engine(32, 860)      # 32 x 2580 would be ~83 GB of activations: sized exactly instead
+    assert (c.max_batch, c.max_frames) == (32, 860) and len(made) == 3 and a is not b
