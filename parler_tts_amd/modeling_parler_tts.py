@@ -544,7 +544,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             caps = dict(max_batch=B, max_ctx=max(P + max_length, 64), max_enc=max(N, 16), max_prompt=max(P + 1 + T, 8))
             if e is not None:
                 caps = {k: max(v, int(getattr(e.cfg, k))) for k, v in caps.items()}
-                e.close()
+                engines.pop(key).close()  # gone from the cache before the new one is built: a failed creation must not leave a closed engine behind
             for k in [k for k in engines if k[:3] != key[:3]]:  # the model moved / changed dtype / weight format: stale engines go
                 engines.pop(k).close()
             d = self.config.decoder
