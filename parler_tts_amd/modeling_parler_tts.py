@@ -433,7 +433,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             path = snapshot_download(path, allow_patterns=["*.json", "*.safetensors"], **hub_kw)
             if not any(f.endswith(".safetensors") for f in os.listdir(path)):  # legacy repos ship pytorch_model.bin only
                 path = snapshot_download(pretrained_model_name_or_path, allow_patterns=["*.json", "*.bin"], **hub_kw)
-        cfg = config or ParlerTTSConfig.from_pretrained(path)
+        cfg = copy.deepcopy(config) if config is not None else ParlerTTSConfig.from_pretrained(path)  # overrides never touch the caller's object
         for k, v in overrides.items():  # transformers semantics: a kwarg naming a config attribute overrides it, any other is an error
             if not hasattr(cfg, k):
                 raise TypeError(f"{cls.__name__}.from_pretrained() got an unexpected keyword argument '{k}'")
