@@ -18,6 +18,10 @@ timeout 200 python tools/dac_probe.py 2>&1 | grep "B=1 T=860\|B=32" >> $S
 echo "## batch-32 GEMM nodes in a cold dependent chain, phase stamps (tools/chain_probe32: build it on the CPU first)" >> $S
 [ -x tools/chain_probe32 ] && timeout 120 tools/chain_probe32 >> $S 2>&1 || echo "tools/chain_probe32 missing" >> $S
 
+echo "## decode at batch 64 / 128 per GPU (default library): parity vs the oracle, then the step time" >> $S
+tests big "above_32"
+for B in 64 128; do timeout 200 python tools/step_probe2.py $B b$B 2>&1 | grep "step_probe2\|Error\|error" | tail -2 >> $S; done
+
 echo "## PTTS_DECODE_STREAMS (in the tree): e2e generate() of 32 utterances, 860 frames, 1 / 2 / 4 sub-batches" >> $S
 cat > $O/e2e32.py <<'PY'
 import os, sys, time, torch

@@ -79,3 +79,16 @@ def test_fused_residual_units_44khz(monkeypatch):
     for b in range(2):
         assert _rel_rms(fused[b], ref[b]) <= 3e-2, b
         assert _rel_rms(fused[b], plain[b]) <= 1e-2, b
+
+
+@pytest.mark.parametrize("bsz", [40, 64, 128])
+def test_decode_batch_above_32_default_library(bsz):
+    """Not an experiment of a patch but of a configuration: decode at batch > 32 per GPU (whole-node throughput lever: the step is
+    latency-bound at 32, so utterances per step are nearly free until the KV traffic dominates). The engine takes the prefill-sized code
+    path there (rows_prep + 128-row PRO_COPY passes, plain fc2, no producer statistics); the suite only covers batch <= 32. Mini width,
+    2 layers, ragged masks, 3 teacher-forced steps vs the oracle at the default tolerances."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=61)
+    for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
+        err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=21, P=6, steps=3, masks=True, seed=bsz)
+        assert err < tol, (bsz, prec, err)
