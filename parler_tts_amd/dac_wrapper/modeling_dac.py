@@ -104,7 +104,10 @@ class DACModel(torch.nn.Module):
         m.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
         return m
 
-    def _get_engine(self, batch: int, frames: int, need_encoder: bool = False) -> DacEngine:
+    def _get_engine(self, batch: int, frames: int, need_encoder: bool = False, whole_batch: bool = False) -> DacEngine:
+        """An engine that decodes `frames` frames of up to `batch` utterances per pass. decode() / encode() loop over sub-batches of the
+        engine's ``max_batch``, so the activation buffers (~0.8 MB per frame-utterance at 44.1 kHz: 32 x 2580 frames would be 65 GB) are
+        bounded by sizing the sub-batch, not the request; ``whole_batch`` (chunked decode into one output buffer) needs them all at once."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("DACModel runs on the HIP engine only: move the model to a cuda device (no CPU fallback)")
@@ -113,7 +116,9 @@ class DACModel(torch.nn.Module):
         # at least the precision of the reference's bf16 codec; float32 is the exact-f32 parity mode
         ok32 = self.config.latent_dim % 32 == 0 and self.decoder_dim % (32 << len(self.decoder_rates)) == 0  # 16x16x32 MFMA steps
         compute = torch.bfloat16 if (self._dummy.dtype == torch.bfloat16 and ok32) else torch.float32
-        if (e is None or self._engine_dev != dev or e.max_batch < batch or e.max_frames < frames or (need_encoder and e.encoder_dim <= 0)
+        nf = max(frames, 64)
+        nb = max(batch, 1) if whole_batch else min(max(batch, 1), max(1, self.MAX_GROWN_FRAME_UTTERANCES // nf))
+        if (e is None or self._engine_dev != dev or e.max_batch < nb or e.max_frames < frames or (need_encoder and e.encoder_dim <= 0)
                 or e.compute_dtype != compute):
             if e is not None:
                 e.close()
@@ -124,7 +129,6 @@ class DACModel(torch.nn.Module):
             if need_encoder and not has_enc:
                 raise RuntimeError("DACModel.encode: the checkpoint holds no 'model.encoder.*' tensors")
             keep_enc = need_encoder or (e is not None and e.encoder_dim > 0)  # the encoder is built on first use only
-            nb, nf = max(batch, 1), max(frames, 64)
             if e is not None and self._engine_dev == dev and e.compute_dtype == compute:
                 # capacities grow with the calls (a wide batch after a long utterance keeps room for both: no re-packing when a server
                 # alternates) as long as the activation buffers stay moderate: they scale with batch x frames, ~1 MB per frame-utterance
@@ -193,7 +197,7 @@ class DACModel(torch.nn.Module):
         codes = audio_codes[0]
         B, _, T = codes.shape
         n_frames = T - first_frame if n_frames is None else n_frames
-        eng = self._get_engine(B, min(T, n_frames + halo))  # window = n_frames + halo frames
+        eng = self._get_engine(B, min(T, n_frames + halo), whole_batch=True)  # window = n_frames + halo frames, every utterance in one pass
         return DACDecoderOutput(eng.decode_chunk(codes, first_frame, n_frames, halo, out=out, n_emit=n_emit))
 
     def forward(self, tensor):

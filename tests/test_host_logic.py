@@ -373,5 +373,10 @@ def test_dac_engine_capacities_grow_within_a_memory_bound(monkeypatch):
     a = d._get_engine(1, 2580)
     b = d._get_engine(8, 860)       # 8 x 2580 = 20640 frame-utterances: inside the bound, the engine keeps room for both shapes
     assert (b.max_batch, b.max_frames) == (8, 2580) and d._get_engine(1, 2580) is b and d._get_engine(8, 860) is b and len(made) == 2
-    c = d._get_engine(32, 860)      # 32 x 2580 would be ~83 GB of activations: sized exactly instead
+    c = d._get_engine(32, 860)      # 32 x 2580 would be ~65 GB of activations: sized exactly instead
     assert (c.max_batch, c.max_frames) == (32, 860) and len(made) == 3 and a is not b
+    big = d._get_engine(32, 2580)   # a request beyond the bound is served in sub-batches (decode() loops over the engine's max_batch)
+    assert (big.max_batch, big.max_frames) == (11, 2580) and big.max_batch * big.max_frames <= P.DACModel.MAX_GROWN_FRAME_UTTERANCES
+    assert d._get_engine(128, 2580) is big and len(made) == 4
+    whole = d._get_engine(32, 100, whole_batch=True)  # chunked decode writes every utterance of the chunk in one pass
+    assert whole.max_batch == 32 and whole.max_frames >= 100
