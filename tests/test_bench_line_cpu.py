@@ -80,3 +80,24 @@ def test_live_pmc_result_replaces_the_committed_pass_and_failures_fall_back(monk
     monkeypatch.setattr(bench, "measure_traffic_live", lambda bs, **k: None)  # rocprofv3 missing / child failed: the committed pass is quoted
     r = bench.measure_decode_roofline(_model("mini"), 1, torch.device("cpu"))
     assert isinstance(r["traffic"], int) and not r["traffic_note"].startswith("LIVE")
+
+
+def test_watchdog_prints_the_line_collected_so_far_and_exits_cleanly(tmp_path):
+    """bench.py arms a watchdog before its optional side measurements: if one hangs (a dead streamer thread, a stuck HIP call), the
+    process prints the JSON line with what has been measured and exits 0 - the contract numbers are never lost to a side measurement."""
+    import subprocess
+    import time
+
+    script = tmp_path / "w.py"
+    script.write_text(f"import sys, time\nsys.path.insert(0, {ROOT!r})\nimport bench\n"
+                      "out = {'metric': 'm', 'value': 1.5, 'roofline': {'frac': 0.1}, 'cpu_baseline': {'value': 0.1}}\n"
+                      "disarm = bench.arm_watchdog(out, 1.0)\nout['bs32'] = {'value': 2.0}\ntime.sleep(30)\nprint('never')\n")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and time.time() - t0 < 25 and "never" not in r.stdout
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["value"] == 1.5 and j["bs32"] == {"value": 2.0} and "watchdog" in j and j["cpu_baseline"] == {"value": 0.1}
+    script.write_text(f"import sys, time\nsys.path.insert(0, {ROOT!r})\nimport bench\nout = {{'value': 1.0}}\ndisarm = bench.arm_watchdog(out, 1.0)\n"
+                      "disarm()\ntime.sleep(2.0)\nprint('finished normally')\n")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("finished normally") and "watchdog" not in r.stdout
