@@ -101,3 +101,48 @@ def test_watchdog_prints_the_line_collected_so_far_and_exits_cleanly(tmp_path):
                       "disarm()\ntime.sleep(2.0)\nprint('finished normally')\n")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("finished normally") and "watchdog" not in r.stdout
+
+
+def test_main_prints_one_contract_line_with_everything_stubbed(monkeypatch, capsys):
+    """bench.main() end to end on the CPU with the GPU parts replaced (model, measurements, device calls): guards the assembly of the
+    contract line itself - key names, order of the side measurements, watchdog arming / disarming - against edits made without a GPU."""
+    import types
+
+    import __graft_entry__ as ge
+
+    class FakeModel:
+        def __init__(self):
+            self.calls = []
+
+        def generate(self, **kw):
+            self.calls.append(kw["input_ids"].shape[0])
+            return torch.zeros(kw["input_ids"].shape[0], bench.FRAMES * 512)
+
+    fake = FakeModel()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(ge, "build", lambda: None)
+    monkeypatch.setattr(bench, "build_model", lambda rank, world, device, dtype, which="mini": fake)
+    monkeypatch.setattr(bench, "synthetic_batch", lambda bs, rank, device: (torch.zeros(bs, bench.N_DESC, dtype=torch.long), torch.zeros(bs, bench.N_PROMPT, dtype=torch.long)))
+    monkeypatch.setattr(bench, "measure_decode_roofline", lambda model, bs, device: {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None})
+    monkeypatch.setattr(bench, "measure_ttft", lambda model, bs, device, reps=20: 9.0)
+    monkeypatch.setattr(bench, "measure_ttfa", lambda model, device: {"ttfa_p50_ms": 37.0})
+    monkeypatch.setattr(bench, "measure_sampling_step", lambda model, bs, device: {"ratio_sampling_over_greedy": 1.04})
+    monkeypatch.setattr(bench, "cpu_baseline", lambda: {"value": 0.15, "unit": "audio-seconds/sec", "cores": 4, "kind": "port", "sample": "stub"})
+    bench.main()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["unit"] == "audio-seconds/sec" and j["dtype"] == "bf16" and "workload" in j["config"] and "model" not in j["config"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["gpu_over_cpu"] == round(j["value"] / 0.15, 1)
+    assert j["bs32"]["roofline"]["bound"] == "hbm" and j["streaming"] == {"ttfa_p50_ms": 37.0} and j["sampling"]["ratio_sampling_over_greedy"] == 1.04
+    assert "watchdog" not in j
+    assert fake.calls == [1, 1, 1, 32, 32]  # 1 warm-up + 2 timed steps at bs = 1, then the bs = 32 side measurement (warm-up + timed)
