@@ -601,7 +601,10 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         launch <= 64-192 workgroups on 256 CUs; two independent chains interleave on the idle CUs at the price of streaming the
         weights once per chain. Not measured yet."""
         n = int(getattr(self, "decode_streams", 0) or os.environ.get("PTTS_DECODE_STREAMS", "1") or 1)
-        return n if n > 1 and B >= 8 * n and B % n == 0 else 1
+        # smallest sub-batch worth its own engine: 8 by default; 4 lets batch 5..8 run as two GEMV-step sub-batches (0.84 ms at 4 utterances
+        # against 1.33 ms for 8 on the MFMA strips) - to be measured with the rest (tools/experimental/run_all.sh)
+        min_sub = int(getattr(self, "decode_streams_min_sub", 0) or os.environ.get("PTTS_DECODE_STREAMS_MIN_SUB", "8") or 8)
+        return n if n > 1 and B >= min_sub * n and B % n == 0 else 1
 
     # -- the pieces of generate() that stay on the torch side (once per call, off the per-token loop) ---------------
     def _encode_description_eager(self, input_ids, attention_mask):

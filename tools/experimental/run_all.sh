@@ -36,8 +36,17 @@ for n in (1, 2, 4):
     m.generate(**kw); torch.cuda.synchronize()
     t0 = time.perf_counter(); m.generate(**kw); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"[e2e bs=32] decode_streams={n}: {dt * 1e3:.1f} ms per generate() = {32 * bench.AUDIO_S / dt:.1f} audio-s/s", flush=True)
+# batch 8 as two GEMV-step sub-batches of 4 (decode_streams_min_sub = 4) against the single MFMA-strip engine
+d, p = bench.synthetic_batch(8, 0, dev)
+kw = dict(input_ids=d, prompt_input_ids=p, do_sample=False, max_new_tokens=bench.NEW_TOKENS, min_new_tokens=bench.NEW_TOKENS)
+m.decode_streams_min_sub = 4
+for n in (1, 2):
+    m.decode_streams = n
+    m.generate(**kw); torch.cuda.synchronize()
+    t0 = time.perf_counter(); m.generate(**kw); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"[e2e bs=8] decode_streams={n}: {dt * 1e3:.1f} ms per generate() = {8 * bench.AUDIO_S / dt:.1f} audio-s/s", flush=True)
 PY
-timeout 300 python $O/e2e32.py 2>&1 | grep "e2e bs=32" >> $S
+timeout 400 python $O/e2e32.py 2>&1 | grep "e2e bs=" >> $S
 
 for V in fc2_last_arriver xattn_groups lm_batch32_both; do
   echo "## $V" >> $S
