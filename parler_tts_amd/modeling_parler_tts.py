@@ -535,9 +535,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             raise NotImplementedError("decoder_weights_fp8 needs the model in bfloat16 (e4m3 weights, bf16 activations)")
         # One engine per batch-size class, capacities grow-only inside a class. The engine tunes itself to its max_batch at creation (KV
         # splits of the self-attention, GEMV step up to 4 utterances vs MFMA strips), so a single-utterance call must not land on an engine
-        # sized for 32 (1 KV split instead of 4), and a server that alternates between a wide batch and a long single utterance must not
-        # re-pack ~1.5 GB of weights and re-capture the step graphs on every call. Two resident engines cost two packed weight copies.
-        key = (dev, dt, fp8, "small" if B <= 4 else "large")
+        # sized for 32 (1 KV split instead of 4; 5..8 utterances run 2), and a server that alternates between a wide batch and a long single utterance must not
+        # re-pack ~1.5 GB of weights and re-capture the step graphs on every call. Each resident engine costs one packed weight copy (~1.5 GB for Mini-v1).
+        key = (dev, dt, fp8, "b<=4" if B <= 4 else ("b<=8" if B <= 8 else "b>8"))  # GEMV step / fused cross block, 2 KV splits / no split
         engines = self.__dict__.setdefault("_engines", {})
         e = engines.get(key)
         if e is None or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 + T or e.cfg.max_ctx < P + max_length:

@@ -342,6 +342,9 @@ def test_decoder_engines_are_cached_per_batch_class_and_only_grow(monkeypatch):
     grown = m._get_engine(2, 64, 40, 1200)  # same class, more capacity: re-created once with the maximum of old and new
     assert one.closed and len(made) == 3 and vars(grown.cfg) == dict(max_batch=2, max_ctx=1240, max_enc=64, max_prompt=41)
     assert m._get_engine(1, 16, 8, 64) is grown and m._get_engine(4, 64, 40, 1200) is not grown and len(made) == 4
+    mid = m._get_engine(8, 16, 8, 64)  # 5..8 utterances: a class of its own (2 KV splits), neither the GEMV-step engine nor the wide one
+    assert mid is not wide and mid.cfg.max_batch == 8 and m._get_engine(6, 16, 8, 64) is mid and m._get_engine(9, 16, 8, 64) is wide
+    made.remove(mid)
     m._engine = None
     assert m._engine is None and m._get_engine(1, 16, 8, 64) not in made[:4] and len(made) == 5
     m.enable_fp8_weights(False)  # any weight-format / placement change drops the cache as well

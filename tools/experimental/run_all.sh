@@ -40,7 +40,7 @@ for n in (1, 2, 4):
 d, p = bench.synthetic_batch(8, 0, dev)
 kw = dict(input_ids=d, prompt_input_ids=p, do_sample=False, max_new_tokens=bench.NEW_TOKENS, min_new_tokens=bench.NEW_TOKENS)
 m.decode_streams_min_sub = 4
-m._engine = None  # drop the engines sized for 32 utterances: batch 8 gets its own (2 KV splits instead of 1)
+m._engine = None  # fresh engines for this leg
 for n in (1, 2):
     m.decode_streams = n
     m.generate(**kw); torch.cuda.synchronize()
