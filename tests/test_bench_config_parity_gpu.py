@@ -74,6 +74,44 @@ def _teacher_forced_engine(eng, enc, pr, seq, n_pass):
     return out
 
 
+def _first_unsafe(step_logits, spec, L):
+    """number of columns determined by passes whose oracle top-2 margin is >= 2e-4 (the fp32 noise band is ~1e-5)"""
+    for s_, lg in enumerate(step_logits):
+        lg = lg.clone()
+        lg[:, spec.eos_token_id] = -float("inf")  # min_new_tokens blocks EOS on every pass of this run
+        top2 = torch.topk(lg, 2, dim=-1)[0]
+        if float((top2[:, 0] - top2[:, 1]).min()) < 2e-4:
+            return s_ + 1  # columns [0, s_] are determined by safe passes
+    return L
+
+
+def _oracle_run_from_golden_ids(spec, sd, enc, pr, L):
+    """The oracle's 868-pass greedy run without 868 sequential CPU passes on the GPU box: the ids of that run are a committed fixture
+    (tests/golden/bench_parity_ids.npz, oracle/make_bench_parity_golden.py); ONE batched causal forward teacher-forced on them gives
+    the logits of every pass (same arithmetic as the cached steps up to summation order, ~1e-6). The fixture is only an accelerator:
+    unless it is this machine's oracle's own arg-max on every pass before the first unsafe margin, None is returned and the caller
+    runs the sequential loop."""
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", "bench_parity_ids.npz")
+    if os.environ.get("PTTS_PARITY_SEQUENTIAL") or not os.path.exists(path):
+        return None
+    ids = torch.from_numpy(np.load(path)["ids"].astype(np.int64))
+    if tuple(ids.shape) != (spec.num_codebooks, L):
+        return None
+    _, pattern = DO.build_delay_pattern_mask(ids[:, :1], spec.bos_token_id, spec.pad_token_id, L, spec.num_codebooks)
+    fed = DO.apply_delay_pattern_mask(ids, pattern)[:, : L - 1]
+    with torch.no_grad():
+        lg = DO.DecoderOracle(spec, sd).forward(fed, enc, None, pr, None)[:, -(L - 1):]  # [rows, pass, V]: pass s predicts column s + 1
+    step_logits = [lg[:, s].contiguous() for s in range(L - 1)]
+    safe = _first_unsafe(step_logits, spec, L)
+    m = lg[:, : safe - 1].clone()
+    m[..., spec.eos_token_id] = -float("inf")
+    if not torch.equal(m.argmax(-1), ids[:, 1:safe]):
+        return None
+    return ids, step_logits
+
+
 def test_fp32_bs1_all_868_passes_and_free_running_ids():
     bench, model, dev = _bench_model(torch.float32)
     spec = DO.MINI_V1
@@ -83,24 +121,24 @@ def test_fp32_bs1_all_868_passes_and_free_running_ids():
     gp = DO.GenParams(max_length=L, min_new_tokens=bench.NEW_TOKENS)
     torch.set_num_threads(min(os.cpu_count() or 8, 16))
     t0 = time.time()
-    ref = DO.sample_loop(DO.DecoderOracle(spec, sd), enc.cpu(), None, pr.cpu(), None, gp, keep_logits=True)
+    fast = _oracle_run_from_golden_ids(spec, sd, enc.cpu(), pr.cpu(), L)
+    if fast is not None:
+        import types
+
+        ref = types.SimpleNamespace(sequences=fast[0], step_logits=fast[1])
+    else:
+        ref = DO.sample_loop(DO.DecoderOracle(spec, sd), enc.cpu(), None, pr.cpu(), None, gp, keep_logits=True)
     t_or = time.time() - t0
     assert ref.sequences.shape[1] == L and len(ref.step_logits) == bench.NEW_TOKENS
-    safe = L
-    for s_, lg in enumerate(ref.step_logits):  # first pass whose arg-max margin is inside the fp32 noise band
-        lg = lg.clone()
-        lg[:, spec.eos_token_id] = -float("inf")  # min_new_tokens blocks EOS on every pass of this run
-        top2 = torch.topk(lg, 2, dim=-1)[0]
-        if float((top2[:, 0] - top2[:, 1]).min()) < 2e-4:
-            safe = s_ + 1  # columns [0, s_] are determined by safe passes
-            break
+    safe = _first_unsafe(ref.step_logits, spec, L)  # first pass whose arg-max margin is inside the fp32 noise band
     eng = model._get_engine(1, bench.N_DESC, bench.N_PROMPT, L)
     eng.set_gen_params(max_length=L, min_new_tokens=bench.NEW_TOKENS)
     outs = _teacher_forced_engine(eng, enc, pr, ref.sequences.to(dev), bench.NEW_TOKENS)
     errs = torch.tensor([float((a - b).abs().max()) for a, b in zip(outs, ref.step_logits)])
     worst, at = float(errs.max()), int(errs.argmax())
     _log(f"[fp32 bs=1] 868 teacher-forced passes: max |dlogit| {worst:.2e} at pass {at} (mean of per-pass max {float(errs.mean()):.2e}); "
-         f"oracle {t_or:.0f} s; first pass with oracle margin < 2e-4: {safe} of {L} columns")
+         f"oracle {t_or:.0f} s ({'one batched forward on the golden ids' if fast is not None else 'sequential free run'}); "
+         f"first pass with oracle margin < 2e-4: {safe} of {L} columns")
     assert worst <= TOL_FP32, (worst, at)
     assert safe >= 8, f"oracle margins too small too early ({safe})"
     ids = eng.generate_ids(enc, None, pr, None).cpu()  # free-running: prefill + 867 hipGraph replays
