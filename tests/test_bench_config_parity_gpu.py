@@ -43,11 +43,20 @@ def _log(msg):
         pass
 
 
-def _bench_model(dtype):
+_MASTER = []  # bench.build_model's fp32 CPU model, built once per session (its random init of ~1.2 G parameters takes ~25 s of box time)
+
+
+def _bench_model(dtype, dev=None):
+    """The model bench.py benchmarks: `bench.build_model` constructs it in fp32 on the CPU and casts / moves it; here the CPU master is
+    kept and every test gets its own copy cast and moved the same way (identical tensors, checked on the CPU in tests/test_bench_line_cpu.py)."""
+    import copy
+
     import bench
 
-    dev = torch.device("cuda", 0)
-    model = bench.build_model(0, 1, dev, dtype)
+    dev = dev if dev is not None else torch.device("cuda", 0)
+    if not _MASTER:
+        _MASTER.append(bench.build_model(0, 1, torch.device("cpu"), torch.float32))
+    model = copy.deepcopy(_MASTER[0]).to(device=dev, dtype=dtype)
     return bench, model, dev
 
 

@@ -146,3 +146,20 @@ def test_main_prints_one_contract_line_with_everything_stubbed(monkeypatch, caps
     assert j["bs32"]["roofline"]["bound"] == "hbm" and j["streaming"] == {"ttfa_p50_ms": 37.0} and j["sampling"]["ratio_sampling_over_greedy"] == 1.04
     assert "watchdog" not in j
     assert fake.calls == [1, 1, 1, 32, 32]  # 1 warm-up + 2 timed steps at bs = 1, then the bs = 32 side measurement (warm-up + timed)
+
+
+def test_parity_tests_model_copy_equals_bench_build_model():
+    """tests/test_bench_config_parity_gpu.py builds bench.py's model once (fp32, CPU) and hands every test a cast copy instead of paying
+    the random init three times on the GPU box: the copy must be tensor-for-tensor what bench.build_model(dtype) returns."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_bench_config_parity_gpu as T
+
+    _, got, _ = T._bench_model(torch.bfloat16, dev=torch.device("cpu"))
+    want = bench.build_model(0, 1, torch.device("cpu"), torch.bfloat16)
+    a, b = got.state_dict(), want.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) and a[k].dtype == b[k].dtype for k in a)
+    wa, wb = got.audio_encoder._weights, want.audio_encoder._weights
+    assert wa.keys() == wb.keys() and all(torch.equal(wa[k], wb[k]) for k in wa)
+    assert got.dtype == torch.bfloat16 and got._engine is None and got is not T._MASTER[0]
+    _, again, _ = T._bench_model(torch.float32, dev=torch.device("cpu"))
+    assert len(T._MASTER) == 1 and again.dtype == torch.float32 and torch.equal(again.state_dict()["embed_prompts.weight"], T._MASTER[0].state_dict()["embed_prompts.weight"])
