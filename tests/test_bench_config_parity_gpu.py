@@ -130,7 +130,11 @@ def test_fp32_bs1_all_868_passes_and_free_running_ids():
     gp = DO.GenParams(max_length=L, min_new_tokens=bench.NEW_TOKENS)
     torch.set_num_threads(min(os.cpu_count() or 8, 16))
     t0 = time.time()
-    fast = _oracle_run_from_golden_ids(spec, sd, enc.cpu(), pr.cpu(), L)
+    try:
+        fast = _oracle_run_from_golden_ids(spec, sd, enc.cpu(), pr.cpu(), L)
+    except Exception as e:  # noqa: BLE001 — the fixture is an accelerator only: any problem with it means the sequential loop, not a failure
+        _log(f"[fp32 bs=1] golden-ids fast path unavailable ({e!r}): running the sequential oracle loop")
+        fast = None
     if fast is not None:
         import types
 
