@@ -312,6 +312,194 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #undef PTTS_EMIT_ROW
 }
 
+// Fused residual unit (default; PTTS_DAC_NO_FUSE_RES=1 restores the two-launch path for A/B): one residual unit of the two narrow blocks
+// (C = 192 / 96) in ONE launch (measured on MI355X, profiles/r03_experiments.txt: 860 frames 3.62 -> 3.25 ms, batch 32 109.4 -> 97.5 ms):
+//   y = Snake_a(conv_k7_dil(x) + b7)  ->  bf16 tile in LDS  ->  out = skip + conv_k1(y) + b1 ; act = Snake_a1(out)
+// The workgroup owns all C channels of 128 frames (NW * 3 strips = C / 16), so the k1 GEMM's operand never leaves the CU: the unit's
+// HBM traffic drops from 16 to 12 bytes per element (no bf16 round trip of y) and one launch per unit goes away (per-layer table,
+// profiles/r02_dac_layers.txt: k7 + k1 = 339 us at C = 192, 260 us at C = 96, the k1 half bound by its epilogue traffic).
+// Phase A is conv_lds_kernel<3, NW, 1, 54>'s loop; the y tile overlays the two slab buffers once the last chunk's barrier has passed.
+struct ResArgs {
+  ConvArgs a;           // the k7 conv (x, Wp, bias, alpha = Snake between the two convs, dil, pad, B, Tin, Cin = Cout = C)
+  const void* Wp1;      // k1 weights, packed [C/16][C/32][64][8 bf16]
+  const float* bias1;
+  const float* alpha1;  // Snake of the unit's output (the next layer's input activation)
+  const float* skip;    // fp32 residual stream [B][T][C]
+  float* out_raw;       // fp32 residual stream after the unit (may alias skip), or null
+  void* out_act;        // activated output, bf16 (fp32 if act_f32): NOT the buffer x lives in (neighbouring tiles read x's halo rows)
+  int act_f32;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) resunit_lds_kernel(ResArgs ra) {
+  constexpr int CSW = 3, FT = 8, TF = FT * 16, KS = 1, MAXHALO = 54;
+  constexpr int C = NW * CSW * 16;
+  constexpr int KCH = 32 * KS, RS = KS * 64 + 32, SL = KS * 4, NT = NW * 64;
+  constexpr int MAXROWS = TF + MAXHALO;
+  constexpr int NST = (MAXROWS * SL + NT - 1) / NT;
+  constexpr int RS2 = C * 2 + 32;  // y tile row stride: an odd multiple of 32 bytes, conflict-free ds_read_b128 like the slab
+  constexpr int NK1 = C / 32;      // k-steps of the k1 GEMM
+  constexpr int LDS_BYTES = (2 * MAXROWS * RS) > (TF * RS2) ? (2 * MAXROWS * RS) : (TF * RS2);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const ConvArgs& a = ra.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, j = lane & 15;
+  const int ntile = (a.Tn + TF - 1) / TF;
+  const int tile = blockIdx.x % ntile, b = blockIdx.x / ntile;
+  const int strip0 = wave * CSW;
+  const int cpt = C / 32, nk = a.ntaps * cpt;
+  const int nchunk = C / KCH;
+  const int NS = a.ntaps * KS;
+  const int t0 = tile * TF;
+  const int o0 = -a.pad;
+  const int halo = (a.ntaps - 1) * a.dil;
+  const int nslot = (TF + halo) * SL;
+  const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)b * a.Tin * C * 2;
+  const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + (size_t)strip0 * nk * 64 + lane;
+  const int lrow = j * RS + q * 16;
+  unsigned char* slab0 = lds;
+  unsigned char* slab1 = lds + MAXROWS * RS;
+
+  f32x4 acc[CSW][FT];
+#pragma unroll
+  for (int s = 0; s < CSW; ++s)
+#pragma unroll
+    for (int f = 0; f < FT; ++f) acc[s][f] = f32x4{0, 0, 0, 0};
+
+  uint4 stg[NST];
+#define RU_SLAB_FETCH(CC)                                                                                               \
+  _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
+    const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL, ti_ = t0 + o0 + r_;                              \
+    stg[i_] = make_uint4(0, 0, 0, 0);                                                                                    \
+    if (idx_ < nslot && ti_ >= 0 && ti_ < a.Tin)                                                                          \
+      stg[i_] = *reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * C + (size_t)(CC) * KCH) * 2 + sl_ * 16);               \
+  }
+#define RU_SLAB_COMMIT(BUFP)                                                                                            \
+  _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
+    const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL;                                                  \
+    if (idx_ < nslot) *reinterpret_cast<uint4*>((BUFP) + r_ * RS + sl_ * 16) = stg[i_];                                    \
+  }
+#define RU_W_FETCH(WF, CC, S)                                                                                           \
+  do {                                                                                                                  \
+    const int tap_ = (S) / KS, kk_ = (S) - tap_ * KS;                                                                     \
+    const float4* wp_ = Wp + (size_t)(tap_ * cpt + (CC) * KS + kk_) * 64;                                                 \
+    _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_) WF[s_] = wp_[(size_t)s_ * nk * 64];                               \
+  } while (0)
+#define RU_B_FETCH(BV, SB, S, F0)                                                                                       \
+  do {                                                                                                                  \
+    const int tap_ = (S) / KS, kk_ = (S) - tap_ * KS;                                                                     \
+    const unsigned char* sp_ = (SB) + (tap_ * a.dil + (F0) * 16) * RS + kk_ * 64 + lrow;                                  \
+    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) BV[f_] = *reinterpret_cast<const uint4*>(sp_ + f_ * 16 * RS);       \
+  } while (0)
+#define RU_MFMA_HALF(WC, BV, F0)                                                                                        \
+  _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_)                      \
+    acc[s_][(F0) + f_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WC[s_]), __builtin_bit_cast(bf16x8, BV[f_]), acc[s_][(F0) + f_], 0, 0, 0);
+#define RU_STEP(WC, WN)                                                                                                 \
+  {                                                                                                                     \
+    const unsigned char* sb_ = (c & 1) ? slab1 : slab0;                                                                   \
+    unsigned char* nb_ = (c & 1) ? slab0 : slab1;                                                                         \
+    const bool more_ = c + 1 < nchunk, lastst_ = st + 1 == NS;                                                            \
+    const int nc_ = lastst_ ? c + 1 : c, ns_ = lastst_ ? 0 : st + 1;                                                      \
+    const bool next_ = nc_ < nchunk;                                                                                      \
+    if (st == 0 && more_) { RU_SLAB_FETCH(c + 1); }                                                                       \
+    RU_W_FETCH(WN, next_ ? nc_ : c, next_ ? ns_ : st);                                                                    \
+    RU_B_FETCH(bB, sb_, st, 4);                                                                                           \
+    RU_MFMA_HALF(WC, bA, 0)                                                                                               \
+    if (!lastst_) RU_B_FETCH(bA, sb_, st + 1, 0);                                                                         \
+    RU_MFMA_HALF(WC, bB, 4)                                                                                               \
+    if (lastst_) {                                                                                                        \
+      if (more_) { RU_SLAB_COMMIT(nb_); }                                                                                 \
+      __syncthreads();                                                                                                    \
+      if (more_) RU_B_FETCH(bA, nb_, 0, 0);                                                                               \
+      ++c;                                                                                                                \
+      st = 0;                                                                                                             \
+    } else {                                                                                                              \
+      ++st;                                                                                                               \
+    }                                                                                                                     \
+  }
+  float4 w0[CSW], w1[CSW];
+  uint4 bA[4], bB[4];
+  RU_W_FETCH(w0, 0, 0);
+  RU_SLAB_FETCH(0);
+  RU_SLAB_COMMIT(slab0);
+  __syncthreads();
+  RU_B_FETCH(bA, slab0, 0, 0);
+  int c = 0, st = 0;
+  const int total = nchunk * NS;
+  for (int g = 0; g < total; g += 2) {
+    RU_STEP(w0, w1)
+    if (g + 1 < total) RU_STEP(w1, w0)
+  }
+#undef RU_STEP
+#undef RU_MFMA_HALF
+#undef RU_B_FETCH
+#undef RU_W_FETCH
+#undef RU_SLAB_COMMIT
+#undef RU_SLAB_FETCH
+  // ---- phase A epilogue: y = Snake(acc + b7) as bf16 into the LDS tile [frame][C] (the loop's last barrier has retired every slab read)
+  unsigned char* ytile = lds;
+  auto put_y = [&](const f32x4 av, const int s, const int f) {
+    const int co = (strip0 + s) * 16 + q * 4;
+    const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
+    const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
+    const float4 sv = make_float4(snake_f<true>(av[0] + bs.x, al.x), snake_f<true>(av[1] + bs.y, al.y), snake_f<true>(av[2] + bs.z, al.z),
+                                  snake_f<true>(av[3] + bs.w, al.w));
+    *reinterpret_cast<uint2*>(ytile + (f * 16 + j) * RS2 + co * 2) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+  };
+#define RU_PUT_ROW(S)                                                                                                   \
+  put_y(acc[S][0], S, 0); put_y(acc[S][1], S, 1); put_y(acc[S][2], S, 2); put_y(acc[S][3], S, 3);                         \
+  put_y(acc[S][4], S, 4); put_y(acc[S][5], S, 5); put_y(acc[S][6], S, 6); put_y(acc[S][7], S, 7);
+  RU_PUT_ROW(0)
+  RU_PUT_ROW(1)
+  RU_PUT_ROW(2)
+#undef RU_PUT_ROW
+  __syncthreads();
+  // ---- phase B: the k1 conv as a [C x C] GEMM over the tile; A = this wave's 3 strips of W1, B = y rows out of LDS
+  const float4* W1 = reinterpret_cast<const float4*>(ra.Wp1) + (size_t)strip0 * NK1 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < CSW; ++s)
+#pragma unroll
+    for (int f = 0; f < FT; ++f) acc[s][f] = f32x4{0, 0, 0, 0};
+  const unsigned char* yl = ytile + j * RS2 + q * 16;
+#pragma unroll
+  for (int kk = 0; kk < NK1; ++kk) {
+    float4 wk[CSW];
+#pragma unroll
+    for (int s = 0; s < CSW; ++s) wk[s] = W1[((size_t)s * NK1 + kk) * 64];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const uint4 bv = *reinterpret_cast<const uint4*>(yl + f * 16 * RS2 + kk * 64);
+#pragma unroll
+      for (int s = 0; s < CSW; ++s)
+        acc[s][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk[s]), __builtin_bit_cast(bf16x8, bv), acc[s][f], 0, 0, 0);
+    }
+  }
+  // ---- phase B epilogue: + bias + residual, fp32 stream out, Snake of the unit's output
+  auto emit = [&](const f32x4 av, const int s, const int f) {
+    const int jj = t0 + f * 16 + j;
+    if (jj >= a.Tn) return;
+    const int co = (strip0 + s) * 16 + q * 4;
+    const float4 bs = *reinterpret_cast<const float4*>(ra.bias1 + co);
+    const size_t o = ((size_t)b * a.Tn + (size_t)jj) * C + co;
+    const float4 sk = *reinterpret_cast<const float4*>(ra.skip + o);
+    const float4 v = make_float4(av[0] + bs.x + sk.x, av[1] + bs.y + sk.y, av[2] + bs.z + sk.z, av[3] + bs.w + sk.w);
+    if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
+    if (ra.out_act) {
+      const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + co);
+      const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+      if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+      else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
+    }
+  };
+#define RU_EMIT_ROW(S)                                                                                                  \
+  emit(acc[S][0], S, 0); emit(acc[S][1], S, 1); emit(acc[S][2], S, 2); emit(acc[S][3], S, 3);                             \
+  emit(acc[S][4], S, 4); emit(acc[S][5], S, 5); emit(acc[S][6], S, 6); emit(acc[S][7], S, 7);
+  RU_EMIT_ROW(0)
+  RU_EMIT_ROW(1)
+  RU_EMIT_ROW(2)
+#undef RU_EMIT_ROW
+}
+
 // final Conv1d(C -> 1, k7, pad 3) + tanh; weights [7][C] in LDS. One thread per OS = 4 consecutive output samples: the 10 input rows
 // they touch are read once (60 float4 loads per sample instead of 168; the kernel was 187 us of the 860-frame decode, L1-bound on
 // the 7x re-read). Per sample the fma order is unchanged (bias, then tap 0..6 x channel 0..C-1), so the exact-f32 mode is bit-identical.
@@ -916,6 +1104,27 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   return PTTS_OK;
 }
 
+// one residual unit (k7 dilated conv -> Snake -> k1 conv -> + skip -> Snake) in one launch; out_act must not be x's buffer
+static bool resunit_fusable(const ConvLayer& c7, const ConvLayer& c1) {
+  const char* ev = getenv("PTTS_DAC_NO_FUSE_RES");  // read per call: a test can switch it inside one process
+  const bool on = !(ev && atoi(ev));
+  return on && c7.bf16 && c1.bf16 && !c7.transposed && !c1.transposed && c7.stride == 1 && c1.stride == 1 && c7.ksize == 7 && c1.ksize == 1 &&
+         c7.Cin == c7.Cout && c1.Cin == c7.Cout && c1.Cout == c7.Cout && (c7.Cout == 192 || c7.Cout == 96) && 6 * c7.dil <= 54 && c7.alpha && c1.alpha;
+}
+static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, const float* skip, float* out_raw, void* out_act, int B, int T,
+                       hipStream_t st, bool act_f32) {
+  ResArgs r = {};
+  r.a.x = x; r.a.Wp = c7.Wp; r.a.bias = c7.bias; r.a.alpha = c7.alpha; r.a.dil = c7.dil; r.a.pad = (c7.ksize - 1) * c7.dil / 2;
+  r.a.B = B; r.a.Tin = T; r.a.Tn = T; r.a.Cin = c7.Cin; r.a.Cout = c7.Cout; r.a.ntaps = 7; r.a.nphase = 1; r.a.stride = 1;
+  r.Wp1 = c1.Wp; r.bias1 = c1.bias; r.alpha1 = c1.alpha; r.skip = skip; r.out_raw = out_raw; r.out_act = out_act; r.act_f32 = act_f32 ? 1 : 0;
+  const dim3 grid((unsigned)(((T + 127) / 128) * B));
+  if (c7.Cout == 192) hipLaunchKernelGGL((resunit_lds_kernel<4>), grid, dim3(256), 0, st, r);
+  else hipLaunchKernelGGL((resunit_lds_kernel<2>), grid, dim3(128), 0, st, r);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "residual-unit launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
 // decode the window [t0, t0 + T) of codes rows with stride `ld`; samples [skip, hop*T) of the window go to wave_dev rows of out_ld
 static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld, int t0, float* wave_dev, int skip, long long out_ld,
                              int32_t B, int32_t T, void* stream, int emit = -1) {
@@ -947,9 +1156,14 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
     Tcur *= up.stride;
     for (int ri = 0; ri < 3; ++ri) {
       const ConvLayer& c7 = d->convs[li++];
-      PTTS_TRY(run_conv(d, c7, cur, nullptr, nullptr, d->bufS, B, Tcur, st));
       const ConvLayer& c1 = d->convs[li++];
       const bool last = bi + 1 == c.num_rates && ri == 2;  // feeds the final Conv1d(C -> 1): fp32 activations
+      if (resunit_fusable(c7, c1)) {  // experimental: both convs in one launch; the output goes to the OTHER activation buffer
+        PTTS_TRY(run_resunit(c7, c1, cur, d->bufY, c1.write_raw ? d->bufY : nullptr, other, B, Tcur, st, last));
+        std::swap(cur, other);
+        continue;
+      }
+      PTTS_TRY(run_conv(d, c7, cur, nullptr, nullptr, d->bufS, B, Tcur, st));
       PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st, last));
     }
   }

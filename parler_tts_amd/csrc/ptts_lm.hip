@@ -89,6 +89,7 @@ struct ptts_engine {
   int B = 0, N = 0, P = 0;
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
+  bool xattn_groups = true;   // the fused LN2 + cross-q + cross-attention kernel also at batch 9..32, in groups of 8 utterances (PTTS_NO_XATTN_GROUPS=1: two nodes)
   int kv_ub = 0;         // host-side upper bound of the self-KV positions written so far (prefill + one per decode forward)
   int kv_bound = 0;      // attention fetch bound of the next decode forward: kv_ub + 1 rounded up to 64, <= max_ctx
   std::map<int, hipGraphExec_t> graphs;  // key: 2 * batch size + folded-cross-block flag
@@ -416,19 +417,21 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       }
     }
     const int KTw = Elem<WT>::KT;
-    if (!prefill && M <= 8 && (H / KTw) % 16 == 0 && (H == 512 || H == 1024 || H == 1536)) {
+    if (!prefill && (M <= 8 || (e->xattn_groups && M <= 32)) && (H / KTw) % 16 == 0 && (H == 512 || H == 1024 || H == 1536)) {
       // decode, small batch: LN2 + cross q projection + cross-attention fused, one workgroup per head
       XAttnArgs x = {};
       x.W = w.cq; x.x = e->h; x.x_ld = H; x.x_row_mul = 1; x.x_row_off = 0; x.gamma = w.ln2_g; x.beta = w.ln2_b; x.K = H;
       x.invK = 1.0f / (float)H; x.kcache = w.k_cross; x.vcache = w.v_cross; x.cap = c.max_enc; x.cur_len = e->cur_len; x.dims = e->dims;
       x.mask = e->enc_mask; x.mask_ld = c.max_enc; x.cos = c.rope ? e->rope_cos : nullptr; x.sin = c.rope ? e->rope_sin : nullptr;
       x.out = e->xw; x.B = M; x.nheads = nh; x.kv_heads = nkc; x.n_rep = nh / nkc; x.scale = scale;
-      const size_t sh = (size_t)M * (H * sizeof(WT) + 16) + 8 * 1024 + (size_t)M * 64 * 4;
+      const int mg = M < 8 ? M : 8;  // utterances per workgroup: batch 9..32 runs as ceil(M / 8) groups in blockIdx.y
+      const size_t sh = (size_t)mg * (H * sizeof(WT) + 16) + 8 * 1024 + (size_t)mg * 64 * 4;
+      const dim3 xg(nh, (M + 7) / 8);
       const bool u16 = ((H / KTw) / 2) % 16 == 0;
-      if (H == 1024 && u16) hipLaunchKernelGGL((xattn_fused_kernel<WT, 16, 4>), dim3(nh), dim3(512), sh, st, x);        // Mini-v1
-      else if (H == 1024) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 4>), dim3(nh), dim3(512), sh, st, x);
-      else if (H == 1536) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 6>), dim3(nh), dim3(512), sh, st, x);           // Large-v1
-      else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 2>), dim3(nh), dim3(512), sh, st, x);                            // hidden 512
+      if (H == 1024 && u16) hipLaunchKernelGGL((xattn_fused_kernel<WT, 16, 4>), xg, dim3(512), sh, st, x);        // Mini-v1
+      else if (H == 1024) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 4>), xg, dim3(512), sh, st, x);
+      else if (H == 1536) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 6>), xg, dim3(512), sh, st, x);           // Large-v1
+      else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 2>), xg, dim3(512), sh, st, x);                            // hidden 512
     } else {
     {  // LN2 + cross q projection
       GemmArgs g = {};
@@ -729,6 +732,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
+  e->xattn_groups = !(getenv("PTTS_NO_XATTN_GROUPS") && atoi(getenv("PTTS_NO_XATTN_GROUPS")));  // measured: 1386 -> 1360 us per batch-32 step (profiles/r03_experiments.txt)
   A(e->alloc(&e->prefix, (size_t)c.max_batch * K * c.max_ctx));
   e->ids_ld = c.max_ctx + 8;
   A(e->alloc(&e->ids, (size_t)c.max_batch * K * e->ids_ld));

@@ -1064,9 +1064,11 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.x;
+  // utterances b0 .. b0 + nb - 1 of this workgroup: one group of <= 8 per blockIdx.y (batch <= 8: one group; batch 9..32: up to 4 groups)
+  const int b0 = blockIdx.y * NWV, nb = min(NWV, a.B - b0), nbmax = min(NWV, a.B);
   const int row_bytes = a.K * (int)sizeof(WT) + 16;
   char* s_x = smem_raw;                                                        // [B][row_bytes]
-  float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)a.B * row_bytes);  // [8 waves][64][4]
+  float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)nbmax * row_bytes);  // [8 waves][64][4]
   float* s_q = s_red + NWV * 256;                                              // [B][64]
   const int nfrag = a.K / KT;
   const int strip = h * 4 + (wave >> 1);
@@ -1075,7 +1077,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
   const int q4 = lane >> 4, j = lane & 15;
   const int r = lane / LPR, c = lane % LPR;
-  const int b = min(wave, a.B - 1);  // attention of utterance b runs on wave b
+  const int b = b0 + min(wave, nb - 1);  // attention of utterance b runs on wave b - b0
   const int N = a.dims->N;
 
   // ---- t = 0: every independent global load of the kernel goes in flight; the residual rows first (critical path:
@@ -1107,9 +1109,9 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
     }
   };
   // ---- LayerNorm of the B rows -> LDS, then the head's 64 q rows ------------------------------------------------------
-  ln_stage<WT, NF4, true, XAttnArgs, false>(a, 0, a.B, s_x, row_bytes, lane, wave, NWV, issue_bulk);  // K == NF4 * 256
+  ln_stage<WT, NF4, true, XAttnArgs, false>(a, b0, nb, s_x, row_bytes, lane, wave, NWV, issue_bulk);  // K == NF4 * 256
   __syncthreads();
-  const char* brow = s_x + (size_t)min(j, a.B - 1) * row_bytes + (size_t)q4 * 16;
+  const char* brow = s_x + (size_t)min(j, nb - 1) * row_bytes + (size_t)q4 * 16;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int tb = t0; tb < t1; tb += UW) {
     if (tb != t0) {
@@ -1133,17 +1135,17 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   if (wave < 4) {  // wave s combines the two K halves of strip s: D[row = q4*4 + e][col = utterance j]
     const f32x4 rr = *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave) * 64 + lane) * 4) +
                      *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave + 1) * 64 + lane) * 4);
-    if (j < a.B) {
+    if (j < nb) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) s_q[j * 64 + wave * 16 + q4 * 4 + e] = rr[e];
     }
   }
   __syncthreads();
-  if (wave >= a.B) return;
+  if (wave >= nb) return;
   // ---- wave b: single-query attention of utterance b over the N description positions -----------------------
   float qv[EPL];
   {
-    const float* qs = s_q + b * 64;
+    const float* qs = s_q + (b - b0) * 64;
     const int d0 = c * EPL;
     if (a.cos) {
       const size_t pos = (size_t)(a.dims->P + a.cur_len[b] - 1);

@@ -187,11 +187,15 @@ class DecoderEngine:
             raise N.NativeLibraryError(f"hipMemcpy(D2D) failed with code {rc}")
         return out
 
-    def ids(self) -> torch.Tensor:
-        """Raw ids [B*K, cur_len] (a copy), exactly what `_sample` returns before the delay mask is applied."""
+    def ids(self, max_cols: Optional[int] = None) -> torch.Tensor:
+        """Raw ids [B*K, cur_len] (a copy), exactly what `_sample` returns before the delay mask is applied. ``max_cols`` caps the
+        columns returned: a caller reading while later steps are still in flight on another stream passes the number of columns it
+        KNOWS to be complete (the device-side length may already count a column whose ids are not visible yet)."""
         p, ld = C.c_void_p(), C.c_int32()
         N.check(self.lib.ptts_ids(self._h, C.byref(p), C.byref(ld)), "ptts_ids")
         cur, _ = self.state()
+        if max_cols is not None:
+            cur = min(cur, int(max_cols))
         return self._copy_out(p.value, (self.B * self.K, cur), torch.int64, row_stride=ld.value)
 
     def step_forward(self):

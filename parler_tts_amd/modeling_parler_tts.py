@@ -251,6 +251,9 @@ class _StepPump:
         self.cur_left = first        # steps still to enqueue before the next boundary; -1 = nothing left to enqueue
         self.in_flight = []          # events of the boundaries enqueued and not yet observed (oldest first)
         self.after = []              # steps enqueued after in_flight[i] (and before in_flight[i + 1])
+        self.enqueued = 0            # decode steps enqueued so far
+        self.at_boundary = []        # value of `enqueued` when in_flight[i] was recorded
+        self.done_steps = 0          # decode steps covered by the last boundary wait_boundary() observed complete
 
     def _enqueue_piece(self):
         n = min(self.piece, self.cur_left)
@@ -258,6 +261,7 @@ class _StepPump:
             self.eng.decode_steps(n)
             self.cur_left -= n
             self.remaining -= n
+            self.enqueued += n
             if self.after:
                 self.after[-1] += n
         if self.cur_left == 0:
@@ -265,6 +269,7 @@ class _StepPump:
             ev.record(self.stream)
             self.in_flight.append(ev)
             self.after.append(0)
+            self.at_boundary.append(self.enqueued)
             self.cur_left = min(self.chunk, self.remaining) if self.remaining > 0 else -1
 
     def stop(self):
@@ -285,6 +290,7 @@ class _StepPump:
             break
         self.in_flight.pop(0)
         self.after.pop(0)
+        self.done_steps = self.at_boundary.pop(0)
         self.max_ahead = max(self.max_ahead, self.chunk)  # only the FIRST boundary is latency-critical: a full chunk ahead afterwards
         return True
 
@@ -862,8 +868,10 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             return eng.ids()
         # Streaming: the decoder graph runs AHEAD on the main stream while the finished columns of the previous chunk are
         # forwarded to the streamer on a side stream (one put per column, like `_sample`; the streamer's un-delay + chunked DAC
-        # decode is enqueued on that side stream too), so the codec never stalls the token loop. Columns are written once, so
-        # reading them while later steps run is safe; steps after every row finished are device-side no-ops.
+        # decode is enqueued on that side stream too), so the codec never stalls the token loop. Only the columns the COMPLETED
+        # boundary event covers are forwarded (given + 1 + steps enqueued up to that boundary): steps still in flight may already
+        # have bumped `cur_len` while their ids column is not visible to a concurrent copy yet (the tail kernel orders the two
+        # stores at workgroup scope only). Steps after every row finished are device-side no-ops.
         chunk = int(getattr(streamer, "play_steps", 16) or 16)
         if self.device.type != "cuda":  # host-logic tests drive this loop with a stand-in engine: same protocol, no streams
             sent, done = given, False
@@ -887,7 +895,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         pump = _StepPump(eng, main, first, chunk, remaining)
         while pump.wait_boundary():      # the oldest chunk in flight has finished; later steps keep the GPU busy meanwhile
             with torch.cuda.stream(side):
-                cols = eng.ids()[:, sent:].cpu()  # one copy for the chunk, then one put per column like `_sample`
+                cols = eng.ids(max_cols=given + 1 + pump.done_steps)[:, sent:].cpu()  # one copy for the chunk, then one put per column like `_sample`
                 for j in range(cols.shape[1]):
                     streamer.put(cols[:, j])
                 sent += cols.shape[1]

@@ -332,6 +332,21 @@ def test_mini_width_batch_12_and_32_producer_statistics_layernorm(bsz):
         assert err < tol, (bsz, prec, err)
 
 
+@pytest.mark.parametrize("bsz", [9, 12, 32])
+@pytest.mark.parametrize("grouped", [True, False])
+def test_fused_cross_block_in_groups_of_eight(bsz, grouped, monkeypatch):
+    """Batch 9..32: the cross block's LN2 + q projection + cross-attention run in the batch <= 8 fused kernel, one workgroup per (head,
+    group of 8 utterances); ragged last group at 9 and 12. PTTS_NO_XATTN_GROUPS=1 (read at engine creation) keeps the two-node path
+    (producer-statistics LayerNorm GEMM + attention kernel) alive for A/B. Default tolerances."""
+    if not grouped:
+        monkeypatch.setenv("PTTS_NO_XATTN_GROUPS", "1")
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=49)
+    for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
+        err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=21, P=6, steps=4, masks=True, seed=bsz)
+        assert err < tol, (bsz, prec, err)
+
+
 def test_large_v1_width_two_layers_bf16_and_fp32_batch():
     """Large-v1 widths (H=1536, 24 heads, F=6144; init_large_model.py:25-43) with 2 layers, batch 1 and 12:
     6-float4 LayerNorm rows, 6 / 12-wave K splits, the prep-kernel (M > 8) path."""
