@@ -64,7 +64,9 @@ def build_model(rank: int, world: int, device: torch.device, dtype: torch.dtype,
     from parler_tts_amd.synthetic import random_dac_state_dict
 
     torch.manual_seed(1234)
-    model = P.ParlerTTSForConditionalGeneration(model_config(which))
+    # ranks != 0 allocate without drawing (their tensors are overwritten by rank 0's broadcast: no ~25 s random init per rank, and the
+    # broadcast is observable - a rank that missed it would run on whatever the allocator returned)
+    model = P.ParlerTTSForConditionalGeneration(model_config(which), init_weights=(rank == 0 or world == 1))
     # A trained checkpoint never emits the 64 padding ids >= codebook_size (vocab 1088 = 1024 + 64); random LM heads would,
     # and generate() (like the reference :3627-3636) drops every frame containing one. Zero those rows so each
     # utterance decodes exactly FRAMES frames (the arithmetic per step is unchanged).
@@ -77,6 +79,31 @@ def build_model(rank: int, world: int, device: torch.device, dtype: torch.dtype,
         from parler_tts_amd.distributed import broadcast_model_weights
 
         broadcast_model_weights(model, src=0)
+    return model
+
+
+def build_model_on_device(device: torch.device, dtype: torch.dtype, which: str):
+    """Side measurements on other shapes (Large-v1): the same architecture allocated empty and filled ON THE GPU (N(0, 0.02) matrices,
+    LayerNorm (1, 0), sinusoidal tables kept) - seconds instead of the ~40 s host-side init of 1.5 G parameters. Values do not matter
+    for a step-time / throughput figure; the parity tests build their Large models from the oracle's seeded weights instead."""
+    import parler_tts_amd as P
+    from parler_tts_amd.synthetic import random_dac_state_dict
+
+    model = P.ParlerTTSForConditionalGeneration(model_config(which), init_weights=False)
+    model.audio_encoder.load_state_dict({"model." + k: v for k, v in random_dac_state_dict(seed=4321).items()})
+    model = model.to(device=device, dtype=dtype)
+    g = torch.Generator(device=device).manual_seed(1234)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "embed_positions" in name:
+                continue
+            if p.dim() == 1:
+                p.fill_(0.0 if name.endswith("bias") else 1.0)
+            else:
+                p.copy_((torch.randn(p.shape, device=device, generator=g) * 0.02).to(p.dtype))
+        for k in range(K_CODEBOOKS):
+            getattr(model.decoder.lm_heads, str(k)).weight[1024:] = 0.0
+    model._engine = None
     return model
 
 
@@ -135,8 +162,8 @@ def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool):
         return (7 if folded else 8) * layers + 2
     if bs <= 8:   # MFMA strips with fused prologues + the fused LN2 / cross-q / cross-attention kernel
         return 7 * layers + 2
-    if bs <= 32 and hidden in (1024, 1536):  # rows_prep(LN1), QKV, attention, out_proj, LNS+cross-q, cross-attn, out_proj, LNS+fc1, fc2
-        return 9 * layers + 3
+    if bs <= 32 and hidden in (1024, 1536):  # rows_prep(LN1), QKV, attention, out_proj, fused LN2+cross-q+cross-attn (groups of 8), out_proj, LNS+fc1, fc2
+        return 8 * layers + 3
     return None
 
 
@@ -150,9 +177,9 @@ def latency_model(nodes: int, us_per_launch: float) -> dict:
                     "in-kernel grid barriers measured no cheaper at >= 128 workgroups (same file)"}
 
 
-def measure_traffic_live(bs: int, steps: int = 24, timeout_s: int = 90):
-    """`--live-pmc` (off by default until validated on the GPU box): HBM bytes per decode step measured during THIS run instead of read
-    from profiles/: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains) over
+def measure_traffic_live(bs: int, context: int, steps: int = 24, timeout_s: int = 120):
+    """HBM bytes per decode step measured during THIS run, AT THE CONTEXT THE STEP IS TIMED AT (default; `--no-live-pmc` reads the
+    committed pass under profiles/ instead): two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains) over
     tools/prof_eager.py (the step's kernels launched eagerly: --pmc does not survive graph replays in this image), summarised by
     tools/pmc_report2.py with the guide's gfx950 correction (FETCH_SIZE x2). Returns the report's dict or None (any failure, no
     rocprofv3, already running under a profiler): the caller then falls back to the committed pass."""
@@ -166,7 +193,9 @@ def measure_traffic_live(bs: int, steps: int = 24, timeout_s: int = 90):
         return None
     tmp = tempfile.mkdtemp(prefix="ptts_pmc_", dir="/tmp")
     try:
-        env = dict(os.environ, PROF_B=str(bs), PROF_STEPS=str(steps), TMPDIR="/tmp")
+        # a prompt of `context - steps - 1` positions puts the eager steps where the timed replays ran: the last 16 steps sit at
+        # contexts context-16 .. context-1
+        env = dict(os.environ, PROF_B=str(bs), PROF_STEPS=str(steps), PROF_P=str(max(8, context - steps - 1)), TMPDIR="/tmp")
         dbs = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, counter)
@@ -177,7 +206,7 @@ def measure_traffic_live(bs: int, steps: int = 24, timeout_s: int = 90):
                 return None
             dbs[counter] = found[0]
         out_json = os.path.join(tmp, "traffic.json")
-        context = N_PROMPT + 1 + steps  # self-KV positions when the eager run ends
+        context = max(8, context - steps - 1) + 1 + steps - 8  # mean self-KV length over the 16 steps summarised
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_report2.py"), dbs["FETCH_SIZE"], dbs["WRITE_SIZE"], str(min(16, steps - 1)),
                             str(context), str(bs), out_json], timeout=60, capture_output=True)
         if r.returncode != 0 or not os.path.exists(out_json):
@@ -191,10 +220,10 @@ def measure_traffic_live(bs: int, steps: int = 24, timeout_s: int = 90):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-LIVE_PMC = False  # set by --live-pmc
+LIVE_PMC = True  # cleared by --no-live-pmc
 
 
-def measure_decode_roofline(model, bs: int, device) -> dict:
+def measure_decode_roofline(model, bs: int, device, live_pmc: bool = True) -> dict:
     """HIP events (on the stream the graph is launched on) around 400 replays of the captured decode step at
     mid-context. Algorithmic bytes per step = W_step*s + B*2*layers*H*(Lc+N)*s + B*(K*H*s + K*V*4)."""
     eng = _prefilled_engine(model, bs, device)
@@ -211,7 +240,7 @@ def measure_decode_roofline(model, bs: int, device) -> dict:
     achieved = bytes_step / step_s / 1e9
     traffic, tnote = None, "PMC pass not available for this configuration"
     pmc = os.path.join(ROOT, "profiles", f"r02_pmc_step_bs{bs}.json")
-    live = measure_traffic_live(bs) if (LIVE_PMC and es == 2 and H == 1024 and L == 24 and ws == 2) else None
+    live = measure_traffic_live(bs, lc) if (LIVE_PMC and live_pmc and es == 2 and H == 1024 and L == 24 and ws == 2 and bs <= 32) else None
     if live is not None or (es == 2 and H == 1024 and os.path.exists(pmc)):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
         j = live if live is not None else json.load(open(pmc))
         traffic = int(j["traffic_bytes_per_step"])
@@ -318,17 +347,22 @@ def cpu_baseline(budget_s: float = 20.0) -> dict:
     prompt = torch.randn(1, N_PROMPT, spec.hidden_size, generator=g) * 0.02
     ids = torch.full((9, 1), spec.bos_token_id, dtype=torch.long)
     with torch.no_grad():
-        # bs=1 decode is GEMV-sized: more threads than memory channels only adds synchronisation cost. Sweep a few thread
-        # counts on 2 cached steps each (untimed warm-up) and keep the fastest; `cores` reports the threads actually used.
+        # bs=1 decode is GEMV-sized: more threads than memory channels only adds synchronisation cost. Sweep the thread
+        # count (4 .. 64; 2 untimed + 10 timed cached passes each, median) and keep the fastest; `cores` = the threads actually used.
         orc.forward(ids, enc, None, prompt, None)
-        best, cores = None, 1
+        best, cores, sweep = None, 1, {}
         for nt in sorted({c for c in (4, 8, 16, 32, 64) if c <= ncpu} | {min(ncpu, 8)}):
             torch.set_num_threads(nt)
-            orc.forward(torch.zeros(9, 1, dtype=torch.long))
-            ts = time.perf_counter()
-            for _ in range(2):
+            for _ in range(2):  # untimed: thread pool spin-up at this width
                 orc.forward(torch.zeros(9, 1, dtype=torch.long))
-            dt = (time.perf_counter() - ts) / 2
+            per = []
+            for _ in range(10):
+                ts = time.perf_counter()
+                orc.forward(torch.zeros(9, 1, dtype=torch.long))
+                per.append(time.perf_counter() - ts)
+            per.sort()
+            dt = per[len(per) // 2]  # median of 10 cached passes
+            sweep[str(nt)] = round(dt * 1e3, 2)
             if best is None or dt < best:
                 best, cores = dt, nt
         torch.set_num_threads(cores)
@@ -355,7 +389,56 @@ def cpu_baseline(budget_s: float = 20.0) -> dict:
             "sample": f"oracle/ fp32 Mini-v1 bs=1, all timed: prefill of {N_PROMPT + 1} positions ({t_prefill:.2f} s) + {steps} cached decode passes "
                       f"({t_steps / max(steps, 1) * 1e3:.1f} ms each) + DAC decode of the {frames} frames they complete ({t_dac:.2f} s) = {audio:.2f} s of audio in "
                       f"{total:.1f} s on {cores} threads (thread count swept, host has {ncpu}); T5 encoder excluded",
-            "ms_per_decode_step": round(t_steps / max(steps, 1) * 1e3, 2)}
+            "ms_per_decode_step": round(t_steps / max(steps, 1) * 1e3, 2),
+            "thread_sweep_ms_per_step": sweep}  # median of 10 cached passes per thread count; `cores` = the fastest
+
+
+def _timed_generate(model, bs: int, device, reps: int = 1) -> float:
+    """seconds per generate() of `bs` utterances x 860 frames (one warm-up, then the mean of `reps` timed calls)"""
+    d, p = synthetic_batch(bs, 0, device)
+    kw = dict(input_ids=d, prompt_input_ids=p, do_sample=False, max_new_tokens=NEW_TOKENS, min_new_tokens=NEW_TOKENS)
+    model.generate(**kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        wav = model.generate(**kw)
+    torch.cuda.synchronize()
+    assert wav.shape == (bs, FRAMES * 512), wav.shape
+    return (time.perf_counter() - t0) / reps
+
+
+def _trim_roofline(r: dict) -> dict:
+    return {k: r[k] for k in ("achieved", "peak", "unit", "frac", "us_per_launch", "bytes_per_launch", "context") if k in r}
+
+
+def measure_fp32_parity_mode(device) -> dict:
+    """The engine mode whose greedy ids are BIT-EXACT against the fp32 oracle on this very configuration (all 869 columns:
+    tests/test_bench_config_parity_gpu.py) and whose DAC runs exact-f32 MFMA (waveform RMS <= 1e-4): north_star's "bit-exact greedy
+    token ids" bar, timed. Its own model object (fp32 weights, same seeds); released afterwards."""
+    model = build_model_on_device(device, torch.float32, "mini")
+    dt = _timed_generate(model, 1, device)
+    rf = measure_decode_roofline(model, 1, device, live_pmc=False)
+    out = {"value": round(AUDIO_S / dt, 3), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1), "dtype": "f32 (fp32 weights / KV / activations, exact-f32 MFMA DAC)",
+           "roofline": _trim_roofline(rf)}
+    model._engine = None
+    return out
+
+
+def measure_large(device) -> dict:
+    """BASELINE configs[3] / configs[4] per-GPU shapes: parler-tts-large-v1 (30 layers, H 1536, F 6144; init_large_model.py:25-43),
+    bf16 with 1 utterance per GPU, then e4m3 weights with 1 and 4 utterances per GPU. Random weights drawn on the device."""
+    model = build_model_on_device(device, torch.bfloat16, "large")
+    out = {}
+    dt = _timed_generate(model, 1, device)
+    out["bf16_bs1"] = {"value": round(AUDIO_S / dt, 3), "ms_per_step": round(dt * 1e3, 1), "roofline": _trim_roofline(measure_decode_roofline(model, 1, device, live_pmc=False))}
+    model.enable_fp8_weights()
+    for bs in (1, 4):
+        dt = _timed_generate(model, bs, device)
+        out[f"fp8w_bs{bs}"] = {"value": round(bs * AUDIO_S / dt, 3), "ms_per_step": round(dt * 1e3, 1),
+                               "roofline": _trim_roofline(measure_decode_roofline(model, bs, device, live_pmc=False))}
+    out["unit"] = "audio-seconds/sec"
+    model._engine = None
+    return out
 
 
 def arm_watchdog(out: dict, seconds: float):
@@ -375,7 +458,7 @@ def arm_watchdog(out: dict, seconds: float):
             except Exception:  # noqa: BLE001 — a half-written side object: keep the contract fields only
                 line = json.dumps({k: v for k, v in out.items() if isinstance(v, (int, float, str, bool, type(None)))})
             print(line, flush=True)
-            os._exit(0)
+            os._exit(3 if os.environ.get("PTTS_BENCH_STRICT") else 0)  # the builder's own runs surface a hung side measurement in the exit status
 
     threading.Thread(target=run, daemon=True).start()
     return done.set
@@ -410,11 +493,12 @@ def main():
     ap.add_argument("--sample", action="store_true", help="do_sample=True (temperature 1.0, top_k 50: the reference's default generation mode) instead of greedy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bs=32 / TTFT side measurements")
-    ap.add_argument("--live-pmc", action="store_true", help="measure roofline.traffic in this run (two rocprofv3 --pmc child passes, +~45 s) "
-                                                            "instead of reading the committed pass under profiles/")
+    ap.add_argument("--live-pmc", action="store_true", help="(default since round 3) measure roofline.traffic in this run: two rocprofv3 --pmc child "
+                                                            "passes at the timed context, ~20 s per batch size")
+    ap.add_argument("--no-live-pmc", action="store_true", help="read roofline.traffic from the committed pass under profiles/ (context 57) instead")
     args = ap.parse_args()
     global LIVE_PMC
-    LIVE_PMC = bool(args.live_pmc)
+    LIVE_PMC = not args.no_live_pmc
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -474,13 +558,17 @@ def main():
     elapsed = time.perf_counter() - t0
     assert wav.shape == (args.bs, FRAMES * 512), wav.shape
     n_ranks = world
+    per_rank = [elapsed]
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        n_ranks = dist.get_world_size()  # the ranks the process group actually holds
+        n_ranks = dist.get_world_size()  # the ranks the process group (RCCL) actually holds
+        tdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(n_ranks)]
+        dist.all_gather(every, mine)
+        per_rank = [float(x.item()) for x in every]
+        elapsed = max(per_rank)  # the slowest rank bounds the job
     value = n_ranks * args.bs * args.steps * AUDIO_S / elapsed
 
     out = None
@@ -495,6 +583,11 @@ def main():
                                    f"{N_PROMPT} prompt tokens, {FRAMES} frames = {AUDIO_S:.3f} s audio/utterance ({NEW_TOKENS} decoder passes, hipGraph decode, DAC on-GPU)",
                        "global_batch": n_ranks * args.bs, "frames": FRAMES, "parallelism": f"utterance-sharded x{n_ranks}, weights broadcast once"},
         }
+        if world > 1:
+            out["config"]["world_size_reported_by_process_group"] = n_ranks
+            out["config"]["backend"] = os.environ.get("PTTS_DIST_BACKEND", "nccl") + (" (RCCL)" if os.environ.get("PTTS_DIST_BACKEND", "nccl") == "nccl" else "")
+            out["per_rank_ms_per_step"] = [round(t / args.steps * 1e3, 2) for t in per_rank]
+            out["per_rank_value"] = [round(args.bs * args.steps * AUDIO_S / t, 3) for t in per_rank]
         if world > 1 and ndev < world:
             out["config"]["note"] = f"functional run: {world} ranks share {ndev} GPU(s), backend {os.environ.get('PTTS_DIST_BACKEND', 'nccl')}; not a scaling measurement"
         if not args.no_extras:
@@ -505,7 +598,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a required object of the line: measured before the optional side measurements
         out["cpu_baseline"] = cpu_baseline()
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    disarm = arm_watchdog(out, float(os.environ.get("PTTS_BENCH_WATCHDOG_S", "420"))) if (rank == 0 and world == 1) else (lambda: None)
+    disarm = arm_watchdog(out, float(os.environ.get("PTTS_BENCH_WATCHDOG_S", "600"))) if (rank == 0 and world == 1) else (lambda: None)
     if rank == 0 and world == 1 and not args.no_extras and args.bs != 32 and args.model == "mini":
         # side measurement of BASELINE configs[2] (bs=32, same model): one warm-up + one timed generate()
         try:
@@ -522,6 +615,15 @@ def main():
                            "roofline": measure_decode_roofline(model, 32, device)}
         except Exception as e:  # side measurement must never break the contract line
             out["bs32"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_extras and args.model == "mini" and args.dtype == "bf16":
+        try:  # the whole-node lever: 128 utterances per GPU (the step is latency-bound at 32, utterances per step are nearly free until the KV stream dominates)
+            dt = _timed_generate(model, 128, device)
+            out["bs128"] = {"value": round(128 * AUDIO_S / dt, 2), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1),
+                            "roofline": _trim_roofline(measure_decode_roofline(model, 128, device, live_pmc=False))}
+            for key in [k for k in getattr(model, "__dict__", {}).get("_engines", {}) if k[-1] == "b>8"]:  # its 11 GB KV arena is not needed any further
+                model.__dict__["_engines"].pop(key).close()
+        except Exception as e:
+            out["bs128"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_extras and args.bs == 1:
         try:
             out["streaming"] = measure_ttfa(model, device)
@@ -532,6 +634,16 @@ def main():
             out["sampling"] = measure_sampling_step(model, args.bs, device)
         except Exception as e:
             out["sampling"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_extras and args.model == "mini" and args.dtype == "bf16":
+        try:  # the bit-exact (fp32) engine on the same configuration (its own model object: 288 GB of HBM hold all of them)
+            out["fp32_parity_mode"] = measure_fp32_parity_mode(device)
+            out["fp32_parity_mode"]["gpu_over_cpu"] = round(out["fp32_parity_mode"]["value"] / out["cpu_baseline"]["value"], 1) if "cpu_baseline" in out else None
+        except Exception as e:
+            out["fp32_parity_mode"] = {"error": repr(e)[:200]}
+        try:  # Large-v1 shapes (configs[3] / configs[4] per GPU)
+            out["large"] = measure_large(device)
+        except Exception as e:
+            out["large"] = {"error": repr(e)[:200]}
     disarm()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -14,7 +14,7 @@ from .modeling_parler_tts import (
     build_delay_pattern_mask,
 )
 from .streamer import ParlerTTSStreamer
-
+from .distributed import broadcast_model_weights, generate_sharded, shard_batch, shard_range
 
 
 def register_with_transformers() -> bool:
@@ -52,4 +52,4 @@ REGISTERED_WITH_TRANSFORMERS = register_with_transformers()
 
 __all__ = ["DACConfig", "DACModel", "ParlerTTSConfig", "ParlerTTSDecoderConfig", "ParlerTTSForCausalLM",
            "ParlerTTSForConditionalGeneration", "ParlerTTSLogitsProcessor", "ParlerTTSStreamer",
-           "apply_delay_pattern_mask", "build_delay_pattern_mask"]
+           "apply_delay_pattern_mask", "build_delay_pattern_mask", "broadcast_model_weights", "generate_sharded", "shard_batch", "shard_range"]

@@ -85,3 +85,101 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# kwargs of generate() whose leading dimension is the utterance batch (rows of `decoder_input_ids` are batch * num_codebooks)
+_BATCH_KW = ("input_ids", "attention_mask", "prompt_input_ids", "prompt_attention_mask", "prompt_hidden_states", "input_values")
+
+
+def _world(group=None):
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
+    """``model.generate(...)`` for a batch spread over the ranks of the process group (one process per GPU):
+    the utterances are partitioned statically and contiguously (``shard_range``), every rank runs ITS utterances through its own
+    replica, and the waveforms come back in input order - the launcher-side "copy device -> host per rank and concatenate" of
+    §8(e), done with one small metadata all-gather and one padded gather. No collective touches the token loop. The reference's
+    own pattern for collecting generated audio across ranks is pad-then-gather too (training/run_parler_tts_training.py:1156-1161,
+    `accelerator.pad_across_processes` + `gather_for_metrics`).
+
+    Every rank passes the FULL batch (same tensors on every rank, as a data loader that is not sharded yields them).
+    ``dst``: rank that receives the result, or ``None`` for all ranks. Returns (on the receiving ranks) a ``GenerateOutput`` with
+    ``.sequences`` = waveform float32 [batch, samples] zero-padded to the longest utterance of the whole batch (on the CPU) and
+    ``["audios_length"]`` = per-utterance lengths, exactly what the single-process call returns for the same batch under greedy
+    decoding; ``None`` on the other ranks. With sampling each rank draws from its own generator (torch.manual_seed per rank).
+    Without an initialised process group this is ``model.generate`` (world size 1)."""
+    import torch.distributed as dist
+
+    from .modeling_parler_tts import GenerateOutput
+
+    rank, world = _world(group)
+    K = model.config.decoder.num_codebooks
+    full = dict(kwargs)
+    if inputs is not None:
+        full["input_ids"] = inputs
+    enc_out = full.get("encoder_outputs")
+    if enc_out is not None and not torch.is_tensor(enc_out):
+        enc_out = enc_out[0] if isinstance(enc_out, (tuple, list)) else enc_out.last_hidden_state
+    sizes = [int(full[k].shape[0]) for k in _BATCH_KW if full.get(k) is not None] + ([int(enc_out.shape[0])] if enc_out is not None else [])
+    if not sizes:
+        raise ValueError("generate_sharded needs a batched input (`input_ids` or `encoder_outputs`)")
+    B = sizes[0]
+    if any(s != B for s in sizes):
+        raise ValueError(f"inconsistent batch sizes {sizes}")
+    lo, hi = shard_range(B, rank, world)
+    local = dict(full)
+    for k in _BATCH_KW:
+        if local.get(k) is not None:
+            local[k] = local[k][lo:hi]
+    if enc_out is not None:
+        local["encoder_outputs"] = (enc_out[lo:hi],)
+    if local.get("decoder_input_ids") is not None:
+        local["decoder_input_ids"] = local["decoder_input_ids"][lo * K: hi * K]
+    local.pop("streamer", None)
+    if full.get("streamer") is not None:
+        raise ValueError("generate_sharded: a streamer serves ONE utterance on one rank; call model.generate(streamer=...) there")
+    local["return_dict_in_generate"] = True
+    if hi > lo:
+        out = model.generate(**local)
+        wav = out.sequences.detach().float().cpu()
+        lens = [int(x) for x in out["audios_length"]]
+    else:  # more ranks than utterances: this rank idles
+        wav, lens = torch.zeros(0, 1), []
+    if world == 1:
+        return GenerateOutput(sequences=wav, audios_length=lens)
+    # ---- metadata: rows and padded width of every rank's block ------------------------------------------------------------
+    backend = dist.get_backend(group)
+    cdev = model.device if backend == "nccl" else torch.device("cpu")  # RCCL moves device tensors, gloo host tensors
+    meta = torch.tensor([wav.shape[0], wav.shape[1]], dtype=torch.int64, device=cdev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    rows = [int(m[0]) for m in metas]
+    width = max([int(m[1]) for m in metas if int(m[0]) > 0] or [1])
+    max_rows = max(rows)
+    # ---- payload: one padded block per rank = [waveforms | lengths] ---------------------------------------------------------
+    block = torch.zeros(max_rows, width + 1, dtype=torch.float32)
+    if wav.shape[0]:
+        block[: wav.shape[0], : wav.shape[1]] = wav
+        block[: wav.shape[0], width] = torch.tensor(lens, dtype=torch.float32)  # sample counts < 2^24: exact in fp32
+    block = block.to(cdev)
+    if dst is None:
+        blocks = [torch.zeros_like(block) for _ in range(world)]
+        dist.all_gather(blocks, block, group=group)
+    else:
+        blocks = [torch.zeros_like(block) for _ in range(world)] if rank == dst else None
+        dist.gather(block, blocks, dst=dst, group=group)
+        if rank != dst:
+            return None
+    parts, all_lens = [], []
+    for r in range(world):
+        b = blocks[r][: rows[r]].cpu()
+        parts.append(b[:, :width])
+        all_lens += [int(v) for v in b[:, width].tolist()]
+    wav_all = torch.cat(parts, dim=0)
+    longest = max(all_lens) if all_lens else 0
+    return GenerateOutput(sequences=wav_all[:, : max(longest, 1)], audios_length=all_lens)

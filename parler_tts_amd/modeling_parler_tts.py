@@ -229,6 +229,21 @@ def _single_device(device_map):
     return torch.device(device_map)
 
 
+def _build_uninitialised(factory):
+    """Runs a module factory with transformers' weight initialisation switched off (the tensors are allocated, their values are
+    whatever the allocator returned): for replicas whose weights arrive right afterwards. Falls back to the plain factory on
+    transformers releases without the context manager."""
+    try:
+        from transformers.initialization import no_init_weights
+    except Exception:  # noqa: BLE001
+        try:
+            from transformers.modeling_utils import no_init_weights
+        except Exception:  # noqa: BLE001
+            return factory()
+    with no_init_weights():
+        return factory()
+
+
 def _default_generation_config(config: ParlerTTSConfig):
     from transformers import GenerationConfig
 
@@ -301,7 +316,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
     main_input_name = "input_ids"
 
     def __init__(self, config: Optional[ParlerTTSConfig] = None, text_encoder: Optional[nn.Module] = None,
-                 audio_encoder: Optional[nn.Module] = None, decoder: Optional[ParlerTTSForCausalLM] = None):
+                 audio_encoder: Optional[nn.Module] = None, decoder: Optional[ParlerTTSForCausalLM] = None, init_weights: bool = True):
+        """``init_weights=False``: allocate the parameters without drawing them (a replica that is about to receive its weights from
+        a checkpoint or from rank 0's broadcast: the random init of the 1.2 G parameters of Mini-v1 + T5 takes ~15-25 s of host time)."""
         super().__init__()
         if config is None and (text_encoder is None or audio_encoder is None or decoder is None):
             raise ValueError("Either a configuration has to be provided, or all three of text encoder, audio encoder and Parler-TTS decoder.")
@@ -318,15 +335,19 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if text_encoder is None:
             from transformers import AutoModelForTextEncoding
 
-            text_encoder = AutoModelForTextEncoding.from_config(config.text_encoder)  # third-party T5 encoder (:2345-2348)
+            if init_weights:
+                text_encoder = AutoModelForTextEncoding.from_config(config.text_encoder)  # third-party T5 encoder (:2345-2348)
+            else:
+                text_encoder = _build_uninitialised(lambda: AutoModelForTextEncoding.from_config(config.text_encoder))
         self.text_encoder = text_encoder
         self.audio_encoder = audio_encoder if audio_encoder is not None else DACModel(config.audio_encoder)
-        self.decoder = decoder if decoder is not None else ParlerTTSForCausalLM(config.decoder)
+        self.decoder = decoder if decoder is not None else ParlerTTSForCausalLM(config.decoder, init_weights=init_weights)
         H = config.decoder.hidden_size
         if config.text_encoder.hidden_size != H and xh is None:
             self.enc_to_dec_proj = nn.Linear(config.text_encoder.hidden_size, H)  # :2388-2392
         self.embed_prompts = nn.Embedding(config.vocab_size, H)  # :2395
-        self.embed_prompts.weight.data.normal_(mean=0.0, std=config.decoder.initializer_factor)
+        if init_weights:
+            self.embed_prompts.weight.data.normal_(mean=0.0, std=config.decoder.initializer_factor)
         self.prompt_cross_attention = config.prompt_cross_attention
         if config.prompt_cross_attention:
             self.embed_positions = _Holder()
@@ -574,6 +595,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
     def _engine(self, value):
         if value is None:
             self.__dict__["_engines"] = {}
+            for e in self.__dict__.get("_split_engines") or []:  # the stream-split loop's engines hold packed copies of the same weights
+                e.close()
+            self.__dict__["_split_engines"], self.__dict__["_split_key"] = [], None
         self.__dict__["_engine_last"] = value
 
     def _get_split_engines(self, n: int, Bsub: int, N: int, P: int, max_length: int, T: int = 0) -> List[DecoderEngine]:
@@ -681,6 +705,12 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if getattr(gc, "cache_implementation", None) == "quantized":
             raise ValueError("This model does not support the quantized cache. If you want your model to support quantized "
                              "cache, please open an issue on the Parler-TTS repository https://github.com/huggingface/parler-tts")
+        if getattr(gc, "cache_implementation", None) == "sliding_window":
+            # the reference clamps the self-attention cache to `config.sliding_window` (:3269-3270; a field its own config classes do not
+            # define, so the stock model raises AttributeError there). A windowed cache changes the arithmetic; the HIP engine's static
+            # arena does not implement it, and nothing is silently ignored.
+            raise NotImplementedError("cache_implementation='sliding_window' is not implemented by the HIP engine (its KV arena is a full static "
+                                      "cache: use cache_implementation=None or 'static')")
         check_generation_mode(gc)  # greedy / sampling only (:3574-3578)
         dev = self.device
         d = self.config.decoder

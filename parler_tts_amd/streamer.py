@@ -72,6 +72,8 @@ class ParlerTTSStreamer:
         if n == 0:
             return np.zeros(0, dtype=np.float32)
         f0 = start_sample // self.hop_length
+        if n - f0 <= 0:  # nothing new (e.g. stride 0 and no valid frame since the last put): an empty tail, as the windowed decode returns
+            return np.zeros(0, dtype=np.float32)
         if hasattr(self.audio_encoder, "decode_chunk"):  # native chunk entry: reads the window in place (ptts_dac_decode_chunk)
             out = self.audio_encoder.decode_chunk(codes[None, ...], f0, n - f0, self.halo_frames).audio_values
             return out[0, 0, start_sample - f0 * self.hop_length:].cpu().float().numpy()
@@ -111,8 +113,10 @@ class ParlerTTSStreamer:
             else:  # same slices as above, computed from the tail only
                 codes = self._valid_codes(self.token_cache)
                 total = codes.shape[-1] * self.hop_length
-                tail = self._decode_from(codes, max(self.to_yield, 0)) if total > max(self.to_yield, 0) else np.zeros(0, dtype=np.float32)
-                n_emit = total - self.stride - self.to_yield  # len(audio_values[to_yield:-stride])
+                # len(audio_values[to_yield:-stride]); quirk kept: with stride 0 the reference's slice is [to_yield:-0] = EMPTY while
+                # to_yield still advances (streamer.py:121-122), i.e. the reference streamer drops the audio - so does this one
+                n_emit = total - self.stride - self.to_yield if self.stride != 0 else 0
+                tail = self._decode_from(codes, max(self.to_yield, 0)) if (total > max(self.to_yield, 0) and n_emit > 0) else np.zeros(0, dtype=np.float32)
                 self.on_finalized_audio(tail[: max(n_emit, 0)] if self.to_yield >= 0 else np.zeros(0, dtype=np.float32))
                 self.to_yield += total - self.to_yield - self.stride
 

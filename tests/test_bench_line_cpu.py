@@ -25,8 +25,9 @@ def _model(which, dtype=torch.bfloat16, fp8=False):
     return m
 
 
-@pytest.mark.parametrize("which,bs,step_us,nodes", [("mini", 1, 617.6, 170), ("mini", 32, 1515.6, 219), ("mini", 8, 1330.0, 170), ("large", 1, 1030.0, 212)])
+@pytest.mark.parametrize("which,bs,step_us,nodes", [("mini", 1, 617.6, 170), ("mini", 32, 1515.6, 195), ("mini", 8, 1330.0, 170), ("large", 1, 1030.0, 212)])
 def test_roofline_object_arithmetic(monkeypatch, which, bs, step_us, nodes):
+    monkeypatch.setattr(bench, "LIVE_PMC", False)  # no rocprofv3 child on the CPU tier: the committed pass is quoted
     monkeypatch.setattr(bench, "_prefilled_engine", lambda model, b, device, **gen: _Eng())
     monkeypatch.setattr(bench, "_timed_replays", lambda eng, n: step_us * 1e-6)
     r = bench.measure_decode_roofline(_model(which), bs, torch.device("cpu"))
@@ -52,6 +53,7 @@ def test_roofline_object_arithmetic(monkeypatch, which, bs, step_us, nodes):
 
 
 def test_roofline_counts_one_byte_weights_for_the_fp8_gemv_step(monkeypatch):
+    monkeypatch.setattr(bench, "LIVE_PMC", False)
     monkeypatch.setattr(bench, "_prefilled_engine", lambda model, b, device, **gen: _Eng())
     monkeypatch.setattr(bench, "_timed_replays", lambda eng, n: 1e-3)
     r8 = bench.measure_decode_roofline(_model("large", fp8=True), 4, torch.device("cpu"))
@@ -65,7 +67,7 @@ def test_roofline_counts_one_byte_weights_for_the_fp8_gemv_step(monkeypatch):
 def test_step_graph_node_counts_follow_the_forward_structure():
     assert bench.step_graph_nodes(1, 24, 1024, True) == 170 and bench.step_graph_nodes(1, 24, 1024, False) == 194
     assert bench.step_graph_nodes(4, 30, 1536, False) == 242 and bench.step_graph_nodes(8, 24, 1024, False) == 170
-    assert bench.step_graph_nodes(32, 24, 1024, False) == 219 and bench.step_graph_nodes(32, 24, 512, False) is None
+    assert bench.step_graph_nodes(32, 24, 1024, False) == 195 and bench.step_graph_nodes(32, 24, 512, False) is None  # 8 nodes per layer + heads prep / heads / tail
     assert bench.step_graph_nodes(64, 24, 1024, False) is None
 
 
@@ -73,11 +75,15 @@ def test_live_pmc_result_replaces_the_committed_pass_and_failures_fall_back(monk
     monkeypatch.setattr(bench, "_prefilled_engine", lambda model, b, device, **gen: _Eng())
     monkeypatch.setattr(bench, "_timed_replays", lambda eng, n: 6e-4)
     monkeypatch.setattr(bench, "LIVE_PMC", True)
-    monkeypatch.setattr(bench, "measure_traffic_live", lambda bs, **k: {"traffic_bytes_per_step": 7.7e8, "context": 57, "algorithmic_mb": 736.6,
-                                                                       "source": "LIVE in this bench run: rocprofv3 --pmc ..."})
+    asked = []
+    monkeypatch.setattr(bench, "measure_traffic_live", lambda bs, context, **k: asked.append((bs, context)) or {
+        "traffic_bytes_per_step": 7.7e8, "context": context - 8, "algorithmic_mb": 776.6, "source": "LIVE in this bench run: rocprofv3 --pmc ..."})
     r = bench.measure_decode_roofline(_model("mini"), 1, torch.device("cpu"))
     assert r["traffic"] == 770000000 and r["traffic_note"].startswith("LIVE in this bench run")
-    monkeypatch.setattr(bench, "measure_traffic_live", lambda bs, **k: None)  # rocprofv3 missing / child failed: the committed pass is quoted
+    assert asked == [(1, r["context"])]  # measured at the context the step is timed at
+    r = bench.measure_decode_roofline(_model("mini"), 1, torch.device("cpu"), live_pmc=False)  # side objects skip the child passes
+    assert asked == [(1, r["context"])] and not r["traffic_note"].startswith("LIVE")
+    monkeypatch.setattr(bench, "measure_traffic_live", lambda bs, context, **k: None)  # rocprofv3 missing / child failed: the committed pass is quoted
     r = bench.measure_decode_roofline(_model("mini"), 1, torch.device("cpu"))
     assert isinstance(r["traffic"], int) and not r["traffic_note"].startswith("LIVE")
 
@@ -128,7 +134,9 @@ def test_main_prints_one_contract_line_with_everything_stubbed(monkeypatch, caps
     monkeypatch.setattr(ge, "build", lambda: None)
     monkeypatch.setattr(bench, "build_model", lambda rank, world, device, dtype, which="mini": fake)
     monkeypatch.setattr(bench, "synthetic_batch", lambda bs, rank, device: (torch.zeros(bs, bench.N_DESC, dtype=torch.long), torch.zeros(bs, bench.N_PROMPT, dtype=torch.long)))
-    monkeypatch.setattr(bench, "measure_decode_roofline", lambda model, bs, device: {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None})
+    monkeypatch.setattr(bench, "measure_decode_roofline", lambda model, bs, device, live_pmc=True: {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None})
+    monkeypatch.setattr(bench, "measure_fp32_parity_mode", lambda device: {"value": 12.0, "unit": "audio-seconds/sec"})
+    monkeypatch.setattr(bench, "measure_large", lambda device: {"bf16_bs1": {"value": 9.0}})
     monkeypatch.setattr(bench, "measure_ttft", lambda model, bs, device, reps=20: 9.0)
     monkeypatch.setattr(bench, "measure_ttfa", lambda model, device: {"ttfa_p50_ms": 37.0})
     monkeypatch.setattr(bench, "measure_sampling_step", lambda model, bs, device: {"ratio_sampling_over_greedy": 1.04})
@@ -145,7 +153,10 @@ def test_main_prints_one_contract_line_with_everything_stubbed(monkeypatch, caps
     assert j["cpu_baseline"]["kind"] == "port" and j["gpu_over_cpu"] == round(j["value"] / 0.15, 1)
     assert j["bs32"]["roofline"]["bound"] == "hbm" and j["streaming"] == {"ttfa_p50_ms": 37.0} and j["sampling"]["ratio_sampling_over_greedy"] == 1.04
     assert "watchdog" not in j
-    assert fake.calls == [1, 1, 1, 32, 32]  # 1 warm-up + 2 timed steps at bs = 1, then the bs = 32 side measurement (warm-up + timed)
+    assert j["bs128"]["roofline"] == {"achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1} and j["bs128"]["unit"] == "audio-seconds/sec"
+    assert j["fp32_parity_mode"]["value"] == 12.0 and j["fp32_parity_mode"]["gpu_over_cpu"] == 80.0 and j["large"] == {"bf16_bs1": {"value": 9.0}}
+    # 1 warm-up + 2 timed steps at bs = 1, then the bs = 32 and bs = 128 side measurements (warm-up + timed each)
+    assert fake.calls == [1, 1, 1, 32, 32, 128, 128]
 
 
 def test_parity_tests_model_copy_equals_bench_build_model():

@@ -130,3 +130,63 @@ def test_world_size_2_model_weight_broadcast():
     assert same1 and dac1, "rank 1 did not receive rank 0's weights bit-exactly"
     assert inv0 and inv1
     assert n0 == n1 and n0 < np0, f"{n0} collectives for {np0} parameter tensors: small tensors must be coalesced"
+
+
+def _sharded_generate_worker(rank, world, port, q):
+    """`distributed.generate_sharded` over gloo: every rank holds the same oracle-backed stand-in model (tests/test_generate_glue_cpu.py)
+    and the FULL batch; rank 0 must get what the single-process call returns, in input order, with the per-utterance lengths."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+
+    from test_generate_glue_cpu import _model
+    from parler_tts_amd.distributed import generate_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        m, _, _, _ = _model(eos_gain=6.0)  # EOS reachable: utterances of different lengths -> ragged blocks, zero padding
+        g = torch.Generator().manual_seed(1)
+        desc, prompt_ids = torch.randint(3, 128, (3, 9), generator=g), torch.randint(3, 128, (3, 4), generator=g)
+        mask = torch.ones(3, 9, dtype=torch.long)
+        mask[1, 6:] = 0
+        kw = dict(input_ids=desc, attention_mask=mask, prompt_input_ids=prompt_ids, do_sample=False, max_length=40, min_new_tokens=3)
+        res = {}
+        for dst in (0, None):
+            out = generate_sharded(m, dst=dst, **kw)
+            res[dst] = None if out is None else (out.sequences.clone(), list(out["audios_length"]))
+        one = generate_sharded(m, dst=0, input_ids=desc[:1], prompt_input_ids=prompt_ids[:1], do_sample=False, max_length=24, min_new_tokens=3)  # rank 1 idles
+        single = m.generate(return_dict_in_generate=True, **kw) if rank == 0 else None
+        single1 = m.generate(return_dict_in_generate=True, input_ids=desc[:1], prompt_input_ids=prompt_ids[:1], do_sample=False, max_length=24,
+                             min_new_tokens=3) if rank == 0 else None
+        ok = True
+        if rank == 0:
+            for dst in (0, None):
+                w, lens = res[dst]
+                ok = ok and lens == list(single["audios_length"]) and w.shape == single.sequences.shape and torch.equal(w, single.sequences.float().cpu())
+            ok = ok and one is not None and list(one["audios_length"]) == list(single1["audios_length"]) and torch.equal(one.sequences, single1.sequences.float().cpu())
+            ok = ok and len(set(single["audios_length"])) > 1  # the case really is ragged
+        else:
+            ok = res[0] is None and res[None] is not None and one is None
+        q.put((rank, bool(ok), None if res[None] is None else res[None][1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_generate_sharded_equals_the_single_process_call():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_generate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1], "rank 0: the gathered waveforms / lengths differ from the single-process generate()"
+    assert res[1][1], "rank 1: wrong return protocol (None for dst=0, the full result for dst=None)"
+    assert res[0][2] == res[1][2] and len(res[0][2]) == 3  # dst=None: every rank holds the same lengths, in input order

@@ -411,34 +411,26 @@ def test_fused_cross_attention_block_masks_and_rope(rope):
 
 def test_full_mini_v1_fp32_greedy_ids_bit_exact():
     """BASELINE.json configs[0] numerics at the FULL Mini-v1 shape (24 layers, H=1024, F=4096, K=9, V=1088): greedy token
-    ids of the fp32 engine vs the oracle's CPU fp32 path, free-running from the same description / prompt tensors.
-    Compared up to the first step whose top-2 margin in the oracle is < 2e-4 (fp32 summation-order noise on Mini logits
-    is ~2e-6): everything before that must be bit-exact, and at least 20 columns must be covered."""
+    ids of the fp32 engine vs the oracle's CPU fp32 path, free-running from the same description / prompt tensors: ALL 33
+    columns bit-exact. The input seed was scanned on the oracle (min top-2 margin over the run 1.45e-3 against ~3e-6 of fp32
+    summation-order noise); the margin is asserted, not used as a guard."""
     spec = DO.MINI_V1
     sd = DO.make_decoder_weights(spec, seed=1234)
-    g = torch.Generator().manual_seed(1)
+    g = torch.Generator().manual_seed(4)
     N, P, L = 16, 8, 33
     enc = torch.randn(1, N, spec.hidden_size, generator=g)
     prompt = torch.randn(1, P, spec.hidden_size, generator=g) * 0.5
     orc = DO.DecoderOracle(spec, sd)
     gp = DO.GenParams(max_length=L, min_new_tokens=L - 1)
     ref = DO.sample_loop(orc, enc, None, prompt, None, gp, keep_logits=True)
-    safe = ref.sequences.shape[1]
-    for s_, lg in enumerate(ref.step_logits):
-        lg = lg.clone()
-        lg[:, spec.eos_token_id] = -float("inf")
-        top2 = torch.topk(lg, 2, dim=-1)[0]
-        if float((top2[:, 0] - top2[:, 1]).min()) < 2e-4:
-            safe = s_ + 1  # columns [0, s_] are safe; column s_+1 was chosen at an unsafe step
-            break
-    assert safe >= 20, f"oracle margins too small too early ({safe})"
+    assert ref.min_margin >= 5 * C.MARGIN, ref.min_margin
     eng = make_engine(spec, sd, torch.float32, max_batch=1, max_ctx=64, max_enc=16, max_prompt=16)
     eng.set_gen_params(max_length=L, min_new_tokens=L - 1)
     eng.prefill(enc, None, prompt, None, sample=False)
-    assert (eng.logits().cpu() - ref.step_logits[0]).abs().max() < 2e-4
+    assert (eng.logits().cpu() - ref.step_logits[0]).abs().max() < 5e-5
     ids = eng.generate_ids(enc, None, prompt, None).cpu()
-    assert ids.shape == ref.sequences.shape
-    assert torch.equal(ids[:, :safe], ref.sequences[:, :safe])
+    assert ids.shape == ref.sequences.shape == (spec.num_codebooks, L)
+    assert torch.equal(ids, ref.sequences)
 
 
 def test_fused_lm_heads_checkpoint_layout():

@@ -130,3 +130,54 @@ def test_dac_decode_chunk_equals_full_decode_window(spec_name, T, first, n, halo
     assert float((chunk - full).abs().max()) <= 1e-5, float((chunk - full).abs().max())
     with pytest.raises(ValueError, match="bad chunk"):
         dac.decode_chunk(codes, T - 3, 5, halo)
+
+
+def test_stride_zero_end_with_nothing_new_posts_the_stop_signal():
+    """stride 0 (explicit, or play_steps == num_codebooks): when `end()` finds no frame beyond what the last `put` emitted, the native
+    chunk entry must not be called with an empty window (ptts_dac_decode_chunk rejects n_frames < 1 - `end()` would raise before
+    posting the stop signal and the consumer would block until its timeout). The incremental and the literal re-decode paths must
+    yield the same chunks, an empty final one included (with stride 0 the reference's `audio_values[to_yield:-stride]` is the empty
+    slice `[to_yield:-0]` while `to_yield` advances, streamer.py:121-122: every chunk is empty - quirk kept by both paths). A second run
+    with stride 1 and a stream that ends ON a boundary exercises the non-empty chunks + the empty-window guard."""
+    from parler_tts_amd.streamer import ParlerTTSStreamer
+
+    g, _ = _gold()
+    dac = DA.DacOracle(DA.DAC_TINY, DA.make_dac_weights(DA.DAC_TINY, seed=int(g["dac_seed"])))
+    hop = DA.DAC_TINY.hop_length
+
+    class Codec:
+        config = types.SimpleNamespace(sampling_rate=hop * 86, frame_rate=86, codebook_size=1024, num_codebooks=9)
+        device = torch.device("cpu")
+        decoder_rates = DA.DAC_TINY.decoder_rates
+
+        def decode(self, audio_codes, audio_scales=None):
+            return types.SimpleNamespace(audio_values=dac.decode(audio_codes[0]))
+
+        def decode_chunk(self, audio_codes, first_frame, n_frames=None, halo=16):
+            assert n_frames is None or n_frames >= 1, "ptts_dac_decode_chunk rejects an empty window"
+            codes = audio_codes[0]
+            n_frames = codes.shape[-1] - first_frame if n_frames is None else n_frames
+            w0 = max(0, first_frame - halo)
+            wav = dac.decode(codes[:, :, w0: first_frame + n_frames])
+            return types.SimpleNamespace(audio_values=wav[:, :, (first_frame - w0) * hop:])
+
+    model = types.SimpleNamespace(decoder=types.SimpleNamespace(num_codebooks=9), audio_encoder=Codec(), generation_config=_gc(),
+                                  device=torch.device("cpu"), use_audio_scales=True, use_4dim_audio_codes=True)
+    import parler_tts_amd as P
+
+    K, play = 9, 12
+    L = 2 * play  # the stream ends exactly on a play_steps boundary: nothing new at end()
+    raw = torch.randint(0, 1024, (K, L), generator=torch.Generator().manual_seed(3))
+    for stride in (0, 1):
+        outs = []
+        for incremental in (False, True):
+            st = ParlerTTSStreamer(model, play_steps=play, stride=stride, incremental=incremental, timeout=5.0)
+            st.put(P.build_delay_pattern_mask(torch.full((K, 1), 1025), 1025, 1024, L, K)[0])
+            for j in range(1, L):
+                st.put(raw[:, j])
+            st.end()
+            outs.append([c for c in st])  # raises queue.Empty after 5 s if the stop signal was never posted
+        assert [len(c) for c in outs[0]] == [len(c) for c in outs[1]], stride
+        assert len(outs[1]) == 3 and (stride != 0 or all(len(c) == 0 for c in outs[1]))
+        for a, b in zip(*outs):
+            assert np.allclose(a, b, atol=2e-6)

@@ -7,12 +7,13 @@ import torch
 from quick_probe import rand_sd
 from parler_tts_amd.engine import DecoderEngine
 B = int(os.environ.get("PROF_B", "1")); steps = int(os.environ.get("PROF_STEPS", "20"))
+P = int(os.environ.get("PROF_P", "32"))  # prompt positions: a long prompt puts the eager steps at the context bench.py times (P + 1 + steps)
 dev = torch.device("cuda:0"); H, L, F, K, V = 1024, 24, 4096, 9, 1088
 eng = DecoderEngine(hidden_size=H, num_layers=L, num_heads=16, ffn_dim=F, num_codebooks=K, vocab_size=V, max_positions=4096,
-                    dtype=torch.bfloat16, max_batch=B, max_ctx=940, max_enc=64, max_prompt=40)
+                    dtype=torch.bfloat16, max_batch=B, max_ctx=max(940, P + 72), max_enc=64, max_prompt=P + 8)
 eng.load_state_dict(rand_sd(H, L, F, K, V, 4096, dev))
-eng.set_gen_params(max_length=869, min_new_tokens=868)
-eng.prefill(torch.randn(B, 64, H, device=dev), None, torch.randn(B, 32, H, device=dev), None, sample=False)
+eng.set_gen_params(max_length=steps + 40, min_new_tokens=steps + 39)
+eng.prefill(torch.randn(B, 64, H, device=dev), None, torch.randn(B, P, H, device=dev), None, sample=False)
 tok = torch.randint(0, 1024, (B * K,), device=dev)
 for i in range(steps):
     eng.push_tokens(tok); eng.step_forward()
