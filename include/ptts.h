@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 4
+#define PTTS_ABI_VERSION 5
 
 enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
 
@@ -121,6 +121,12 @@ int ptts_set_audio_prefix(ptts_engine* e, const int64_t* codes_dev, int32_t B, i
  *   prompt_mask_dev[B, P] int32 or NULL (prompt_attention_mask) */
 int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_dev, const float* prompt_dev,
                  const int32_t* prompt_mask_dev, int32_t B, int32_t N, int32_t P, int32_t sample, void* stream);
+
+/* Blocks the calling thread until the first token of the last ptts_prefill(sample != 0) is materialised on the device (an event recorded
+ * right after the sampler tail): time-to-first-token as SURVEY.md §8(d) defines it. Work enqueued behind the tail by the same call (the
+ * static cross-attention fold for the decode steps) is NOT waited for. Replaces the host sync a caller of the reference would place after
+ * the first `_sample` iteration (:3564). */
+int ptts_first_token_sync(ptts_engine* e);
 
 /* n_steps iterations of {embed(delay-masked last column) -> layers -> LM heads -> tail}; replayed from a
  * captured hipGraph. Steps after every row has finished are no-ops (device-side check), so callers may

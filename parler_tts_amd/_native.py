@@ -44,7 +44,7 @@ class PttsDacConfig(C.Structure):
     ]
 
 
-ABI_VERSION = 4  # PTTS_ABI_VERSION in include/ptts.h
+ABI_VERSION = 5  # PTTS_ABI_VERSION in include/ptts.h
 
 # every symbol include/ptts.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64P = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
@@ -58,6 +58,7 @@ SYMBOLS = {
     "ptts_weights_ready": (C.c_int, [_VP]),
     "ptts_set_gen_params": (C.c_int, [_VP, C.POINTER(PttsGenParams)]),
     "ptts_prefill": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "ptts_first_token_sync": (C.c_int, [_VP]),
     "ptts_decode_steps": (C.c_int, [_VP, _I32, _VP]),
     "ptts_state": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32), _VP]),
     "ptts_ids": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I32)]),

@@ -46,6 +46,8 @@ struct ptts_engine {
   hipStream_t own_stream = nullptr;
   hipStream_t fold_stream = nullptr;   // cross-attention folding runs here, beside the rest of the prefill
   hipEvent_t ev_kv = nullptr, ev_fold = nullptr;  // cross K/V cache written / folded matrices ready
+  hipEvent_t ev_first = nullptr;                  // first token of the last prefill materialised (recorded right after the sampler tail)
+  bool first_recorded = false;
   std::vector<void*> allocs;
   std::vector<LayerW> L;
   void* embed = nullptr;       // [K][V+1][H]
@@ -58,8 +60,8 @@ struct ptts_engine {
   bool use_gemv = false;     // decode step at batch <= gemv_rows on the row-per-wave GEMV kernels
   int gemv_rows = 1;         // 1 (fp32 parity engine) or GV_MAX_ROWS
   int xfold_ne = 0;          // > 0: static cross-attention folding available (positions per head in the folded layout)
+  FoldLayer* fold_layers = nullptr;  // [layers] operand pointers of the fold kernels (device memory, written once at create)
   bool xfold_valid = false;  // the folded matrices of the CURRENT call are in place (single utterance)
-  bool fold_pending = false; // the fold is still running on fold_stream: the caller's stream has not been made to wait for it yet
   bool w8 = false;           // cfg.weights_fp8: e4m3 row-major weights for the GEMV step (the MFMA paths use the exact bf16 dequantisation)
   std::set<std::string> loaded_fp8, required_fp8;
   std::set<std::string> loaded, required;
@@ -74,6 +76,7 @@ struct ptts_engine {
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   float* lnstat = nullptr;             // strip statistics of the residual rows (EPI_RESID -> PRO_LNS), [max_batch][H/16][2]
   bool use_lns = true;                 // 8 < batch <= 32 decode: LayerNorm fused into the consumer GEMM (no rows_prep node)
+  bool use_fo = true;                  // batch > 8 decode: engine-dtype activations in MFMA B-fragment order (PTTS_NO_FO=1: row-major, for A/B)
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
   int cross_waves = 4; // waves per cross-attention workgroup on the GEMV step: one 8-deep batch of row groups per wave covers max_enc
@@ -152,20 +155,24 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   const size_t lds_cap = 160 * 1024 - 1024;
   // prefill-sized M with prepared (PRO_COPY) activations: 128-row passes (8 MFMA tiles per weight fragment) so the
   // strip's weights are re-streamed from L2 M/128 times instead of M/32
-  const int max_rows = (PRO == PRO_COPY && a.M > 32) ? 128 : 32;
+  // (fragment-order activations, decode at batch > 32: 64-row passes, ONE pass per workgroup via blockIdx.z - twice the workgroups and
+  // half the B fragments per workgroup of a 128-row pass)
+  const bool msplit = PRO == PRO_COPY && a.x_fo && a.M > 32;
+  const int max_rows = msplit ? 64 : ((PRO == PRO_COPY && a.M > 32) ? 128 : 32);
   int rpp = a.M < max_rows ? a.M : max_rows;
-  auto tiles = [](int r) { return r > 32 ? 8 : (r > 16 ? 2 : 1); };
+  auto tiles = [](int r) { return r > 64 ? 8 : (r > 32 ? 4 : (r > 16 ? 2 : 1)); };
   while (rpp > 1 && rpp * row_bytes + (size_t)W * tiles(rpp) * 1024 > lds_cap) --rpp;
   if (rpp * row_bytes + (size_t)W * 1024 > lds_cap) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm K=%d does not fit in LDS", a.K);
   a.rows_per_pass = rpp;
   const int mtp = tiles(rpp);
   const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
-  const dim3 grid(a.N / 16), block(W * 64);
+  a.m_split = msplit ? 1 : 0;
+  const dim3 grid(a.N / 16, 1, msplit ? (a.M + rpp - 1) / rpp : 1), block(W * 64);
   int rc;
   if constexpr (PRO == PRO_COPY) {
     static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
     // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
-    if (a.M > block_min_m && EPI != EPI_GELU) {  // prefill-sized: register-blocked kernel, no K split
+    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo) {  // prefill-sized: register-blocked kernel, no K split
       const int nstrips = a.N / 16;
       const int ns = (nstrips % 4 == 0 && nstrips >= 128) ? 4 : (nstrips % 2 == 0 ? 2 : 0);  // N = 1024: 2 strips per wave keeps > 500 waves in flight
       if (ns) {
@@ -177,14 +184,16 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
         return PTTS_OK;
       }
     }
-    if (mtp == 8) {
-      rc = full ? launch_gemm_inst<WT, PRO, EPI, 8, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 8, false>(a, grid, block, sh, st);
+    if (mtp >= 4) {
+      if (mtp == 8) rc = full ? launch_gemm_inst<WT, PRO, EPI, 8, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 8, false>(a, grid, block, sh, st);
+      else rc = full ? launch_gemm_inst<WT, PRO, EPI, 4, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 4, false>(a, grid, block, sh, st);
       PTTS_TRY(rc);
       hipError_t e8 = hipGetLastError();
       if (e8 != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e8));
       return PTTS_OK;
     }
   }
+  if (mtp > 2) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm: %d activation rows per pass need the PRO_COPY path", rpp);
   if (full) rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, true>(a, grid, block, sh, st);
   else rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, false>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, false>(a, grid, block, sh, st);
   PTTS_TRY(rc);
@@ -198,9 +207,9 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
 // the next LayerNorm prep kernel adds them (and the residual) in a fixed order: deterministic, no atomics.
 constexpr int FC2_KSPLIT = 4;
 template <typename WT>
-bool splitk_ok(int M, int N, int K) {
+bool splitk_ok(int M, int N, int K, bool fo) {
   const int nfrag = K / Elem<WT>::KT;
-  return M > 8 && M <= 32 && N % 16 == 0 && nfrag % (FC2_KSPLIT * 16) == 0;
+  return M > 8 && M <= (fo ? 256 : 32) && N % 16 == 0 && nfrag % (FC2_KSPLIT * 16) == 0;
 }
 template <typename WT>
 int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of partials
@@ -211,12 +220,14 @@ int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of 
   if (!W) return ptts_fail(PTTS_E_INVALID, "split-K gemm K=%d", a.K);
   a.ksplit = per_split; a.frags_per_wave = per_split / W; a.invK = 1.0f / (float)a.K;
   a.out_split_stride = (long long)a.M * a.out_ld;
-  a.rows_per_pass = a.M;
-  const int mtp = a.M > 16 ? 2 : 1;
-  const dim3 grid(a.N / 16, FC2_KSPLIT), block(W * 64);
+  a.rows_per_pass = a.M > 32 ? 64 : a.M;  // batch > 32 (fragment-order activations only): 64-row passes over blockIdx.z
+  a.m_split = a.M > 32 ? 1 : 0;
+  const int mtp = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
+  const dim3 grid(a.N / 16, FC2_KSPLIT, (a.M + a.rows_per_pass - 1) / a.rows_per_pass), block(W * 64);
   const size_t sh = (size_t)W * mtp * 1024;
   int rc = mtp == 1 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 1, true>(a, grid, block, sh, st)
-                    : launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 2, true>(a, grid, block, sh, st);
+           : (mtp == 2 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 2, true>(a, grid, block, sh, st)
+                       : launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 4, true>(a, grid, block, sh, st));
   PTTS_TRY(rc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
@@ -253,7 +264,9 @@ int gemm_with_prologue(ptts_engine* e, GemmArgs g, hipStream_t st) {
     if (g.lnstat && g.M <= 32 && (size_t)g.M * ((size_t)g.K * sizeof(WT) + 16) + 16 * 1024 <= 159 * 1024 && (g.K == 1024 || g.K == 1536))
       return launch_gemm<WT, PRO_LNS, EPI>(g, st);
   }
-  PTTS_TRY((launch_prep<WT, PRO>(g, e->xw, st)));
+  GemmArgs gp = g;
+  gp.out_fo = g.x_fo;  // the prep kernel writes the rows in the order the consumer reads them (x_fo set by the caller: decode, batch > 8)
+  PTTS_TRY((launch_prep<WT, PRO>(gp, e->xw, st)));
   g.x = reinterpret_cast<const float*>(e->xw);
   g.x_ld = g.K; g.x_row_mul = 1; g.x_row_off = 0;
   return launch_gemm<WT, PRO_COPY, EPI>(g, st);
@@ -379,12 +392,14 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   }
   bool fc2_pending = false;
   const bool lns = e->use_lns && !prefill && M > 8 && M <= 32;  // LayerNorm statistics carried by the producer GEMM (PRO_LNS)
+  // decode at batch > 8: engine-dtype activations travel between kernels in MFMA B-fragment order (ptts_lm_kernels.h: fo_vec_index)
+  const int fo = (e->use_fo && !prefill && M > 8) ? 1 : 0;
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
     {  // LN1 + fused QKV projection
       GemmArgs g = {};
       g.W = w.qkv; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
-      g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H;
+      g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H; g.x_fo = fo;
       if (fc2_pending) { g.part = e->hpart; g.S = FC2_KSPLIT; fc2_pending = false; }  // folded by the prep kernel (M > 8)
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
@@ -401,13 +416,13 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
       a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
-      a.direct_out = e->S_self == 1 ? e->xw : nullptr;
+      a.direct_out = e->S_self == 1 ? e->xw : nullptr; a.out_fo = fo;
       PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
       GemmArgs g = {};
       g.W = w.o; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
-      g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
       if (lns) g.stats_out = e->lnstat;  // strip statistics of the new residual rows for LN2 (PRO_LNS)
       if (e->S_self == 1) {
         g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
@@ -423,7 +438,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       x.W = w.cq; x.x = e->h; x.x_ld = H; x.x_row_mul = 1; x.x_row_off = 0; x.gamma = w.ln2_g; x.beta = w.ln2_b; x.K = H;
       x.invK = 1.0f / (float)H; x.kcache = w.k_cross; x.vcache = w.v_cross; x.cap = c.max_enc; x.cur_len = e->cur_len; x.dims = e->dims;
       x.mask = e->enc_mask; x.mask_ld = c.max_enc; x.cos = c.rope ? e->rope_cos : nullptr; x.sin = c.rope ? e->rope_sin : nullptr;
-      x.out = e->xw; x.B = M; x.nheads = nh; x.kv_heads = nkc; x.n_rep = nh / nkc; x.scale = scale;
+      x.out = e->xw; x.B = M; x.nheads = nh; x.kv_heads = nkc; x.n_rep = nh / nkc; x.scale = scale; x.out_fo = fo;
       const int mg = M < 8 ? M : 8;  // utterances per workgroup: batch 9..32 runs as ceil(M / 8) groups in blockIdx.y
       const size_t sh = (size_t)mg * (H * sizeof(WT) + 16) + 8 * 1024 + (size_t)mg * 64 * 4;
       const dim3 xg(nh, (M + 7) / 8);
@@ -436,7 +451,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     {  // LN2 + cross q projection
       GemmArgs g = {};
       g.W = w.cq; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln2_g; g.beta = w.ln2_b;
-      g.out = e->qc; g.out_ld = H; g.M = M; g.N = H; g.K = H;
+      g.out = e->qc; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
       if (lns) g.lnstat = e->lnstat;
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
@@ -448,13 +463,13 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 1;
       a.kv_heads = nkc; a.n_rep = nh / nkc;
       a.fused_append = 0; a.scale = scale;
-      a.direct_out = e->xw;  // the description is short: never split, softmax finished in the attention kernel
+      a.direct_out = e->xw; a.out_fo = fo;  // the description is short: never split, softmax finished in the attention kernel
       PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->cross_waves)));  // decode: as few waves as cover the description (no LDS combine at 1)
     }
     }
     {  // cross out_proj + residual, activations read straight from the attention output
       GemmArgs g = {};
-      g.W = w.co; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
+      g.W = w.co; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1; g.x_fo = fo;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
       if (lns) g.stats_out = e->lnstat;  // for LN3
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
@@ -467,11 +482,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       GemmArgs g2 = {};
       g2.W = w.fc2; g2.x_ld = F; g2.x_row_mul = 1; g2.out = e->h; g2.out_ld = H; g2.M = M; g2.N = H; g2.K = F;
       if (big) {
-        g.out = reinterpret_cast<float*>(e->xw2);
+        g.out = reinterpret_cast<float*>(e->xw2); g.x_fo = fo; g.out_fo = fo;
         if (lns) g.lnstat = e->lnstat;
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
-        g2.x = reinterpret_cast<const float*>(e->xw2);
-        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F)) {
+        g2.x = reinterpret_cast<const float*>(e->xw2); g2.x_fo = fo;
+        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0)) {
           g2.out = e->hpart;  // h += sum of the partials happens in the next layer's LN1 prep kernel
           PTTS_TRY((launch_gemm_splitk<WT>(g2, st)));
           fc2_pending = true;
@@ -490,6 +505,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     GemmArgs g = {};
     g.W = e->heads; g.x = e->h; g.x_ld = H; g.x_row_mul = Q; g.x_row_off = Q - 1; g.gamma = e->lnf_g; g.beta = e->lnf_b;
     g.out = e->logits; g.out_ld = c.num_codebooks * c.vocab_size; g.M = B; g.N = c.num_codebooks * c.vocab_size; g.K = H;
+    g.x_fo = (e->use_fo && !prefill && B > 8) ? 1 : 0;
     PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
   }
   hipError_t err = hipGetLastError();
@@ -516,19 +532,15 @@ int launch_tail(ptts_engine* e, hipStream_t st, bool embed_next) {
   return PTTS_OK;
 }
 
-// static cross-attention folding for the utterance just prefilled (xfold_*_kernel): 2 small GEMM-like kernels per layer
+// static cross-attention folding for the utterance just prefilled (xfold_*_kernel): 2 launches covering every layer
 template <typename WT, bool W8>
 int fold_cross(ptts_engine* e, hipStream_t st) {
   const ptts_config& c = e->cfg;
-  const int H = c.hidden_size, nh = c.num_heads, NE = e->xfold_ne, n_rep = nh / e->nkc;
+  const int H = c.hidden_size, nh = c.num_heads, NE = e->xfold_ne, n_rep = nh / e->nkc, L = c.num_layers;
   const float qscale = 1.44269504088896340736f / sqrtf((float)(H / nh));
-  for (int l = 0; l < c.num_layers; ++l) {
-    const LayerW& w = e->L[l];
-    hipLaunchKernelGGL((xfold_m_kernel<WT, W8>), dim3((H / 8 + 63) / 64, NE, nh), dim3(64), 0, st, w.cq_rm, w.cq_sc, w.k_cross,
-                       reinterpret_cast<WT*>(w.xM), H, NE, c.max_enc, n_rep, e->dims, qscale);
-    hipLaunchKernelGGL((xfold_u_kernel<WT, W8>), dim3((nh * NE + 63) / 64, H), dim3(64), 0, st, w.co_rm, w.co_sc, w.v_cross,
-                       reinterpret_cast<WT*>(w.xU), H, NE, nh, c.max_enc, n_rep, e->dims);
-  }
+  hipLaunchKernelGGL((xfold_m_kernel<WT, W8>), dim3((H / 8 + 63) / 64, NE, L * nh), dim3(64), 0, st, e->fold_layers, nh, H, NE, c.max_enc, n_rep,
+                     e->dims, qscale);
+  hipLaunchKernelGGL((xfold_u_kernel<WT, W8>), dim3((nh * NE + 63) / 64, H, L), dim3(64), 0, st, e->fold_layers, H, NE, nh, c.max_enc, n_rep, e->dims);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "cross-attention fold launch failed: %s", hipGetErrorString(err));
   return PTTS_OK;
@@ -614,7 +626,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   auto fail = [&](int r) { ptts_engine_destroy(e); return r; };
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate failed"));
   if (hipStreamCreateWithFlags(&e->fold_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_kv, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_fold, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&e->ev_fold, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_first, hipEventDisableTiming) != hipSuccess)
     return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate / hipEventCreate failed"));
   const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size, nh = c.num_heads;
   const size_t es = e->esize;
@@ -675,6 +687,16 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
       snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.bias", l, m); e->required.insert(nm);
     }
   }
+  if (e->xfold_ne) {
+    std::vector<FoldLayer> fl(c.num_layers);
+    for (int l = 0; l < c.num_layers; ++l) {
+      const LayerW& w = e->L[l];
+      fl[l] = FoldLayer{w.cq_rm, w.cq_sc, w.k_cross, w.xM, w.co_rm, w.co_sc, w.v_cross, w.xU};
+    }
+    A(e->alloc(&e->fold_layers, (size_t)c.num_layers));
+    if (hipMemcpy(e->fold_layers, fl.data(), fl.size() * sizeof(FoldLayer), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(ptts_fail(PTTS_E_HIP, "hipMemcpy(fold operand table) failed"));
+  }
   A(e->alloc_bytes(&e->embed, (size_t)K * (V + 1) * H * es));
   A(e->alloc_bytes(&e->heads, (size_t)K * V * H * es));
   if (e->use_gemv) A(e->alloc_bytes(&e->heads_rm, (size_t)K * V * H * (e->w8 ? 1 : es)));
@@ -727,8 +749,9 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));
   A(e->alloc(&e->logits, (size_t)c.max_batch * K * V));
   A(e->alloc(&e->sort_buf, 16));
-  A(e->alloc_bytes(&e->xw, rows * H * es));
-  A(e->alloc_bytes(&e->xw2, std::max(rows * F, enc_rows * (size_t)H) * es));
+  A(e->alloc_bytes(&e->xw, (rows + 16) * H * es));  // + 16 rows: fragment order addresses whole 16-row tiles
+  A(e->alloc_bytes(&e->xw2, std::max((rows + 16) * F, enc_rows * (size_t)H) * es));
+  e->use_fo = !(getenv("PTTS_NO_FO") && atoi(getenv("PTTS_NO_FO")));
   A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
@@ -761,6 +784,7 @@ extern "C" void ptts_engine_destroy(ptts_engine* e) {
   if (e->fold_stream) hipStreamDestroy(e->fold_stream);
   if (e->ev_kv) hipEventDestroy(e->ev_kv);
   if (e->ev_fold) hipEventDestroy(e->ev_fold);
+  if (e->ev_first) hipEventDestroy(e->ev_first);
   delete e;
 }
 
@@ -935,6 +959,8 @@ extern "C" int ptts_set_audio_prefix(ptts_engine* e, const int64_t* codes_dev, i
   return PTTS_OK;
 }
 
+static int precapture_graphs(ptts_engine* e);
+
 extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_dev, const float* prompt_dev,
                             const int32_t* prompt_mask_dev, int32_t B, int32_t N, int32_t P, int32_t sample, void* stream) {
   PTTS_CHECK(e && enc_dev, PTTS_E_INVALID, "null argument");
@@ -986,34 +1012,34 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   e->prefill_T = 0;
   PTTS_TRY(rc_fwd);
   e->kv_ub = P + 1 + (batched ? T : 0);  // self-KV positions written by this pass
-  if (e->xfold_ne && B == 1) {
-    // the fold only needs the cross K/V cache (first kernels of the prefill): it runs on its own stream beside the layer stack,
-    // and what follows on the caller's stream (teacher-forced prefix columns, then every decode step) waits for it; the first
-    // token (tail below) does not, so time-to-first-token is unchanged by the fold
-    // (measured: run beside the prefill the fold did not shorten time-to-first-token (8.98 vs 8.44 ms) and the first streamed
-    // chunk came 23 ms later (61.5 vs 38 ms time-to-first-audio): the decode steps wait on the second queue. Default: same stream.)
-    static const bool sync_fold = !(getenv("PTTS_FOLD_ASYNC") && atoi(getenv("PTTS_FOLD_ASYNC")));
-    hipStream_t fs = sync_fold ? st : e->fold_stream;
-    if (!sync_fold) PTTS_HIP(hipStreamWaitEvent(fs, e->ev_kv, 0));
-    if (c.dtype == PTTS_F32) PTTS_TRY((fold_cross<float, false>(e, fs)));
-    else if (e->w8) PTTS_TRY((fold_cross<bf16_t, true>(e, fs)));
-    else PTTS_TRY((fold_cross<bf16_t, false>(e, fs)));
-    if (!sync_fold) PTTS_HIP(hipEventRecord(e->ev_fold, fs));
-    e->xfold_valid = true;
-    e->fold_pending = !sync_fold;
-    if (e->fold_pending && T > 0 && !batched) { PTTS_HIP(hipStreamWaitEvent(st, e->ev_fold, 0)); e->fold_pending = false; }
-  }
   if (batched) hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, T + 1);
-  for (int j = 1; j <= (batched ? 0 : T); ++j) {
+  for (int j = 1; j <= (batched ? 0 : T); ++j) {  // (un-folded cross block: the fold below has not run yet)
     hipLaunchKernelGGL(push_prefix_col_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, j, B, K, c.bos_token_id);
     hipLaunchKernelGGL(set_len_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->cur_len, B, j + 1);
     advance_kv(e);
     PTTS_TRY(forward_dispatch(e, false, st, true));
   }
   if (sample) PTTS_TRY(launch_tail(e, st, true));  // also embeds the sampled column for the first decode step
-  if (e->fold_pending) { PTTS_HIP(hipStreamWaitEvent(st, e->ev_fold, 0)); e->fold_pending = false; }  // later work on st sees the folded matrices
+  e->first_recorded = false;
+  if (sample) { PTTS_HIP(hipEventRecord(e->ev_first, st)); e->first_recorded = true; }
+  if (e->xfold_ne && B == 1) {
+    // The fold only needs the cross K/V cache. It is enqueued AFTER the sampler tail, so the first token is materialised before the
+    // fold's two launches run (time-to-first-token does not pay for it); every decode step that follows on `st` sees the folded
+    // matrices by stream order. (Round 2 ran 48 per-layer launches BEFORE the tail: +0.8 ms of time-to-first-token. Running it on a
+    // second stream beside the prefill was measured and lost: 8.98 vs 8.44 ms to the first token, and the first streamed chunk 23 ms
+    // later, the decode steps waiting on the second hardware queue; PTTS_FOLD_ASYNC=1 keeps that variant for A/B.)
+    static const bool sync_fold = !(getenv("PTTS_FOLD_ASYNC") && atoi(getenv("PTTS_FOLD_ASYNC")));
+    hipStream_t fs = sync_fold ? st : e->fold_stream;
+    if (!sync_fold) PTTS_HIP(hipStreamWaitEvent(fs, e->ev_kv, 0));
+    if (c.dtype == PTTS_F32) PTTS_TRY((fold_cross<float, false>(e, fs)));
+    else if (e->w8) PTTS_TRY((fold_cross<bf16_t, true>(e, fs)));
+    else PTTS_TRY((fold_cross<bf16_t, false>(e, fs)));
+    if (!sync_fold) { PTTS_HIP(hipEventRecord(e->ev_fold, fs)); PTTS_HIP(hipStreamWaitEvent(st, e->ev_fold, 0)); }
+    e->xfold_valid = true;
+  }
   e->h_ready = sample != 0;
   e->prefilled = true;
+  if (sample) PTTS_TRY(precapture_graphs(e));  // device loop ahead: its step graphs for every context bucket of this call
   return PTTS_OK;
 }
 
@@ -1021,10 +1047,10 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
 // (capture records, it does not execute; the legacy NULL stream cannot be captured) and replayed into the caller's.
 static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   // the node set of the step depends on the batch size and on the folded cross block; the attention fetch bound (a kernel argument)
-  // on the 64-position bucket of the context
+  // on the 64-position bucket of the context (forward<> reads it from e->kv_bound while capturing)
   const int key = e->B * 2 + (e->xfold_valid ? 1 : 0) + 4096 * (e->kv_bound / 64);
   auto it = e->graphs.find(key);
-  if (it != e->graphs.end()) { *out = it->second; return PTTS_OK; }
+  if (it != e->graphs.end()) { if (out) *out = it->second; return PTTS_OK; }
   hipGraph_t g = nullptr;
   hipStream_t st = e->own_stream;
   PTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1039,8 +1065,28 @@ static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   hipGraphDestroy(g);
   if (ie != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
   e->graphs[key] = ex;
-  *out = ex;
+  if (out) *out = ex;
   return PTTS_OK;
+}
+
+// Every 64-position bucket this call can reach is captured NOW, at prefill (host work that overlaps the prefill kernels already
+// enqueued), not in the middle of generation: a first long utterance or stream would otherwise stall for a capture + instantiate of
+// ~170-270 nodes every 64 frames, on the latency-critical streaming path. Graphs are cached for the engine's life, so only the first
+// call of a (batch, fold, bucket) pays. PTTS_NO_PRECAPTURE=1: capture lazily as before (A/B).
+static int precapture_graphs(ptts_engine* e) {
+  static const bool off = getenv("PTTS_NO_PRECAPTURE") && atoi(getenv("PTTS_NO_PRECAPTURE"));
+  if (off) return PTTS_OK;
+  const int cap = e->cfg.max_ctx, saved_ub = e->kv_ub, saved_bound = e->kv_bound;
+  const int last_ub = std::min(cap - 1, e->P + e->gp.max_length);  // positions the longest run of this call writes
+  int rc = PTTS_OK;
+  for (int ub = saved_ub + 1; ub <= last_ub && rc == PTTS_OK; ) {
+    e->kv_bound = g_no_kv_bound ? cap : std::min(cap, (ub + 1 + 63) / 64 * 64);
+    rc = get_graph(e, nullptr);
+    ub = e->kv_bound;  // first upper bound of the next bucket: (ub + 1 + 63) / 64 * 64 > kv_bound
+    if (g_no_kv_bound) break;
+  }
+  e->kv_ub = saved_ub; e->kv_bound = saved_bound;
+  return rc;
 }
 
 extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) {
@@ -1062,6 +1108,14 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
     PTTS_TRY(get_graph(e, &ex));  // cached per (batch, fold, 64-position bucket)
     PTTS_HIP(hipGraphLaunch(ex, st));
   }
+  return PTTS_OK;
+}
+
+extern "C" int ptts_first_token_sync(ptts_engine* e) {
+  PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
+  PTTS_CHECK(e->prefilled && e->first_recorded, PTTS_E_INVALID, "ptts_first_token_sync: no sampling prefill to wait for");
+  PTTS_DEVICE(e->cfg.device);
+  PTTS_HIP(hipEventSynchronize(e->ev_first));
   return PTTS_OK;
 }
 

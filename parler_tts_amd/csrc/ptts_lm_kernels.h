@@ -103,10 +103,36 @@ struct GemmArgs {
   float* stats_out;    // EPI_RESID: [M][N/16][2] strip statistics of the updated residual rows, or null
   int ksplit;          // split-K over blockIdx.y (PRO_COPY only): weight fragments per split, 0 = off
   long long out_split_stride;  // elements between the partial outputs of two splits
+  int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
+  int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
+  int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
 #ifdef PTTS_TIMING
   long long* dbg;      // phase timestamps (s_memtime) of workgroup 0 / wave 0
 #endif
 };
+
+// ---- activations in MFMA B-fragment order ("FO") -----------------------------------------------------------------------------
+// Decode at batch > 8: the engine-dtype activation rows that a PRO_COPY GEMM consumes are written by their producers (rows_prep,
+// attention, fused cross block, fc1's GELU epilogue) in the order the consumer's MFMA loop reads them:
+//   X_fo[M/16 tiles][K/KT fragments][64 lanes][16 B], lane l of fragment (mt, t) = row mt*16 + (l & 15), k = t*KT + (l >> 4)*EPL + e
+// (the weight packing with rows <-> utterances), so one B-fragment load of a wave is ONE contiguous 1 KiB instead of 16 rows x 64 B
+// (half-used 128-B lines; measured: M = 128 GEMMs of 2 MB weights took 11-12 us, the K = 4096 one 34 us, profiles/r03_step_bf16_bs128_v0.txt).
+// Index of the 16-byte vector that holds elements (m, k .. k + EPL - 1), k % EPL == 0:
+template <typename WT> __device__ __forceinline__ size_t fo_vec_index(int m, int k, int nfrag) {
+  constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL;
+  return ((size_t)(m >> 4) * nfrag + k / KT) * 64 + ((k % KT) / EPL) * 16 + (m & 15);
+}
+// store 4 consecutive elements (k % 4 == 0) of row m: row-major [M][K] or fragment order
+template <typename WT> __device__ __forceinline__ void act_store4(WT* base, int m, int k, int K, int fo, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void act_store4<float>(float* base, int m, int k, int K, int fo, float a, float b, float c, float d) {
+  float4* p = fo ? reinterpret_cast<float4*>(base) + fo_vec_index<float>(m, k, K / Elem<float>::KT) : reinterpret_cast<float4*>(base + (size_t)m * K + k);
+  *p = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void act_store4<bf16_t>(bf16_t* base, int m, int k, int K, int fo, float a, float b, float c, float d) {
+  uint2* p = fo ? reinterpret_cast<uint2*>(reinterpret_cast<uint4*>(base) + fo_vec_index<bf16_t>(m, k & ~7, K / Elem<bf16_t>::KT)) + ((k >> 2) & 1)
+                : reinterpret_cast<uint2*>(base + (size_t)m * K + k);
+  *p = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
 
 template <typename WT> struct MfmaStep;
 template <> struct MfmaStep<bf16_t> {
@@ -460,7 +486,9 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   const int q = lane >> 4, j = lane & 15;
   if (PRO == PRO_COPY) a.out += (size_t)blockIdx.y * a.out_split_stride;
 
-  for (int m0 = 0; m0 < a.M; m0 += a.rows_per_pass) {
+  const int m_first = (PRO == PRO_COPY && a.m_split) ? (int)blockIdx.z * a.rows_per_pass : 0;
+  const int m_last = (PRO == PRO_COPY && a.m_split) ? min(a.M, m_first + a.rows_per_pass) : a.M;
+  for (int m0 = m_first; m0 < m_last; m0 += a.rows_per_pass) {
     const int nrows = min(a.rows_per_pass, a.M - m0);
     PTTS_STAMP(PTTS_DBG(a), 0);
     // 0. EPI_RESID: the residual values this wave will update are fetched now, not after the reduction (one cold
@@ -498,13 +526,18 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     // 3. MFMA over this wave's K slice; B fragments come from LDS (rows beyond nrows are clamped: their output
     //    columns are never stored). All LDS reads of a group are issued before its first MFMA.
     const char* brow[MTP];
+    const bool xfo = PRO == PRO_COPY && a.x_fo;  // B fragments in fragment order: fragment t of row tile mt is 1 KiB at ((tile * nfrag + t) * 64 + lane) * 16
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt) {
       const int rloc = min(mt * 16 + j, nrows - 1);
-      brow[mt] = PRO == PRO_COPY
-                     ? reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)((m0 + rloc) * a.x_row_mul + a.x_row_off) * a.x_ld + (size_t)kb * KT) + (size_t)q * 16
-                     : s_x + (size_t)rloc * row_bytes + (size_t)q * 16;
+      if (xfo)  // rows past M inside the last tile hold stale data: their output columns are never stored
+        brow[mt] = reinterpret_cast<const char*>(a.x) + (((size_t)((m0 >> 4) + min(mt, (nrows - 1) >> 4)) * nfrag + kb) * 64 + lane) * 16;
+      else
+        brow[mt] = PRO == PRO_COPY
+                       ? reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)((m0 + rloc) * a.x_row_mul + a.x_row_off) * a.x_ld + (size_t)kb * KT) + (size_t)q * 16
+                       : s_x + (size_t)rloc * row_bytes + (size_t)q * 16;
     }
+    const size_t bstep = xfo ? (size_t)1024 : (size_t)(KT * sizeof(WT));  // bytes between consecutive fragments of one row tile
     f32x4 acc[MTP], acc2[MTP];  // two independent accumulator chains per tile (MFMA dependent latency)
 #pragma unroll
     for (int mt = 0; mt < MTP; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -523,7 +556,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
 #pragma unroll
           for (int mt = 0; mt < MTP; ++mt)
             if (FULL || tb + uh + u < t1)
-              bfr[mt][u] = *reinterpret_cast<const uint4*>(brow[mt] + (size_t)(tb + uh + u) * (KT * sizeof(WT)));
+              bfr[mt][u] = *reinterpret_cast<const uint4*>(brow[mt] + (size_t)(tb + uh + u) * bstep);
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           if (FULL || tb + uh + u < t1) {
@@ -555,9 +588,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
           *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) =
               make_float4(gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
         } else if (EPI == EPI_GELU_WT) {
-          WT* o = reinterpret_cast<WT*>(a.out) + (size_t)m * a.out_ld + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) store_from_f32<WT>(o + e, gelu_erf(r[e]));
+          act_store4<WT>(reinterpret_cast<WT*>(a.out), m, n, a.out_ld, a.out_fo, gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
         } else if (EPI == EPI_RESID) {
           float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
           float4 o = mt == wave ? resid_pre : *p;
@@ -691,7 +722,7 @@ __global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
 // one pass, row held in registers (K == NF4 * 256): every load of the row (+ pending split-K partials + gamma/beta) is in
 // flight at once - one dependent round trip instead of the three of the generic two-pass loop below
 template <typename WT, int NF4>
-__device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* out, int lane) {
+__device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* dst, int lane) {
   float* xr = const_cast<float*>(a.x) + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
   float4 v[NF4], g[NF4], bt[NF4];
 #pragma unroll
@@ -734,7 +765,7 @@ __device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* o
   const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
 #pragma unroll
   for (int i = 0; i < NF4; ++i)
-    lds_store4<WT>(reinterpret_cast<char*>(out), (lane + 64 * i) * 4, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
+    act_store4<WT>(dst, m, (lane + 64 * i) * 4, a.K, a.out_fo, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
                    (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
 }
 
@@ -743,9 +774,8 @@ __global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= a.M) return;
-  WT* out = dst + (size_t)m * a.K;
-  if (PRO == PRO_LN && a.K == 1024) { prep_ln_row_regs<WT, 4>(a, m, out, lane); return; }  // Mini-v1
-  if (PRO == PRO_LN && a.K == 1536) { prep_ln_row_regs<WT, 6>(a, m, out, lane); return; }  // Large-v1
+  if (PRO == PRO_LN && a.K == 1024) { prep_ln_row_regs<WT, 4>(a, m, dst, lane); return; }  // Mini-v1
+  if (PRO == PRO_LN && a.K == 1536) { prep_ln_row_regs<WT, 6>(a, m, dst, lane); return; }  // Large-v1
   if (PRO == PRO_LN) {
     const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
     if (a.part) {  // pending split-K partials of the previous fc2 (+ residual): h += sum_s part[s], in fixed order
@@ -775,18 +805,13 @@ __global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restri
       const float4 t = *reinterpret_cast<const float4*>(xr + k);
       const float4 g = *reinterpret_cast<const float4*>(a.gamma + k);
       const float4 bt = *reinterpret_cast<const float4*>(a.beta + k);
-      store_from_f32<WT>(out + k + 0, (t.x - mean) * rstd * g.x + bt.x);
-      store_from_f32<WT>(out + k + 1, (t.y - mean) * rstd * g.y + bt.y);
-      store_from_f32<WT>(out + k + 2, (t.z - mean) * rstd * g.z + bt.z);
-      store_from_f32<WT>(out + k + 3, (t.w - mean) * rstd * g.w + bt.w);
+      act_store4<WT>(dst, m, k, a.K, a.out_fo, (t.x - mean) * rstd * g.x + bt.x, (t.y - mean) * rstd * g.y + bt.y, (t.z - mean) * rstd * g.z + bt.z,
+                     (t.w - mean) * rstd * g.w + bt.w);
     }
   } else {
     for (int k = lane * 4; k < a.K; k += 256) {
       const float4 o = stage_elem<PRO>(a, m, k);
-      store_from_f32<WT>(out + k + 0, o.x);
-      store_from_f32<WT>(out + k + 1, o.y);
-      store_from_f32<WT>(out + k + 2, o.z);
-      store_from_f32<WT>(out + k + 3, o.w);
+      act_store4<WT>(dst, m, k, a.K, a.out_fo, o.x, o.y, o.z, o.w);
     }
   }
 }
@@ -824,6 +849,7 @@ struct AttnArgs {
   int cross;           // 1: length = dims->N, mask over all positions; 0: causal self-attention, mask over positions < P
   int fused_append;
   float scale;
+  int out_fo;          // direct_out in MFMA B-fragment order (fo_vec_index) instead of row-major [rows][H]
 };
 
 // load EPL consecutive floats of a row chunk, optionally RoPE-rotated (x*cos + rotate_half(x)*sin, modeling:409-436)
@@ -1015,7 +1041,11 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       lv += wgt * s_ml[i][1];
     }
     if (a.direct_out) {  // unsplit launch: this workgroup saw every key, finish the softmax here
-      store_from_f32<WT>(reinterpret_cast<WT*>(a.direct_out) + (size_t)row * a.H + h * 64 + tid, lv > 0.f ? ov / lv : 0.f);
+      const int kcol = h * 64 + tid;
+      WT* dst = reinterpret_cast<WT*>(a.direct_out);
+      if (a.out_fo) dst += fo_vec_index<WT>(row, kcol & ~(EPL - 1), a.H / Elem<WT>::KT) * EPL + (kcol & (EPL - 1));
+      else dst += (size_t)row * a.H + kcol;
+      store_from_f32<WT>(dst, lv > 0.f ? ov / lv : 0.f);
       return;
     }
     a.part[((size_t)row * a.S + s) * a.H + h * 64 + tid] = ov;
@@ -1056,6 +1086,7 @@ struct XAttnArgs {
   int B, nheads;
   int kv_heads, n_rep; // cross K/V heads (grouped-query attention)
   float scale;
+  int out_fo;          // out in MFMA B-fragment order (fo_vec_index) for the out_proj GEMM at batch > 8
 };
 
 template <typename WT, int UW, int NF4>
@@ -1214,7 +1245,8 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
     float res[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) res[e] = o[e] * inv;
-    reinterpret_cast<uint4*>(reinterpret_cast<WT*>(a.out) + (size_t)b * a.K + h * 64)[c] = pack16(res, WT());
+    if (a.out_fo) reinterpret_cast<uint4*>(a.out)[fo_vec_index<WT>(b, h * 64 + c * EPL, a.K / KT)] = pack16(res, WT());
+    else reinterpret_cast<uint4*>(reinterpret_cast<WT*>(a.out) + (size_t)b * a.K + h * 64)[c] = pack16(res, WT());
   }
 }
 
@@ -1243,20 +1275,27 @@ template <typename WT, bool W8> struct RmRow {  // one row-major weight row as f
   }
 };
 
-// M[(h*NE + n)][k] = qscale * sum_d K[h/n_rep][n][d] * Wq[h*64 + d][k]; one thread = 8 consecutive k. grid (H/8/64, NE, heads), 64 threads
+// per-layer operands of the fold: one launch covers every layer (48 launches of ~16 us each were 0.8 ms on the first-token path)
+struct FoldLayer {
+  const void* wq; const float* wq_sc; const void* kcache; void* M;
+  const void* wo; const float* wo_sc; const void* vcache; void* U;
+};
+
+// M[(h*NE + n)][k] = qscale * sum_d K[h/n_rep][n][d] * Wq[h*64 + d][k]; one thread = 8 consecutive k. grid (H/8/64, NE, layers*heads), 64 threads
 template <typename WT, bool W8>
-__global__ void __launch_bounds__(64) xfold_m_kernel(const void* __restrict__ Wq, const float* __restrict__ wsc, const void* __restrict__ kcache,
-                                                     WT* __restrict__ M, int H, int NE, int cap, int n_rep, const DevDims* dims, float qscale) {
-  const int k = (blockIdx.x * 64 + threadIdx.x) * 8, n = blockIdx.y, h = blockIdx.z;
+__global__ void __launch_bounds__(64) xfold_m_kernel(const FoldLayer* __restrict__ layers, int nheads, int H, int NE, int cap, int n_rep,
+                                                     const DevDims* dims, float qscale) {
+  const int k = (blockIdx.x * 64 + threadIdx.x) * 8, n = blockIdx.y, l = blockIdx.z / nheads, h = blockIdx.z - l * nheads;
   if (k >= H) return;
-  WT* out = M + ((size_t)h * NE + n) * H + k;
+  const FoldLayer fl = layers[l];
+  WT* out = reinterpret_cast<WT*>(fl.M) + ((size_t)h * NE + n) * H + k;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (n < dims->N) {
-    const WT* kr = reinterpret_cast<const WT*>(kcache) + ((size_t)(h / n_rep) * cap + n) * 64;
+    const WT* kr = reinterpret_cast<const WT*>(fl.kcache) + ((size_t)(h / n_rep) * cap + n) * 64;
     for (int d = 0; d < 64; ++d) {
       const float kd = Elem<WT>::ld(kr + d);
       float w[8];
-      RmRow<WT, W8>::ld8(Wq, wsc, h * 64 + d, H, k, w);
+      RmRow<WT, W8>::ld8(fl.wq, fl.wq_sc, h * 64 + d, H, k, w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = fmaf(kd, w[e], acc[e]);
     }
@@ -1265,24 +1304,25 @@ __global__ void __launch_bounds__(64) xfold_m_kernel(const void* __restrict__ Wq
   for (int e = 0; e < 8; ++e) store_from_f32<WT>(out + e, acc[e] * qscale);
 }
 
-// U[o][h*NE + n] = sum_d Wo[o][h*64 + d] * V[h/n_rep][n][d]; one thread = one (o, h, n). grid (NE*heads/64, H), 64 threads
+// U[o][h*NE + n] = sum_d Wo[o][h*64 + d] * V[h/n_rep][n][d]; one thread = one (o, h, n). grid (NE*heads/64, H, layers), 64 threads
 template <typename WT, bool W8>
-__global__ void __launch_bounds__(64) xfold_u_kernel(const void* __restrict__ Wo, const float* __restrict__ wsc, const void* __restrict__ vcache,
-                                                     WT* __restrict__ U, int H, int NE, int heads, int cap, int n_rep, const DevDims* dims) {
+__global__ void __launch_bounds__(64) xfold_u_kernel(const FoldLayer* __restrict__ layers, int H, int NE, int heads, int cap, int n_rep,
+                                                     const DevDims* dims) {
   const int col = blockIdx.x * 64 + threadIdx.x, o = blockIdx.y;
   if (col >= heads * NE) return;
+  const FoldLayer fl = layers[blockIdx.z];
   const int h = col / NE, n = col - h * NE;
   float acc = 0.f;
   if (n < dims->N) {
-    const WT* vr = reinterpret_cast<const WT*>(vcache) + ((size_t)(h / n_rep) * cap + n) * 64;
+    const WT* vr = reinterpret_cast<const WT*>(fl.vcache) + ((size_t)(h / n_rep) * cap + n) * 64;
     for (int d0 = 0; d0 < 64; d0 += 8) {
       float w[8];
-      RmRow<WT, W8>::ld8(Wo, wsc, o, H, h * 64 + d0, w);
+      RmRow<WT, W8>::ld8(fl.wo, fl.wo_sc, o, H, h * 64 + d0, w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc = fmaf(w[e], Elem<WT>::ld(vr + d0 + e), acc);
     }
   }
-  store_from_f32<WT>(U + (size_t)o * heads * NE + col, acc);
+  store_from_f32<WT>(reinterpret_cast<WT*>(fl.U) + (size_t)o * heads * NE + col, acc);
 }
 
 // prefill: write all Q new K/V rows (RoPE on k) into the self cache.  grid (Q, heads, B), 64 threads

@@ -153,6 +153,11 @@ class DecoderEngine:
         self.B, self.P = B, P
         self._keep = keep  # inputs are consumed asynchronously by the enqueued kernels
 
+    def first_token_sync(self):
+        """Blocks until the first token of the last sampling ``prefill`` exists on the device (``ptts_first_token_sync``): the end of
+        time-to-first-token; work the prefill enqueued behind the sampler tail (cross-attention fold) is not waited for."""
+        N.check(self.lib.ptts_first_token_sync(self._h), "ptts_first_token_sync")
+
     def set_audio_prefix(self, codes: Optional[torch.Tensor]):
         """Voice prompt for the NEXT ``prefill``: un-delayed audio codes int64 [B, K, T] (or [B*K, T]); ``None`` clears it."""
         if codes is None or codes.shape[-1] == 0:
