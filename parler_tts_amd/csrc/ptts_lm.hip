@@ -10,6 +10,7 @@
 #include "ptts_common.h"
 #include "ptts_lm_kernels.h"
 #include "ptts_gemv.h"
+#include "ptts_strip_w8.h"
 
 thread_local std::string g_ptts_err;
 int ptts_fail(int code, const char* fmt, ...) {
@@ -34,6 +35,9 @@ struct LayerW {
   void *qkv_rm = nullptr, *o_rm = nullptr, *cq_rm = nullptr, *co_rm = nullptr, *fc1_rm = nullptr, *fc2_rm = nullptr;
   // weights_fp8: the row-major copies hold OCP e4m3 bytes, one power-of-two scale per output row
   float *qkv_sc = nullptr, *o_sc = nullptr, *cq_sc = nullptr, *co_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
+  // weights_fp8, engines that decode on the MFMA strips (max_batch > GV_MAX_ROWS): e4m3 strips [N/16][K/64][64][16 B] (same scales).
+  // The cross q projection stays bf16: it lives inside the fused cross-block kernel.
+  void *qkv_p8 = nullptr, *o_p8 = nullptr, *co_p8 = nullptr, *fc1_p8 = nullptr, *fc2_p8 = nullptr;
   void *xM = nullptr, *xU = nullptr;  // folded cross-attention of the current single utterance: M [heads*NE][H], U [H][heads*NE] (engine dtype)
 };
 
@@ -56,6 +60,8 @@ struct ptts_engine {
   float *lnf_g = nullptr, *lnf_b = nullptr;
   void* heads = nullptr;  // [K*V][H] packed
   void* heads_rm = nullptr;  // [K*V][H] row-major (GEMV step)
+  void* heads_p8 = nullptr;  // [K*V][H] e4m3 strips (weights_fp8, MFMA decode)
+  bool w8_strips = false;    // weights_fp8 engine whose decode step runs on the MFMA strips: e4m3 strip copies are allocated
   float* heads_sc = nullptr;
   bool use_gemv = false;     // decode step at batch <= gemv_rows on the row-per-wave GEMV kernels
   int gemv_rows = 1;         // 1 (fp32 parity engine) or GV_MAX_ROWS
@@ -76,6 +82,7 @@ struct ptts_engine {
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   float* lnstat = nullptr;             // strip statistics of the residual rows (EPI_RESID -> PRO_LNS), [max_batch][H/16][2]
   bool use_lns = true;                 // 8 < batch <= 32 decode: LayerNorm fused into the consumer GEMM (no rows_prep node)
+  bool attn_exact = true;              // batch > 8 decode self-attention fetches exactly the rows each utterance has (PTTS_NO_ATTN_EXACT=1: the kv_bound bucket)
   bool use_fo = true;                  // batch > 8 decode: engine-dtype activations in MFMA B-fragment order (PTTS_NO_FO=1: row-major, for A/B)
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
@@ -92,6 +99,7 @@ struct ptts_engine {
   int B = 0, N = 0, P = 0;
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
+  int xattn_groups_max = 256; // largest batch that runs the fused cross block in groups of 8 (PTTS_XATTN_GROUPS_MAX; above: rows_prep + q GEMM + attention)
   bool xattn_groups = true;   // the fused LN2 + cross-q + cross-attention kernel also at batch 9..32, in groups of 8 utterances (PTTS_NO_XATTN_GROUPS=1: two nodes)
   int kv_ub = 0;         // host-side upper bound of the self-KV positions written so far (prefill + one per decode forward)
   int kv_bound = 0;      // attention fetch bound of the next decode forward: kv_ub + 1 rounded up to 64, <= max_ctx
@@ -169,6 +177,13 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   a.m_split = msplit ? 1 : 0;
   const dim3 grid(a.N / 16, 1, msplit ? (a.M + rpp - 1) / rpp : 1), block(W * 64);
   int rc;
+  if constexpr (sizeof(WT) == 2) {
+    if (a.W8 && full && a.K % 64 == 0) {  // e4m3 strips (weights_fp8): same grid / LDS, half the weight bytes; -1 = no instance, bf16 strips below
+      rc = ptts_strip_w8_launch(PRO, EPI, mtp, a, grid, block, sh, st);
+      if (rc == 0) return PTTS_OK;
+      if (rc != -1) return PTTS_E_HIP;
+    }
+  }
   if constexpr (PRO == PRO_COPY) {
     static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
     // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
@@ -225,6 +240,13 @@ int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of 
   const int mtp = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
   const dim3 grid(a.N / 16, FC2_KSPLIT, (a.M + a.rows_per_pass - 1) / a.rows_per_pass), block(W * 64);
   const size_t sh = (size_t)W * mtp * 1024;
+  if constexpr (sizeof(WT) == 2) {
+    if (a.W8) {
+      const int r8 = ptts_strip_w8_launch(PRO_COPY, EPI_STORE, mtp, a, grid, block, sh, st);
+      if (r8 == 0) return PTTS_OK;
+      if (r8 != -1) return PTTS_E_HIP;
+    }
+  }
   int rc = mtp == 1 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 1, true>(a, grid, block, sh, st)
            : (mtp == 2 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 2, true>(a, grid, block, sh, st)
                        : launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 4, true>(a, grid, block, sh, st));
@@ -398,7 +420,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const LayerW& w = e->L[l];
     {  // LN1 + fused QKV projection
       GemmArgs g = {};
-      g.W = w.qkv; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
+      g.W = w.qkv; g.W8 = w.qkv_p8; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
       g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H; g.x_fo = fo;
       if (fc2_pending) { g.part = e->hpart; g.S = FC2_KSPLIT; fc2_pending = false; }  // folded by the prep kernel (M > 8)
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
@@ -417,11 +439,12 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
       a.direct_out = e->S_self == 1 ? e->xw : nullptr; a.out_fo = fo;
+      a.exact_len = (!prefill && M > 8 && e->attn_exact) ? 1 : 0;
       PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
       GemmArgs g = {};
-      g.W = w.o; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
+      g.W = w.o; g.W8 = w.o_p8; g.wscale = w.o_sc; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
       if (lns) g.stats_out = e->lnstat;  // strip statistics of the new residual rows for LN2 (PRO_LNS)
       if (e->S_self == 1) {
@@ -432,7 +455,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       }
     }
     const int KTw = Elem<WT>::KT;
-    if (!prefill && (M <= 8 || (e->xattn_groups && M <= 32)) && (H / KTw) % 16 == 0 && (H == 512 || H == 1024 || H == 1536)) {
+    if (!prefill && (M <= 8 || (e->xattn_groups && M <= e->xattn_groups_max)) && (H / KTw) % 16 == 0 && (H == 512 || H == 1024 || H == 1536)) {
       // decode, small batch: LN2 + cross q projection + cross-attention fused, one workgroup per head
       XAttnArgs x = {};
       x.W = w.cq; x.x = e->h; x.x_ld = H; x.x_row_mul = 1; x.x_row_off = 0; x.gamma = w.ln2_g; x.beta = w.ln2_b; x.K = H;
@@ -469,7 +492,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     }
     {  // cross out_proj + residual, activations read straight from the attention output
       GemmArgs g = {};
-      g.W = w.co; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1; g.x_fo = fo;
+      g.W = w.co; g.W8 = w.co_p8; g.wscale = w.co_sc; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1; g.x_fo = fo;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
       if (lns) g.stats_out = e->lnstat;  // for LN3
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
@@ -477,10 +500,10 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     {  // LN3 + fc1 + GELU, then fc2 + residual. Above 8 rows the GELU output is written in the engine dtype so fc2
        // stages it with plain copies too.
       GemmArgs g = {};
-      g.W = w.fc1; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln3_g; g.beta = w.ln3_b;
+      g.W = w.fc1; g.W8 = w.fc1_p8; g.wscale = w.fc1_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln3_g; g.beta = w.ln3_b;
       g.out_ld = F; g.M = M; g.N = F; g.K = H;
       GemmArgs g2 = {};
-      g2.W = w.fc2; g2.x_ld = F; g2.x_row_mul = 1; g2.out = e->h; g2.out_ld = H; g2.M = M; g2.N = H; g2.K = F;
+      g2.W = w.fc2; g2.W8 = w.fc2_p8; g2.wscale = w.fc2_sc; g2.x_ld = F; g2.x_row_mul = 1; g2.out = e->h; g2.out_ld = H; g2.M = M; g2.N = H; g2.K = F;
       if (big) {
         g.out = reinterpret_cast<float*>(e->xw2); g.x_fo = fo; g.out_fo = fo;
         if (lns) g.lnstat = e->lnstat;
@@ -503,7 +526,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   }
   {  // final LayerNorm + all K LM heads as one [K*V, H] projection, last position of each utterance only
     GemmArgs g = {};
-    g.W = e->heads; g.x = e->h; g.x_ld = H; g.x_row_mul = Q; g.x_row_off = Q - 1; g.gamma = e->lnf_g; g.beta = e->lnf_b;
+    g.W = e->heads; g.W8 = e->heads_p8; g.wscale = e->heads_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = Q; g.x_row_off = Q - 1; g.gamma = e->lnf_g; g.beta = e->lnf_b;
     g.out = e->logits; g.out_ld = c.num_codebooks * c.vocab_size; g.M = B; g.N = c.num_codebooks * c.vocab_size; g.K = H;
     g.x_fo = (e->use_fo && !prefill && B > 8) ? 1 : 0;
     PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
@@ -633,7 +656,10 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   e->L.resize(c.num_layers);
   // single-utterance decode step on the row-per-wave GEMV kernels: shapes whose rows are whole 1 KiB chunks
   const int gmode = c.dtype == PTTS_F32 ? GV_F32 : GV_BF16;
-  e->use_gemv = ptts_gemv_k_ok(H, gmode) && ptts_gemv_k_ok(F, gmode) && H <= 2048 && !(getenv("PTTS_NO_GEMV") && atoi(getenv("PTTS_NO_GEMV")));
+  // (an engine created for more than GV_MAX_ROWS utterances never takes the GEMV step: it does not hold the row-major copies either -
+  // the model-level cache keeps one engine per batch-size class, each with the weight copies its own decode step streams)
+  e->use_gemv = ptts_gemv_k_ok(H, gmode) && ptts_gemv_k_ok(F, gmode) && H <= 2048 && c.max_batch <= GV_MAX_ROWS &&
+                !(getenv("PTTS_NO_GEMV") && atoi(getenv("PTTS_NO_GEMV")));
   e->gemv_rows = c.dtype == PTTS_F32 ? 1 : GV_MAX_ROWS;
   if (const char* ev = getenv("PTTS_GEMV_ROWS")) e->gemv_rows = std::max(1, std::min(e->gemv_rows, atoi(ev)));  // A/B knob (tools/)
   e->w8 = c.weights_fp8 != 0;
@@ -641,9 +667,10 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   // description tokens, full cross K/V heads not required (n_rep handled), folded widths must be GEMV shapes
   if (e->use_gemv && !c.rope && c.max_enc <= 64 && ptts_gemv_k_ok(nh * 64, gmode) && !(getenv("PTTS_NO_XFOLD") && atoi(getenv("PTTS_NO_XFOLD"))))
     e->xfold_ne = 64;
-  if (e->w8 && (c.dtype != PTTS_BF16 || !e->use_gemv)) {
+  e->w8_strips = e->w8 && !e->use_gemv && !(getenv("PTTS_NO_W8_STRIPS") && atoi(getenv("PTTS_NO_W8_STRIPS")));
+  if (e->w8 && (c.dtype != PTTS_BF16 || H % 512 || F % 512 || H > 2048)) {
     ptts_engine_destroy(e);
-    return ptts_fail(PTTS_E_UNSUPPORTED, "weights_fp8 needs the bf16 engine and GEMV-step shapes (hidden / ffn multiples of 512, hidden <= 2048)");
+    return ptts_fail(PTTS_E_UNSUPPORTED, "weights_fp8 needs the bf16 engine and hidden / ffn sizes that are multiples of 512 (hidden <= 2048)");
   }
 #define A(expr) if ((rc = (expr)) != PTTS_OK) return fail(rc)
   for (int l = 0; l < c.num_layers; ++l) {
@@ -664,12 +691,17 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
       if (e->xfold_ne) {
         A(e->alloc_bytes(&w.xM, (size_t)nh * e->xfold_ne * H * es)); A(e->alloc_bytes(&w.xU, (size_t)nh * e->xfold_ne * H * es));
       }
-      if (e->w8) {
-        A(e->alloc(&w.qkv_sc, nq)); A(e->alloc(&w.o_sc, H)); A(e->alloc(&w.cq_sc, H)); A(e->alloc(&w.co_sc, H));
-        A(e->alloc(&w.fc1_sc, F)); A(e->alloc(&w.fc2_sc, H));
-        const char* qm[] = {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "encoder_attn.q_proj",
-                            "encoder_attn.out_proj", "fc1", "fc2"};
-        for (const char* m : qm) { char nm[160]; snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.weight", l, m); e->required_fp8.insert(nm); }
+    }
+    if (e->w8) {  // row scales serve both e4m3 layouts (row-major for the GEMV step, strips for the MFMA step)
+      const int nq = H + 2 * e->nkv * 64;
+      A(e->alloc(&w.qkv_sc, nq)); A(e->alloc(&w.o_sc, H)); A(e->alloc(&w.cq_sc, H)); A(e->alloc(&w.co_sc, H));
+      A(e->alloc(&w.fc1_sc, F)); A(e->alloc(&w.fc2_sc, H));
+      const char* qm[] = {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "encoder_attn.q_proj",
+                          "encoder_attn.out_proj", "fc1", "fc2"};
+      for (const char* m : qm) { char nm[160]; snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.weight", l, m); e->required_fp8.insert(nm); }
+      if (e->w8_strips) {
+        A(e->alloc_bytes(&w.qkv_p8, (size_t)nq * H)); A(e->alloc_bytes(&w.o_p8, (size_t)H * H)); A(e->alloc_bytes(&w.co_p8, (size_t)H * H));
+        A(e->alloc_bytes(&w.fc1_p8, (size_t)F * H)); A(e->alloc_bytes(&w.fc2_p8, (size_t)F * H));
       }
     }
     A(e->alloc(&w.ln1_g, H)); A(e->alloc(&w.ln1_b, H)); A(e->alloc(&w.ln2_g, H)); A(e->alloc(&w.ln2_b, H));
@@ -700,6 +732,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc_bytes(&e->embed, (size_t)K * (V + 1) * H * es));
   A(e->alloc_bytes(&e->heads, (size_t)K * V * H * es));
   if (e->use_gemv) A(e->alloc_bytes(&e->heads_rm, (size_t)K * V * H * (e->w8 ? 1 : es)));
+  if (e->w8_strips) A(e->alloc_bytes(&e->heads_p8, (size_t)K * V * H));
   if (e->w8) {
     A(e->alloc(&e->heads_sc, (size_t)K * V));
     for (int k = 0; k < K; ++k) { char nm[96]; snprintf(nm, sizeof nm, "lm_heads.%d.weight", k); e->required_fp8.insert(nm); }
@@ -752,9 +785,11 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc_bytes(&e->xw, (rows + 16) * H * es));  // + 16 rows: fragment order addresses whole 16-row tiles
   A(e->alloc_bytes(&e->xw2, std::max((rows + 16) * F, enc_rows * (size_t)H) * es));
   e->use_fo = !(getenv("PTTS_NO_FO") && atoi(getenv("PTTS_NO_FO")));
+  e->attn_exact = !(getenv("PTTS_NO_ATTN_EXACT") && atoi(getenv("PTTS_NO_ATTN_EXACT")));
   A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
+  if (const char* ev = getenv("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));
   e->xattn_groups = !(getenv("PTTS_NO_XATTN_GROUPS") && atoi(getenv("PTTS_NO_XATTN_GROUPS")));  // measured: 1386 -> 1360 us per batch-32 step (profiles/r03_experiments.txt)
   A(e->alloc(&e->prefix, (size_t)c.max_batch * K * c.max_ctx));
   e->ids_ld = c.max_ctx + 8;
@@ -907,28 +942,35 @@ extern "C" int ptts_load_weight_fp8(ptts_engine* e, const char* name_c, const ui
   hipStream_t st = pick_stream(e, stream);
   const ptts_config& c = e->cfg;
   const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size;
-  uint8_t* dst = nullptr;
+  uint8_t *dst = nullptr, *p8 = nullptr;
   float* sc = nullptr;
+  bool known = false;
   int N = 0, Kd = 0, row0 = 0, l = -1, k = -1;
   char tail[128] = {0};
   if (sscanf(name_c, "model.decoder.layers.%d.%127s", &l, tail) == 2) {
     PTTS_CHECK(l >= 0 && l < c.num_layers, PTTS_E_INVALID, "%s: layer index out of range", name_c);
     LayerW& w = e->L[l];
     const std::string t(tail);
-    struct { const char* n; void* rm; float* sc; int N, Kd, row0; } mats[] = {
-        {"self_attn.q_proj.weight", w.qkv_rm, w.qkv_sc, H, H, 0}, {"self_attn.k_proj.weight", w.qkv_rm, w.qkv_sc, e->nkv * 64, H, H},
-        {"self_attn.v_proj.weight", w.qkv_rm, w.qkv_sc, e->nkv * 64, H, H + e->nkv * 64}, {"self_attn.out_proj.weight", w.o_rm, w.o_sc, H, H, 0},
-        {"encoder_attn.q_proj.weight", w.cq_rm, w.cq_sc, H, H, 0}, {"encoder_attn.out_proj.weight", w.co_rm, w.co_sc, H, H, 0},
-        {"fc1.weight", w.fc1_rm, w.fc1_sc, F, H, 0}, {"fc2.weight", w.fc2_rm, w.fc2_sc, H, F, 0}};
+    struct { const char* n; void* rm; void* p8; float* sc; int N, Kd, row0; } mats[] = {
+        {"self_attn.q_proj.weight", w.qkv_rm, w.qkv_p8, w.qkv_sc, H, H, 0}, {"self_attn.k_proj.weight", w.qkv_rm, w.qkv_p8, w.qkv_sc, e->nkv * 64, H, H},
+        {"self_attn.v_proj.weight", w.qkv_rm, w.qkv_p8, w.qkv_sc, e->nkv * 64, H, H + e->nkv * 64}, {"self_attn.out_proj.weight", w.o_rm, w.o_p8, w.o_sc, H, H, 0},
+        {"encoder_attn.q_proj.weight", w.cq_rm, nullptr, w.cq_sc, H, H, 0}, {"encoder_attn.out_proj.weight", w.co_rm, w.co_p8, w.co_sc, H, H, 0},
+        {"fc1.weight", w.fc1_rm, w.fc1_p8, w.fc1_sc, F, H, 0}, {"fc2.weight", w.fc2_rm, w.fc2_p8, w.fc2_sc, H, F, 0}};
     for (auto& m : mats)
-      if (t == m.n) { dst = (uint8_t*)m.rm; sc = m.sc; N = m.N; Kd = m.Kd; row0 = m.row0; }
+      if (t == m.n) { dst = (uint8_t*)m.rm; p8 = (uint8_t*)m.p8; sc = m.sc; N = m.N; Kd = m.Kd; row0 = m.row0; known = true; }
   } else if (sscanf(name_c, "lm_heads.%d.weight", &k) == 1) {
     PTTS_CHECK(k >= 0 && k < K, PTTS_E_INVALID, "%s: codebook index out of range", name_c);
-    dst = (uint8_t*)e->heads_rm; sc = e->heads_sc; N = V; Kd = H; row0 = k * V;
+    dst = (uint8_t*)e->heads_rm; p8 = (uint8_t*)e->heads_p8; sc = e->heads_sc; N = V; Kd = H; row0 = k * V; known = true;
   }
-  PTTS_CHECK(dst && sc, PTTS_E_INVALID, "%s has no e4m3 copy (only the decode-step projection matrices do)", name_c);
+  PTTS_CHECK(known && sc, PTTS_E_INVALID, "%s has no e4m3 copy (only the decode-step projection matrices do)", name_c);
   PTTS_CHECK(shape[0] == N && shape[1] == Kd, PTTS_E_INVALID, "%s: expected shape [%d, %d]", name_c, N, Kd);
-  PTTS_HIP(hipMemcpyAsync(dst + (size_t)row0 * Kd, q_dev, (size_t)N * Kd, hipMemcpyDeviceToDevice, st));
+  // row-major bytes for the GEMV step (engines of <= GV_MAX_ROWS utterances), strip order for the MFMA step (wider engines)
+  if (dst) PTTS_HIP(hipMemcpyAsync(dst + (size_t)row0 * Kd, q_dev, (size_t)N * Kd, hipMemcpyDeviceToDevice, st));
+  if (p8) {
+    PTTS_CHECK(N % 16 == 0 && Kd % 64 == 0 && row0 % 16 == 0, PTTS_E_INVALID, "%s: [%d, %d] at row %d is not a whole number of 16 x 64 e4m3 strips", name_c, N, Kd, row0);
+    const size_t total = (size_t)(N / 16) * (Kd / 64) * 64;
+    hipLaunchKernelGGL(pack_w8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q_dev, reinterpret_cast<uint4*>(p8), N, Kd, row0 / 16, Kd / 64);
+  }
   PTTS_HIP(hipMemcpyAsync(sc + row0, scale_dev, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
   e->loaded_fp8.insert(name_c);
   return PTTS_OK;

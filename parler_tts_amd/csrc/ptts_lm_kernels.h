@@ -103,6 +103,8 @@ struct GemmArgs {
   float* stats_out;    // EPI_RESID: [M][N/16][2] strip statistics of the updated residual rows, or null
   int ksplit;          // split-K over blockIdx.y (PRO_COPY only): weight fragments per split, 0 = off
   long long out_split_stride;  // elements between the partial outputs of two splits
+  const void* W8;      // e4m3 strips [N/16][K/64 fragment pairs][64 lanes][16 B] (weights_fp8 engines), or null: bf16 / fp32 strips in W
+  const float* wscale; // W8: one power-of-two scale per weight row [N], applied to the fp32 accumulators
   int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
   int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
   int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
@@ -149,6 +151,29 @@ template <> struct MfmaStep<float> {
     return c;
   }
 };
+
+// ---- e4m3 weight strips (weights_fp8 engines, decode at batch >= 5) -------------------------------------------------------------
+// A lane's 16 bytes hold its 8 weights of TWO consecutive k fragments (bytes 0-7: k = 64p + (l >> 4)*8 + e, bytes 8-15: + 32): one
+// 1 KiB wave-load per fragment PAIR, half the bytes of the bf16 strips. e4m3 -> bf16 is exact (3 mantissa bits into 7) and done in
+// registers by v_cvt_scalef32_pk_bf16_fp8 (scale 1.0): 4 VALU ops per A fragment beside an HBM-bound stream; the MFMA is the same
+// mfma_f32_16x16x32_bf16 with bf16 activations, i.e. the arithmetic of the bf16 engine on the exact dequantisation, and the per-row
+// power-of-two scale multiplies the fp32 accumulators (exact, commutes with the sum).
+__device__ __forceinline__ uint4 e4m3x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+  const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+  return make_uint4(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d));
+}
+// row-major e4m3 bytes [N][K] (rows of one projection, landing at strip `strip0`) -> strip order; one thread = one lane's 16 bytes
+static __global__ void pack_w8_kernel(const uint8_t* __restrict__ src, uint4* __restrict__ dst, int N, int K, int strip0, int npair_total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int npair = K / 64;
+  if (idx >= (size_t)(N / 16) * npair * 64) return;
+  const int lane = idx & 63, p = (int)((idx >> 6) % npair), s = (int)((idx >> 6) / npair);
+  const uint8_t* r = src + (size_t)(s * 16 + (lane & 15)) * K + 64 * p + (lane >> 4) * 8;
+  const uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 32);
+  dst[((size_t)(strip0 + s) * npair_total + p) * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
 
 #ifdef PTTS_TIMING
 #define PTTS_STAMP(ptr, i) do { if ((ptr) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) (ptr)[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -469,8 +494,10 @@ template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value =
 
 // a.rows_per_pass rows (<= 16*MTP) of activations are staged per pass; LDS = staging + cross-wave reduction.
 // FULL: every wave owns a whole number of 8-fragment groups and K % 256 == 0 -> straight-line code, no predicates.
-template <typename WT, int PRO, int EPI, int MTP, bool FULL>
+// W8 (bf16 engine, FULL only): the strip's weights are e4m3 fragment pairs (a.W8) + row scales (a.wscale) instead of a.W.
+template <typename WT, int PRO, int EPI, int MTP, bool FULL, bool W8 = false>
 __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_kernel(GemmArgs a) {
+  static_assert(!W8 || (FULL && sizeof(WT) == 2), "e4m3 strips: bf16 engine, FULL variant");
   constexpr int KT = Elem<WT>::KT, U = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
@@ -482,7 +509,9 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   const int per = FULL ? a.frags_per_wave : (nfrag + W - 1) / W;
   const int t0 = wave * per, t1 = FULL ? t0 + per : min(nfrag, t0 + per);
   const int kb = PRO == PRO_COPY ? a.ksplit * (int)blockIdx.y : 0;  // split-K: this workgroup's first weight fragment
-  const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + ((size_t)strip * nfrag + kb) * 64 + lane;
+  // W8: one uint4 per fragment PAIR (t0, kb and every 8-fragment group are even)
+  const uint4* Wp = W8 ? reinterpret_cast<const uint4*>(a.W8) + ((size_t)strip * (nfrag >> 1) + (kb >> 1)) * 64 + lane
+                       : reinterpret_cast<const uint4*>(a.W) + ((size_t)strip * nfrag + kb) * 64 + lane;
   const int q = lane >> 4, j = lane & 15;
   if (PRO == PRO_COPY) a.out += (size_t)blockIdx.y * a.out_split_stride;
 
@@ -498,7 +527,9 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
       resid_pre = *reinterpret_cast<const float4*>(a.out + (size_t)(m0 + wave * 16 + j) * a.out_ld + strip * 16 + q * 4);
     // 1. the first group of weight fragments goes in flight as early as possible - but AFTER this thread's first
     //    activation loads (issue order = return order; the activations are the critical path, the weights are bulk).
-    uint4 afr[U];
+    uint4 afr[W8 ? U / 2 : U];
+    float4 wsc4 = make_float4(1.f, 1.f, 1.f, 1.f);  // W8: scales of this lane's 4 output rows (D[row = q*4 + e]), fetched with the first loads
+    if (W8) wsc4 = *reinterpret_cast<const float4*>(a.wscale + strip * 16 + q * 4);
     // stage 0 = rendezvous only, 1 = loads only, 2 = both (see ln_rows for why LayerNorm waves split the two)
     auto issue_w = [&](int stage) __attribute__((always_inline)) {
       if (stage != 1) {
@@ -506,9 +537,14 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
         __builtin_amdgcn_s_barrier();  // no fence: every wave's activation loads are queued before anybody's weights
       }
       if (stage != 0) {
+        if constexpr (W8) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+          for (int u = 0; u < U / 2; ++u) afr[u] = ld_nt16(Wp + (size_t)((t0 >> 1) + u) * 64);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (FULL || t0 + u < t1) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep the issue order: nothing that waits on a load moves above these
       }
     };
@@ -543,9 +579,14 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     for (int mt = 0; mt < MTP; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int tb = t0; tb < t1; tb += U) {
       if (tb != t0) {
+        if constexpr (W8) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (FULL || tb + u < t1) afr[u] = ld_nt16(Wp + (size_t)(tb + u) * 64);
+          for (int u = 0; u < U / 2; ++u) afr[u] = ld_nt16(Wp + (size_t)((tb >> 1) + u) * 64);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (FULL || tb + u < t1) afr[u] = ld_nt16(Wp + (size_t)(tb + u) * 64);
+        }
       }
       constexpr int UB = MTP == 1 ? 8 : (MTP == 2 ? 4 : 2);  // B-fragment reads hoisted per sub-group (VGPR budget: MTP*UB uint4)
 #pragma unroll
@@ -560,10 +601,17 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           if (FULL || tb + uh + u < t1) {
+            uint4 af;
+            if constexpr (W8) {  // fragment uh + u = half ((uh + u) & 1) of pair (uh + u) >> 1, converted in registers
+              const uint4 pr = afr[(uh + u) >> 1];
+              af = ((uh + u) & 1) ? e4m3x8_to_bf16x8(pr.z, pr.w) : e4m3x8_to_bf16x8(pr.x, pr.y);
+            } else {
+              af = afr[uh + u];
+            }
 #pragma unroll
             for (int mt = 0; mt < MTP; ++mt) {
-              if (u & 1) acc2[mt] = MfmaStep<WT>::run(afr[uh + u], bfr[mt][u], acc2[mt]);
-              else acc[mt] = MfmaStep<WT>::run(afr[uh + u], bfr[mt][u], acc[mt]);
+              if (u & 1) acc2[mt] = MfmaStep<WT>::run(af, bfr[mt][u], acc2[mt]);
+              else acc[mt] = MfmaStep<WT>::run(af, bfr[mt][u], acc[mt]);
             }
           }
         }
@@ -578,6 +626,7 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     for (int mt = wave; mt < MTP; mt += W) {
       f32x4 r = *reinterpret_cast<const f32x4*>(s_red + ((size_t)mt * 64 + lane) * 4);
       for (int w = 1; w < W; ++w) r += *reinterpret_cast<const f32x4*>(s_red + (((size_t)w * MTP + mt) * 64 + lane) * 4);
+      if (W8) { r[0] *= wsc4.x; r[1] *= wsc4.y; r[2] *= wsc4.z; r[3] *= wsc4.w; }
       const int mloc = mt * 16 + j;
       const int m = m0 + mloc;
       const int n = strip * 16 + q * 4;  // D[row = (l>>4)*4 + r][col = l&15]
@@ -850,6 +899,9 @@ struct AttnArgs {
   int fused_append;
   float scale;
   int out_fo;          // direct_out in MFMA B-fragment order (fo_vec_index) instead of row-major [rows][H]
+  int exact_len;       // decode self-attention at batch > 8: wait for the device-resident length (one scalar round trip) and fetch only the
+                       // rows this utterance has, instead of everything below kv_bound (the 64-position bucket: up to 63 unused rows per
+                       // (utterance, head), ~7-13 % of the K/V bytes at mid context; at batch 1..8 the extra round trip costs more than it saves)
 };
 
 // load EPL consecutive floats of a row chunk, optionally RoPE-rotated (x*cos + rotate_half(x)*sin, modeling:409-436)
@@ -939,10 +991,12 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
   uint4 kf[U], vf[U];
   int mk[U];
+  // exact_len: self-attention decode, rows [0, P + cur_len - 1) are in the cache; the row of the new position comes from registers
+  const int fetch_bound = a.exact_len ? min(a.kv_bound, P + cl - 1) : a.kv_bound;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int t = (wv + u * TW) * RPI + r;
-    const int tc = t < a.kv_bound ? t : 0;
+    const int tc = t < fetch_bound ? t : 0;
     kf[u] = Kb[(size_t)tc * LPR + c];
     vf[u] = Vb[(size_t)tc * LPR + c];
     mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
@@ -1662,7 +1716,7 @@ __global__ void __launch_bounds__(1024) tail_kernel(TailArgs a) {
 }
 
 // manual path: append caller-chosen tokens (user LogitsProcessorList / StoppingCriteria ran on the host side)
-__global__ void push_tokens_kernel(const long long* tokens, const int* finished, long long* ids, int ids_ld, int* cur_len,
+static __global__ void push_tokens_kernel(const long long* tokens, const int* finished, long long* ids, int ids_ld, int* cur_len,
                                    int* unfinished, int* has_eos, int B, int K, int eos) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= B * K) return;
@@ -1673,13 +1727,13 @@ __global__ void push_tokens_kernel(const long long* tokens, const int* finished,
   if (tk == eos) has_eos[row] = 1;
   if (finished && finished[row] && unfinished[row] > 0) unfinished[row] = -(t + 1);
 }
-__global__ void bump_len_kernel(int* cur_len, int B) {
+static __global__ void bump_len_kernel(int* cur_len, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) cur_len[b] += 1;
 }
 
 // voice prompt, teacher forcing: column j (1 <= j <= T_prefix) of the raw ids = the delay pattern's value there
-__global__ void push_prefix_col_kernel(long long* ids, int ids_ld, const DevDims* dims, int j, int B, int K, int bos) {
+static __global__ void push_prefix_col_kernel(long long* ids, int ids_ld, const DevDims* dims, int j, int B, int K, int bos) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= B * K) return;
   const int k = row % K;
@@ -1687,18 +1741,18 @@ __global__ void push_prefix_col_kernel(long long* ids, int ids_ld, const DevDims
   ids[(size_t)row * ids_ld + j] = j <= k ? (long long)bos : dd.prefix[(size_t)row * dd.prefix_ld + (j - k - 1)];
 }
 // all T voice-prompt columns of the raw ids at once (batched multi-column prefill)
-__global__ void push_prefix_all_kernel(long long* ids, int ids_ld, const DevDims* dims, int T, int B, int K, int bos) {
+static __global__ void push_prefix_all_kernel(long long* ids, int ids_ld, const DevDims* dims, int T, int B, int K, int bos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * K * T) return;
   const int row = i / T, j = 1 + i % T, k = row % K;
   const DevDims dd = *dims;
   ids[(size_t)row * ids_ld + j] = j <= k ? (long long)bos : dd.prefix[(size_t)row * dd.prefix_ld + (j - k - 1)];
 }
-__global__ void set_len_kernel(int* cur_len, int B, int v) {
+static __global__ void set_len_kernel(int* cur_len, int B, int v) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) cur_len[b] = v;
 }
-__global__ void reset_state_kernel(long long* ids, int ids_ld, int* cur_len, int* unfinished, int* has_eos, int* first_unf,
+static __global__ void reset_state_kernel(long long* ids, int ids_ld, int* cur_len, int* unfinished, int* has_eos, int* first_unf,
                                    int B, int K, int bos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * K) {
@@ -1712,11 +1766,11 @@ __global__ void reset_state_kernel(long long* ids, int ids_ld, int* cur_len, int
   }
 }
 
-__global__ void set_params_kernel(DevDims* dd, DevGen* dg, DevDims d, DevGen g) {
+static __global__ void set_params_kernel(DevDims* dd, DevGen* dg, DevDims d, DevGen g) {
   *dd = d;
   *dg = g;
 }
 
-__global__ void fill_int_kernel(int* p, int v, size_t n) {
+static __global__ void fill_int_kernel(int* p, int v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

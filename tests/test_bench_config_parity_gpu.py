@@ -296,8 +296,8 @@ def test_large_v1_full_depth_bf16_and_fp8_weights():
     """BASELINE configs[3] / configs[4] at FULL depth: parler-tts-large-v1 decoder (30 layers, H 1536, 24 heads, F 6144;
     helpers/model_init_scripts/init_large_model.py:25-43), 64 teacher-forced passes each:
       bf16, 1 utterance (GEMV step) and 8 utterances (MFMA strips + fused cross block) vs the bf16-quantised oracle;
-      e4m3 weights, 1 and 4 utterances per GPU (GEMV step streaming 1-byte weights) vs the oracle evaluating the SAME quantised
-      model (oracle/fp8_oracle.py). Error bar as on Mini-v1: max |dlogit| <= TOL_BF16_LARGE, every arg-max flip inside twice the
+      e4m3 weights, 1 and 4 utterances per GPU (GEMV step streaming 1-byte weights) and 8 (MFMA strips streaming e4m3 fragment pairs)
+      vs the oracle evaluating the SAME quantised model (oracle/fp8_oracle.py). Error bar as on Mini-v1: max |dlogit| <= TOL_BF16_LARGE, every arg-max flip inside twice the
       measured error, agreement >= 97 %."""
     from oracle import fp8_oracle as FO
 
@@ -317,7 +317,7 @@ def test_large_v1_full_depth_bf16_and_fp8_weights():
     t0 = time.time()
     qsd = FO.quantize_decoder_weights(sd)
     t_q = time.time() - t0
-    for bsz in (1, 4):
+    for bsz in (1, 4, 8):  # 8 = the e4m3 MFMA strips (configs[4] names "fp8 MFMA"; weights are e4m3, operands bf16 after an exact in-register convert)
         t0 = time.time()
         worst, frac, unexplained = _teacher_forced_batched(spec, sd, qsd, bsz, steps, seed=400 + bsz, weights_fp8=True)
         _log(f"[large e4m3-weights bs={bsz}] 30 layers, {steps + 1} teacher-forced passes: max |dlogit| {worst:.2e} vs the quantised oracle; identical arg-max "

@@ -298,12 +298,16 @@ def test_gemv_step_batch_2_to_4(bsz):
         assert err < tol, (bsz, prec, err)
 
 
-@pytest.mark.parametrize("width,bsz", [("mini", 1), ("mini", 3), ("mini", 12), ("large", 1), ("large", 4)])
+@pytest.mark.parametrize("width,bsz", [("mini", 1), ("mini", 3), ("mini", 8), ("mini", 12), ("mini", 32), ("mini", 40), ("large", 1), ("large", 4),
+                                       ("large", 8), ("large", 12)])
 def test_fp8_weight_mode_matches_the_quantised_oracle(width, bsz):
     """weights_fp8 (BASELINE configs[4]): the engine quantises the projection matrices itself (e4m3, power-of-two row scales);
     the oracle evaluates the SAME quantised model (oracle/fp8_oracle.py, hand-rounded e4m3) with its bf16 arithmetic. Batch 1 /
-    3 / 4: GEMV step streaming the 1-byte weights (v_cvt_pk_f32_fp8 + fma); batch 12: MFMA strips on the exact bf16
-    dequantisation. Same tolerance as the bf16 mode: the two sides differ by summation order only."""
+    3 / 4: GEMV step streaming the 1-byte weights (v_cvt_pk_f32_fp8 + fma). Batch >= 5: MFMA strips streaming e4m3 fragment
+    pairs converted to bf16 in registers (v_cvt_scalef32_pk_bf16_fp8), row scales on the fp32 accumulators - fused prologues at
+    8, prepared rows / producer statistics at 12 and 32 (1 and 2 row tiles), 64-row passes at 40; the cross q projection inside
+    the fused cross-block kernel and the prefill read the exact bf16 dequantisation. Same tolerance as the bf16 mode: the two
+    sides differ by summation order only."""
     from oracle import fp8_oracle as FO
 
     kw = dict(num_hidden_layers=2, max_position_embeddings=512)
