@@ -158,10 +158,8 @@ NODE_FLOOR_US = 2.13  # a dependent, trivial kernel node inside a hipGraph on MI
 
 def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool):
     """Kernel nodes of the captured decode step (csrc/ptts_lm.hip forward<> + tail), by batch-size regime."""
-    if bs <= 4:   # GEMV step: LN1+QKV, attention, combine+out_proj, [LN2+Mx, softmax+Up | LN2+q, cross-attn, out_proj], LN3+fc1, fc2
+    if bs <= 8:   # GEMV step (bf16 engine): LN1+QKV, attention, combine+out_proj, [LN2+Mx, softmax+Up | LN2+q, cross-attn, out_proj], LN3+fc1, fc2
         return (7 if folded else 8) * layers + 2
-    if bs <= 8:   # MFMA strips with fused prologues + the fused LN2 / cross-q / cross-attention kernel
-        return 7 * layers + 2
     if bs <= 32 and hidden in (1024, 1536):  # rows_prep(LN1), QKV, attention, out_proj, fused LN2+cross-q+cross-attn (groups of 8), out_proj, LNS+fc1, fc2
         return 8 * layers + 3
     return None
@@ -256,8 +254,8 @@ def measure_decode_roofline(model, bs: int, device, live_pmc: bool = True) -> di
     try:  # side information only: must never break the contract line
         nodes = step_graph_nodes(bs, L, H, folded)
         if nodes:
-            out["kernel"] += f" ({nodes} kernel nodes)" + (f": batch <= 4 runs {7 if folded else 8} row-per-wave GEMV / attention nodes per layer + LM heads "
-                                                            "+ sampler/embed tail" if bs <= 4 else "")
+            out["kernel"] += f" ({nodes} kernel nodes)" + (f": batch <= 8 runs {7 if folded else 8} row-per-wave GEMV / attention nodes per layer + LM heads "
+                                                            "+ sampler/embed tail" if bs <= 8 else "")
             out["latency_model"] = latency_model(nodes, step_s * 1e6)
     except Exception:  # noqa: BLE001
         pass

@@ -109,6 +109,14 @@ __device__ __forceinline__ uint4 ld_nt16(const uint4* p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// 8 OCP e4m3 bytes -> 8 packed bf16 (exact: 3 mantissa bits into 7), 4 x v_cvt_scalef32_pk_bf16_fp8 with scale 1.0
+__device__ __forceinline__ uint4 e4m3x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+  const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+  return make_uint4(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d));
+}
+
 // ---- cross-lane reductions without LDS ---------------------------------------------------------------------
 // __shfl_xor lowers to ds_bpermute (an LDS round trip, ~100 cycles each; 12 of them were most of the LayerNorm
 // chain in the first profile). These use DPP row operations inside a 16-lane row and v_permlane16/32_swap (gfx950)

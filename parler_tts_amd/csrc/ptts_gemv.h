@@ -7,7 +7,7 @@ enum { GV_LN = 0, GV_ATTN = 1, GV_COPY = 2, GV_SOFTMAX = 3 };  // SOFTMAX: per-h
 enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2 };
 enum { GV_F32 = 0, GV_BF16 = 1, GV_BF16_W8 = 2 };  // engine dtype of activations / weights; W8 = OCP e4m3 weights, bf16 activations
 
-constexpr int GV_MAX_ROWS = 4;  // utterances one GEMV launch serves (batch 1..4); above that the MFMA strip kernels take over
+constexpr int GV_MAX_ROWS = 8;  // utterances one GEMV launch serves (instances for 1, 2..4 and 5..8); above that the MFMA strip kernels take over
 
 struct GemvArgs {
   const void* W;        // row-major [N][K]: engine dtype, or e4m3 bytes (W8)

@@ -184,13 +184,17 @@ __device__ __forceinline__ void gv_softmax_wave(const GemvArgs& a, char* s_x, in
 }
 
 // NCH = chunks per lane per row (K = NCH * 64 * EPL), R = weight rows per wave, S = KV splits (GV_ATTN), MB = utterances the
-// instance is built for (1 or GV_MAX_ROWS; a.M <= MB of them are live), W8 = e4m3 weights + per-row scale.
+// instance is built for (1, 4 or GV_MAX_ROWS = 8; a.M <= MB of them are live), W8 = e4m3 weights + per-row scale.
+// MB = 8 (batch 5..8): the activation chunks of MG utterances sit in registers at a time (MG * NCH <= 40 vectors), the wave's weight
+// registers are reused for every group; groups past the live batch are skipped (workgroup-uniform).
 template <typename WT, int NCH, int R, int PRO, int EPI, int S, int MB, bool W8>
 __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_kernel(GemvArgs a) {
   constexpr bool HASPRO = PRO != GV_COPY;
   constexpr int EPL = Elem<WT>::EPL;
   constexpr int NF4 = NCH * EPL / 4;  // float4 per lane of one fp32 row (K / 256)
   constexpr int NPW = HASPRO ? MB : 0;  // prologue waves
+  constexpr int MG = (MB <= 4 || MB * NCH <= 40) ? MB : ((MB / 2) * NCH <= 40 ? MB / 2 : MB / 4);  // utterances per register group
+  constexpr int NG = MB / MG;
   typedef typename GvDot<WT, W8>::WV WV;
   extern __shared__ __attribute__((aligned(16))) char s_x[];  // HASPRO: the prepared rows, engine dtype [MB][K]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -213,14 +217,19 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
   float res_pre = 0.f, wsc = 1.f;
   if (EPI == GV_RESID && elive) res_pre = a.out[(size_t)em * a.out_ld + r0 + er];
   if (W8 && elive) wsc = a.wscale[r0 + er];
-  uint4 xv[MB][NCH];
-  if (!HASPRO) {
+  uint4 xv[MG][NCH];
+  auto load_x = [&](int g) __attribute__((always_inline)) {  // activation chunks of utterances g*MG .. g*MG + MG - 1 (absent ones clamped: computed, dropped)
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MG; ++m) {
+      const int mm = MB == 1 ? 0 : min(g * MG + m, a.M - 1);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        xv[m][c] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.xw) + (size_t)(MB == 1 ? 0 : min(m, a.M - 1)) * a.xw_ld)[c * 64 + lane];
-  }
+      for (int c = 0; c < NCH; ++c) {
+        if (HASPRO) xv[m][c] = *reinterpret_cast<const uint4*>(s_x + (size_t)mm * ROW_BYTES + (size_t)(c * 64 + lane) * 16);
+        else xv[m][c] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.xw) + (size_t)mm * a.xw_ld)[c * 64 + lane];
+      }
+    }
+  };
+  if (!HASPRO) load_x(0);
   WV wv[R][NCH];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -232,28 +241,47 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
   if (HASPRO) {
     __builtin_amdgcn_sched_barrier(0);  // the weight loads stay above the barrier
     __syncthreads();
+    load_x(0);
+  }
+  // e4m3 weights serving several utterances: convert each weight chunk to packed bf16 ONCE and run the bf16 dot products on it
+  // (the per-utterance v_cvt_pk_f32_fp8 + fma path converted every chunk MB times: at 8 utterances the e4m3 step was slower than bf16)
+  constexpr bool W8B = W8 && MB > 1;
+  uint4 wb[W8B ? R : 1][W8B ? NCH : 1];
+  if constexpr (W8B) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) xv[m][c] = *reinterpret_cast<const uint4*>(s_x + (size_t)(MB == 1 ? 0 : min(m, a.M - 1)) * ROW_BYTES + (size_t)(c * 64 + lane) * 16);
+      for (int c = 0; c < NCH; ++c) wb[r][c] = e4m3x8_to_bf16x8(wv[r][c].x, wv[r][c].y);
   }
   float v = 0.f;
 #pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    float acc[R], acc2[R];
+  for (int g = 0; g < NG; ++g) {
+    if (g > 0) {
+      if (g * MG >= a.M) break;  // no live utterance in this group or the following ones
+      load_x(g);
+    }
 #pragma unroll
-    for (int r = 0; r < R; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+    for (int m = 0; m < MG; ++m) {
+      float acc[R], acc2[R];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+      for (int r = 0; r < R; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if constexpr (W8B) {
+            if (c & 1) acc2[r] = GvDot<bf16_t, false>::run(wb[r][c], xv[m][c], acc2[r]);
+            else acc[r] = GvDot<bf16_t, false>::run(wb[r][c], xv[m][c], acc[r]);
+          } else {
+            if (c & 1) acc2[r] = GvDot<WT, W8>::run(wv[r][c], xv[m][c], acc2[r]);
+            else acc[r] = GvDot<WT, W8>::run(wv[r][c], xv[m][c], acc[r]);
+          }
+        }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (c & 1) acc2[r] = GvDot<WT, W8>::run(wv[r][c], xv[m][c], acc2[r]);
-        else acc[r] = GvDot<WT, W8>::run(wv[r][c], xv[m][c], acc[r]);
+        const float t = wave_sum(acc[r] + acc2[r]);
+        v = lane == (g * MG + m) * R + r ? t : v;
       }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float t = wave_sum(acc[r] + acc2[r]);
-      v = lane == m * R + r ? t : v;
     }
   }
   if (elive) {

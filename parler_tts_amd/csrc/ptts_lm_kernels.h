@@ -158,12 +158,6 @@ template <> struct MfmaStep<float> {
 // registers by v_cvt_scalef32_pk_bf16_fp8 (scale 1.0): 4 VALU ops per A fragment beside an HBM-bound stream; the MFMA is the same
 // mfma_f32_16x16x32_bf16 with bf16 activations, i.e. the arithmetic of the bf16 engine on the exact dequantisation, and the per-row
 // power-of-two scale multiplies the fp32 accumulators (exact, commutes with the sum).
-__device__ __forceinline__ uint4 e4m3x8_to_bf16x8(uint32_t lo, uint32_t hi) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-  const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
-  const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
-  return make_uint4(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d));
-}
 // row-major e4m3 bytes [N][K] (rows of one projection, landing at strip `strip0`) -> strip order; one thread = one lane's 16 bytes
 static __global__ void pack_w8_kernel(const uint8_t* __restrict__ src, uint4* __restrict__ dst, int N, int K, int strip0, int npair_total) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -233,7 +233,7 @@ def test_mini_width_two_layers_fp32_and_bf16():
         eng.close()
 
 
-def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64, weights_fp8=False, oracle_sd=None):
+def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64, weights_fp8=False, oracle_sd=None, max_batch=None):
     g = torch.Generator().manual_seed(seed)
     enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
     prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
@@ -248,7 +248,7 @@ def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, se
     ref = [orc.forward(torch.full((bsz * 9, 1), 1025), enc, enc_mask, prompt, prompt_mask)[:, -1]]
     for s in range(steps):
         ref.append(orc.forward(step_ids[s][:, None])[:, -1])
-    eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=max_ctx, max_enc=max(N, 16), max_prompt=P + 1, weights_fp8=weights_fp8)
+    eng = make_engine(spec, sd, dtype, max_batch=max_batch or bsz, max_ctx=max_ctx, max_enc=max(N, 16), max_prompt=P + 1, weights_fp8=weights_fp8)
     eng.set_gen_params(max_length=16)
     eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
     outs = [eng.logits().cpu()]
@@ -286,11 +286,12 @@ def test_single_utterance_gemv_step_long_context_all_split_counts():
         assert err < 5e-5, (max_ctx, err)
 
 
-@pytest.mark.parametrize("bsz", [2, 3, 4])
-def test_gemv_step_batch_2_to_4(bsz):
-    """Batch 2..4 on the bf16 engine runs the GEMV step with every weight row read once for all utterances (MB = 4 instances:
-    one prologue wave per utterance, M dot products per weight chunk); the fp32 parity engine keeps the MFMA strip path there.
-    Ragged masks per utterance, 5 teacher-forced steps vs the oracle."""
+@pytest.mark.parametrize("bsz", [2, 3, 4, 5, 6, 8])
+def test_gemv_step_batch_2_to_8(bsz):
+    """Batch 2..8 on the bf16 engine runs the GEMV step with every weight row read once for all utterances (MB = 4 / 8 instances:
+    one prologue wave per utterance, M dot products per weight chunk; at 5..8 the K = 4096 activation chunks pass through the
+    registers in two groups of 4 utterances, groups past the live batch are skipped); the fp32 parity engine keeps the MFMA strip
+    path there. Ragged masks per utterance, 5 teacher-forced steps vs the oracle."""
     spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
     sd = DO.make_decoder_weights(spec, seed=53)
     for dtype, prec, tol in ((torch.bfloat16, "bf16", 2e-2), (torch.float32, "fp32", 5e-5)):
@@ -323,6 +324,24 @@ def test_fp8_weight_mode_matches_the_quantised_oracle(width, bsz):
     err_unq = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=6, steps=1, masks=True, seed=20 + bsz,
                                         weights_fp8=True, oracle_sd=None)
     assert err_unq > err
+
+
+@pytest.mark.parametrize("bsz,fp8", [(3, False), (6, False), (6, True), (8, True)])
+def test_mfma_strips_with_fused_prologues_on_a_wide_engine(bsz, fp8):
+    """An engine created for 12 utterances (no row-major GEMV copies) called with 3 / 6 / 8: the decode step runs the MFMA strips with
+    the fused LayerNorm / split-KV-combine prologues and the fused cross block (the batch <= 8 path of engines that cannot take the
+    GEMV step); with weights_fp8 the strips stream e4m3 fragment pairs there too."""
+    from oracle import fp8_oracle as FO
+
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=67)
+    qsd = FO.quantize_decoder_weights(sd) if fp8 else None
+    err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=6, steps=4, masks=True, seed=30 + bsz, weights_fp8=fp8,
+                                    oracle_sd=qsd, max_batch=12)
+    assert err < 2e-2, (bsz, fp8, err)
+    if not fp8:
+        err = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=bsz, N=21, P=6, steps=4, masks=True, seed=30 + bsz, max_batch=12)
+        assert err < 5e-5, (bsz, err)
 
 
 @pytest.mark.parametrize("bsz", [12, 32])
