@@ -12,11 +12,14 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
+#include "../parler_tts_amd/csrc/ptts_gemv_kernels.h"   // the product's GEMV kernel, for variants E / F (same chain, real node)
+int ptts_fail(int code, const char*, ...) { return code; }
+thread_local std::string g_ptts_err;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 constexpr int H = 1024, NROWS = 3072, HEADS = 16, SPLITS = 4, LAYERS = 24;
 
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ float wave_sum_shfl(float v) {
   for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
@@ -41,7 +44,7 @@ __device__ __forceinline__ void producer(int wg, const uint4* __restrict__ W, co
       a += __uint_as_float(w[r][c].x << 16) * xv[2 * c].x + __uint_as_float(w[r][c].y << 16) * xv[2 * c].y + __uint_as_float(w[r][c].z << 16) * xv[2 * c + 1].x +
            __uint_as_float(w[r][c].w << 16) * xv[2 * c + 1].y;
     }
-    a = wave_sum(a);
+    a = wave_sum_shfl(a);
     if (lane == r) out = a * 1e-3f + 1.0f;
   }
   if (lane < 3) {
@@ -84,7 +87,7 @@ __device__ __forceinline__ void consumer(int cw, const uint4* __restrict__ KV, c
   }
   float acc = qv;
   for (int u = 0; u < 6; ++u) acc += __uint_as_float(kv[u].x << 16) * 1e-6f + __uint_as_float(kv[u].w << 16) * 1e-6f;
-  acc = wave_sum(acc);
+  acc = wave_sum_shfl(acc);
   __shared__ float red[4];
   if ((tid & 63) == 0) red[tid >> 6] = acc;
   __syncthreads();
@@ -109,7 +112,8 @@ int main() {
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int REPS = 40;
-  for (int variant = 0; variant < 4; ++variant) {
+  float *gamma, *beta; CK(hipMalloc(&gamma, H * 4)); CK(hipMalloc(&beta, H * 4)); CK(hipMemset(gamma, 0, H * 4)); CK(hipMemset(beta, 0, H * 4));
+  for (int variant = 0; variant < 6; ++variant) {
     CK(hipMemset(counters, 0, 64 * 4));
     hipGraph_t g; hipGraphExec_t ex;
     // the graph is replayed REPS + 3 times: counters are monotonic over the whole run, so each replay gets its own graph of targets? No:
@@ -122,7 +126,13 @@ int main() {
       if (variant == 0) { hipLaunchKernelGGL(k_producer, dim3(256), dim3(256), 0, st, Wl, x, q); hipLaunchKernelGGL(k_consumer, dim3(64), dim3(256), 0, st, KVl, q, out); }
       else if (variant == 1) hipLaunchKernelGGL(k_merged, dim3(320), dim3(256), 0, st, Wl, x, q, KVl, out, counters, 192u * (l + 1), err);
       else if (variant == 2) hipLaunchKernelGGL(k_producer, dim3(256), dim3(256), 0, st, Wl, x, q);
-      else hipLaunchKernelGGL(k_consumer, dim3(64), dim3(256), 0, st, KVl, q, out);
+      else if (variant == 3) hipLaunchKernelGGL(k_consumer, dim3(64), dim3(256), 0, st, KVl, q, out);
+      else {  // E: the product's LN1 + QKV node (LayerNorm prologue wave + 4 GEMV waves, 3 rows per wave) in the producer's place; F: + consumer
+        GemvArgs ga = {};
+        ga.W = Wl; ga.x = x; ga.x_ld = H; ga.gamma = gamma; ga.beta = beta; ga.out = q; ga.out_ld = NROWS; ga.N = NROWS; ga.K = H; ga.M = 1; ga.invK = 1.0f / H;
+        hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, 3, GV_LN, GV_STORE, 1, 1, false>), dim3(256), dim3(320), H * 2, st, ga);
+        if (variant == 5) hipLaunchKernelGGL(k_consumer, dim3(64), dim3(256), 0, st, KVl, q, out);
+      }
       hipLaunchKernelGGL(k_rest, dim3(4), dim3(256), 0, st, out, x);
     }
     CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
@@ -133,7 +143,8 @@ int main() {
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     int herr = 0; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
-    const char* names[] = {"A two launches (QKV GEMV -> attention) + rest", "B one launch with per-head hand-off + rest", "C producer only + rest", "D consumer only + rest"};
+    const char* names[] = {"A two launches (QKV GEMV -> attention) + rest", "B one launch with per-head hand-off + rest", "C producer only + rest", "D consumer only + rest",
+                           "E product gemv_kernel<LN,QKV> only + rest", "F product gemv_kernel<LN,QKV> -> attention-like + rest"};
     printf("[handoff_probe] %-52s %.2f us per layer%s\n", names[variant], ms * 1e3 / REPS / LAYERS, herr ? "  (SPIN LIMIT HIT: hand-off did not complete)" : "");
     hipGraphExecDestroy(ex); hipGraphDestroy(g);
   }
