@@ -150,7 +150,7 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
         lens = [int(x) for x in out["audios_length"]]
     else:  # more ranks than utterances: this rank idles
         wav, lens = torch.zeros(0, 1), []
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):  # no process group: the plain call (a one-rank group still runs the collectives)
         return GenerateOutput(sequences=wav, audios_length=lens)
     # ---- metadata: rows and padded width of every rank's block ------------------------------------------------------------
     backend = dist.get_backend(group)

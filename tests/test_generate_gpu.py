@@ -371,19 +371,36 @@ def test_generate_with_fp8_weights_tracks_the_quantised_oracle():
     assert not m._engine.weights_fp8
 
 
-def test_stream_split_device_loop_equals_per_half_runs():
-    """model.decode_streams = 2 (experimental, off by default): 16 utterances run as two sub-batches of 8 on two engines and two HIP
-    streams. Utterances never interact and each sub-batch runs the batch-8 kernels, so the waveform must equal, bit for bit, the
-    two halves generated one after the other on the ordinary single engine."""
-    m, spec, sd, dsd = _tiny_model(seed=2)
+def test_generate_sharded_over_rccl_world_size_1_equals_generate():
+    """`parler_tts_amd.generate_sharded` on the RCCL ("nccl") backend: device tensors through all_gather / gather, the weights through
+    `broadcast_model_weights`. One GPU is all the build environment reaches, so the process group has ONE rank (the world-size-2
+    protocol is proven over gloo in tests/test_distributed_cpu.py): the result must equal the plain `generate()` call - waveforms,
+    lengths, input order - with an EOS-bearing model (ragged lengths, zero padding)."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    import parler_tts_amd as P
+
+    m, *_ = C.tiny_model(seed=0, eos_gain=6.0)
     m = m.to("cuda")
-    g = torch.Generator().manual_seed(11)
-    desc, prompt_ids = torch.randint(3, 128, (16, 7), generator=g).cuda(), torch.randint(3, 128, (16, 4), generator=g).cuda()
-    kw = dict(do_sample=False, max_new_tokens=24, min_new_tokens=24)
-    halves = [m.generate(input_ids=desc[i: i + 8], prompt_input_ids=prompt_ids[i: i + 8], **kw) for i in (0, 8)]
-    m.decode_streams = 2
-    assert m._decode_streams(16) == 2
-    both = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, **kw)
-    m.decode_streams = 0
-    assert both.shape == (16, halves[0].shape[1]) and torch.equal(both, torch.cat(halves, dim=0))
-    assert len(m._split_engines) == 2 and float(both.abs().max()) > 0
+    g = torch.Generator().manual_seed(1)
+    desc, prompt_ids = torch.randint(3, 128, (3, 9), generator=g).cuda(), torch.randint(3, 128, (3, 4), generator=g).cuda()
+    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_length=40, min_new_tokens=3)
+    want = m.generate(return_dict_in_generate=True, **kw)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = P.broadcast_model_weights(m, src=0)
+        assert n >= 1 and m._engine is None
+        for dst in (0, None):
+            got = P.generate_sharded(m, dst=dst, **kw)
+            assert list(got["audios_length"]) == list(want["audios_length"])
+            assert got.sequences.shape == want.sequences.shape and torch.equal(got.sequences, want.sequences.float().cpu())
+    finally:
+        dist.destroy_process_group()
