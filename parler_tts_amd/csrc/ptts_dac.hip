@@ -542,6 +542,54 @@ __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* _
   }
 }
 
+// The same final convolution, LDS-tiled (C == 96, k7: the 44.1 kHz decoder). conv_out_tanh_kernel's threads each walk their own
+// input rows (a wave-load touches 64 different 384-byte rows: 169 MB at 1.4 TB/s, 121 us of the 860-frame decode). Here a workgroup
+// owns OUT_TILE consecutive samples: the (OUT_TILE + 6) x 96 input tile is ONE contiguous 27 KB block, staged into LDS with coalesced
+// float4 loads; rows are 100 floats apart (400 B = 36 dwords mod 64: the 16 lanes of a ds_read_b128 service group hit 16 distinct
+// 4-bank slots), the 7 x 96 weights are read as wave-uniform broadcasts. Thread t then computes sample t with EXACTLY the fma order
+// of the reference restatement (bias, tap 0..6 x channel 0..95): the exact-f32 mode stays bit-identical to the direct kernel.
+constexpr int OUT_TILE = 64, OUT_C = 96, OUT_ROW = 100;  // 64 samples per (one-wave) workgroup: 28 KB of LDS, 5 workgroups per CU
+__global__ void __launch_bounds__(OUT_TILE) conv_out_tanh_lds_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                     float* __restrict__ out, int T, int skip, long long out_ld, int t_end) {
+  __shared__ __attribute__((aligned(16))) float sx[(OUT_TILE + 6) * OUT_ROW];
+  __shared__ __attribute__((aligned(16))) float sw[7 * OUT_C];
+  const int b = blockIdx.y, t0 = blockIdx.x * OUT_TILE, tid = threadIdx.x;
+  if (t0 + OUT_TILE <= skip || t0 >= t_end) return;  // workgroup-uniform: nothing of this tile is emitted
+  for (int i = tid; i < 7 * OUT_C / 4; i += OUT_TILE) reinterpret_cast<float4*>(sw)[i] = reinterpret_cast<const float4*>(w)[i];
+  const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * T * OUT_C);
+  constexpr int NV = (OUT_TILE + 6) * (OUT_C / 4), UL = 9;  // 1680 float4 of the tile (rows t0 - 3 .. t0 + OUT_TILE + 2), 9 loads in flight per thread
+  for (int i0 = tid; i0 < NV; i0 += UL * OUT_TILE) {
+    float4 v[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int i = min(i0 + u * OUT_TILE, NV - 1), r = i / (OUT_C / 4), ti = t0 - 3 + r;
+      v[u] = (ti >= 0 && ti < T) ? xb[(size_t)ti * (OUT_C / 4) + (i - r * (OUT_C / 4))] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero outside [0, T)
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int i = i0 + u * OUT_TILE, r = i / (OUT_C / 4);
+      if (i < NV) *reinterpret_cast<float4*>(sx + r * OUT_ROW + (i - r * (OUT_C / 4)) * 4) = v[u];
+    }
+  }
+  __syncthreads();
+  const int t = t0 + tid;
+  if (t >= T || t < skip || t >= t_end) return;
+  float acc = bias[0];
+#pragma unroll 1
+  for (int tap = 0; tap < 7; ++tap) {
+    const int ti = t - 3 + tap;
+    if (ti < 0 || ti >= T) continue;  // the direct kernel skips out-of-range rows too (no fma with the zero padding)
+    const float* xr = sx + (tid + tap) * OUT_ROW;
+    const float* wr = sw + tap * OUT_C;
+#pragma unroll
+    for (int c4 = 0; c4 < OUT_C / 4; ++c4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + c4 * 4), wv = *reinterpret_cast<const float4*>(wr + c4 * 4);
+      acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+    }
+  }
+  out[(size_t)b * out_ld + (t - skip)] = tanhf(acc);
+}
+
 // first encoder Conv1d(1 -> C, k7, pad 3) on the raw waveform: one thread per (sample, 4 channels); writes the raw
 // result (residual skip of the first unit) and its Snake. HBM-bound (C floats out per sample), trivially parallel.
 __global__ void conv_in_kernel(const float* __restrict__ wave, const float* __restrict__ w /*[C][7]*/, const float* __restrict__ bias,
@@ -1167,9 +1215,16 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
       PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st, last));
     }
   }
-  const size_t n = (size_t)B * ((Tcur + OUT_OS - 1) / OUT_OS);
-  hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)7 * d->out_C * 4, st, cur, d->out_w, d->out_b,
-                     wave_dev, B, Tcur, d->out_C, 7, skip, out_ld, emit < 0 ? Tcur : std::min(Tcur, skip + emit));
+  const int t_end = emit < 0 ? Tcur : std::min(Tcur, skip + emit);
+  static const bool out_direct = getenv("PTTS_DAC_OUT_DIRECT") && atoi(getenv("PTTS_DAC_OUT_DIRECT"));  // A/B: the per-thread kernel
+  if (d->out_C == OUT_C && !out_direct && B <= 65535) {
+    hipLaunchKernelGGL(conv_out_tanh_lds_kernel, dim3((unsigned)((Tcur + OUT_TILE - 1) / OUT_TILE), (unsigned)B), dim3(OUT_TILE), 0, st, (const float*)cur,
+                       d->out_w, d->out_b, wave_dev, Tcur, skip, out_ld, t_end);
+  } else {
+    const size_t n = (size_t)B * ((Tcur + OUT_OS - 1) / OUT_OS);
+    hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)7 * d->out_C * 4, st, cur, d->out_w, d->out_b,
+                       wave_dev, B, Tcur, d->out_C, 7, skip, out_ld, t_end);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
