@@ -73,10 +73,27 @@ def broadcast_model_weights(model, src: int = 0, bucket_bytes: int = 64 << 20) -
     dev = model.device
     model.audio_encoder._weights = {k: v.to(dev) for k, v in model.audio_encoder._weights.items()}
     tensors = [p.data for p in model.parameters()] + list(model.audio_encoder._weights.values())
+    _check_same_layout(tensors, dev)
     n = broadcast_tensors(tensors, src=src, bucket_bytes=bucket_bytes)
     model._engine = None  # engines re-pack lazily from the received tensors
     model.audio_encoder._engine = None
     return n
+
+
+def _check_same_layout(tensors, dev) -> None:
+    """Every rank must walk the same tensor list (count and total size): a replica built differently (e.g. an un-tied embedding) would
+    otherwise die inside a mismatched collective or hang. One tiny all-gather before the weights move."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([len(tensors), sum(t.numel() * t.element_size() for t in tensors)], dtype=torch.int64, device=cdev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    layouts = {(int(e[0]), int(e[1])) for e in every}
+    if len(layouts) != 1:
+        raise RuntimeError(f"broadcast_model_weights: replicas differ in their tensor lists (count, bytes) = {sorted(layouts)}; "
+                           "build every rank's model from the same config (ParlerTTSForConditionalGeneration(config, init_weights=False) on ranks != 0)")
 
 
 def max_over_ranks(value: float, device=None) -> float:

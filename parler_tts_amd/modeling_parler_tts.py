@@ -241,7 +241,15 @@ def _build_uninitialised(factory):
         except Exception:  # noqa: BLE001
             return factory()
     with no_init_weights():
-        return factory()
+        module = factory()
+    # weight tying is part of the skipped initialisation in some transformers releases (T5: encoder.embed_tokens <-> shared): redo it,
+    # so that every replica has the SAME parameter list as an initialised one (the weight broadcast walks model.parameters())
+    if hasattr(module, "tie_weights"):
+        try:
+            module.tie_weights()
+        except Exception:  # noqa: BLE001
+            pass
+    return module
 
 
 def _default_generation_config(config: ParlerTTSConfig):

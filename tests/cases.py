@@ -89,7 +89,7 @@ GEN_FIXED_SEEDS = {False: (2, 101), True: (2, 100)}  # rope -> (model seed, inpu
 GEN_VOICE_SEEDS = (0, 4)  # 7.9e-4
 
 
-def tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False):
+def tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False, init_weights=True):
     import parler_tts_amd as P
     from oracle import dac_oracle as DA
     from transformers import T5Config
@@ -100,7 +100,7 @@ def tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False):
                                    hidden_size=128, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025, rope_embeddings=rope)
     dac = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2], encoder_dim=16)
     cfg = P.ParlerTTSConfig.from_sub_models_config(t5, dac, dec, vocab_size=128, prompt_cross_attention=prompt_cross_attention)
-    m = P.ParlerTTSForConditionalGeneration(cfg)
+    m = P.ParlerTTSForConditionalGeneration(cfg, init_weights=init_weights)
     spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "rope_embeddings": rope})
     sd = DO.make_decoder_weights(spec, seed=1234 + seed)
     if eos_gain:

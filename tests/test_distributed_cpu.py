@@ -95,8 +95,14 @@ def _model_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        m, _, _, _ = tiny_model(seed=0)
+        # rank 0 draws its weights; rank 1 is built the way bench.py builds ranks != 0: allocated WITHOUT initialisation (text encoder
+        # under transformers' no_init_weights, its embedding tie redone so the parameter lists match), then overwritten by the broadcast
+        m, _, _, _ = tiny_model(seed=0, init_weights=(rank == 0))
         if rank != 0:  # a replica that must be overwritten: different decoder / text-encoder / prompt-embedding / codec tensors
+            with torch.no_grad():
+                for p in m.parameters():  # uninitialised memory may hold anything (NaN included): give it defined, wrong values
+                    if p.is_floating_point():
+                        p.nan_to_num_(0.0, 0.0, 0.0)
             torch.manual_seed(999)
             with torch.no_grad():
                 for p in m.parameters():
