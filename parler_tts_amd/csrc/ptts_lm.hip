@@ -413,9 +413,16 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     return PTTS_OK;
   }
   bool fc2_pending = false;
+  // KV splits of the self-attention: the engine's split factor at decode (long context, few rows); ONE at prefill - the context is the
+  // prompt (tens of positions) and there is one workgroup per (head, position) anyway: splitting 4 ways + a combine kernel cost
+  // 15 + 9 us per layer on the time-to-first-token path against ~7 us unsplit (profiles/r03_prefill_kernels.txt)
+  const int S_used = prefill ? 1 : e->S_self;
   const bool lns = e->use_lns && !prefill && M > 8 && M <= 32;  // LayerNorm statistics carried by the producer GEMM (PRO_LNS)
   // decode at batch > 8: engine-dtype activations travel between kernels in MFMA B-fragment order (ptts_lm_kernels.h: fo_vec_index)
-  const int fo = (e->use_fo && !prefill && M > 8) ? 1 : 0;
+  // (and the prefill while its rows stay on the strip kernels, M <= 256: a single utterance's 33-position prefill is 240 latency-bound
+  // launches on the time-to-first-token path; PTTS_NO_FO_PREFILL=1 keeps the row-major layout there for A/B)
+  static const bool fo_prefill = !(getenv("PTTS_NO_FO_PREFILL") && atoi(getenv("PTTS_NO_FO_PREFILL")));
+  const int fo = (e->use_fo && M > 8 && (!prefill || (fo_prefill && M <= 256))) ? 1 : 0;
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
     {  // LN1 + fused QKV projection
@@ -436,18 +443,18 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.kcache = w.k_self; a.vcache = w.v_self; a.cap = c.max_ctx; a.kv_bound = prefill ? c.max_ctx : e->kv_bound; a.cur_len = prefill ? nullptr : e->cur_len; a.dims = e->dims;
       a.mask = e->prompt_mask; a.mask_ld = e->max_prompt;
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
-      a.part = e->part; a.stats = e->stats; a.S = e->S_self; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
+      a.part = e->part; a.stats = e->stats; a.S = S_used; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
-      a.direct_out = e->S_self == 1 ? e->xw : nullptr; a.out_fo = fo;
+      a.direct_out = S_used == 1 ? e->xw : nullptr; a.out_fo = fo;
       a.exact_len = (!prefill && M > 8 && e->attn_exact) ? 1 : 0;
       PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
       GemmArgs g = {};
-      g.W = w.o; g.W8 = w.o_p8; g.wscale = w.o_sc; g.part = e->part; g.stats = e->stats; g.S = e->S_self; g.nheads = nh;
+      g.W = w.o; g.W8 = w.o_p8; g.wscale = w.o_sc; g.part = e->part; g.stats = e->stats; g.S = S_used; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
       if (lns) g.stats_out = e->lnstat;  // strip statistics of the new residual rows for LN2 (PRO_LNS)
-      if (e->S_self == 1) {
+      if (S_used == 1) {
         g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
         PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
       } else {
@@ -528,7 +535,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     GemmArgs g = {};
     g.W = e->heads; g.W8 = e->heads_p8; g.wscale = e->heads_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = Q; g.x_row_off = Q - 1; g.gamma = e->lnf_g; g.beta = e->lnf_b;
     g.out = e->logits; g.out_ld = c.num_codebooks * c.vocab_size; g.M = B; g.N = c.num_codebooks * c.vocab_size; g.K = H;
-    g.x_fo = (e->use_fo && !prefill && B > 8) ? 1 : 0;
+    g.x_fo = (e->use_fo && B > 8 && (!prefill || (fo_prefill && B <= 256))) ? 1 : 0;
     PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
   }
   hipError_t err = hipGetLastError();
