@@ -568,11 +568,12 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         fp8 = bool(getattr(self, "decoder_weights_fp8", False))
         if fp8 and dt != torch.bfloat16:
             raise NotImplementedError("decoder_weights_fp8 needs the model in bfloat16 (e4m3 weights, bf16 activations)")
-        # One engine per batch-size class, capacities grow-only inside a class. The engine tunes itself to its max_batch at creation (KV
-        # splits of the self-attention, GEMV step up to 4 utterances vs MFMA strips), so a single-utterance call must not land on an engine
-        # sized for 32 (1 KV split instead of 4; 5..8 utterances run 2), and a server that alternates between a wide batch and a long single utterance must not
-        # re-pack ~1.5 GB of weights and re-capture the step graphs on every call. Each resident engine costs one packed weight copy (~1.5 GB for Mini-v1).
-        key = (dev, dt, fp8, "b<=4" if B <= 4 else ("b<=8" if B <= 8 else "b>8"))  # GEMV step / fused cross block, 2 KV splits / no split
+        # One engine per batch-size class, capacities grow-only inside a class. The engine tunes itself to its max_batch at creation: KV
+        # splits of the self-attention (4 up to 4 utterances, 2 for 5..8, none above) and which weight copies it holds (row-major for the
+        # GEMV step up to 8 utterances; MFMA strips only - bf16 or e4m3 - above). So a single-utterance call must not land on an engine
+        # sized for 32, and a server that alternates between a wide batch and a long single utterance must not re-pack the weights and
+        # re-capture the step graphs on every call. Each resident engine costs its own weight copies (~0.7-1.5 GB for Mini-v1).
+        key = (dev, dt, fp8, "b<=4" if B <= 4 else ("b<=8" if B <= 8 else "b>8"))
         engines = self.__dict__.setdefault("_engines", {})
         e = engines.get(key)
         if e is None or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 + T or e.cfg.max_ctx < P + max_length:
