@@ -312,8 +312,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #undef PTTS_EMIT_ROW
 }
 
-// Fused residual unit (default; PTTS_DAC_NO_FUSE_RES=1 restores the two-launch path for A/B): one residual unit of the two narrow blocks
-// (C = 192 / 96) in ONE launch (measured on MI355X, profiles/r03_experiments.txt: 860 frames 3.62 -> 3.25 ms, batch 32 109.4 -> 97.5 ms):
+// Fused residual unit (default; PTTS_DAC_NO_FUSE_RES=1 restores the two-launch path for A/B): one residual unit of the three narrower blocks
+// (C = 384 / 192 / 96) in ONE launch (measured on MI355X, profiles/r03_experiments.txt: 860 frames 3.62 -> 3.25 ms, batch 32 109.4 -> 97.5 ms):
 //   y = Snake_a(conv_k7_dil(x) + b7)  ->  bf16 tile in LDS  ->  out = skip + conv_k1(y) + b1 ; act = Snake_a1(out)
 // The workgroup owns all C channels of 128 frames (NW * 3 strips = C / 16), so the k1 GEMM's operand never leaves the CU: the unit's
 // HBM traffic drops from 16 to 12 bytes per element (no bf16 round trip of y) and one launch per unit goes away (per-layer table,
@@ -330,6 +330,12 @@ struct ResArgs {
   int act_f32;
 };
 
+// dynamic LDS of resunit_lds_kernel<NW>: the two slab buffers of phase A, overlaid by the y tile [128 frames][C bf16 + pad] of phase B
+// (NW = 8, C = 384: 100 KB - above the 64 KB a static __shared__ array may declare, hence dynamic for every instance)
+template <int NW> struct ResunitLds {
+  static constexpr int C = NW * 3 * 16, slabs = 2 * (128 + 54) * (64 + 32), ytile = 128 * (C * 2 + 32);
+  static constexpr int bytes = slabs > ytile ? slabs : ytile;
+};
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) resunit_lds_kernel(ResArgs ra) {
   constexpr int CSW = 3, FT = 8, TF = FT * 16, KS = 1, MAXHALO = 54;
@@ -339,8 +345,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   constexpr int NST = (MAXROWS * SL + NT - 1) / NT;
   constexpr int RS2 = C * 2 + 32;  // y tile row stride: an odd multiple of 32 bytes, conflict-free ds_read_b128 like the slab
   constexpr int NK1 = C / 32;      // k-steps of the k1 GEMM
-  constexpr int LDS_BYTES = (2 * MAXROWS * RS) > (TF * RS2) ? (2 * MAXROWS * RS) : (TF * RS2);
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  static_assert(ResunitLds<NW>::bytes >= 2 * MAXROWS * RS && ResunitLds<NW>::bytes >= TF * RS2, "LDS size");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const ConvArgs& a = ra.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & 15;
@@ -1156,8 +1162,13 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
 static bool resunit_fusable(const ConvLayer& c7, const ConvLayer& c1) {
   const char* ev = getenv("PTTS_DAC_NO_FUSE_RES");  // read per call: a test can switch it inside one process
   const bool on = !(ev && atoi(ev));
+  // the C = 384 block's units too (8 waves, 100 KB of LDS, one workgroup per CU): batch 32 83.3 -> 77.9 ms, 860 frames 3.39 -> 3.28 ms
+  // (profiles/r03_pmc_dac_mfma.txt); PTTS_DAC_NO_FUSE_384=1 keeps them as two launches for A/B
+  const char* e384 = getenv("PTTS_DAC_NO_FUSE_384");
+  const bool fuse384 = !(e384 && atoi(e384));
   return on && c7.bf16 && c1.bf16 && !c7.transposed && !c1.transposed && c7.stride == 1 && c1.stride == 1 && c7.ksize == 7 && c1.ksize == 1 &&
-         c7.Cin == c7.Cout && c1.Cin == c7.Cout && c1.Cout == c7.Cout && (c7.Cout == 192 || c7.Cout == 96) && 6 * c7.dil <= 54 && c7.alpha && c1.alpha;
+         c7.Cin == c7.Cout && c1.Cin == c7.Cout && c1.Cout == c7.Cout && (c7.Cout == 192 || c7.Cout == 96 || (c7.Cout == 384 && fuse384)) && 6 * c7.dil <= 54 &&
+         c7.alpha && c1.alpha;
 }
 static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, const float* skip, float* out_raw, void* out_act, int B, int T,
                        hipStream_t st, bool act_f32) {
@@ -1166,8 +1177,16 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
   r.a.B = B; r.a.Tin = T; r.a.Tn = T; r.a.Cin = c7.Cin; r.a.Cout = c7.Cout; r.a.ntaps = 7; r.a.nphase = 1; r.a.stride = 1;
   r.Wp1 = c1.Wp; r.bias1 = c1.bias; r.alpha1 = c1.alpha; r.skip = skip; r.out_raw = out_raw; r.out_act = out_act; r.act_f32 = act_f32 ? 1 : 0;
   const dim3 grid((unsigned)(((T + 127) / 128) * B));
-  if (c7.Cout == 192) hipLaunchKernelGGL((resunit_lds_kernel<4>), grid, dim3(256), 0, st, r);
-  else hipLaunchKernelGGL((resunit_lds_kernel<2>), grid, dim3(128), 0, st, r);
+  if (c7.Cout == 384) {
+    static bool attr_set = false;  // 100 KB of dynamic LDS needs the opt-in
+    if (!attr_set) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8>::bytes);
+      if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((resunit_lds_kernel<8>), grid, dim3(512), ResunitLds<8>::bytes, st, r);
+  } else if (c7.Cout == 192) hipLaunchKernelGGL((resunit_lds_kernel<4>), grid, dim3(256), ResunitLds<4>::bytes, st, r);
+  else hipLaunchKernelGGL((resunit_lds_kernel<2>), grid, dim3(128), ResunitLds<2>::bytes, st, r);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "residual-unit launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;

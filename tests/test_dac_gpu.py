@@ -235,8 +235,10 @@ def test_errors():
         dac.decode(torch.zeros(1, 8, 4, dtype=torch.long).cuda())
 
 
-def test_fused_residual_units_44khz(monkeypatch):
-    """Default bf16-operand path: the residual units of the two narrow blocks (C = 192, 96) run as one launch each (k7 -> Snake -> bf16 tile in
+@pytest.mark.parametrize("fuse384", [True, False])
+def test_fused_residual_units_44khz(fuse384, monkeypatch):
+    """(fuse384 = False: PTTS_DAC_NO_FUSE_384=1 keeps the C = 384 block's units as two launches: the round-3 baseline, still a supported A/B path.)
+    Default bf16-operand path: the residual units of the three narrower blocks (C = 384, 192, 96) run as one launch each (k7 -> Snake -> bf16 tile in
     LDS -> k1 -> + skip -> Snake). Same arithmetic as the two-launch path up to the rounding of the intermediate to bf16 (both do it), so
     the two waveforms agree far inside the bf16 bar, and the fused one meets the bar against the fp32 oracle on its own. T = 150 frames
     spans several 128-frame tiles with a ragged last one at every rate; batch 2."""
@@ -246,6 +248,8 @@ def test_fused_residual_units_44khz(monkeypatch):
     sd = DA.make_dac_weights(spec, seed=4321)
     codes = torch.randint(0, 1024, (2, 9, 150), generator=torch.Generator().manual_seed(8))
     ref = DA.DacOracle(spec, sd).decode(codes)
+    if not fuse384:
+        monkeypatch.setenv("PTTS_DAC_NO_FUSE_384", "1")
     d = DacEngine(max_batch=2, max_frames=160, compute_dtype=torch.bfloat16)
     d.load_state_dict(sd)
     fused = d.decode(codes.cuda()).cpu()
