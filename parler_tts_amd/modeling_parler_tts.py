@@ -797,7 +797,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if not manual and streamer is None and dev.type == "cuda" and getattr(self, "overlap_codec", False) and max_length - K >= 96:
             output_ids, wav_pre = self._run_device_loop_overlap(eng, enc, enc_mask, prompt, prompt_mask, max_length, delayed.shape[1])
         elif not manual:
-            output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, delayed.shape[1])
+            output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, delayed.shape[1], min_new)
         else:
             hf_list = None
             if extras:
@@ -847,16 +847,20 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         return wav
 
     # -- default path: the whole `_sample` loop runs on the device -------------------------------------------------------
-    def _run_device_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, given: int = 1):
+    def _run_device_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, given: int = 1, min_new: int = 0):
         eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=True)  # BOS column + voice-prompt columns, then the first sampled one
         remaining = max_length - given - 1
         if streamer is None:
-            done = False
+            done, made = False, 1  # columns generated so far (the prefill's tail produced the first)
             while not done and remaining > 0:
                 n = min(64, remaining)
                 eng.decode_steps(n)
                 remaining -= n
-                _, done = eng.state()
+                made += n
+                # no row can finish while EOS is still blocked by min_new_tokens (and max_length is not reached): the host does not
+                # synchronise with the device inside that stretch, the graph launches of the next chunk queue up behind this one
+                if made > min_new or remaining == 0:
+                    _, done = eng.state()
             return eng.ids()
         # Streaming: the decoder graph runs AHEAD on the main stream while the finished columns of the previous chunk are
         # forwarded to the streamer on a side stream (one put per column, like `_sample`; the streamer's un-delay + chunked DAC
