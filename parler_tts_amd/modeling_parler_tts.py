@@ -473,7 +473,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             if not hasattr(cfg, k):
                 raise TypeError(f"{cls.__name__}.from_pretrained() got an unexpected keyword argument '{k}'")
             setattr(cfg, k, v)
-        model = cls(cfg)
+        model = cls(cfg, init_weights=False)  # every tensor comes from the checkpoint (strict load below): no ~15-25 s random init first
         gpath = os.path.join(path, "generation_config.json")
         if os.path.exists(gpath):
             from transformers import GenerationConfig
