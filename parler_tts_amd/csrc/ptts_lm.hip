@@ -66,6 +66,7 @@ struct ptts_engine {
   bool use_gemv = false;     // decode step at batch <= gemv_rows on the row-per-wave GEMV kernels
   int gemv_rows = 1;         // 1 (fp32 parity engine) or GV_MAX_ROWS
   int xfold_ne = 0;          // > 0: static cross-attention folding available (positions per head in the folded layout)
+  KvLayer* kv_layers = nullptr;      // [layers] operands of the batched cross K/V projection (device memory, written once at create)
   FoldLayer* fold_layers = nullptr;  // [layers] operand pointers of the fold kernels (device memory, written once at create)
   bool xfold_valid = false;  // the folded matrices of the CURRENT call are in place (single utterance)
   bool w8 = false;           // cfg.weights_fp8: e4m3 row-major weights for the GEMV step (the MFMA paths use the exact bf16 dequantisation)
@@ -175,7 +176,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   const int mtp = tiles(rpp);
   const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
   a.m_split = msplit ? 1 : 0;
-  const dim3 grid(a.N / 16, 1, msplit ? (a.M + rpp - 1) / rpp : 1), block(W * 64);
+  const dim3 grid(a.N / 16, 1, msplit ? (a.M + rpp - 1) / rpp : ((EPI == EPI_KV && a.kv_layers) ? a.kv_nlayers : 1)), block(W * 64);
   int rc;
   if constexpr (sizeof(WT) == 2) {
     if (a.W8 && full && a.K % 64 == 0) {  // e4m3 strips (weights_fp8): same grid / LDS, half the weight bytes; -1 = no instance, bf16 strips below
@@ -187,7 +188,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   if constexpr (PRO == PRO_COPY) {
     static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
     // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
-    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo) {  // prefill-sized: register-blocked kernel, no K split
+    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers) {  // prefill-sized: register-blocked kernel, no K split
       const int nstrips = a.N / 16;
       const int ns = (nstrips % 4 == 0 && nstrips >= 128) ? 4 : (nstrips % 2 == 0 ? 2 : 0);  // N = 1024: 2 strips per wave keeps > 500 waves in flight
       if (ns) {
@@ -310,11 +311,14 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const size_t n = (size_t)B * e->N * H;
     hipLaunchKernelGGL((convert_kernel<WT, float>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, e->qc,
                        reinterpret_cast<WT*>(e->xw2), n);
-    for (int l = 0; l < c.num_layers; ++l) {
+    static const bool kv_batched = !(getenv("PTTS_NO_KV_BATCHED") && atoi(getenv("PTTS_NO_KV_BATCHED")));
+    const bool one_launch = kv_batched && B * e->N <= 256;  // strip-kernel sized: every layer's K/V projection in ONE launch (blockIdx.z = layer)
+    for (int l = 0; l < (one_launch ? 1 : c.num_layers); ++l) {
       GemmArgs g = {};
       g.W = e->L[l].ckv; g.M = B * e->N; g.N = 2 * nkc * 64; g.K = H;
       g.x = reinterpret_cast<const float*>(e->xw2); g.x_ld = H; g.x_row_mul = 1; g.x_row_off = 0;
       g.kcache = e->L[l].k_cross; g.vcache = e->L[l].v_cross; g.kv_rows_per_b = e->N; g.kv_cap = c.max_enc; g.nheads = nkc;
+      if (one_launch) { g.kv_layers = e->kv_layers; g.kv_nlayers = c.num_layers; }
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_KV>(g, st)));
     }
     if (e->xfold_ne && B == 1) hipEventRecord(e->ev_kv, st);  // the fold (ptts_prefill) may start now, beside the layer stack
@@ -725,6 +729,13 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
       snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.weight", l, m); e->required.insert(nm);
       snprintf(nm, sizeof nm, "model.decoder.layers.%d.%s.bias", l, m); e->required.insert(nm);
     }
+  }
+  {
+    std::vector<KvLayer> kl(c.num_layers);
+    for (int l = 0; l < c.num_layers; ++l) kl[l] = KvLayer{e->L[l].ckv, e->L[l].k_cross, e->L[l].v_cross};
+    A(e->alloc(&e->kv_layers, (size_t)c.num_layers));
+    if (hipMemcpy(e->kv_layers, kl.data(), kl.size() * sizeof(KvLayer), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(ptts_fail(PTTS_E_HIP, "hipMemcpy(cross K/V operand table) failed"));
   }
   if (e->xfold_ne) {
     std::vector<FoldLayer> fl(c.num_layers);

@@ -80,6 +80,8 @@ enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2, PRO_COPY = 3, PRO_LNS = 4 };  //
 // over K, and the separate rows_prep_kernel node (25 % of the batch-32 step in round 1) disappears.
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3, EPI_GELU_WT = 4 };  // _WT: output in the engine dtype
 
+struct KvLayer { const void* W; void* k; void* v; };  // one layer's operands of the batched cross K/V projection (EPI_KV over blockIdx.z)
+
 struct GemmArgs {
   const void* W;       // packed strips
   const float* x;      // PLAIN/LN input; x row index = m * x_row_mul + x_row_off
@@ -105,6 +107,8 @@ struct GemmArgs {
   long long out_split_stride;  // elements between the partial outputs of two splits
   const void* W8;      // e4m3 strips [N/16][K/64 fragment pairs][64 lanes][16 B] (weights_fp8 engines), or null: bf16 / fp32 strips in W
   const float* wscale; // W8: one power-of-two scale per weight row [N], applied to the fp32 accumulators
+  const KvLayer* kv_layers;  // PRO_COPY + EPI_KV: blockIdx.z selects the layer (W, kcache, vcache from this table): the description's K/V
+  int kv_nlayers;            // of EVERY layer in one launch (24 launches of ~8 us sat on the time-to-first-token path); null = W / kcache / vcache
   int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
   int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
   int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
@@ -498,6 +502,10 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   const int row_bytes = a.K * (int)sizeof(WT) + 16;
   char* s_x = smem_raw;                                                                   // [rows_per_pass][row_bytes]
   float* s_red = reinterpret_cast<float*>(smem_raw + (PRO == PRO_COPY ? 0 : (size_t)a.rows_per_pass * row_bytes));  // [W][MTP][64][4]
+  if (PRO == PRO_COPY && EPI == EPI_KV && a.kv_layers) {  // batched over the layers
+    const KvLayer t = a.kv_layers[blockIdx.z];
+    a.W = t.W; a.kcache = t.k; a.vcache = t.v;
+  }
   const int strip = blockIdx.x;
   const int nfrag = a.K / KT;
   const int per = FULL ? a.frags_per_wave : (nfrag + W - 1) / W;
