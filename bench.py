@@ -407,7 +407,7 @@ def _timed_generate(model, bs: int, device, reps: int = 1) -> float:
 
 
 def _trim_roofline(r: dict) -> dict:
-    return {k: r[k] for k in ("achieved", "peak", "unit", "frac", "us_per_launch", "bytes_per_launch", "context") if k in r}
+    return {k: r[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "bytes_per_launch", "context") if k in r}
 
 
 def measure_fp32_parity_mode(device) -> dict:

@@ -153,7 +153,7 @@ def test_main_prints_one_contract_line_with_everything_stubbed(monkeypatch, caps
     assert j["cpu_baseline"]["kind"] == "port" and j["gpu_over_cpu"] == round(j["value"] / 0.15, 1)
     assert j["bs32"]["roofline"]["bound"] == "hbm" and j["streaming"] == {"ttfa_p50_ms": 37.0} and j["sampling"]["ratio_sampling_over_greedy"] == 1.04
     assert "watchdog" not in j
-    assert j["bs128"]["roofline"] == {"achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1} and j["bs128"]["unit"] == "audio-seconds/sec"
+    assert j["bs128"]["roofline"] == {"achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None} and j["bs128"]["unit"] == "audio-seconds/sec"
     assert j["fp32_parity_mode"]["value"] == 12.0 and j["fp32_parity_mode"]["gpu_over_cpu"] == 80.0 and j["large"] == {"bf16_bs1": {"value": 9.0}}
     # 1 warm-up + 2 timed steps at bs = 1, then the bs = 32 and bs = 128 side measurements (warm-up + timed each)
     assert fake.calls == [1, 1, 1, 32, 32, 128, 128]
