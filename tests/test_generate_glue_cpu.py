@@ -218,3 +218,24 @@ def test_masks_encoder_outputs_and_num_return_sequences_glue():
                    prompt_input_ids=prompt_ids, prompt_attention_mask=pmask, max_new_tokens=24, min_new_tokens=24)
     assert c.shape == (4, 32 * 16)
     assert torch.allclose(c[0], a[0], atol=1e-4) and torch.allclose(c[1], a[0], atol=1e-4) and torch.allclose(c[2], a[1], atol=1e-4) and torch.allclose(c[3], a[1], atol=1e-4)
+
+
+def test_device_loop_polls_the_device_only_once_eos_can_fire():
+    """The default loop synchronises with the device (ptts_state) only where a row could have finished: never while `min_new_tokens`
+    still blocks EOS, once per 64-step chunk afterwards, and once at max_length. Same ids either way."""
+    m, spec, sd, dac = _model()
+    eng = m._get_engine(1, 0, 0, 0)
+    polls = []
+    orig_state = eng.state
+    eng.state = lambda: (polls.append(1), orig_state())[1]
+    g = torch.Generator().manual_seed(3)
+    desc, prompt_ids = torch.randint(3, 128, (1, 9), generator=g), torch.randint(3, 128, (1, 4), generator=g)
+    a = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=150, min_new_tokens=150)
+    assert len(polls) == 1  # EOS blocked throughout: one poll, at max_length
+    polls.clear()
+    b = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=150, min_new_tokens=70)
+    assert len(polls) == 2  # chunks end at 65, 129, 150 generated columns: 65 <= 70 is not polled, 129 and 150 are
+    polls.clear()
+    c = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=150, min_new_tokens=0)
+    assert len(polls) == 3
+    assert torch.equal(a, b) and torch.equal(a, c)  # EOS never wins in this model (its logit rows are zeroed): the same utterance
