@@ -187,8 +187,9 @@ __device__ __forceinline__ void gv_softmax_wave(const GemvArgs& a, char* s_x, in
 // instance is built for (1, 4 or GV_MAX_ROWS = 8; a.M <= MB of them are live), W8 = e4m3 weights + per-row scale.
 // MB = 8 (batch 5..8): the activation chunks of MG utterances sit in registers at a time (MG * NCH <= 40 vectors), the wave's weight
 // registers are reused for every group; groups past the live batch are skipped (workgroup-uniform).
-template <typename WT, int NCH, int R, int PRO, int EPI, int S, int MB, bool W8>
+template <typename WT, int NCH, int R, int PRO, int EPI, int S, int MB, bool W8, bool STG = false>
 __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_kernel(GemvArgs a) {
+  static_assert(!STG || (PRO == GV_COPY && MB == 8), "staged activation rows: GV_COPY nodes of the 5..8-utterance instances only");
   constexpr bool HASPRO = PRO != GV_COPY;
   constexpr int EPL = Elem<WT>::EPL;
   constexpr int NF4 = NCH * EPL / 4;  // float4 per lane of one fp32 row (K / 256)
@@ -224,12 +225,14 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
       const int mm = MB == 1 ? 0 : min(g * MG + m, a.M - 1);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (HASPRO) xv[m][c] = *reinterpret_cast<const uint4*>(s_x + (size_t)mm * ROW_BYTES + (size_t)(c * 64 + lane) * 16);
+        if (HASPRO || STG) xv[m][c] = *reinterpret_cast<const uint4*>(s_x + (size_t)mm * ROW_BYTES + (size_t)(c * 64 + lane) * 16);
         else xv[m][c] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.xw) + (size_t)mm * a.xw_ld)[c * 64 + lane];
       }
     }
   };
-  if (!HASPRO) load_x(0);
+  // GV_COPY with 5..8 utterances: each wave of the plain path pulls all M activation rows out of the L2 for R weight rows (8 : 1 bytes
+  // at R = 1). Staged, the four waves of the workgroup copy the rows into LDS once and read their chunks from there.
+  if (!HASPRO && !STG) load_x(0);
   WV wv[R][NCH];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -237,6 +240,24 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
     const WV* wp = reinterpret_cast<const WV*>(reinterpret_cast<const char*>(a.W) + (size_t)((unsigned)row * (unsigned)(ROW_BYTES / (W8 ? (int)sizeof(WT) : 1)))) + lane;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) wv[r][c] = gv_ld_nt<WV>(wp + c * 64);
+  }
+  if constexpr (STG) {
+    {
+      constexpr int PER_ROW = NCH * 64, TOT = MB * PER_ROW / 256;  // 16-byte vectors per row / per thread over the MB rows
+      uint4 t[TOT];
+#pragma unroll
+      for (int i = 0; i < TOT; ++i) {
+        const int idx = (int)threadIdx.x + i * 256, m = min(idx / PER_ROW, a.M - 1), k = idx % PER_ROW;
+        t[i] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.xw) + (size_t)m * a.xw_ld)[k];
+      }
+#pragma unroll
+      for (int i = 0; i < TOT; ++i) {
+        const int idx = (int)threadIdx.x + i * 256;
+        *reinterpret_cast<uint4*>(s_x + (size_t)idx * 16) = t[i];  // row m of the tile starts at m * ROW_BYTES = m * PER_ROW * 16
+      }
+      __syncthreads();
+      load_x(0);
+    }
   }
   if (HASPRO) {
     __builtin_amdgcn_sched_barrier(0);  // the weight loads stay above the barrier

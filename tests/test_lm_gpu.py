@@ -289,14 +289,25 @@ def test_single_utterance_gemv_step_long_context_all_split_counts():
 @pytest.mark.parametrize("bsz", [2, 3, 4, 5, 6, 8])
 def test_gemv_step_batch_2_to_8(bsz):
     """Batch 2..8 on the bf16 engine runs the GEMV step with every weight row read once for all utterances (MB = 4 / 8 instances:
-    one prologue wave per utterance, M dot products per weight chunk; at 5..8 the K = 4096 activation chunks pass through the
-    registers in two groups of 4 utterances, groups past the live batch are skipped); the fp32 parity engine keeps the MFMA strip
-    path there. Ragged masks per utterance, 5 teacher-forced steps vs the oracle."""
+    one prologue wave per utterance, M dot products per weight chunk; at 5..8 the K = 4096 activation rows of fc2 are staged in LDS
+    once per workgroup and pass through the registers in two groups of 4 utterances, groups past the live batch are skipped); the
+    fp32 parity engine keeps the MFMA strip path there. Ragged masks per utterance, 5 teacher-forced steps vs the oracle."""
     spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
     sd = DO.make_decoder_weights(spec, seed=53)
     for dtype, prec, tol in ((torch.bfloat16, "bf16", 2e-2), (torch.float32, "fp32", 5e-5)):
         err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=21, P=6, steps=5, masks=True, seed=10 + bsz)
         assert err < tol, (bsz, prec, err)
+
+
+@pytest.mark.parametrize("bsz", [5, 8])
+def test_gemv_step_large_width_batch_5_and_8(bsz):
+    """Large-v1 width (H 1536, ffn 6144) at 5..8 utterances: the K = 6144 activation rows of fc2 (12 chunks per lane per utterance)
+    pass through the registers in four groups of 2 utterances (96 KiB would not fit the un-opted dynamic LDS; staging them measured
+    no gain there), the K = 1536 nodes in one group of 8."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512, hidden_size=1536, num_attention_heads=24, ffn_dim=6144)
+    sd = DO.make_decoder_weights(spec, seed=61)
+    err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=6, steps=4, masks=True, seed=40 + bsz)
+    assert err < 2e-2, (bsz, err)
 
 
 @pytest.mark.parametrize("width,bsz", [("mini", 1), ("mini", 3), ("mini", 8), ("mini", 12), ("mini", 32), ("mini", 40), ("large", 1), ("large", 4),
