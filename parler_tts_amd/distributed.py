@@ -125,7 +125,7 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
     `accelerator.pad_across_processes` + `gather_for_metrics`).
 
     Every rank passes the FULL batch (same tensors on every rank, as a data loader that is not sharded yields them).
-    ``dst``: rank that receives the result, or ``None`` for all ranks. Returns (on the receiving ranks) a ``GenerateOutput`` with
+    ``dst``: rank (within ``group``) that receives the result, or ``None`` for all ranks. Returns (on the receiving ranks) a ``GenerateOutput`` with
     ``.sequences`` = waveform float32 [batch, samples] zero-padded to the longest utterance of the whole batch (on the CPU) and
     ``["audios_length"]`` = per-utterance lengths, exactly what the single-process call returns for the same batch under greedy
     decoding; ``None`` on the other ranks. With sampling each rank draws from its own generator (torch.manual_seed per rank).
@@ -189,7 +189,8 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
         dist.all_gather(blocks, block, group=group)
     else:
         blocks = [torch.zeros_like(block) for _ in range(world)] if rank == dst else None
-        dist.gather(block, blocks, dst=dst, group=group)
+        # `dst` counts within `group` (like `rank` above); the collective addresses ranks of the default group
+        dist.gather(block, blocks, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
         if rank != dst:
             return None
     parts, all_lens = [], []

@@ -164,6 +164,8 @@ def _sharded_generate_worker(rank, world, port, q):
         for dst in (0, None):
             out = generate_sharded(m, dst=dst, **kw)
             res[dst] = None if out is None else (out.sequences.clone(), list(out["audios_length"]))
+        grp = dist.new_group([0, 1])
+        sub = generate_sharded(m, dst=1, group=grp, **kw)  # an explicit group, result on ITS rank 1
         one = generate_sharded(m, dst=0, input_ids=desc[:1], prompt_input_ids=prompt_ids[:1], do_sample=False, max_length=24, min_new_tokens=3)  # rank 1 idles
         single = m.generate(return_dict_in_generate=True, **kw) if rank == 0 else None
         single1 = m.generate(return_dict_in_generate=True, input_ids=desc[:1], prompt_input_ids=prompt_ids[:1], do_sample=False, max_length=24,
@@ -175,8 +177,10 @@ def _sharded_generate_worker(rank, world, port, q):
                 ok = ok and lens == list(single["audios_length"]) and w.shape == single.sequences.shape and torch.equal(w, single.sequences.float().cpu())
             ok = ok and one is not None and list(one["audios_length"]) == list(single1["audios_length"]) and torch.equal(one.sequences, single1.sequences.float().cpu())
             ok = ok and len(set(single["audios_length"])) > 1  # the case really is ragged
+            ok = ok and sub is None
         else:
             ok = res[0] is None and res[None] is not None and one is None
+            ok = ok and sub is not None and list(sub["audios_length"]) == res[None][1] and torch.equal(sub.sequences, res[None][0])
         q.put((rank, bool(ok), None if res[None] is None else res[None][1]))
     finally:
         dist.destroy_process_group()
