@@ -91,3 +91,22 @@ def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_binding(tmp_path)
     out = subprocess.check_output([str(exe)]).decode().split()
     assert [int(x) for x in out] == [N.ABI_VERSION, C.sizeof(N.PttsConfig), C.sizeof(N.PttsGenParams), C.sizeof(N.PttsDacConfig),
                                      N.PttsConfig.rope_theta.offset, N.PttsGenParams.seed.offset, N.PttsDacConfig.compute_dtype.offset]
+
+
+def test_torch_free_cxx_client_of_the_header_builds_and_links(tmp_path):
+    """tools/cabi_probe.hip is a plain C++ client of include/ptts.h (engine create, weight load by the reference's tensor names, prefill,
+    graph-replayed decode steps, DAC decode - device pointers and sizes only, no torch): it must compile against the header and link
+    against libptts_hip.so as the header's consumers would. Without arguments it prints its usage before touching the GPU."""
+    import shutil
+    import subprocess
+
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    N, _ = _lib()
+    exe = str(tmp_path / "cabi_probe")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cabi_probe.hip"),
+           "-o", exe, "-L" + os.path.dirname(N.LIB_PATH), "-lptts_hip", "-Wl,-rpath," + os.path.dirname(N.LIB_PATH)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "usage:" in r.stderr, (r.returncode, r.stderr[-500:])

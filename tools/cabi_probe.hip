@@ -1,0 +1,268 @@
+// Torch-free GPU probe over the C ABI (include/ptts.h): decode-step latency of the decoder-LM engine and DAC decode time, with
+// synthetic weights filled on the device. Starts in seconds on a fresh box (no `import torch`: 1-2 minutes of GPU-box time per call),
+// and doubles as the plain-C++ example of the boundary: everything the product does per token / per frame is reached through the
+// symbols declared in include/ptts.h with device pointers and sizes only.
+//
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/cabi_probe.hip -o tools/cabi_probe \
+//         -Lparler_tts_amd -lptts_hip -Wl,-rpath,'$ORIGIN/../parler_tts_amd'
+//   tools/cabi_probe lm  <batch> [large] [fp32] [ctx=<prompt positions>] [tag=<text>]   (env knobs as for tools/step_probe2.py)
+//   tools/cabi_probe dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>]
+//
+// `lm` prints three readings of 250 graph replays each at growing context, like tools/step_probe2.py; `dac` prints ms per decode and
+// TFLOP/s at 1.608 GFLOP per frame.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ptts.h"
+
+#define HIPCHK(x)                                                                                         \
+  do {                                                                                                    \
+    hipError_t e_ = (x);                                                                                  \
+    if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); exit(2); } \
+  } while (0)
+#define PT(x)                                                                                             \
+  do {                                                                                                    \
+    int r_ = (x);                                                                                         \
+    if (r_ != PTTS_OK) { fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #x, r_, ptts_last_error()); exit(3); } \
+  } while (0)
+
+// value i of stream `seed`: a hash mapped to a uniform variate of standard deviation `std` around `mean`
+__global__ void fill_kernel(float* p, size_t n, unsigned seed, float std, float mean) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)i * 2654435761u ^ (seed * 40503u + 0x9e3779b9u);
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  const float u = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;  // [-1, 1)
+  p[i] = mean + std * 1.7320508f * u;
+}
+__global__ void fill_codes_kernel(long long* p, size_t n, unsigned seed, int vocab) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)i * 2654435761u ^ (seed * 40503u + 0x9e3779b9u);
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13;
+  p[i] = (long long)(h % (unsigned)vocab);
+}
+
+struct Filler {
+  float* buf = nullptr;
+  size_t cap = 0;
+  unsigned seed = 1;
+  hipStream_t st = nullptr;
+  float* get(size_t n, float std, float mean) {
+    if (n > cap) {
+      if (buf) HIPCHK(hipFree(buf));
+      HIPCHK(hipMalloc(&buf, n * sizeof(float)));
+      cap = n;
+    }
+    fill_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(buf, n, seed++, std, mean);
+    HIPCHK(hipGetLastError());
+    return buf;
+  }
+};
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static const char* opt(int argc, char** argv, const char* key) {  // "key=value" -> value, bare "key" -> "", absent -> nullptr
+  const size_t n = strlen(key);
+  for (int i = 3; i < argc; ++i) {
+    if (!strncmp(argv[i], key, n) && argv[i][n] == '=') return argv[i] + n + 1;
+    if (!strcmp(argv[i], key)) return "";
+  }
+  return nullptr;
+}
+
+static int run_lm(int argc, char** argv) {
+  const int B = atoi(argv[2]);
+  const bool large = opt(argc, argv, "large") != nullptr, fp32 = opt(argc, argv, "fp32") != nullptr;
+  const char* tag = opt(argc, argv, "tag") ? opt(argc, argv, "tag") : "";
+  const int P = opt(argc, argv, "ctx") ? atoi(opt(argc, argv, "ctx")) : 32;
+  const int H = large ? 1536 : 1024, L = large ? 30 : 24, F = large ? 6144 : 4096, NH = large ? 24 : 16, K = 9, V = 1088, NE = 64;
+  hipStream_t st;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  ptts_config c;
+  memset(&c, 0, sizeof c);
+  c.hidden_size = H; c.num_layers = L; c.num_heads = NH; c.ffn_dim = F; c.num_codebooks = K; c.vocab_size = V; c.max_positions = 4096;
+  c.rope = 0; c.rope_theta = 10000.f; c.pad_token_id = 1024; c.eos_token_id = 1024; c.bos_token_id = 1025;
+  c.dtype = fp32 ? PTTS_F32 : PTTS_BF16; c.max_batch = B; c.max_ctx = P + 908; c.max_enc = NE; c.max_prompt = P + 8; c.device = 0;
+  ptts_engine* e = nullptr;
+  const double t_create = now_s();
+  PT(ptts_engine_create(&c, &e));
+  Filler f;
+  f.st = st;
+  auto load = [&](const std::string& name, std::vector<int64_t> shape, float std, float mean) {
+    size_t n = 1;
+    for (int64_t s : shape) n *= (size_t)s;
+    const float* p = f.get(n, std, mean);
+    PT(ptts_load_weight(e, name.c_str(), p, PTTS_F32, shape.data(), (int32_t)shape.size(), st));
+  };
+  const std::string p = "model.decoder.";
+  for (int k = 0; k < K; ++k) load(p + "embed_tokens." + std::to_string(k) + ".weight", {V + 1, H}, 0.02f, 0.f);
+  load(p + "embed_positions.weights", {4096, H}, 0.02f, 0.f);
+  for (int i = 0; i < L; ++i) {
+    const std::string lp = p + "layers." + std::to_string(i) + ".";
+    for (const char* att : {"self_attn", "encoder_attn"}) {
+      for (const char* pr : {"q_proj", "k_proj", "v_proj", "out_proj"}) load(lp + att + "." + pr + ".weight", {H, H}, 0.02f, 0.f);
+      load(lp + att + "_layer_norm.weight", {H}, 0.f, 1.f);
+      load(lp + att + "_layer_norm.bias", {H}, 0.f, 0.f);
+    }
+    load(lp + "fc1.weight", {F, H}, 0.02f, 0.f);
+    load(lp + "fc2.weight", {H, F}, 0.02f, 0.f);
+    load(lp + "final_layer_norm.weight", {H}, 0.f, 1.f);
+    load(lp + "final_layer_norm.bias", {H}, 0.f, 0.f);
+  }
+  load(p + "layer_norm.weight", {H}, 0.f, 1.f);
+  load(p + "layer_norm.bias", {H}, 0.f, 0.f);
+  for (int k = 0; k < K; ++k) load("lm_heads." + std::to_string(k) + ".weight", {V, H}, 0.02f, 0.f);
+  PT(ptts_weights_ready(e));
+  HIPCHK(hipStreamSynchronize(st));
+  const double t_loaded = now_s();
+  ptts_gen_params gp;
+  memset(&gp, 0, sizeof gp);
+  gp.max_length = 869; gp.min_new_tokens = 868; gp.do_sample = 0; gp.temperature = 1.f; gp.top_k = 0; gp.top_p = 1.f; gp.use_eos_gate = 1; gp.seed = 0;
+  PT(ptts_set_gen_params(e, &gp));
+  float *enc = nullptr, *prompt = nullptr;
+  HIPCHK(hipMalloc(&enc, (size_t)B * NE * H * 4));
+  HIPCHK(hipMalloc(&prompt, (size_t)B * P * H * 4));
+  fill_kernel<<<dim3((unsigned)(((size_t)B * NE * H + 255) / 256)), dim3(256), 0, st>>>(enc, (size_t)B * NE * H, 777u, 1.f, 0.f);
+  fill_kernel<<<dim3((unsigned)(((size_t)B * P * H + 255) / 256)), dim3(256), 0, st>>>(prompt, (size_t)B * P * H, 778u, 1.f, 0.f);
+  HIPCHK(hipStreamSynchronize(st));
+  double t0 = now_s();
+  PT(ptts_prefill(e, enc, nullptr, prompt, nullptr, B, NE, P, 1, st));
+  PT(ptts_first_token_sync(e));
+  const double ttft1 = now_s() - t0;
+  HIPCHK(hipStreamSynchronize(st));
+  t0 = now_s();
+  PT(ptts_prefill(e, enc, nullptr, prompt, nullptr, B, NE, P, 1, st));
+  PT(ptts_first_token_sync(e));
+  const double ttft2 = now_s() - t0;
+  PT(ptts_decode_steps(e, 50, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double us[3];
+  hipEvent_t ev0, ev1;
+  HIPCHK(hipEventCreate(&ev0));
+  HIPCHK(hipEventCreate(&ev1));
+  for (int r = 0; r < 3; ++r) {
+    HIPCHK(hipEventRecord(ev0, st));
+    PT(ptts_decode_steps(e, 250, st));
+    HIPCHK(hipEventRecord(ev1, st));
+    HIPCHK(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    us[r] = ms * 1e3 / 250;
+  }
+  int32_t cur = 0, fin = 0;
+  PT(ptts_state(e, &cur, &fin, st));
+  const double wb = ((double)L * (6.0 * H * H + 2.0 * H * F) + (double)K * V * H) * (fp32 ? 4 : 2);
+  printf("[cabi_probe lm %s%s%s] B=%d: %.1f %.1f %.1f us/step  (weights %.0f MB/step -> %.2f TB/s at the middle reading; prefill+first token %.2f ms "
+         "(first call, pre-capture) / %.2f ms; create+load %.1f s; cur_len %d)\n",
+         tag, large ? " large" : "", fp32 ? " fp32" : "", B, us[0], us[1], us[2], wb / 1e6, wb / 1e6 / us[1], ttft1 * 1e3, ttft2 * 1e3,
+         t_loaded - t_create, cur);
+  fflush(stdout);
+  ptts_engine_destroy(e);
+  return 0;
+}
+
+static int run_dac(int argc, char** argv) {
+  const int B = atoi(argv[2]);
+  const int T = opt(argc, argv, "frames") ? atoi(opt(argc, argv, "frames")) : 860;
+  const int reps = opt(argc, argv, "reps") ? atoi(opt(argc, argv, "reps")) : 5;
+  const bool f32 = opt(argc, argv, "f32") != nullptr;
+  const char* tag = opt(argc, argv, "tag") ? opt(argc, argv, "tag") : "";
+  hipStream_t st;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  ptts_dac_config c;
+  memset(&c, 0, sizeof c);
+  c.num_codebooks = 9; c.codebook_size = 1024; c.codebook_dim = 8; c.latent_dim = 1024; c.decoder_dim = 1536; c.num_rates = 4;
+  const int rates[4] = {8, 8, 4, 2};
+  for (int i = 0; i < 4; ++i) c.rates[i] = rates[i];
+  c.compute_dtype = f32 ? PTTS_F32 : PTTS_BF16; c.max_batch = B; c.max_frames = T; c.device = 0; c.encoder_dim = 0;
+  ptts_dac* d = nullptr;
+  PT(ptts_dac_create(&c, &d));
+  Filler f;
+  f.st = st;
+  auto load = [&](const std::string& name, std::vector<int64_t> shape, float std, float mean) {
+    size_t n = 1;
+    for (int64_t s : shape) n *= (size_t)s;
+    const float* p = f.get(n, std, mean);
+    PT(ptts_dac_load_weight(d, name.c_str(), p, shape.data(), (int32_t)shape.size(), st));
+    HIPCHK(hipStreamSynchronize(st));  // the scratch buffer is refilled by the next call
+  };
+  auto conv = [&](const std::string& name, int cout, int cin, int k, bool transposed) {
+    const float std = 1.0f / sqrtf((float)cin * (transposed ? 2 : k));
+    if (transposed) load(name + ".weight", {cin, cout, k}, std, 0.f);
+    else load(name + ".weight", {cout, cin, k}, std, 0.f);
+    load(name + ".bias", {cout}, 0.01f, 0.f);
+  };
+  auto alpha = [&](const std::string& name, int ch) { load(name + ".alpha", {1, ch, 1}, 0.1f, 1.0f); };
+  int ch = c.decoder_dim;
+  conv("decoder.model.0", ch, c.latent_dim, 7, false);
+  for (int bi = 0; bi < 4; ++bi) {
+    const int cin = ch >> bi, cout = ch >> (bi + 1), s = rates[bi];
+    const std::string b = "decoder.model." + std::to_string(bi + 1) + ".block.";
+    alpha(b + "0", cin);
+    conv(b + "1", cout, cin, 2 * s, true);
+    for (int ri = 0; ri < 3; ++ri) {
+      const std::string r = b + std::to_string(ri + 2) + ".block.";
+      alpha(r + "0", cout);
+      conv(r + "1", cout, cout, 7, false);
+      alpha(r + "2", cout);
+      conv(r + "3", cout, cout, 1, false);
+    }
+  }
+  alpha("decoder.model.5", ch >> 4);
+  load("decoder.model.6.weight", {1, ch >> 4, 7}, 1.0f / sqrtf((float)(ch >> 4) * 7), 0.f);
+  load("decoder.model.6.bias", {1}, 0.f, 0.f);
+  for (int q = 0; q < 9; ++q) {
+    const std::string qn = "quantizer.quantizers." + std::to_string(q) + ".";
+    load(qn + "codebook.weight", {1024, 8}, 1.f, 0.f);
+    load(qn + "out_proj.weight", {1024, 8, 1}, 0.35f, 0.f);
+    load(qn + "out_proj.bias", {1024}, 0.01f, 0.f);
+  }
+  PT(ptts_dac_weights_ready(d));
+  long long* codes = nullptr;
+  float* wave = nullptr;
+  const size_t ncodes = (size_t)B * 9 * T, nwave = (size_t)B * T * 512;
+  HIPCHK(hipMalloc(&codes, ncodes * 8));
+  HIPCHK(hipMalloc(&wave, nwave * 4));
+  fill_codes_kernel<<<dim3((unsigned)((ncodes + 255) / 256)), dim3(256), 0, st>>>(codes, ncodes, 99u, 1024);
+  PT(ptts_dac_decode(d, (const int64_t*)codes, wave, B, T, st));
+  HIPCHK(hipStreamSynchronize(st));
+  hipEvent_t ev0, ev1;
+  HIPCHK(hipEventCreate(&ev0));
+  HIPCHK(hipEventCreate(&ev1));
+  HIPCHK(hipEventRecord(ev0, st));
+  for (int r = 0; r < reps; ++r) PT(ptts_dac_decode(d, (const int64_t*)codes, wave, B, T, st));
+  HIPCHK(hipEventRecord(ev1, st));
+  HIPCHK(hipEventSynchronize(ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+  ms /= reps;
+  std::vector<float> head(4096);
+  HIPCHK(hipMemcpy(head.data(), wave, head.size() * 4, hipMemcpyDeviceToHost));
+  double ss = 0;
+  bool finite = true;
+  for (float v : head) { ss += (double)v * v; finite = finite && std::isfinite(v); }
+  const double flops = 1.608e9 * (double)B * T;
+  printf("[cabi_probe dac %s%s] B=%d frames=%d: %.3f ms per decode = %.1f TFLOP/s (%.1f %% of %s)  [first 4096 samples rms %.3g%s]\n", tag,
+         f32 ? " f32" : " bf16", B, T, ms, flops / ms / 1e9, 100.0 * flops / ms / 1e9 / (f32 ? 157.3 : 2500.0), f32 ? "157 TF f32 MFMA" : "2.5 PF bf16 MFMA",
+         sqrt(ss / head.size()), finite ? "" : ", NOT FINITE");
+  fflush(stdout);
+  ptts_dac_destroy(d);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3 || (strcmp(argv[1], "lm") && strcmp(argv[1], "dac"))) {
+    fprintf(stderr, "usage: %s lm <batch> [large] [fp32] [ctx=<prompt positions>] [tag=<text>]\n       %s dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>]\n", argv[0], argv[0]);
+    return 1;
+  }
+  if (ptts_abi_version() != PTTS_ABI_VERSION) { fprintf(stderr, "libptts_hip.so has ABI %d, the header %d\n", ptts_abi_version(), PTTS_ABI_VERSION); return 1; }
+  return !strcmp(argv[1], "lm") ? run_lm(argc, argv) : run_dac(argc, argv);
+}
