@@ -110,3 +110,24 @@ def test_torch_free_cxx_client_of_the_header_builds_and_links(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "usage:" in r.stderr, (r.returncode, r.stderr[-500:])
+    # its `cmp` mode (A/B of two dumps: logits blocks + free-running ids) runs on the host
+    import numpy as np
+
+    def dump(path, logits, ids):
+        with open(path, "wb") as f:
+            np.array([0x70747473, logits.shape[1], logits.shape[2], logits.shape[0]], dtype=np.int64).tofile(f)
+            logits.astype(np.float32).tofile(f)
+            np.array(ids.shape, dtype=np.int64).tofile(f)
+            ids.astype(np.int64).tofile(f)
+
+    rng = np.random.default_rng(0)
+    lg, ids = rng.standard_normal((3, 18, 40)), rng.integers(0, 1024, (18, 12))
+    lg2, ids2 = lg.copy(), ids.copy()
+    lg2[1, 4, :] = -lg2[1, 4, :]  # one row's arg-max moves
+    ids2[3, 7] += 1
+    a, b, c = (str(tmp_path / n) for n in ("a.bin", "b.bin", "c.bin"))
+    dump(a, lg, ids), dump(b, lg, ids), dump(c, lg2, ids2)
+    r = subprocess.run([exe, "cmp", a, b], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "max |a - b| = 0 " in r.stdout and "identical" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([exe, "cmp", a, c], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 4 and "1 arg-max flips of 54 rows" in r.stdout and "differ from column 7" in r.stdout, (r.returncode, r.stdout, r.stderr)

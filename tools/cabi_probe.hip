@@ -5,8 +5,15 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/cabi_probe.hip -o tools/cabi_probe \
 //         -Lparler_tts_amd -lptts_hip -Wl,-rpath,'$ORIGIN/../parler_tts_amd'
-//   tools/cabi_probe lm  <batch> [large] [fp32] [ctx=<prompt positions>] [tag=<text>]   (env knobs as for tools/step_probe2.py)
-//   tools/cabi_probe dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>]
+//   tools/cabi_probe lm  <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]]
+//   tools/cabi_probe dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>] [dump=<file>]
+//   tools/cabi_probe cmp <file a> <file b>
+//   (environment knobs as for tools/step_probe2.py: PTTS_NO_GEMV, PTTS_GEMV_ROWS, PTTS_GEMV_STAGE, PTTS_NO_FO, PTTS_DAC_NO_FUSE_RES ...)
+//
+// `dump=` writes what the run computed (lm: the fp32 logits of the prefill and of <n> teacher-forced eager steps on fixed pseudo-random
+// tokens, then the ids of the free-running graph-replayed steps; dac: the waveform), `cmp` compares two dumps (max |difference|, arg-max
+// flips, first differing id): the seconds-long A/B check that a kernel variant behind an environment knob computes what the default
+// path computes, before the oracle-backed parity tests are spent on it.
 //
 // `lm` prints three readings of 250 graph replays each at growing context, like tools/step_probe2.py; `dac` prints ms per decode and
 // TFLOP/s at 1.608 GFLOP per frame.
@@ -50,6 +57,39 @@ __global__ void fill_codes_kernel(long long* p, size_t n, unsigned seed, int voc
   p[i] = (long long)(h % (unsigned)vocab);
 }
 
+// weights_fp8: one workgroup per row - power-of-two scale from the row maximum, round-to-nearest-even onto the OCP e4m3 grid, the bytes to
+// q, the scale to sc, and the row overwritten with its exact dequantisation (what ptts_load_weight must receive, parler_tts_amd/quant.py)
+__global__ void __launch_bounds__(256) quant_e4m3_rows_kernel(float* w, unsigned char* q, float* sc, int Kd) {
+  __shared__ float red[256];
+  float* row = w + (size_t)blockIdx.x * Kd;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < Kd; i += 256) m = fmaxf(m, fabsf(row[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const float amax = red[0];
+  const float scale = amax > 0.f ? exp2f(ceilf(log2f(amax / 448.f))) : 1.f;
+  if (threadIdx.x == 0) sc[blockIdx.x] = scale;
+  for (int i = threadIdx.x; i < Kd; i += 256) {
+    const float x = fminf(fmaxf(row[i] / scale, -448.f), 448.f), ax = fabsf(x);
+    int e = ax > 0.f ? (int)floorf(log2f(ax)) : -6;
+    e = e < -6 ? -6 : e;                                   // subnormals share the quantum of the smallest normal binade
+    float v = rintf(ax / exp2f((float)(e - 3))) * exp2f((float)(e - 3));  // 3 mantissa bits
+    v = fminf(v, 448.f);
+    unsigned bits = 0;
+    if (v > 0.f) {
+      int e2 = (int)floorf(log2f(v));
+      if (e2 < -6) bits = (unsigned)rintf(v * 512.f);      // subnormal: multiples of 2^-9
+      else bits = ((unsigned)(e2 + 7) << 3) | (unsigned)rintf((v / exp2f((float)e2) - 1.f) * 8.f);
+    }
+    q[(size_t)blockIdx.x * Kd + i] = (unsigned char)(bits | (x < 0.f ? 0x80u : 0u));
+    row[i] = (x < 0.f ? -v : v) * scale;
+  }
+}
+
 struct Filler {
   float* buf = nullptr;
   size_t cap = 0;
@@ -80,7 +120,9 @@ static const char* opt(int argc, char** argv, const char* key) {  // "key=value"
 
 static int run_lm(int argc, char** argv) {
   const int B = atoi(argv[2]);
-  const bool large = opt(argc, argv, "large") != nullptr, fp32 = opt(argc, argv, "fp32") != nullptr;
+  const bool large = opt(argc, argv, "large") != nullptr, fp32 = opt(argc, argv, "fp32") != nullptr, fp8 = opt(argc, argv, "fp8") != nullptr;
+  const char* dump = opt(argc, argv, "dump");
+  const int dump_steps = opt(argc, argv, "steps") ? atoi(opt(argc, argv, "steps")) : 6;
   const char* tag = opt(argc, argv, "tag") ? opt(argc, argv, "tag") : "";
   const int P = opt(argc, argv, "ctx") ? atoi(opt(argc, argv, "ctx")) : 32;
   const int H = large ? 1536 : 1024, L = large ? 30 : 24, F = large ? 6144 : 4096, NH = large ? 24 : 16, K = 9, V = 1088, NE = 64;
@@ -91,16 +133,26 @@ static int run_lm(int argc, char** argv) {
   c.hidden_size = H; c.num_layers = L; c.num_heads = NH; c.ffn_dim = F; c.num_codebooks = K; c.vocab_size = V; c.max_positions = 4096;
   c.rope = 0; c.rope_theta = 10000.f; c.pad_token_id = 1024; c.eos_token_id = 1024; c.bos_token_id = 1025;
   c.dtype = fp32 ? PTTS_F32 : PTTS_BF16; c.max_batch = B; c.max_ctx = P + 908; c.max_enc = NE; c.max_prompt = P + 8; c.device = 0;
+  c.weights_fp8 = fp8 ? 1 : 0;
   ptts_engine* e = nullptr;
   const double t_create = now_s();
   PT(ptts_engine_create(&c, &e));
   Filler f;
   f.st = st;
+  unsigned char* qbuf = nullptr;
+  float* scbuf = nullptr;
   auto load = [&](const std::string& name, std::vector<int64_t> shape, float std, float mean) {
     size_t n = 1;
     for (int64_t s : shape) n *= (size_t)s;
-    const float* p = f.get(n, std, mean);
+    float* p = f.get(n, std, mean);
+    const bool q8 = fp8 && shape.size() == 2 && name.find("embed_") == std::string::npos && name.find("encoder_attn.k_proj") == std::string::npos &&
+                    name.find("encoder_attn.v_proj") == std::string::npos;  // the matrices the decode step streams (quant.py: is_fp8_matrix)
+    if (q8) {
+      if (!qbuf) { HIPCHK(hipMalloc(&qbuf, (size_t)F * H)); HIPCHK(hipMalloc(&scbuf, (size_t)(F > V ? F : V) * 4)); }
+      quant_e4m3_rows_kernel<<<dim3((unsigned)shape[0]), dim3(256), 0, st>>>(p, qbuf, scbuf, (int)shape[1]);
+    }
     PT(ptts_load_weight(e, name.c_str(), p, PTTS_F32, shape.data(), (int32_t)shape.size(), st));
+    if (q8) PT(ptts_load_weight_fp8(e, name.c_str(), qbuf, scbuf, shape.data(), 2, st));
   };
   const std::string p = "model.decoder.";
   for (int k = 0; k < K; ++k) load(p + "embed_tokens." + std::to_string(k) + ".weight", {V + 1, H}, 0.02f, 0.f);
@@ -133,6 +185,30 @@ static int run_lm(int argc, char** argv) {
   fill_kernel<<<dim3((unsigned)(((size_t)B * NE * H + 255) / 256)), dim3(256), 0, st>>>(enc, (size_t)B * NE * H, 777u, 1.f, 0.f);
   fill_kernel<<<dim3((unsigned)(((size_t)B * P * H + 255) / 256)), dim3(256), 0, st>>>(prompt, (size_t)B * P * H, 778u, 1.f, 0.f);
   HIPCHK(hipStreamSynchronize(st));
+  FILE* df = nullptr;
+  if (dump && *dump) {  // teacher-forced eager steps: the logits of every forward
+    df = fopen(dump, "wb");
+    if (!df) { fprintf(stderr, "cannot write %s\n", dump); return 1; }
+    const int64_t hdr[4] = {0x70747473 /* 'ptts' */, (int64_t)B * K, V, dump_steps + 1};
+    fwrite(hdr, sizeof hdr, 1, df);
+    std::vector<float> host((size_t)B * K * V);
+    long long* tok = nullptr;
+    HIPCHK(hipMalloc(&tok, (size_t)B * K * 8));
+    PT(ptts_prefill(e, enc, nullptr, prompt, nullptr, B, NE, P, 0, st));
+    for (int s = 0; s <= dump_steps; ++s) {
+      if (s > 0) {
+        fill_codes_kernel<<<dim3((unsigned)((B * K + 255) / 256)), dim3(256), 0, st>>>(tok, (size_t)B * K, 1000u + s, 1024);
+        PT(ptts_push_tokens(e, (const int64_t*)tok, nullptr, st));
+        PT(ptts_step_forward(e, st));
+      }
+      float* lg = nullptr;
+      PT(ptts_logits(e, &lg));
+      HIPCHK(hipMemcpyAsync(host.data(), lg, host.size() * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      fwrite(host.data(), 4, host.size(), df);
+    }
+    HIPCHK(hipFree(tok));
+  }
   double t0 = now_s();
   PT(ptts_prefill(e, enc, nullptr, prompt, nullptr, B, NE, P, 1, st));
   PT(ptts_first_token_sync(e));
@@ -159,11 +235,22 @@ static int run_lm(int argc, char** argv) {
   }
   int32_t cur = 0, fin = 0;
   PT(ptts_state(e, &cur, &fin, st));
-  const double wb = ((double)L * (6.0 * H * H + 2.0 * H * F) + (double)K * V * H) * (fp32 ? 4 : 2);
-  printf("[cabi_probe lm %s%s%s] B=%d: %.1f %.1f %.1f us/step  (weights %.0f MB/step -> %.2f TB/s at the middle reading; prefill+first token %.2f ms "
-         "(first call, pre-capture) / %.2f ms; create+load %.1f s; cur_len %d)\n",
-         tag, large ? " large" : "", fp32 ? " fp32" : "", B, us[0], us[1], us[2], wb / 1e6, wb / 1e6 / us[1], ttft1 * 1e3, ttft2 * 1e3,
-         t_loaded - t_create, cur);
+  if (df) {  // the ids of the free-running greedy run (prefill + 800 graph-replayed steps)
+    int64_t* ids = nullptr;
+    int32_t ld = 0;
+    PT(ptts_ids(e, &ids, &ld));
+    std::vector<int64_t> host((size_t)B * K * cur);
+    HIPCHK(hipMemcpy2D(host.data(), (size_t)cur * 8, ids, (size_t)ld * 8, (size_t)cur * 8, (size_t)B * K, hipMemcpyDeviceToHost));
+    const int64_t hdr[2] = {(int64_t)B * K, cur};
+    fwrite(hdr, sizeof hdr, 1, df);
+    fwrite(host.data(), 8, host.size(), df);
+    fclose(df);
+  }
+  const double wb = ((double)L * (6.0 * H * H + 2.0 * H * F) + (double)K * V * H) * (fp32 ? 4 : (fp8 ? 1 : 2));
+  printf("[cabi_probe lm %s%s%s%s] B=%d: %.1f %.1f %.1f us/step  (weights %.0f MB/step -> %.2f TB/s at the middle reading; prefill+first token %.2f ms "
+         "(first call, pre-capture) / %.2f ms; create+load %.0f ms; cur_len %d)\n",
+         tag, large ? " large" : "", fp32 ? " fp32" : "", fp8 ? " fp8" : "", B, us[0], us[1], us[2], wb / 1e6, wb / 1e6 / us[1], ttft1 * 1e3, ttft2 * 1e3,
+         (t_loaded - t_create) * 1e3, cur);
   fflush(stdout);
   ptts_engine_destroy(e);
   return 0;
@@ -175,6 +262,7 @@ static int run_dac(int argc, char** argv) {
   const int reps = opt(argc, argv, "reps") ? atoi(opt(argc, argv, "reps")) : 5;
   const bool f32 = opt(argc, argv, "f32") != nullptr;
   const char* tag = opt(argc, argv, "tag") ? opt(argc, argv, "tag") : "";
+  const char* dump = opt(argc, argv, "dump");
   hipStream_t st;
   HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   ptts_dac_config c;
@@ -249,6 +337,18 @@ static int run_dac(int argc, char** argv) {
   double ss = 0;
   bool finite = true;
   for (float v : head) { ss += (double)v * v; finite = finite && std::isfinite(v); }
+  if (dump && *dump) {  // the whole waveform, in the logits container (rows = utterances)
+    FILE* df = fopen(dump, "wb");
+    if (!df) { fprintf(stderr, "cannot write %s\n", dump); return 1; }
+    std::vector<float> host(nwave);
+    HIPCHK(hipMemcpy(host.data(), wave, nwave * 4, hipMemcpyDeviceToHost));
+    const int64_t hdr[4] = {0x70747473, B, (int64_t)T * 512, 1};
+    fwrite(hdr, sizeof hdr, 1, df);
+    fwrite(host.data(), 4, host.size(), df);
+    const int64_t none[2] = {0, 0};
+    fwrite(none, sizeof none, 1, df);
+    fclose(df);
+  }
   const double flops = 1.608e9 * (double)B * T;
   printf("[cabi_probe dac %s%s] B=%d frames=%d: %.3f ms per decode = %.1f TFLOP/s (%.1f %% of %s)  [first 4096 samples rms %.3g%s]\n", tag,
          f32 ? " f32" : " bf16", B, T, ms, flops / ms / 1e9, 100.0 * flops / ms / 1e9 / (f32 ? 157.3 : 2500.0), f32 ? "157 TF f32 MFMA" : "2.5 PF bf16 MFMA",
@@ -258,9 +358,72 @@ static int run_dac(int argc, char** argv) {
   return 0;
 }
 
+struct Dump {
+  int64_t rows = 0, cols = 0, blocks = 0, id_rows = 0, id_cols = 0;
+  std::vector<float> v;
+  std::vector<int64_t> ids;
+  bool read(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    int64_t hdr[4];
+    bool ok = fread(hdr, sizeof hdr, 1, f) == 1 && hdr[0] == 0x70747473;
+    if (ok) {
+      rows = hdr[1]; cols = hdr[2]; blocks = hdr[3];
+      v.resize((size_t)rows * cols * blocks);
+      ok = fread(v.data(), 4, v.size(), f) == v.size();
+    }
+    int64_t ih[2];
+    if (ok && fread(ih, sizeof ih, 1, f) == 1) {
+      id_rows = ih[0]; id_cols = ih[1];
+      ids.resize((size_t)id_rows * id_cols);
+      ok = fread(ids.data(), 8, ids.size(), f) == ids.size();
+    }
+    fclose(f);
+    return ok;
+  }
+};
+
+// 0: identical, 4: same shape but different values (printed), 1: unreadable / different shapes
+static int run_cmp(const char* pa, const char* pb) {
+  Dump a, b;
+  if (!a.read(pa) || !b.read(pb)) { fprintf(stderr, "cannot read %s / %s\n", pa, pb); return 1; }
+  if (a.rows != b.rows || a.cols != b.cols || a.blocks != b.blocks) { fprintf(stderr, "different shapes\n"); return 1; }
+  double mx = 0, mxabs = 0;
+  long long flips = 0, nan = 0;
+  int worst_block = -1;
+  for (int64_t blk = 0; blk < a.blocks; ++blk)
+    for (int64_t r = 0; r < a.rows; ++r) {
+      const float* x = &a.v[(size_t)(blk * a.rows + r) * a.cols];
+      const float* y = &b.v[(size_t)(blk * a.rows + r) * a.cols];
+      int64_t ax = 0, ay = 0;
+      for (int64_t c = 0; c < a.cols; ++c) {
+        if (!std::isfinite(x[c]) || !std::isfinite(y[c])) { ++nan; continue; }
+        const double d = fabs((double)x[c] - (double)y[c]);
+        if (d > mx) { mx = d; worst_block = (int)blk; }
+        mxabs = fmax(mxabs, fabs((double)x[c]));
+        if (x[c] > x[ax]) ax = c;
+        if (y[c] > y[ay]) ay = c;
+      }
+      flips += ax != ay;
+    }
+  long long first_id = -1;
+  if (a.id_rows == b.id_rows && a.id_cols == b.id_cols)
+    for (int64_t c = 0; c < a.id_cols && first_id < 0; ++c)
+      for (int64_t r = 0; r < a.id_rows; ++r)
+        if (a.ids[(size_t)r * a.id_cols + c] != b.ids[(size_t)r * b.id_cols + c]) { first_id = c; break; }
+  printf("[cabi_probe cmp] %lld blocks of [%lld, %lld]: max |a - b| = %.3g (block %d; max |a| = %.3g), %lld arg-max flips of %lld rows, %lld non-finite; ids [%lld, %lld]: %s",
+         (long long)a.blocks, (long long)a.rows, (long long)a.cols, mx, worst_block, mxabs, flips, (long long)(a.rows * a.blocks), nan, (long long)a.id_rows,
+         (long long)a.id_cols, a.id_rows != b.id_rows || a.id_cols != b.id_cols ? "different shapes" : (first_id < 0 ? "identical" : "differ"));
+  if (first_id >= 0) printf(" from column %lld", first_id);
+  printf("\n");
+  return (mx == 0 && nan == 0 && first_id < 0 && a.id_cols == b.id_cols) ? 0 : 4;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 4 && !strcmp(argv[1], "cmp")) return run_cmp(argv[2], argv[3]);
   if (argc < 3 || (strcmp(argv[1], "lm") && strcmp(argv[1], "dac"))) {
-    fprintf(stderr, "usage: %s lm <batch> [large] [fp32] [ctx=<prompt positions>] [tag=<text>]\n       %s dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>]\n", argv[0], argv[0]);
+    fprintf(stderr, "usage: %s lm <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]]\n"
+                    "       %s dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>] [dump=<file>]\n       %s cmp <file a> <file b>\n", argv[0], argv[0], argv[0]);
     return 1;
   }
   if (ptts_abi_version() != PTTS_ABI_VERSION) { fprintf(stderr, "libptts_hip.so has ABI %d, the header %d\n", ptts_abi_version(), PTTS_ABI_VERSION); return 1; }
