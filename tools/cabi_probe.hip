@@ -5,7 +5,10 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/cabi_probe.hip -o tools/cabi_probe \
 //         -Lparler_tts_amd -lptts_hip -Wl,-rpath,'$ORIGIN/../parler_tts_amd'
-//   tools/cabi_probe lm  <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]]
+//   tools/cabi_probe lm  <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]
+//        eager=<n>: only a prefill + n EAGER decode forwards (ptts_push_tokens + ptts_step_forward), no hipGraph is captured or launched:
+//        the target of `rocprofv3 --pmc ...` passes (which crash on graph replays in this image; tools/prof_eager.py without torch),
+//        e.g. `rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- tools/cabi_probe lm 1 ctx=431 eager=24` = the bench's timed context
 //   tools/cabi_probe dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>] [dump=<file>]
 //   tools/cabi_probe cmp <file a> <file b>
 //   (environment knobs as for tools/step_probe2.py: PTTS_NO_GEMV, PTTS_GEMV_ROWS, PTTS_GEMV_STAGE, PTTS_NO_FO, PTTS_DAC_NO_FUSE_RES ...)
@@ -185,6 +188,21 @@ static int run_lm(int argc, char** argv) {
   fill_kernel<<<dim3((unsigned)(((size_t)B * NE * H + 255) / 256)), dim3(256), 0, st>>>(enc, (size_t)B * NE * H, 777u, 1.f, 0.f);
   fill_kernel<<<dim3((unsigned)(((size_t)B * P * H + 255) / 256)), dim3(256), 0, st>>>(prompt, (size_t)B * P * H, 778u, 1.f, 0.f);
   HIPCHK(hipStreamSynchronize(st));
+  if (opt(argc, argv, "eager")) {
+    const int n = atoi(opt(argc, argv, "eager"));
+    long long* tok = nullptr;
+    HIPCHK(hipMalloc(&tok, (size_t)B * K * 8));
+    fill_codes_kernel<<<dim3((unsigned)((B * K + 255) / 256)), dim3(256), 0, st>>>(tok, (size_t)B * K, 1000u, 1024);
+    PT(ptts_prefill(e, enc, nullptr, prompt, nullptr, B, NE, P, 0, st));
+    for (int s = 0; s < n; ++s) {
+      PT(ptts_push_tokens(e, (const int64_t*)tok, nullptr, st));
+      PT(ptts_step_forward(e, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    printf("[cabi_probe lm %s] B=%d: %d eager decode forwards after a prefill of %d positions done\n", tag, B, n, P + 1);
+    ptts_engine_destroy(e);
+    return 0;
+  }
   FILE* df = nullptr;
   if (dump && *dump) {  // teacher-forced eager steps: the logits of every forward
     df = fopen(dump, "wb");
@@ -422,7 +440,7 @@ static int run_cmp(const char* pa, const char* pb) {
 int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "cmp")) return run_cmp(argv[2], argv[3]);
   if (argc < 3 || (strcmp(argv[1], "lm") && strcmp(argv[1], "dac"))) {
-    fprintf(stderr, "usage: %s lm <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]]\n"
+    fprintf(stderr, "usage: %s lm <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]\n"
                     "       %s dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>] [dump=<file>]\n       %s cmp <file a> <file b>\n", argv[0], argv[0], argv[0]);
     return 1;
   }
