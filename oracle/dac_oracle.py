@@ -156,11 +156,36 @@ def snake1d(x: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
     return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
 
 
+def _rb(x: torch.Tensor) -> torch.Tensor:
+    """fp32 → bf16 (round-to-nearest-even) → fp32: the value a bf16 MFMA operand carries."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
 class DacOracle:
-    def __init__(self, spec: DacSpec, sd: Dict[str, torch.Tensor], prefix: str = ""):
+    """precision="fp32": the restatement as written. precision="bf16": the model the bf16-OPERAND engine evaluates (what
+    ``model.to(device, dtype=torch.bfloat16)`` selects, INFERENCE.md:29-32 → dac_wrapper/modeling_dac.py:138-139 on a bf16 codec):
+    every MFMA conv reads bf16 weights and bf16 activations, accumulates / adds bias / adds the residual / evaluates Snake in fp32.
+    Rounding points, each placed where the HIP kernels round (csrc/ptts_dac.hip):
+      * conv weights of the decoder stack → bf16 once at load (pack_conv_bf16_kernel); biases, alphas, the RVQ tables and the final
+        Conv1d(C→1) + tanh stay fp32;
+      * the latent z = Σ_i out_proj_i(codebook_i[codes]) → bf16 (rvq_gather_kernel, z_bf16);
+      * every Snake output that feeds a conv → bf16 (the producer epilogue's ``out_act``), INCLUDING the activation between the k7 and
+        the k1 conv of a residual unit (the fused unit's LDS tile; the two-launch path rounds the same value);
+      * the residual stream (transposed-conv output, unit outputs) is fp32 and never rounded; the last unit's Snake output, which feeds
+        the fp32 final conv, is not rounded (``act_f32``).
+    ``sin`` is exact here (the kernels use v_sin_f32 in this mode: their distance to this oracle includes that)."""
+
+    def __init__(self, spec: DacSpec, sd: Dict[str, torch.Tensor], prefix: str = "", precision: str = "fp32"):
+        assert precision in ("fp32", "bf16"), precision
         self.spec = spec
+        self.precision = precision
         sd = {k[len(prefix):]: v.detach().to(torch.float32) for k, v in sd.items() if k.startswith(prefix)}
         self.w = fold_weight_norm(sd)
+        if precision == "bf16":
+            n = len(spec.decoder_rates)
+            for k in list(self.w):
+                if k.startswith("decoder.model.") and k.endswith(".weight") and not k.startswith(f"decoder.model.{n + 2}."):
+                    self.w[k] = _rb(self.w[k])
 
     def from_codes(self, codes: torch.Tensor) -> torch.Tensor:
         """codes [B, K, T] int64 → z [B, latent, T] (ResidualVectorQuantize.from_codes)."""
@@ -173,20 +198,21 @@ class DacOracle:
 
     def decode_latents(self, z: torch.Tensor) -> torch.Tensor:
         w, d = self.w, "decoder.model."
-        x = F.conv1d(z, w[d + "0.weight"], w[d + "0.bias"], padding=3)
+        rb = _rb if self.precision == "bf16" else (lambda v: v)  # operand rounding (identity in fp32)
+        x = F.conv1d(rb(z), w[d + "0.weight"], w[d + "0.bias"], padding=3)
         for bi, s in enumerate(self.spec.decoder_rates):
             b = f"{d}{bi + 1}.block."
-            x = snake1d(x, w[b + "0.alpha"])
-            x = F.conv_transpose1d(x, w[b + "1.weight"], w[b + "1.bias"], stride=s, padding=math.ceil(s / 2))
+            x = rb(snake1d(x, w[b + "0.alpha"]))
+            x = F.conv_transpose1d(x, w[b + "1.weight"], w[b + "1.bias"], stride=s, padding=math.ceil(s / 2))  # fp32 residual stream
             for ri, dil in enumerate((1, 3, 9)):
                 r = f"{b}{ri + 2}.block."
-                y = snake1d(x, w[r + "0.alpha"])
+                y = rb(snake1d(x, w[r + "0.alpha"]))
                 y = F.conv1d(y, w[r + "1.weight"], w[r + "1.bias"], dilation=dil, padding=3 * dil)
-                y = snake1d(y, w[r + "2.alpha"])
+                y = rb(snake1d(y, w[r + "2.alpha"]))
                 y = F.conv1d(y, w[r + "3.weight"], w[r + "3.bias"])
                 x = x + y
         n = len(self.spec.decoder_rates)
-        x = snake1d(x, w[f"{d}{n + 1}.alpha"])
+        x = snake1d(x, w[f"{d}{n + 1}.alpha"])  # feeds the fp32 final conv: not rounded
         x = F.conv1d(x, w[f"{d}{n + 2}.weight"], w[f"{d}{n + 2}.bias"], padding=3)
         return torch.tanh(x)
 

@@ -6,6 +6,25 @@ from oracle import decoder_oracle as DO
 from oracle import dac_oracle as DA
 
 
+# relative waveform RMS of the bf16-operand DAC engine against DacOracle(precision="bf16"): 2 x the largest value measured on MI355X
+# over every bf16 codec test (profiles/r04_parity_dac_bf16.txt)
+DAC_BF16_TOL = 2e-3
+
+
+def log_parity(msg, name="r04_parity_dac_bf16.txt"):
+    """print + append to gpurun_out/<name> (copied into profiles/ as the record of the run)."""
+    import os
+
+    print(msg, flush=True)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", name), "a") as f:
+            f.write(msg + "\n")
+    except OSError:
+        pass
+
+
 def spec_from_gold(arr, **kw):
     H, L, nh, F, mp, rope = [int(x) for x in arr[:6]]
     if len(arr) > 6:  # grouped-query fixtures also record the K/V head counts

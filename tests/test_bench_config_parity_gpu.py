@@ -13,7 +13,8 @@ passes, the model / seeds / inputs built by bench.py itself (build_model, synthe
       graph path against the bf16 oracle's own free run: the first diverging column is reported, and asserted to sit on an
       oracle margin inside twice the measured error (a legitimate near-tie flip, after which the two runs are different
       utterances and are not compared any further).
-  (c) DAC: 860 frames through the 44.1 kHz stack, exact-f32 mode RMS <= 1e-4, bf16-operand mode <= 3 % of the signal RMS.
+  (c) DAC: 860 frames through the 44.1 kHz stack, exact-f32 mode RMS <= 1e-4 vs the fp32 oracle; bf16-operand mode (the timed one) vs the
+      bf16-OPERAND oracle <= helpers.DAC_BF16_TOL of the signal RMS at batch 1 and batch 32 (and <= 3 % vs the fp32 oracle).
 
 TOL_BF16 is set from measurement, not by fiat: the engine and the oracle evaluate the SAME quantised model and differ by
 summation order and by where an fp32 value lands relative to a bf16 rounding boundary (a 1-ulp flip of a Linear input is
@@ -223,6 +224,9 @@ def test_bf16_logits_and_argmax_vs_quantised_oracle(bs):
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_dac_860_frames_vs_oracle(mode):
+    """bf16: the timed mode. Pinned against the bf16-OPERAND oracle (same rounded weights / activations, fp32 accumulate; tolerance =
+    2 x measured, helpers.DAC_BF16_TOL), with the loose 3 % bound against the fp32 oracle kept as a second assertion."""
+    from helpers import DAC_BF16_TOL, log_parity
     from parler_tts_amd.engine import DacEngine
     from parler_tts_amd.synthetic import random_dac_state_dict
 
@@ -244,6 +248,39 @@ def test_dac_860_frames_vs_oracle(mode):
         assert rms_err <= 1e-4, rms_err
     else:
         assert rms_err <= 0.03 * rms_sig, (rms_err, rms_sig)
+        refq = DA.DacOracle(DA.DAC_44KHZ, dsd, precision="bf16").decode(codes)[0, 0]
+        eq = float((wav - refq).pow(2).mean().sqrt())
+        log_parity(f"[dac bf16 44khz, 1 x {T} frames] vs bf16 oracle: RMS {eq:.2e} = {eq / rms_sig:.2e} of the signal RMS, max |d| {float((wav - refq).abs().max()):.2e}; "
+                   f"vs fp32 oracle {rms_err / rms_sig:.2e}")
+        assert eq <= DAC_BF16_TOL * rms_sig, (eq, rms_sig)
+
+
+def test_dac_bf16_batch32_860_frames_vs_bf16_oracle():
+    """configs[2]'s codec call: 32 utterances x 860 frames through the bf16-operand kernels (utterance index folded into blockIdx.x).
+    The oracle decodes four of the utterances (the codec treats utterances independently); every utterance of the batch must equal its
+    own single-utterance decode on the same engine (same arithmetic per output sample, whatever the launch geometry)."""
+    from helpers import DAC_BF16_TOL, log_parity
+    from parler_tts_amd.engine import DacEngine
+    from parler_tts_amd.synthetic import random_dac_state_dict
+
+    T, B = 860, 32
+    dsd = random_dac_state_dict(seed=4321)
+    codes = torch.randint(0, 1024, (B, 9, T), generator=torch.Generator().manual_seed(11))
+    torch.set_num_threads(min(os.cpu_count() or 8, 16))
+    dac = DacEngine(max_batch=B, max_frames=T, compute_dtype=torch.bfloat16)
+    dac.load_state_dict({k: v.cuda() for k, v in dsd.items()})
+    wav = dac.decode(codes.cuda())[:, 0].cpu()
+    orq = DA.DacOracle(DA.DAC_44KHZ, dsd, precision="bf16")
+    worst = 0.0
+    for b in (0, 7, 19, 31):
+        refq = orq.decode(codes[b:b + 1])[0, 0]
+        r = float((wav[b] - refq).pow(2).mean().sqrt() / refq.pow(2).mean().sqrt())
+        worst = max(worst, r)
+        assert r <= DAC_BF16_TOL, (b, r)
+    single = torch.stack([dac.decode(codes[b:b + 1].cuda())[0, 0].cpu() for b in (0, 13, 31)])
+    dmax = float((single - wav[[0, 13, 31]]).abs().max())
+    log_parity(f"[dac bf16 44khz, {B} x {T} frames] utterances 0/7/19/31 vs bf16 oracle: worst relative RMS {worst:.2e}; batched vs single-utterance decode max |d| {dmax:.1e}")
+    assert dmax <= 1e-6, dmax
 
 
 def _teacher_forced_batched(spec, sd, oracle_sd, bsz, steps, seed, weights_fp8=False, N=21, P=6, dev=None, dtype=torch.bfloat16):

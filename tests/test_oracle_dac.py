@@ -47,3 +47,31 @@ def test_encode_restatement_equals_transformers_port():
     safe = margin >= 1e-4  # frames whose nearest-code search is clear of fp32 rounding at every stage
     assert int(safe.sum()) > safe.numel() // 2
     assert bool((codes == codes2)[safe[:, None, :].expand_as(codes)].all())
+
+
+@pytest.mark.parametrize("name,T", [("tiny", 13), ("44k", 5)])
+@torch.no_grad()
+def test_bf16_operand_oracle_equals_port_with_rounded_conv_operands(name, T):
+    """DacOracle(precision="bf16") — the model the bf16-operand HIP kernels evaluate — stated a second, independent way: the transformers
+    port with (a) the decoder's conv weights rounded to bf16 and (b) a forward pre-hook on every decoder conv EXCEPT the final Conv1d(C→1)
+    that rounds its input to bf16 (biases / Snake / residual adds stay fp32 module arithmetic). Same rounding points ⇒ same waveform up to
+    fp32 summation order (a value that lands on the other side of a bf16 boundary moves one operand by 2^-8: rare, bounded at 5e-4 rel. RMS);
+    a rounding point put in the wrong place (e.g. the residual stream, or the final conv's input) shows up as ~1e-2."""
+    spec = DA.DAC_TINY if name == "tiny" else DA.DAC_44KHZ
+    sd = DA.make_dac_weights(spec, seed=4321)
+    codes = torch.randint(0, spec.codebook_size, (2, spec.num_codebooks, T), generator=torch.Generator().manual_seed(3))
+    wq = DA.DacOracle(spec, sd, precision="bf16").decode(codes)
+    w32 = DA.DacOracle(spec, sd).decode(codes)
+    port = hf_dac_port(spec, sd)
+    convs = [m for m in port.decoder.modules() if isinstance(m, (torch.nn.Conv1d, torch.nn.ConvTranspose1d))]
+    final = port.decoder.conv2
+    assert final in convs and final.out_channels == 1
+    for m in convs:
+        if m is final:
+            continue
+        m.weight.data = DA._rb(m.weight.data)
+        m.register_forward_pre_hook(lambda mod, args: (DA._rb(args[0]),) + tuple(args[1:]))
+    wp = port.decode(audio_codes=codes).audio_values.reshape(wq.shape)
+    rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())  # noqa: E731
+    assert rel(wq, wp) <= 5e-4, rel(wq, wp)
+    assert 2e-3 <= rel(wq, w32) <= 3e-2, rel(wq, w32)  # and it is a different model from the fp32 one (operand rounding through ~30 convs)
