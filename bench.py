@@ -233,7 +233,8 @@ def measure_decode_roofline(model, bs: int, device, live_pmc: bool = True) -> di
     w_step = L * (4 * H * H + 2 * H * H + 2 * H * F) + Kc * V * H  # 362.3 M for Mini-v1, 1005.9 M for Large-v1
     lc = N_PROMPT + 1 + n_warm + n // 2  # mean self-KV length over the timed replays
     es = 2 if model.dtype == torch.bfloat16 else 4
-    ws = 1 if (getattr(model, "decoder_weights_fp8", False) and bs <= 4) else es  # e4m3 weights are streamed by the GEMV step (batch <= 4)
+    # e4m3 weights are streamed as bytes at EVERY batch size (GEMV step up to 8 utterances, e4m3 MFMA strips above: DESIGN.md §4.1 / §4.2)
+    ws = 1 if getattr(model, "decoder_weights_fp8", False) else es
     bytes_step = w_step * ws + bs * 2 * L * H * (lc + N_DESC) * es + bs * (Kc * H * es + Kc * V * 4)
     achieved = bytes_step / step_s / 1e9
     traffic, tnote = None, "PMC pass not available for this configuration"
@@ -406,6 +407,63 @@ def _timed_generate(model, bs: int, device, reps: int = 1) -> float:
     return (time.perf_counter() - t0) / reps
 
 
+def dac_flops_per_frame(latent: int = 1024, dim: int = 1536, rates=(8, 8, 4, 2)) -> int:
+    """Multiply-adds x 2 of DAC.decode per latent frame (1.608 GFLOP for the 44.1 kHz stack): Conv1d(latent -> dim, k7),
+    per block a transposed conv (k = 2s, stride s: 2 taps per output sample) + 3 residual units (k7 + k1) at the block's rate, the final
+    Conv1d(C -> 1, k7). The RVQ gather, Snake and tanh are not counted."""
+    f, up = 2 * latent * dim * 7, 1
+    for i, s in enumerate(rates):
+        cin, cout = dim >> i, dim >> (i + 1)
+        up *= s
+        f += up * (2 * cin * cout * 2 + 3 * (2 * cout * cout * 7 + 2 * cout * cout))
+    return f + up * 2 * (dim >> len(rates)) * 7
+
+
+def _timed_dac(eng, codes, reps: int) -> float:
+    """seconds per ptts_dac_decode call: HIP events on the stream the codec's kernels are launched on, around `reps` calls (after 2 warm-ups)."""
+    hip = hip_event_timer()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        eng.decode(codes)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
+    hip.hipEventRecord(e0, stream)
+    for _ in range(reps):
+        eng.decode(codes)
+    hip.hipEventRecord(e1, stream)
+    hip.hipEventSynchronize(e1)
+    ms = C.c_float()
+    hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+    return ms.value / 1e3 / reps
+
+
+def measure_dac(device, bs_list=(1, 32), with_f32: bool = True) -> dict:
+    """SURVEY.md §8(d)'s SECOND bound of the path: DAC decode is MFMA-bound. One ptts_dac_decode of bs x 860 frames (what generate() calls
+    after the token loop), timed by HIP events on its launch stream; achieved = algorithmic flops (1.608 GFLOP per frame x frames x bs)
+    / time, against the dense bf16 MFMA peak (2.5 PFLOP/s) in the bf16-operand mode the headline configuration runs, and against the
+    fp32 MFMA peak (157.3 TFLOP/s) in the exact-f32 parity mode. Same synthetic codec weights as the model (seed 4321)."""
+    from parler_tts_amd.engine import DacEngine
+    from parler_tts_amd.synthetic import random_dac_state_dict
+
+    sd = {k: v.to(device) for k, v in random_dac_state_dict(seed=4321).items()}
+    fl = dac_flops_per_frame()
+    out = {"bound": "mfma", "unit": "TFLOP/s", "peak_bf16": 2500.0, "peak_f32": 157.3, "flops_per_frame": fl, "frames": FRAMES,
+           "kernel": "ptts_dac_decode: RVQ gather + 30 conv launches (LDS-tiled bf16 MFMA k7 / transposed convs, fused residual units, tiled final conv + tanh)"}
+    for mode, dt, peak, sizes in (("bf16", torch.bfloat16, 2500.0, bs_list), ("f32", torch.float32, 157.3, (1,) if with_f32 else ())):
+        if not sizes:
+            continue
+        eng = DacEngine(max_batch=max(sizes), max_frames=FRAMES, device=device, compute_dtype=dt)
+        eng.load_state_dict(sd)
+        for bs in sizes:
+            codes = torch.randint(0, 1024, (bs, K_CODEBOOKS, FRAMES), generator=torch.Generator().manual_seed(7)).to(device)
+            sec = _timed_dac(eng, codes, 10 if bs == 1 else 3)
+            ach = fl * FRAMES * bs / sec / 1e12
+            out[f"{mode}_bs{bs}"] = {"ms_per_launch": round(sec * 1e3, 3), "flops_per_launch": fl * FRAMES * bs, "achieved": round(ach, 1), "peak": peak,
+                                     "frac": round(ach / peak, 4), "audio_seconds_per_sec": round(bs * AUDIO_S / sec, 1)}
+        eng.close()
+    return out
+
+
 def _trim_roofline(r: dict) -> dict:
     return {k: r[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "bytes_per_launch", "context") if k in r}
 
@@ -572,6 +630,14 @@ def main():
 
     out = None
     mname = "parler-tts-mini-v1" if args.model == "mini" else "parler-tts-large-v1"
+    ttft_ranks = None
+    if world > 1 and not args.no_extras:  # both halves of the metric on a multi-GPU run: every rank times ITS p50 time-to-first-token, the line carries the max
+        import torch.distributed as dist
+
+        mine = torch.tensor([measure_ttft(model, args.bs, device, reps=9)], device=device if dist.get_backend() == "nccl" else torch.device("cpu"), dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(n_ranks)]
+        dist.all_gather(every, mine)
+        ttft_ranks = [round(float(x.item()), 2) for x in every]
     if rank == 0:
         out = {
             "metric": "audio-seconds/sec (whole node) + p50 time-to-first-token, Mini-v1 bs=1/32", "value": round(value, 3),
@@ -592,7 +658,9 @@ def main():
         if not args.no_extras:
             # (N > 1: the other ranks wait in the final barrier while rank 0 measures; no profiler child passes there - the committed PMC pass is quoted)
             out["roofline"] = measure_decode_roofline(model, args.bs, device, live_pmc=(world == 1))
-            out["ttft_p50_ms"] = round(measure_ttft(model, args.bs, device), 2)
+            out["ttft_p50_ms"] = max(ttft_ranks) if ttft_ranks else round(measure_ttft(model, args.bs, device), 2)
+            if ttft_ranks:
+                out["per_rank_ttft_p50_ms"] = ttft_ranks  # ttft_p50_ms = the slowest rank's p50
         else:
             out["roofline"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a required object of the line: measured before the optional side measurements
@@ -615,11 +683,29 @@ def main():
                            "roofline": measure_decode_roofline(model, 32, device)}
         except Exception as e:  # side measurement must never break the contract line
             out["bs32"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:  # the codec half of the path against ITS bound (MFMA): bf16-operand mode at 1 / 32 utterances, exact-f32 mode at 1
+            out["dac"] = measure_dac(device)
+        except Exception as e:
+            out["dac"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_extras and args.model == "mini" and args.dtype == "bf16":
         try:  # the whole-node lever: 128 utterances per GPU (the step is latency-bound at 32, utterances per step are nearly free until the KV stream dominates)
             dt = _timed_generate(model, 128, device)
             out["bs128"] = {"value": round(128 * AUDIO_S / dt, 2), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1),
                             "roofline": _trim_roofline(measure_decode_roofline(model, 128, device, live_pmc=False))}
+            try:  # the codec's share of that generate(): the model's own DACModel.decode on 128 x 860 frames (sub-batches as generate() runs them)
+                codes128 = torch.randint(0, 1024, (1, 128, K_CODEBOOKS, FRAMES), device=device)
+                model.audio_encoder.decode(codes128, [None])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.audio_encoder.decode(codes128, [None])
+                torch.cuda.synchronize()
+                tc = time.perf_counter() - t0
+                out["bs128"]["codec_ms"] = round(tc * 1e3, 1)
+                out["bs128"]["codec_share_of_generate"] = round(tc / dt, 4)
+                del codes128
+            except Exception as e:  # noqa: BLE001
+                out["bs128"]["codec_ms"] = repr(e)[:120]
             for key in [k for k in getattr(model, "__dict__", {}).get("_engines", {}) if k[-1] == "b>8"]:  # its 11 GB KV arena is not needed any further
                 model.__dict__["_engines"].pop(key).close()
         except Exception as e:

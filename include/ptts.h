@@ -54,15 +54,20 @@ typedef struct {
   float rope_theta;
   int32_t pad_token_id, eos_token_id, bos_token_id;
   int32_t dtype;         /* PTTS_F32 (parity mode, BASELINE configs[0] numerics) | PTTS_BF16 (bf16 weights + KV, fp32 accumulate) */
-  int32_t max_batch;     /* utterances per call */
+  int32_t max_batch;     /* utterances per call. It also selects the decode-step kernels at create time (query: ptts_state / DESIGN.md §4):
+                            <= 4: row-per-wave GEMV step, 4 KV splits; 5..8: GEMV step with 8-utterance register groups, 2 splits; > 8: MFMA
+                            strip step (no row-major weight copies, no batch-1 cross-attention fold). An engine created for > 8 utterances and
+                            called with <= 8 still runs the strip step (correct, slower): size engines per batch class */
   int32_t max_ctx;       /* self-attention KV capacity in positions: P + max_length (cf. _get_cache :3254-3309) */
   int32_t max_enc;       /* cross-attention capacity: description (+ prompt if prompt_cross_attention) tokens */
   int32_t max_prompt;    /* prefill capacity in positions per utterance: P + 1 (prompt tokens + the BOS column) */
   int32_t device;        /* HIP device ordinal */
   int32_t num_kv_heads;       /* grouped-query attention, self (repeat_kv :280-289, :449-452): 0 = num_heads (Mini/Large v1) */
   int32_t num_cross_kv_heads; /* cross-attention K/V heads: 0 = num_kv_heads */
-  int32_t weights_fp8;        /* 1 (dtype PTTS_BF16 only): the decode step at batch <= 4 streams OCP e4m3 weights with one power-of-two
-                                 scale per output row (ptts_load_weight_fp8); every other path uses their exact bf16 dequantisation */
+  int32_t weights_fp8;        /* 1 (dtype PTTS_BF16 only): the decode step streams OCP e4m3 weight bytes with one power-of-two scale per output
+                                 row (ptts_load_weight_fp8) at EVERY batch size: the GEMV step up to 8 utterances, e4m3 MFMA strips above
+                                 (converted to bf16 in registers). Only the prefill and the cross-attention q projection inside the fused
+                                 cross block read the exact bf16 dequantisation */
 } ptts_config;
 
 /* Generation parameters: the subset of GenerationConfig that generate() consumes (:3395-3552). */

@@ -1145,18 +1145,24 @@ struct XAttnArgs {
   int out_fo;          // out in MFMA B-fragment order (fo_vec_index) for the out_proj GEMM at batch > 8
 };
 
-template <typename WT, int UW, int NF4>
+// G = utterances per workgroup (8: one per wave; 4 / 2: at batch > 8 the launch covers heads x ceil(B / G) workgroups - 128 / 256 at 32
+// utterances instead of 64 - and the 8 / G waves of an utterance split the description's row groups and merge through LDS).
+template <typename WT, int UW, int NF4, int G = 8>
 __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8, NWV = 8;
+  constexpr int WPU = NWV / G, UA = U / WPU;  // waves per utterance in the attention phase; row groups per wave and batch
+  static_assert(G == 8 || G == 4 || G == 2, "utterances per workgroup");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.x;
-  // utterances b0 .. b0 + nb - 1 of this workgroup: one group of <= 8 per blockIdx.y (batch <= 8: one group; batch 9..32: up to 4 groups)
-  const int b0 = blockIdx.y * NWV, nb = min(NWV, a.B - b0), nbmax = min(NWV, a.B);
+  // utterances b0 .. b0 + nb - 1 of this workgroup: one group of <= G per blockIdx.y
+  const int b0 = blockIdx.y * G, nb = min(G, a.B - b0), nbmax = min(G, a.B);
   const int row_bytes = a.K * (int)sizeof(WT) + 16;
-  char* s_x = smem_raw;                                                        // [B][row_bytes]
+  char* s_x = smem_raw;                                                        // [G][row_bytes]
   float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)nbmax * row_bytes);  // [8 waves][64][4]
-  float* s_q = s_red + NWV * 256;                                              // [B][64]
+  float* s_q = s_red + NWV * 256;                                              // [G][64]
+  float* s_o = s_q + G * 64;                                                   // [8 waves][64]  (WPU > 1: partial contexts)
+  float* s_ml = s_o + NWV * 64;                                                // [8 waves][2]
   const int nfrag = a.K / KT;
   const int strip = h * 4 + (wave >> 1);
   const int per = nfrag >> 1;  // host guarantees per % UW == 0
@@ -1164,7 +1170,8 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
   const int q4 = lane >> 4, j = lane & 15;
   const int r = lane / LPR, c = lane % LPR;
-  const int b = b0 + min(wave, nb - 1);  // attention of utterance b runs on wave b - b0
+  const int ul = wave / WPU, sub = wave % WPU;  // attention: utterance slot and row-group phase of this wave
+  const int b = b0 + min(ul, nb - 1);
   const int N = a.dims->N;
 
   // ---- t = 0: every independent global load of the kernel goes in flight; the residual rows first (critical path:
@@ -1174,8 +1181,8 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   const uint4* Kb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.kv_heads + h / a.n_rep) * a.cap * 64);
   const uint4* Vb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.kv_heads + h / a.n_rep) * a.cap * 64);
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
-  uint4 kf[U], vf[U];
-  int mk[U];
+  uint4 kf[UA], vf[UA];
+  int mk[UA];
   auto issue_bulk = [&](int stage) __attribute__((always_inline)) {
     if (stage != 1) {
       __builtin_amdgcn_sched_barrier(0);
@@ -1185,8 +1192,8 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
 #pragma unroll
       for (int u = 0; u < UW; ++u) afr[u] = ld_nt16(Wp + (size_t)(t0 + u) * 64);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {  // first 8 row groups (covers N <= 64 bf16 / 32 fp32 in one batch)
-        const int t = u * RPI + r;
+      for (int u = 0; u < UA; ++u) {  // the utterance's first 8 row groups over its WPU waves (covers N <= 64 bf16 / 32 fp32 in one batch)
+        const int t = (u * WPU + sub) * RPI + r;
         const int tc = t < a.cap ? t : 0;
         kf[u] = Kb[(size_t)tc * LPR + c];
         vf[u] = Vb[(size_t)tc * LPR + c];
@@ -1195,7 +1202,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // ---- LayerNorm of the B rows -> LDS, then the head's 64 q rows ------------------------------------------------------
+  // ---- LayerNorm of the rows -> LDS, then the head's 64 q rows ------------------------------------------------------
   ln_stage<WT, NF4, true, XAttnArgs, false>(a, b0, nb, s_x, row_bytes, lane, wave, NWV, issue_bulk);  // K == NF4 * 256
   __syncthreads();
   const char* brow = s_x + (size_t)min(j, nb - 1) * row_bytes + (size_t)q4 * 16;
@@ -1228,8 +1235,9 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
     }
   }
   __syncthreads();
-  if (wave >= nb) return;
-  // ---- wave b: single-query attention of utterance b over the N description positions -----------------------
+  if (WPU == 1 && ul >= nb) return;
+  // ---- wave (b, sub): single-query attention of utterance b over its share of the N description positions ---------------
+  const bool live = ul < nb;
   float qv[EPL];
   {
     const float* qs = s_q + (b - b0) * 64;
@@ -1246,26 +1254,26 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
       for (int e = 0; e < EPL; ++e) qv[e] = qs[d0 + e] * a.scale;
     }
   }
-  const int G = (N + RPI - 1) / RPI;
+  const int NG = (N + RPI - 1) / RPI;
   float m_run = -INFINITY, l_run = 0.f, o[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] = 0.f;
-  for (int g0 = 0; g0 < G; g0 += U) {
-    bool ok[U];
+  for (int g0 = 0; g0 < NG; g0 += U) {
+    bool ok[UA];
     if (g0 != 0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int t = (g0 + u) * RPI + r;
+      for (int u = 0; u < UA; ++u) {
+        const int t = (g0 + u * WPU + sub) * RPI + r;
         const int tc = t < N ? t : 0;
         kf[u] = Kb[(size_t)tc * LPR + c];
         vf[u] = Vb[(size_t)tc * LPR + c];
         mk[u] = mrow ? mrow[tc] : 1;
       }
     }
-    float sc[U], bm = -INFINITY;
+    float sc[UA], bm = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      ok[u] = ((g0 + u) * RPI + r) < N && mk[u] != 0;
+    for (int u = 0; u < UA; ++u) {
+      ok[u] = ((g0 + u * WPU + sub) * RPI + r) < N && mk[u] != 0;
       float kk[EPL];
       unpack16(kf[u], kk, WT());
       float d = 0.f;
@@ -1283,7 +1291,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] *= alpha;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UA; ++u) {
       const float p = ok[u] ? expf(sc[u] - m_new) : 0.f;
       float vv[EPL];
       unpack16(vf[u], vv, WT());
@@ -1296,6 +1304,29 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   l_run = across_groups_reduce<OpSum, LPR>(l_run);
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] = across_groups_reduce<OpSum, LPR>(o[e]);
+  if constexpr (WPU > 1) {  // merge the WPU partial softmaxes of an utterance (fixed wave order: deterministic)
+    if (r == 0) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) s_o[wave * 64 + c * EPL + e] = o[e];
+      if (c == 0) { s_ml[wave * 2] = m_run; s_ml[wave * 2 + 1] = l_run; }
+    }
+    __syncthreads();
+    if (sub != 0 || !live) return;
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < WPU; ++i) M = fmaxf(M, s_ml[(wave + i) * 2]);
+    l_run = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < WPU; ++i) {
+      const float mi = s_ml[(wave + i) * 2];
+      const float wgt = (mi == -INFINITY) ? 0.f : expf(mi - M);
+      l_run += wgt * s_ml[(wave + i) * 2 + 1];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] += wgt * s_o[(wave + i) * 64 + c * EPL + e];
+    }
+  }
   if (r == 0) {
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     float res[EPL];

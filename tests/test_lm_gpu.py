@@ -381,6 +381,25 @@ def test_fused_cross_block_in_groups_of_eight(bsz, grouped, monkeypatch):
         assert err < tol, (bsz, prec, err)
 
 
+@pytest.mark.parametrize("g", [2, 4])
+@pytest.mark.parametrize("bsz,N", [(9, 21), (13, 70), (32, 64)])
+def test_fused_cross_block_with_fewer_utterances_per_workgroup(g, bsz, N, monkeypatch):
+    """PTTS_XATTN_G = 4 / 2 (read at engine creation): above 8 utterances the fused cross block runs heads x ceil(B / g) workgroups (128 / 256
+    at batch 32 instead of 64); the 8 / g waves of an utterance split the description's row groups and merge their partial softmaxes through
+    LDS. Ragged last group, ragged masks, a description longer than one batch of row groups (N = 70), Mini and Large widths."""
+    monkeypatch.setenv("PTTS_XATTN_G", str(g))
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=49)
+    for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
+        err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=N, P=6, steps=3, masks=True, seed=bsz)
+        assert err < tol, (g, bsz, prec, err)
+    if bsz == 13:
+        spec = DO.DecoderSpec(hidden_size=1536, num_attention_heads=24, ffn_dim=6144, num_hidden_layers=2, max_position_embeddings=256)
+        sd = DO.make_decoder_weights(spec, seed=77)
+        err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=N, P=5, steps=3, masks=True, seed=3)
+        assert err < 3e-2, (g, "large", err)
+
+
 def test_large_v1_width_two_layers_bf16_and_fp32_batch():
     """Large-v1 widths (H=1536, 24 heads, F=6144; init_large_model.py:25-43) with 2 layers, batch 1 and 12:
     6-float4 LayerNorm rows, 6 / 12-wave K splits, the prep-kernel (M > 8) path."""
