@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 5
+#define PTTS_ABI_VERSION 6
 
 enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
 
@@ -184,6 +184,16 @@ int ptts_dac_load_weight(ptts_dac* d, const char* name, const float* dev_ptr, co
 int ptts_dac_weights_ready(ptts_dac* d);
 /* codes_dev int64 [B, K, T] -> wave_dev float32 [B, hop*T]  (hop = prod(rates)). */
 int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream);
+/* (ABI v6) The per-sample branch of generate() (modeling_parler_tts.py:3615-3647: after the special-id filter every utterance has its own
+ * number of frames; the reference decodes them one at a time and zero-pads with pad_sequence) as two enqueued calls, no host round trip
+ * between them:
+ *   ptts_dac_compact_codes  - per utterance, drops every frame in which any codebook holds an id outside [0, codebook_size) (:3627-3636)
+ *                             and keeps the rest in order: codes_in/out int64 [B][K][T] (must not alias), frames_out int32 [B] ON THE DEVICE;
+ *   ptts_dac_decode_ragged  - ONE decode pass of codes [B][K][T] in which utterance b is decoded as exactly frames_dev[b] (<= T) frames:
+ *                             rows past its length are the convolutions' zero padding, tiles past it exit at once; wave_dev float32
+ *                             [B][hop*T], zero beyond hop*frames_dev[b] (what pad_sequence(..., padding_value=0) yields, :3643-3647). */
+int ptts_dac_compact_codes(ptts_dac* d, const int64_t* codes_in_dev, int64_t* codes_out_dev, int32_t* frames_out_dev, int32_t B, int32_t T, void* stream);
+int ptts_dac_decode_ragged(ptts_dac* d, const int64_t* codes_dev, const int32_t* frames_dev, float* wave_dev, int32_t B, int32_t T, void* stream);
 /* Streaming / chunked decode (parler_tts/streamer.py:66-131: `apply_delay_pattern_mask` there re-decodes the whole token
  * cache at every `play_steps`; SURVEY.md §8(b) `ptts_dac_decode_chunk`): the window of frames [first_frame - halo (clamped at 0),
  * first_frame + n_frames) of codes_dev int64 [B, K, codes_ld] is decoded and the samples of its frames [first_frame,
@@ -202,6 +212,13 @@ int ptts_dac_decode_chunk(ptts_dac* d, const int64_t* codes_dev, int64_t codes_l
 int ptts_dac_encode(ptts_dac* d, const float* wave_dev, int64_t* codes_dev, int32_t B, int32_t L, int32_t n_quantizers, void* stream);
 /* Debug / parity probe: latents z of the last encode, channels-last fp32 [B, L/hop, latent_dim]. */
 int ptts_dac_debug_latents(ptts_dac* d, float** latents_dev);
+/* (ABI v6) Parity probe: ptts_dac_decode stopped after `stage` (0 = decoder.model.0, then per up-sampling block its transposed conv and its
+ * three residual units: 1 + 4 * num_rates stages). Returns the engine's own buffers with that stage's outputs, valid until the next call:
+ * act [B][rows][channels] (bf16 bits if *act_is_bf16 else fp32: the Snake'd activation the next conv reads), raw [B][rows][channels] fp32
+ * (the residual stream; null for stage 0). Replaces nothing in the reference: it exists so that each conv kernel can be compared with the
+ * oracle's restatement of ONE layer (dac_wrapper/modeling_dac.py:139 -> descript DecoderBlock / ResidualUnit) on identical inputs. */
+int ptts_dac_debug_decode_upto(ptts_dac* d, const int64_t* codes_dev, int32_t B, int32_t T, int32_t stage, void* stream, void** act_dev,
+                               int32_t* act_is_bf16, float** raw_dev, int32_t* rows, int32_t* channels);
 
 #ifdef __cplusplus
 }

@@ -216,6 +216,38 @@ class DacOracle:
         x = F.conv1d(x, w[f"{d}{n + 2}.weight"], w[f"{d}{n + 2}.bias"], padding=3)
         return torch.tanh(x)
 
+    # ---- one stage at a time (per-kernel parity: tests/test_dac_stage_parity_gpu.py) -------------------------------------------------
+    def n_stages(self) -> int:
+        return 1 + 4 * len(self.spec.decoder_rates)
+
+    def stage(self, s: int, act_in: torch.Tensor, raw_in):
+        """Stage `s` of decode_latents on GIVEN inputs (0 = decoder.model.0 on z; per block: the transposed conv, then residual unit 1, 2, 3):
+        (act_in [B, C, T] = the activation the stage's first conv reads - already Snake'd and, in bf16 mode, bf16-valued -, raw_in = the
+        residual stream before the stage) → (raw_out = the stream after the stage, act_out = Snake of it with the NEXT layer's alpha, rounded
+        like decode_latents rounds it, y = the unit's inner activation or None). Same operations, same order as decode_latents."""
+        w, d = self.w, "decoder.model."
+        rb = _rb if self.precision == "bf16" else (lambda v: v)
+        n = len(self.spec.decoder_rates)
+        if s == 0:
+            raw = F.conv1d(act_in, w[d + "0.weight"], w[d + "0.bias"], padding=3)
+            return raw, rb(snake1d(raw, w[d + "1.block.0.alpha"])), None
+        bi, k = divmod(s - 1, 4)
+        b = f"{d}{bi + 1}.block."
+        if k == 0:
+            st = self.spec.decoder_rates[bi]
+            raw = F.conv_transpose1d(act_in, w[b + "1.weight"], w[b + "1.bias"], stride=st, padding=math.ceil(st / 2))
+            return raw, rb(snake1d(raw, w[b + "2.block.0.alpha"])), None
+        ri, dil = k - 1, (1, 3, 9)[k - 1]
+        r = f"{b}{ri + 2}.block."
+        y = F.conv1d(act_in, w[r + "1.weight"], w[r + "1.bias"], dilation=dil, padding=3 * dil)
+        y = rb(snake1d(y, w[r + "2.alpha"]))
+        raw = raw_in + F.conv1d(y, w[r + "3.weight"], w[r + "3.bias"])
+        if ri < 2:
+            return raw, rb(snake1d(raw, w[f"{b}{ri + 3}.block.0.alpha"])), y
+        if bi + 1 < n:
+            return raw, rb(snake1d(raw, w[f"{d}{bi + 2}.block.0.alpha"])), y
+        return raw, snake1d(raw, w[f"{d}{n + 1}.alpha"]), y  # feeds the fp32 final conv: not rounded
+
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
         """codes [B, K, T] → waveform [B, 1, hop·T]  (DACModel.decode, modeling_dac.py:138-139)."""
         return self.decode_latents(self.from_codes(codes))

@@ -44,7 +44,7 @@ class PttsDacConfig(C.Structure):
     ]
 
 
-ABI_VERSION = 5  # PTTS_ABI_VERSION in include/ptts.h
+ABI_VERSION = 6  # PTTS_ABI_VERSION in include/ptts.h
 
 # every symbol include/ptts.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64P = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
@@ -72,9 +72,12 @@ SYMBOLS = {
     "ptts_dac_load_weight": (C.c_int, [_VP, C.c_char_p, _VP, _I64P, _I32, _VP]),
     "ptts_dac_weights_ready": (C.c_int, [_VP]),
     "ptts_dac_decode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
+    "ptts_dac_compact_codes": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP]),
+    "ptts_dac_decode_ragged": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP]),
     "ptts_dac_decode_chunk": (C.c_int, [_VP, _VP, C.c_int64, _I32, _I32, _I32, _VP, C.c_int64, _I32, _I32, _VP]),
     "ptts_dac_encode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "ptts_dac_debug_latents": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "ptts_dac_debug_decode_upto": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_I32)]),
 }
 
 _lib: Optional[C.CDLL] = None

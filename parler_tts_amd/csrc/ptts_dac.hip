@@ -41,7 +41,12 @@ struct ConvArgs {
   int dil, pad, transposed;  // tap offset: conv  tap*dil - pad ; transposed (stride = nphase)  (ph + pad)/nphase - tap
   int B, Tin, Cin, Cout, ntaps, nphase;
   int stride, Tn;      // input stride of a down-sampling conv (else 1); output frames per phase (Tin unless strided)
+  const int* lens;     // ragged decode (ptts_dac_decode_ragged): latent frames per utterance [B] on the device, or null. Utterance b then has
+  int len_mul;         // lens[b] * len_mul valid input rows (= output rows per phase): rows beyond read as the zero padding, tiles beyond exit
 };
+
+// valid input rows of utterance b (buffers keep the full stride a.Tin)
+__device__ __forceinline__ int valid_rows(const ConvArgs& a, int b) { return a.lens ? min(a.Tin, a.lens[b] * a.len_mul) : a.Tin; }
 
 // FAST (bf16-operand mode, whose activations are rounded to bf16 anyway): v_sin_f32 on a*x / 2pi instead of the ~100-instruction
 // exact sinf - the Snake epilogue of the 42 M-element layers was ~100 us of VALU per layer (profiles/r02_dac_layers.txt).
@@ -73,7 +78,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int tile = blockIdx.x % ntile, ph = (blockIdx.x / ntile) % a.nphase, b = blockIdx.x / (ntile * a.nphase);
   const int strip0 = blockIdx.y * CS;
   const int nstrips = a.Cout / 16;
-  if (tile * fpb + wave * 32 >= a.Tn) return;
+  const int Tv = valid_rows(a, b), Tnv = a.lens ? Tv : a.Tn;  // ragged decode: this utterance's rows
+  if (tile * fpb + wave * 32 >= Tnv) return;
   constexpr int KC = BF ? 32 : 16;      // channels per k-step
   const int cpt = a.Cin / KC;           // k-steps per tap
   const int nk = a.ntaps * cpt;
@@ -96,8 +102,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int ti0_ = (j0 + j) * a.stride + off_, ti1_ = ti0_ + 16 * a.stride;                                            \
     B0 = make_float4(0, 0, 0, 0);                                                                                        \
     B1 = make_float4(0, 0, 0, 0);                                                                                        \
-    if (ti0_ >= 0 && ti0_ < a.Tin) B0 = *reinterpret_cast<const float4*>(xb + ((size_t)ti0_ * a.Cin + cc_ * KC) * (BF ? 2 : 4) + q * 16);  \
-    if (ti1_ >= 0 && ti1_ < a.Tin) B1 = *reinterpret_cast<const float4*>(xb + ((size_t)ti1_ * a.Cin + cc_ * KC) * (BF ? 2 : 4) + q * 16);  \
+    if (ti0_ >= 0 && ti0_ < Tv) B0 = *reinterpret_cast<const float4*>(xb + ((size_t)ti0_ * a.Cin + cc_ * KC) * (BF ? 2 : 4) + q * 16);  \
+    if (ti1_ >= 0 && ti1_ < Tv) B1 = *reinterpret_cast<const float4*>(xb + ((size_t)ti1_ * a.Cin + cc_ * KC) * (BF ? 2 : 4) + q * 16);  \
     _Pragma("unroll") for (int s_ = 0; s_ < CS; ++s_) WF[s_] = Wp[((size_t)(strip0 + s_) * nk + (KS)) * 64];             \
   } while (0)
   float4 wf[CS], b0, b1;
@@ -133,7 +139,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int Tout = a.Tn * a.nphase;
   auto emit = [&](const f32x4& av, int s, int half) {
     const int jj = j0 + half * 16 + j;
-    if (jj >= a.Tn) return;
+    if (jj >= Tnv) return;
     const int co = (strip0 + s) * 16 + q * 4;
     const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
     const size_t o = ((size_t)b * Tout + (size_t)jj * a.nphase + ph) * a.Cout + co;
@@ -189,6 +195,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   const int nchunk = a.Cin / KCH;
   const int NS = a.ntaps * KS;  // k-steps per chunk
   const int t0 = tile * TF;
+  const int Tv = valid_rows(a, b), Tnv = a.lens ? Tv : a.Tn;  // ragged decode: this utterance's rows (workgroup-uniform)
+  if (t0 >= Tnv) return;
   // slab row r holds input frame t0 + o0 + r; tap `tap` of output frame t0 + f reads row f + rel(tap)
   const int o0 = a.transposed ? (ph + a.pad) / a.nphase - (a.ntaps - 1) : -a.pad;
   const int halo = a.transposed ? a.ntaps - 1 : (a.ntaps - 1) * a.dil;
@@ -208,7 +216,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
     const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL, ti_ = t0 + o0 + r_;                              \
     stg[i_] = make_uint4(0, 0, 0, 0);                                                                                    \
-    if (idx_ < nslot && ti_ >= 0 && ti_ < a.Tin)                                                                          \
+    if (idx_ < nslot && ti_ >= 0 && ti_ < Tv)                                                                             \
       stg[i_] = *reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * a.Cin + (size_t)(C) * KCH) * 2 + sl_ * 16);            \
   }
 #define PTTS_SLAB_COMMIT(BUF)                                                                                           \
@@ -283,7 +291,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   const int Tout = a.Tn * a.nphase;
   auto emit = [&](const f32x4 av, const int s, const int f) {
     const int jj = t0 + f * 16 + j;
-    if (jj >= a.Tn) return;
+    if (jj >= Tnv) return;
     const int co = (strip0 + s) * 16 + q * 4;
     const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
     const size_t o = ((size_t)b * Tout + (size_t)jj * a.nphase + ph) * a.Cout + co;
@@ -357,6 +365,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   const int nchunk = C / KCH;
   const int NS = a.ntaps * KS;
   const int t0 = tile * TF;
+  const int Tv = valid_rows(a, b);  // ragged decode: this utterance's rows (workgroup-uniform)
+  if (t0 >= Tv) return;
   const int o0 = -a.pad;
   const int halo = (a.ntaps - 1) * a.dil;
   const int nslot = (TF + halo) * SL;
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
     const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL, ti_ = t0 + o0 + r_;                              \
     stg[i_] = make_uint4(0, 0, 0, 0);                                                                                    \
-    if (idx_ < nslot && ti_ >= 0 && ti_ < a.Tin)                                                                          \
+    if (idx_ < nslot && ti_ >= 0 && ti_ < Tv)                                                                             \
       stg[i_] = *reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * C + (size_t)(CC) * KCH) * 2 + sl_ * 16);               \
   }
 #define RU_SLAB_COMMIT(BUFP)                                                                                            \
@@ -483,7 +493,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   // ---- phase B epilogue: + bias + residual, fp32 stream out, Snake of the unit's output
   auto emit = [&](const f32x4 av, const int s, const int f) {
     const int jj = t0 + f * 16 + j;
-    if (jj >= a.Tn) return;
+    if (jj >= Tv) return;
     const int co = (strip0 + s) * 16 + q * 4;
     const float4 bs = *reinterpret_cast<const float4*>(ra.bias1 + co);
     const size_t o = ((size_t)b * a.Tn + (size_t)jj) * C + co;
@@ -512,7 +522,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 // samples [skip, t_end) of every utterance are written to out[b * out_ld + (t - skip)] (skip > 0: the halo frames of a chunk)
 constexpr int OUT_OS = 4;
 __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                     float* __restrict__ out, int B, int T, int C, int ktaps, int skip, long long out_ld, int t_end) {
+                                     float* __restrict__ out, int B, int T, int C, int ktaps, int skip, long long out_ld, int t_end,
+                                     const int* __restrict__ lens, int len_mul) {
   extern __shared__ float sw[];
   for (int i = threadIdx.x; i < ktaps * C; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
@@ -520,6 +531,8 @@ __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* _
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * TG) return;
   const int b = (int)(idx / TG), t0 = (int)(idx % TG) * OUT_OS;
+  const int Tv = lens ? min(T, lens[b] * len_mul) : T;  // ragged decode: samples of this utterance (rows beyond are the zero padding)
+  t_end = min(t_end, Tv);
   if (t0 + OUT_OS <= skip || t0 >= t_end) return;
   float acc[OUT_OS];
 #pragma unroll
@@ -527,7 +540,7 @@ __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* _
   const int half = ktaps / 2;
   for (int r = 0; r < OUT_OS + ktaps - 1; ++r) {  // input row t0 - half + r feeds sample s with tap r - s
     const int ti = t0 - half + r;
-    if (ti < 0 || ti >= T) continue;
+    if (ti < 0 || ti >= Tv) continue;
     const float4* xr = reinterpret_cast<const float4*>(x + ((size_t)b * T + ti) * C);
     for (int c4 = 0; c4 < C / 4; ++c4) {
       const float4 xv = xr[c4];
@@ -544,7 +557,7 @@ __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* _
 #pragma unroll
   for (int s = 0; s < OUT_OS; ++s) {
     const int t = t0 + s;
-    if (t < T && t >= skip && t < t_end) out[(size_t)b * out_ld + (t - skip)] = tanhf(acc[s]);
+    if (t < Tv && t >= skip && t < t_end) out[(size_t)b * out_ld + (t - skip)] = tanhf(acc[s]);
   }
 }
 
@@ -556,10 +569,13 @@ __global__ void conv_out_tanh_kernel(const float* __restrict__ x, const float* _
 // of the reference restatement (bias, tap 0..6 x channel 0..95): the exact-f32 mode stays bit-identical to the direct kernel.
 constexpr int OUT_TILE = 64, OUT_C = 96, OUT_ROW = 100;  // 64 samples per (one-wave) workgroup: 28 KB of LDS, 5 workgroups per CU
 __global__ void __launch_bounds__(OUT_TILE) conv_out_tanh_lds_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                     float* __restrict__ out, int T, int skip, long long out_ld, int t_end) {
+                                                                     float* __restrict__ out, int T, int skip, long long out_ld, int t_end,
+                                                                     const int* __restrict__ lens, int len_mul) {
   __shared__ __attribute__((aligned(16))) float sx[(OUT_TILE + 6) * OUT_ROW];
   __shared__ __attribute__((aligned(16))) float sw[7 * OUT_C];
   const int b = blockIdx.y, t0 = blockIdx.x * OUT_TILE, tid = threadIdx.x;
+  const int Tv = lens ? min(T, lens[b] * len_mul) : T;  // ragged decode: samples of this utterance (rows beyond are the zero padding)
+  t_end = min(t_end, Tv);
   if (t0 + OUT_TILE <= skip || t0 >= t_end) return;  // workgroup-uniform: nothing of this tile is emitted
   for (int i = tid; i < 7 * OUT_C / 4; i += OUT_TILE) reinterpret_cast<float4*>(sw)[i] = reinterpret_cast<const float4*>(w)[i];
   const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * T * OUT_C);
@@ -569,7 +585,7 @@ __global__ void __launch_bounds__(OUT_TILE) conv_out_tanh_lds_kernel(const float
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
       const int i = min(i0 + u * OUT_TILE, NV - 1), r = i / (OUT_C / 4), ti = t0 - 3 + r;
-      v[u] = (ti >= 0 && ti < T) ? xb[(size_t)ti * (OUT_C / 4) + (i - r * (OUT_C / 4))] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero outside [0, T)
+      v[u] = (ti >= 0 && ti < Tv) ? xb[(size_t)ti * (OUT_C / 4) + (i - r * (OUT_C / 4))] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero outside [0, Tv)
     }
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
@@ -579,12 +595,12 @@ __global__ void __launch_bounds__(OUT_TILE) conv_out_tanh_lds_kernel(const float
   }
   __syncthreads();
   const int t = t0 + tid;
-  if (t >= T || t < skip || t >= t_end) return;
+  if (t >= Tv || t < skip || t >= t_end) return;
   float acc = bias[0];
 #pragma unroll 1
   for (int tap = 0; tap < 7; ++tap) {
     const int ti = t - 3 + tap;
-    if (ti < 0 || ti >= T) continue;  // the direct kernel skips out-of-range rows too (no fma with the zero padding)
+    if (ti < 0 || ti >= Tv) continue;  // the direct kernel skips out-of-range rows too (no fma with the zero padding)
     const float* xr = sx + (tid + tap) * OUT_ROW;
     const float* wr = sw + tap * OUT_C;
 #pragma unroll
@@ -737,8 +753,9 @@ __global__ void rvq_table_kernel(const float* __restrict__ cb, const float* __re
 // z[b][t][c] = sum_i table[i][codes[b][i][t]][c]   (sequential over i, like from_codes)
 // codes rows have stride `ld` frames and the window starts at frame `t0` (chunked / streaming decode reads a slice in place)
 __global__ void rvq_gather_kernel(const long long* __restrict__ codes, const float* __restrict__ table, void* __restrict__ z,
-                                  int K, int T, int ncodes, int latent, int z_bf16, long long ld, int t0) {
+                                  int K, int T, int ncodes, int latent, int z_bf16, long long ld, int t0, const int* __restrict__ lens) {
   const int t = blockIdx.x, b = blockIdx.y;
+  if (lens && t >= lens[b]) return;  // ragged decode: frames beyond the utterance's length are never read
   __shared__ int s_code[32];
   if (threadIdx.x < K) {
     long long cde = codes[((size_t)b * K + threadIdx.x) * ld + t0 + t];
@@ -1085,9 +1102,10 @@ extern "C" int ptts_dac_weights_ready(ptts_dac* d) {
 }
 
 static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float* skip, float* out_raw, void* out_act, int B, int Tin, hipStream_t st,
-                    bool act_f32 = false) {
+                    bool act_f32 = false, const int* lens = nullptr, int len_mul = 1) {
   ConvArgs a = {};
   a.act_f32 = act_f32 ? 1 : 0;
+  a.lens = lens; a.len_mul = len_mul;
   a.x = x; a.Wp = L.Wp; a.bias = L.bias; a.skip = skip; a.out_raw = out_raw; a.out_act = out_act; a.alpha = L.alpha;
   a.B = B; a.Tin = Tin; a.Cin = L.Cin; a.Cout = L.Cout;
   if (!L.transposed) {
@@ -1171,8 +1189,9 @@ static bool resunit_fusable(const ConvLayer& c7, const ConvLayer& c1) {
          c7.alpha && c1.alpha;
 }
 static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, const float* skip, float* out_raw, void* out_act, int B, int T,
-                       hipStream_t st, bool act_f32) {
+                       hipStream_t st, bool act_f32, const int* lens = nullptr, int len_mul = 1) {
   ResArgs r = {};
+  r.a.lens = lens; r.a.len_mul = len_mul;
   r.a.x = x; r.a.Wp = c7.Wp; r.a.bias = c7.bias; r.a.alpha = c7.alpha; r.a.dil = c7.dil; r.a.pad = (c7.ksize - 1) * c7.dil / 2;
   r.a.B = B; r.a.Tin = T; r.a.Tn = T; r.a.Cin = c7.Cin; r.a.Cout = c7.Cout; r.a.ntaps = 7; r.a.nphase = 1; r.a.stride = 1;
   r.Wp1 = c1.Wp; r.bias1 = c1.bias; r.alpha1 = c1.alpha; r.skip = skip; r.out_raw = out_raw; r.out_act = out_act; r.act_f32 = act_f32 ? 1 : 0;
@@ -1192,9 +1211,13 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
   return PTTS_OK;
 }
 
+// parity probe (ptts_dac_debug_decode_upto): the buffers holding a stage's outputs when the decode stops there
+struct DacDebugTap { void* act; int act_is_bf16; float* raw; int rows, channels; };
+
 // decode the window [t0, t0 + T) of codes rows with stride `ld`; samples [skip, hop*T) of the window go to wave_dev rows of out_ld
 static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld, int t0, float* wave_dev, int skip, long long out_ld,
-                             int32_t B, int32_t T, void* stream, int emit = -1) {
+                             int32_t B, int32_t T, void* stream, int emit = -1, const int* lens = nullptr, int stop_stage = -1,
+                             DacDebugTap* tap = nullptr) {
   PTTS_TRY(ptts_dac_weights_ready(d));
   const ptts_dac_config& c = d->cfg;
   PTTS_CHECK(B >= 1 && B <= c.max_batch, PTTS_E_CAPACITY, "batch %d exceeds dac max_batch %d", B, c.max_batch);
@@ -1211,38 +1234,50 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
   }
   const bool bf = c.compute_dtype == PTTS_BF16;
   hipLaunchKernelGGL(rvq_gather_kernel, dim3(T, B), dim3(256), 0, st, (const long long*)codes_dev, d->table, (void*)d->bufZ, c.num_codebooks, T,
-                     c.codebook_size, c.latent_dim, bf ? 1 : 0, ld, t0);
+                     c.codebook_size, c.latent_dim, bf ? 1 : 0, ld, t0, lens);
   float *cur = d->bufA0, *other = d->bufA1;
-  int Tcur = T;
+  int Tcur = T, mul = 1;  // mul: rows per latent frame at the current layer (ragged decode: utterance b has lens[b] * mul valid rows)
   size_t li = 0;
-  PTTS_TRY(run_conv(d, d->convs[li++], d->bufZ, nullptr, nullptr, cur, B, Tcur, st));
+  PTTS_TRY(run_conv(d, d->convs[li++], d->bufZ, nullptr, nullptr, cur, B, Tcur, st, false, lens, mul));
+  int stage = 0;  // 0 = decoder.model.0; per block: the transposed conv, then its three residual units
+  const bool dbg = stop_stage >= 0;
+  auto stop_here = [&](float* raw, int ch, bool act_f32) {
+    if (stage++ != stop_stage) return false;
+    if (tap) { tap->act = cur; tap->act_is_bf16 = (bf && !act_f32) ? 1 : 0; tap->raw = raw; tap->rows = Tcur; tap->channels = ch; }
+    return true;
+  };
+  if (stop_here(nullptr, d->convs[0].Cout, false)) return PTTS_OK;
   for (int bi = 0; bi < c.num_rates; ++bi) {
     const ConvLayer& up = d->convs[li++];
-    PTTS_TRY(run_conv(d, up, cur, nullptr, d->bufY, other, B, Tcur, st));
+    PTTS_TRY(run_conv(d, up, cur, nullptr, d->bufY, other, B, Tcur, st, false, lens, mul));
     std::swap(cur, other);
     Tcur *= up.stride;
+    mul *= up.stride;
+    if (stop_here(d->bufY, up.Cout, false)) return PTTS_OK;
     for (int ri = 0; ri < 3; ++ri) {
       const ConvLayer& c7 = d->convs[li++];
       const ConvLayer& c1 = d->convs[li++];
       const bool last = bi + 1 == c.num_rates && ri == 2;  // feeds the final Conv1d(C -> 1): fp32 activations
-      if (resunit_fusable(c7, c1)) {  // experimental: both convs in one launch; the output goes to the OTHER activation buffer
-        PTTS_TRY(run_resunit(c7, c1, cur, d->bufY, c1.write_raw ? d->bufY : nullptr, other, B, Tcur, st, last));
+      float* raw_out = (c1.write_raw || dbg) ? d->bufY : nullptr;  // the parity probe also wants the stream after a block's last unit (same arithmetic, one more store)
+      if (resunit_fusable(c7, c1)) {  // both convs in one launch; the output goes to the OTHER activation buffer
+        PTTS_TRY(run_resunit(c7, c1, cur, d->bufY, raw_out, other, B, Tcur, st, last, lens, mul));
         std::swap(cur, other);
-        continue;
+      } else {
+        PTTS_TRY(run_conv(d, c7, cur, nullptr, nullptr, d->bufS, B, Tcur, st, false, lens, mul));
+        PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, raw_out, cur, B, Tcur, st, last, lens, mul));
       }
-      PTTS_TRY(run_conv(d, c7, cur, nullptr, nullptr, d->bufS, B, Tcur, st));
-      PTTS_TRY(run_conv(d, c1, d->bufS, d->bufY, c1.write_raw ? d->bufY : nullptr, cur, B, Tcur, st, last));
+      if (stop_here(d->bufY, c1.Cout, last)) return PTTS_OK;
     }
   }
   const int t_end = emit < 0 ? Tcur : std::min(Tcur, skip + emit);
   static const bool out_direct = getenv("PTTS_DAC_OUT_DIRECT") && atoi(getenv("PTTS_DAC_OUT_DIRECT"));  // A/B: the per-thread kernel
   if (d->out_C == OUT_C && !out_direct && B <= 65535) {
     hipLaunchKernelGGL(conv_out_tanh_lds_kernel, dim3((unsigned)((Tcur + OUT_TILE - 1) / OUT_TILE), (unsigned)B), dim3(OUT_TILE), 0, st, (const float*)cur,
-                       d->out_w, d->out_b, wave_dev, Tcur, skip, out_ld, t_end);
+                       d->out_w, d->out_b, wave_dev, Tcur, skip, out_ld, t_end, lens, mul);
   } else {
     const size_t n = (size_t)B * ((Tcur + OUT_OS - 1) / OUT_OS);
     hipLaunchKernelGGL(conv_out_tanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)7 * d->out_C * 4, st, cur, d->out_w, d->out_b,
-                       wave_dev, B, Tcur, d->out_C, 7, skip, out_ld, t_end);
+                       wave_dev, B, Tcur, d->out_C, 7, skip, out_ld, t_end, lens, mul);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac launch failed: %s", hipGetErrorString(e));
@@ -1252,6 +1287,71 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
 extern "C" int ptts_dac_decode(ptts_dac* d, const int64_t* codes_dev, float* wave_dev, int32_t B, int32_t T, void* stream) {
   PTTS_CHECK(d && codes_dev && wave_dev, PTTS_E_INVALID, "null argument");
   return dac_decode_window(d, codes_dev, T, 0, wave_dev, 0, (long long)d->hop * T, B, T, stream);
+}
+
+// Ragged batch (generate()'s per-sample branch, modeling_parler_tts.py:3615-3647: every utterance keeps its own number of frames after
+// the special-id filter; the reference decodes them one by one and zero-pads): ONE pass over codes [B][K][T] in which utterance b is
+// decoded as exactly frames_dev[b] frames - rows beyond its length read as the convolutions' zero padding, tiles beyond it exit at once,
+// its samples beyond hop * frames_dev[b] are zero (the buffer is cleared first). frames_dev: int32 [B] ON THE DEVICE (no host round trip
+// between the filter and the codec), values clamped to [0, T].
+extern "C" int ptts_dac_decode_ragged(ptts_dac* d, const int64_t* codes_dev, const int32_t* frames_dev, float* wave_dev, int32_t B, int32_t T,
+                                      void* stream) {
+  PTTS_CHECK(d && codes_dev && frames_dev && wave_dev, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(B >= 1 && T >= 1, PTTS_E_INVALID, "bad batch / frames");
+  {
+    PTTS_DEVICE(d->cfg.device);
+    PTTS_HIP(hipMemsetAsync(wave_dev, 0, (size_t)B * d->hop * T * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
+  }
+  return dac_decode_window(d, codes_dev, T, 0, wave_dev, 0, (long long)d->hop * T, B, T, stream, -1, frames_dev);
+}
+
+// The filter in front of it (modeling_parler_tts.py:3627-3636): per utterance, drop every frame (column) in which ANY codebook holds an
+// id >= codebook_size (or < 0), keep the others in order. codes_in / codes_out int64 [B][K][T] (may NOT alias), frames_out int32 [B].
+// One workgroup per utterance: keep flags -> block-wide exclusive scan over the T columns -> scatter; columns past the kept count are
+// filled with 0 (a valid id: the ragged decode never reads them).
+__global__ void __launch_bounds__(256) compact_codes_kernel(const long long* __restrict__ in, long long* __restrict__ out, int* __restrict__ frames,
+                                                            int K, int T, int ncodes) {
+  __shared__ int s_wsum[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long* src = in + (size_t)b * K * T;
+  long long* dst = out + (size_t)b * K * T;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < T; c0 += 256) {
+    const int t = c0 + tid;
+    int keep = 0;
+    if (t < T) {
+      keep = 1;
+      for (int k = 0; k < K; ++k) { const long long v = src[(size_t)k * T + t]; if (v < 0 || v >= ncodes) keep = 0; }
+    }
+    // exclusive scan of `keep` over the 256 columns of this chunk: wave ballot + 4 wave totals
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w2 = 0; w2 < wave; ++w2) off += s_wsum[w2];
+    if (keep) for (int k = 0; k < K; ++k) dst[(size_t)k * T + off + before] = src[(size_t)k * T + t];
+    __syncthreads();
+    if (tid == 0) s_base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+  }
+  const int n = s_base;
+  for (int i = tid; i < (T - n) * K; i += 256) dst[(size_t)(i / (T - n)) * T + n + i % (T - n)] = 0;
+  if (tid == 0) frames[b] = n;
+}
+
+extern "C" int ptts_dac_compact_codes(ptts_dac* d, const int64_t* codes_in_dev, int64_t* codes_out_dev, int32_t* frames_out_dev, int32_t B, int32_t T,
+                                      void* stream) {
+  PTTS_CHECK(d && codes_in_dev && codes_out_dev && frames_out_dev, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(B >= 1 && T >= 1 && codes_in_dev != codes_out_dev, PTTS_E_INVALID, "bad batch / frames, or codes_out aliases codes_in");
+  PTTS_DEVICE(d->cfg.device);
+  hipLaunchKernelGGL(compact_codes_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const long long*)codes_in_dev,
+                     (long long*)codes_out_dev, (int*)frames_out_dev, d->cfg.num_codebooks, T, d->cfg.codebook_size);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "compact launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
 }
 
 // Streaming / chunked decode (parler_tts/streamer.py:66-131 re-decodes the WHOLE token cache every `play_steps`): samples of
@@ -1322,6 +1422,22 @@ extern "C" int ptts_dac_encode(ptts_dac* d, const float* wave_dev, int64_t* code
                      d->opw_all, d->opb_all, (long long*)codes_dev, T, c.latent_dim, c.codebook_dim, c.codebook_size, nq);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "dac encode launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+// Debug / parity probe: ptts_dac_decode stopped after `stage` (0 = decoder.model.0; then per up-sampling block: its transposed conv, residual
+// unit 1, 2, 3: 1 + 4 * num_rates stages in all). Hands out the engine's own buffers holding that stage's outputs (valid until the next call):
+// act [B][rows][channels] = the Snake'd activation the next conv reads (bf16 bits if *act_is_bf16, else fp32), raw [B][rows][channels] fp32 =
+// the residual stream (null for stage 0). tests/test_dac_stage_parity_gpu.py feeds stage s - 1's outputs to the oracle's restatement of stage s:
+// every kernel is pinned on IDENTICAL inputs, free of the end-to-end amplification of bf16 rounding flips.
+extern "C" int ptts_dac_debug_decode_upto(ptts_dac* d, const int64_t* codes_dev, int32_t B, int32_t T, int32_t stage, void* stream, void** act_dev,
+                                          int32_t* act_is_bf16, float** raw_dev, int32_t* rows, int32_t* channels) {
+  PTTS_CHECK(d && codes_dev && act_dev && act_is_bf16 && raw_dev && rows && channels, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(stage >= 0 && stage < 1 + 4 * d->cfg.num_rates, PTTS_E_INVALID, "stage %d out of range [0, %d)", stage, 1 + 4 * d->cfg.num_rates);
+  DacDebugTap tap = {};
+  PTTS_TRY(dac_decode_window(d, codes_dev, T, 0, d->bufS /* unused: the decode stops before the final conv */, 0, (long long)d->hop * T, B, T, stream, -1, nullptr,
+                             stage, &tap));
+  *act_dev = tap.act; *act_is_bf16 = tap.act_is_bf16; *raw_dev = tap.raw; *rows = tap.rows; *channels = tap.channels;
   return PTTS_OK;
 }
 

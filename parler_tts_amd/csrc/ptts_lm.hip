@@ -101,7 +101,8 @@ struct ptts_engine {
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
   int xattn_groups_max = 256; // largest batch that runs the fused cross block in groups of 8 (PTTS_XATTN_GROUPS_MAX; above: rows_prep + q GEMM + attention)
-  int xattn_g = 8;            // utterances per workgroup of the fused cross block above 8 utterances (PTTS_XATTN_G = 8 / 4 / 2)
+  int xattn_g = 0;            // utterances per workgroup of the fused cross block above 8 utterances: 0 = by batch size (2 up to 32, 4 up to 64, 8 above), PTTS_XATTN_G = 8 / 4 / 2 forces one
+  bool xattn_g_ok = false;    // the g < 8 instances exist for this width (Mini-v1, Large-v1)
   bool xattn_groups = true;   // the fused LN2 + cross-q + cross-attention kernel also at batch 9..32, in groups of 8 utterances (PTTS_NO_XATTN_GROUPS=1: two nodes)
   int kv_ub = 0;         // host-side upper bound of the self-KV positions written so far (prefill + one per decode forward)
   int kv_bound = 0;      // attention fetch bound of the next decode forward: kv_ub + 1 rounded up to 64, <= max_ctx
@@ -476,7 +477,8 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       x.out = e->xw; x.B = M; x.nheads = nh; x.kv_heads = nkc; x.n_rep = nh / nkc; x.scale = scale; x.out_fo = fo;
       // utterances per workgroup: 8 (one per wave) up to 8 utterances; above, e->xattn_g (8 / 4 / 2: heads x ceil(M / g) workgroups, the 8 / g
       // waves of an utterance split the description's row groups)
-      const int gsz = M <= 8 ? 8 : e->xattn_g;
+      // measured (profiles/r04_experiments.txt, us per step at mid context, g = 8 / 4 / 2): batch 32 1432 / 1381 / 1360, batch 128 2596 / 2682 / 2860
+      const int gsz = M <= 8 ? 8 : (e->xattn_g ? e->xattn_g : (e->xattn_g_ok ? (M <= 32 ? 2 : (M <= 64 ? 4 : 8)) : 8));
       const int mg = M < gsz ? M : gsz;
       const size_t sh = (size_t)mg * (H * sizeof(WT) + 16) + 8 * 1024 + (size_t)gsz * 64 * 4 + 8 * 64 * 4 + 64;
       const dim3 xg(nh, (M + gsz - 1) / gsz);
@@ -818,7 +820,8 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
   if (const char* ev = getenv("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));
-  if (const char* ev = getenv("PTTS_XATTN_G")) { const int g = atoi(ev); if (g == 2 || g == 4 || g == 8) e->xattn_g = ((H == 1024 && ((H / (c.dtype == PTTS_BF16 ? 32 : 16)) / 2) % 16 == 0) || H == 1536) ? g : 8; }
+  e->xattn_g_ok = (H == 1024 && ((H / (c.dtype == PTTS_BF16 ? 32 : 16)) / 2) % 16 == 0) || H == 1536;
+  if (const char* ev = getenv("PTTS_XATTN_G")) { const int g = atoi(ev); if (g == 2 || g == 4 || g == 8) e->xattn_g = e->xattn_g_ok ? g : 8; }
   e->xattn_groups = !(getenv("PTTS_NO_XATTN_GROUPS") && atoi(getenv("PTTS_NO_XATTN_GROUPS")));  // measured: 1386 -> 1360 us per batch-32 step (profiles/r03_experiments.txt)
   A(e->alloc(&e->prefix, (size_t)c.max_batch * K * c.max_ctx));
   e->ids_ld = c.max_ctx + 8;

@@ -190,6 +190,26 @@ class DACModel(torch.nn.Module):
         return DACDecoderOutput(out)
 
     @torch.no_grad()
+    def decode_filtered(self, audio_codes):
+        """Not in the reference wrapper: the per-sample tail of ``generate()`` (modeling_parler_tts.py:3615-3647) in one pass. audio_codes
+        [1, batch, num_codebooks, frames] possibly holding special ids (>= codebook_size): per utterance every frame with a special id is
+        dropped, the rest is decoded, the waveforms are zero-padded to a common length. Returns (audio_values [batch, 1, hop*frames] float32
+        - zero beyond each utterance's length -, kept-frame counts int32 [batch] on the device). The reference loops over the samples with one
+        ``decode`` each; here the filter is one kernel and the codec one RAGGED pass (``ptts_dac_compact_codes`` + ``ptts_dac_decode_ragged``)."""
+        if len(audio_codes) != 1:
+            raise ValueError(f"Expected one frame, got {len(audio_codes)}")
+        codes = audio_codes[0]
+        B, _, T = codes.shape
+        eng = self._get_engine(B, T)
+        out = torch.empty(B, 1, eng.hop * T, dtype=torch.float32, device=self.device)
+        frames = torch.empty(B, dtype=torch.int32, device=self.device)
+        for b0 in range(0, B, eng.max_batch):
+            cc, fr = eng.compact_codes(codes[b0:b0 + eng.max_batch])
+            out[b0:b0 + eng.max_batch] = eng.decode_ragged(cc, fr)
+            frames[b0:b0 + eng.max_batch] = fr
+        return out, frames
+
+    @torch.no_grad()
     def decode_chunk(self, audio_codes, first_frame: int, n_frames: Optional[int] = None, halo: int = 16, out=None, n_emit=None):
         """Streaming decode (not in the reference wrapper; its streamer re-decodes the whole cache, streamer.py:119-122):
         audio_codes [1, 1, num_codebooks, frames] → the samples of frames [first_frame, first_frame + n_frames) as

@@ -302,6 +302,36 @@ class DacEngine:
         return out
 
 
+    def compact_codes(self, codes: torch.Tensor):
+        """codes int64 [B, K, T] → (codes with every frame holding an id outside [0, codebook_size) dropped, the kept ones in order
+        [B, K, T]; kept-frame counts int32 [B]), both on the device (``ptts_dac_compact_codes``; modeling_parler_tts.py:3627-3636)."""
+        if codes.dim() != 3 or codes.shape[1] != self.K:
+            raise ValueError(f"audio_codes must be [batch, {self.K}, frames], got {tuple(codes.shape)}")
+        codes = codes.to(self.device, torch.int64).contiguous()
+        B, _, T = codes.shape
+        out = torch.empty_like(codes)
+        frames = torch.empty(B, dtype=torch.int32, device=self.device)
+        N.check(self.lib.ptts_dac_compact_codes(self._h, C.c_void_p(codes.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), B, T,
+                                                _stream_ptr(device=self.device)), "ptts_dac_compact_codes")
+        self._keep = codes
+        return out, frames
+
+    def decode_ragged(self, codes: torch.Tensor, frames: torch.Tensor) -> torch.Tensor:
+        """codes int64 [B, K, T], frames int32 [B] on the device → waveform float32 [B, 1, hop*T] in which utterance b is the decode of its
+        first frames[b] frames and zero beyond (``ptts_dac_decode_ragged``: one pass, no per-utterance launches)."""
+        if codes.dim() != 3 or codes.shape[1] != self.K:
+            raise ValueError(f"audio_codes must be [batch, {self.K}, frames], got {tuple(codes.shape)}")
+        codes = codes.to(self.device, torch.int64).contiguous()
+        frames = frames.to(self.device, torch.int32).contiguous()
+        B, _, T = codes.shape
+        if frames.shape != (B,):
+            raise ValueError(f"frames must be [batch], got {tuple(frames.shape)}")
+        out = torch.empty(B, 1, self.hop * T, dtype=torch.float32, device=self.device)
+        N.check(self.lib.ptts_dac_decode_ragged(self._h, C.c_void_p(codes.data_ptr()), C.c_void_p(frames.data_ptr()), C.c_void_p(out.data_ptr()), B, T,
+                                                _stream_ptr(device=self.device)), "ptts_dac_decode_ragged")
+        self._keep = (codes, frames)
+        return out
+
     def decode_chunk(self, codes: torch.Tensor, first_frame: int, n_frames: int, halo: int, out: Optional[torch.Tensor] = None,
                      n_emit: Optional[int] = None) -> torch.Tensor:
         """codes int64 [B, K, T] (contiguous, on the device; read in place): decodes the window [first_frame - halo,
@@ -352,6 +382,27 @@ class DacEngine:
         if rc != 0:
             raise N.NativeLibraryError(f"hipMemcpy(D2D) failed with code {rc}")
         return out.transpose(1, 2).contiguous()
+    def debug_stage(self, codes: torch.Tensor, stage: int):
+        """Parity probe (``ptts_dac_debug_decode_upto``): decode stopped after `stage`; returns (act [B, C, rows] float32 - the exact values
+        of the bf16 / fp32 activation buffer -, raw [B, C, rows] float32 residual stream or None)."""
+        codes = codes.to(self.device, torch.int64).contiguous()
+        B, _, T = codes.shape
+        act, raw = C.c_void_p(), C.c_void_p()
+        is_bf, rows, ch = C.c_int32(), C.c_int32(), C.c_int32()
+        N.check(self.lib.ptts_dac_debug_decode_upto(self._h, C.c_void_p(codes.data_ptr()), B, T, int(stage), _stream_ptr(device=self.device), C.byref(act),
+                                                    C.byref(is_bf), C.byref(raw), C.byref(rows), C.byref(ch)), "ptts_dac_debug_decode_upto")
+        hip = N.hip_runtime()
+
+        def grab(ptr, dtype):
+            t = torch.empty(B, rows.value, ch.value, dtype=dtype, device=self.device)
+            rc = hip.hipMemcpyAsync(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(t.numel() * t.element_size()), 3, _stream_ptr(device=self.device))
+            if rc != 0:
+                raise N.NativeLibraryError(f"hipMemcpy(D2D) failed with code {rc}")
+            return t.float().transpose(1, 2).contiguous()
+
+        a = grab(act.value, torch.bfloat16 if is_bf.value else torch.float32)
+        r = grab(raw.value, torch.float32) if raw.value else None
+        return a, r
 
 
 def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

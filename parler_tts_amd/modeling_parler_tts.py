@@ -639,7 +639,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         sub-batches, each on its own engine and HIP stream. Measured in round 3 at batch 32 (2 x 16: 1452 -> 1525 ms per generate(), loses:
         a latency-bound chain does not get shorter with fewer rows) and at batch 8; kept for the >= 64-utterance operating point, where one
         half's bandwidth-bound self-attention can overlap the other half's latency-bound GEMM chain (profiles/r04_experiments.txt)."""
-        n = int(getattr(self, "decode_streams", 0) or os.environ.get("PTTS_DECODE_STREAMS", "1") or 1)
+        n = int(getattr(self, "decode_streams", 0) or os.environ.get("PTTS_DECODE_STREAMS", "0") or 0)
+        if n == 0:  # automatic: two sub-batches where it measured faster (64 utterances: 1929 -> 1784 ms per generate(); 128: 2643 -> 2630, neutral;
+            n = 2 if (64 <= B < 128 and B % 2 == 0 and self.device.type == "cuda") else 1  # 32: loses; four sub-batches: 2.7-3.3x slower)
         # smallest sub-batch worth its own engine: 8 by default; 4 lets batch 5..8 run as two GEMV-step sub-batches (0.84 ms at 4 utterances
         # against 1.33 ms for 8 on the MFMA strips) - to be measured with the rest (tools/experimental/run_all.sh)
         min_sub = int(getattr(self, "decode_streams_min_sub", 0) or os.environ.get("PTTS_DECODE_STREAMS_MIN_SUB", "8") or 8)
@@ -857,7 +859,23 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                                              stopping_criteria, streamer, eos, pad, delayed, hf_list=hf_list)
         if streamer is not None:
             streamer.end()
-        # --- un-delay (:3585-3597) and decode (:3600-3647) -------------------------------------------------------------
+        wav, lengths = self._undelay_and_decode(output_ids, pattern, bos_col, bos, pad, wav_pre)
+        if as_dict:
+            out = GenerateOutput(sequences=wav, audios_length=lengths)
+            if keep_scores:
+                out["scores"] = tuple(self._step_records[0])
+            if keep_logits:
+                out["logits"] = tuple(self._step_records[1])
+            self._step_records = (None, None)
+            return out
+        return wav
+
+    def _undelay_and_decode(self, output_ids, pattern, bos_col, bos, pad, wav_pre=None):
+        """The tail of generate() after the token loop: un-delay (:3585-3597), per-sample special-id filter and codec (:3600-3647).
+        Returns (waveform [B, samples] zero-padded, per-sample lengths)."""
+        d = self.config.decoder
+        K, dev = d.num_codebooks, output_ids.device
+        B = output_ids.shape[0] // K
         # The reference rebuilds the mask from the un-delayed `input_ids` (:3589-3594); only its BOS / PAD triangles are
         # tested (:3596), and audio codes are never BOS / PAD, so the BOS column alone gives the identical keep-mask.
         output_ids = apply_delay_pattern_mask(output_ids, pattern)
@@ -872,7 +890,15 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             else:
                 wav = self.audio_encoder.decode(audio_codes=codes[None], audio_scales=[None] * B).audio_values.squeeze(1)
             lengths = [int(wav.shape[1])] * B
-        else:  # per-sample: drop every column holding a special id, decode, zero-pad (:3627-3647)
+        elif callable(getattr(self.audio_encoder, "decode_filtered", None)):
+            # per-sample branch (:3627-3647: drop every column holding a special id, decode, zero-pad) as ONE filter kernel + ONE ragged
+            # codec pass over the whole batch; the only host synchronisation is the read of the B kept-frame counts for `audios_length`
+            wav_full, frames = self.audio_encoder.decode_filtered(codes[None])
+            hop = wav_full.shape[-1] // max(codes.shape[-1], 1)
+            nf = [int(x) for x in frames.tolist()]
+            lengths = [n * hop if n > 0 else 1 for n in nf]  # an utterance with no valid frame yields torch.zeros(1) in the reference (:3641)
+            wav = wav_full[:, 0, :max(lengths)]
+        else:  # a codec without the ragged entry points (any AutoModel-registered codec: SURVEY §8(b)): the reference's loop, literally
             outs: List[torch.Tensor] = []
             for b in range(B):
                 ok = bad[b].sum(dim=0) == 0
@@ -883,15 +909,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                 outs.append(w)
             lengths = [int(w.shape[0]) for w in outs]
             wav = torch.nn.utils.rnn.pad_sequence(outs, batch_first=True, padding_value=0)
-        if as_dict:
-            out = GenerateOutput(sequences=wav, audios_length=lengths)
-            if keep_scores:
-                out["scores"] = tuple(self._step_records[0])
-            if keep_logits:
-                out["logits"] = tuple(self._step_records[1])
-            self._step_records = (None, None)
-            return out
-        return wav
+        return wav, lengths
 
     # -- default path: the whole `_sample` loop runs on the device -------------------------------------------------------
     def _run_device_loop(self, eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, given: int = 1, min_new: int = 0):

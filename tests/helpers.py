@@ -6,9 +6,11 @@ from oracle import decoder_oracle as DO
 from oracle import dac_oracle as DA
 
 
-# relative waveform RMS of the bf16-operand DAC engine against DacOracle(precision="bf16"): 2 x the largest value measured on MI355X
-# over every bf16 codec test (profiles/r04_parity_dac_bf16.txt)
-DAC_BF16_TOL = 2e-3
+# END-TO-END relative waveform RMS of the bf16-operand DAC engine against DacOracle(precision="bf16"): 2 x the value measured on MI355X at 860
+# frames (9.7e-3, profiles/r04_parity_dac_bf16.txt). It cannot be tighter: the oracle evaluated with float64 accumulation is already 9.0e-3 away
+# from itself (bf16 rounding flips amplified by ~30 layers, profiles/r04_dac_bf16_sensitivity.txt). The tight pin of the bf16 kernels is per stage,
+# on identical inputs: tests/test_dac_stage_parity_gpu.py (4e-4 on each stage's own contribution).
+DAC_BF16_TOL = 2e-2
 
 
 def log_parity(msg, name="r04_parity_dac_bf16.txt"):

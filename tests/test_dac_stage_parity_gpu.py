@@ -1,0 +1,95 @@
+"""GPU: every DAC decode kernel pinned against the oracle's restatement of ONE stage on IDENTICAL inputs (ptts_dac_debug_decode_upto).
+
+Why per stage: end to end, two evaluations of the SAME bf16-operand model that differ only in fp32 summation order are already ~1 % apart on
+the synthetic 44.1 kHz stack (a 1e-7 perturbation moves a few activations across a bf16 rounding boundary, and ~30 layers of Snake / conv
+amplify each 2^-8 flip ~70x; measured on the CPU oracle itself, profiles/r04_dac_bf16_sensitivity.txt). Stage by stage that amplification
+is gone: stage s of the engine and of the oracle read the same tensors (the ENGINE's outputs of stage s - 1), so what is left is
+  * the fp32 residual stream `raw`: summation order of the MFMA accumulation (1e-6) and, for a residual unit, bf16 flips of its INNER
+    activation y (v_sin_f32 / summation order at a rounding boundary): each flip moves one k1-conv operand by 2^-8;
+  * the bf16 activation `act` = bf16(Snake(raw)): compared through the ENGINE's raw, so only flips at that one rounding are left.
+Bars (bf16-operand mode; set from the first MI355X run x 2, record profiles/r04_parity_dac_stages.txt): relative RMS of the stage's own
+contribution to the stream (a unit's raw - raw_in; a transposed conv's raw) <= RAW_TOL;
+act: every element within one bf16 ulp (2^-7 relative) and <= ACT_FLIP of the elements different at all. The negative controls in
+tests/test_oracle_dac.py show what these bars catch: a unit whose inner activation is NOT rounded, a dropped tap, a one-frame halo slip."""
+import pytest
+import torch
+
+from helpers import log_parity
+from oracle import dac_oracle as DA
+
+pytestmark = pytest.mark.gpu
+
+RAW_TOL = {"bf16": 4e-4, "fp32": 2e-5}
+ACT_FLIP = 5e-3
+
+
+def _rel(a, b):
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-20))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_every_stage_matches_the_oracle_on_identical_inputs(mode, fuse, monkeypatch):
+    from parler_tts_amd.engine import DacEngine
+
+    if not fuse:
+        if mode == "fp32":
+            pytest.skip("the fused residual units exist in the bf16-operand mode only")
+        monkeypatch.setenv("PTTS_DAC_NO_FUSE_RES", "1")
+    spec = DA.DAC_44KHZ
+    sd = DA.make_dac_weights(spec, seed=4321)
+    B, T = 2, 37  # 37 latent frames = 296 / 2368 / 9472 / 18944 rows: ragged last tile at every rate, several 128-row tiles from block 1 on
+    codes = torch.randint(0, 1024, (B, 9, T), generator=torch.Generator().manual_seed(8))
+    d = DacEngine(max_batch=B, max_frames=T, compute_dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+    d.load_state_dict(sd)
+    orc = DA.DacOracle(spec, sd, precision=mode)
+    z = orc.from_codes(codes)
+    prev_act, prev_raw = (DA._rb(z) if mode == "bf16" else z), None
+    worst_raw, worst_flip = 0.0, 0.0
+    for s in range(orc.n_stages()):
+        act, raw = d.debug_stage(codes.cuda(), s)
+        act, raw = act.cpu(), (raw.cpu() if raw is not None else None)
+        exp_raw, _, _ = orc.stage(s, prev_act, prev_raw)
+        if raw is not None:
+            # a residual unit is judged on what IT adds to the stream (raw - raw_in: the k1 conv's output), not on the stream, whose
+            # skip term would dilute an error of the unit's own arithmetic by ~3x; a transposed conv on its output
+            unit = s >= 1 and (s - 1) % 4 != 0
+            e = _rel(raw - prev_raw, exp_raw - prev_raw) if unit else _rel(raw, exp_raw)
+            worst_raw = max(worst_raw, e)
+            assert raw.shape == exp_raw.shape and e <= RAW_TOL[mode], (mode, fuse, s, e)
+            assert float((raw - exp_raw).abs().max()) <= 2e-2 * float(exp_raw.abs().max()), (s, "max")
+            src = raw
+        else:
+            src = exp_raw  # stage 0 hands out no stream: its activation is checked through the oracle's own pre-activation
+        # act = round(Snake(stream)) with the NEXT layer's alpha: recomputed from the ENGINE's stream, so only this one rounding can differ
+        exp_act = orc.stage(s, prev_act, prev_raw)[1] if raw is None else _act_of(orc, s, src)
+        diff = (act - exp_act).abs()
+        tol = (2.0 ** -7) * exp_act.abs() + 1e-6 if mode == "bf16" else 1e-5 * (1 + exp_act.abs())
+        frac = float((diff > 1e-6 * (1 + exp_act.abs())).float().mean())
+        worst_flip = max(worst_flip, frac)
+        assert bool((diff <= tol * (4 if raw is None else 1)).all()), (mode, fuse, s, float((diff / tol).max()))
+        if mode == "bf16":
+            assert frac <= ACT_FLIP * (4 if raw is None else 1), (mode, fuse, s, frac)
+        prev_act, prev_raw = act, raw
+    log_parity(f"[dac stages {mode} fused={fuse}] {orc.n_stages()} stages, {B} x {T} frames: worst raw-stream relative RMS {worst_raw:.2e}, "
+               f"worst fraction of activation elements differing (<= 1 bf16 ulp each) {worst_flip:.2e}", name="r04_parity_dac_stages.txt")
+    d.close()
+
+
+def _act_of(orc, s, raw):
+    """Snake of stage s's stream with the next layer's alpha, rounded as decode_latents rounds it (DacOracle.stage's second output, from `raw`)."""
+    w, d = orc.w, "decoder.model."
+    n = len(orc.spec.decoder_rates)
+    rb = DA._rb if orc.precision == "bf16" else (lambda v: v)
+    if s == 0:
+        return rb(DA.snake1d(raw, w[d + "1.block.0.alpha"]))
+    bi, k = divmod(s - 1, 4)
+    b = f"{d}{bi + 1}.block."
+    if k == 0:
+        return rb(DA.snake1d(raw, w[b + "2.block.0.alpha"]))
+    ri = k - 1
+    if ri < 2:
+        return rb(DA.snake1d(raw, w[f"{b}{ri + 3}.block.0.alpha"]))
+    if bi + 1 < n:
+        return rb(DA.snake1d(raw, w[f"{d}{bi + 2}.block.0.alpha"]))
+    return DA.snake1d(raw, w[f"{d}{n + 1}.alpha"])

@@ -125,6 +125,21 @@ def _model(eos_gain=None):
         return types.SimpleNamespace(audio_values=wav[:, :, (first_frame - w0) * hop:])
 
     m.audio_encoder.decode_chunk = decode_chunk
+
+    def decode_filtered(audio_codes):  # ptts_dac_compact_codes + ptts_dac_decode_ragged semantics on the oracle codec
+        codes = audio_codes[0].cpu()
+        B, _, T = codes.shape
+        hop = DA.DAC_TINY.hop_length
+        out, frames = torch.zeros(B, 1, hop * T), torch.zeros(B, dtype=torch.int32)
+        for b in range(B):
+            ok = ((codes[b] >= 1024) | (codes[b] < 0)).sum(dim=0) == 0
+            n = int(ok.sum())
+            frames[b] = n
+            if n:
+                out[b, 0, :hop * n] = dac.decode(codes[b:b + 1, :, ok])[0, 0]
+        return out, frames
+
+    m.audio_encoder.decode_filtered = decode_filtered
     return m, spec, sd, dac
 
 

@@ -27,7 +27,7 @@ def test_exports_every_declared_symbol():
     assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ptts_abi_version() == N.ABI_VERSION == 5
+    assert lib.ptts_abi_version() == N.ABI_VERSION == 6
 
 
 def test_invalid_config_is_value_error_not_crash():

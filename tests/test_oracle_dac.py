@@ -75,3 +75,44 @@ def test_bf16_operand_oracle_equals_port_with_rounded_conv_operands(name, T):
     rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())  # noqa: E731
     assert rel(wq, wp) <= 5e-4, rel(wq, wp)
     assert 2e-3 <= rel(wq, w32) <= 3e-2, rel(wq, w32)  # and it is a different model from the fp32 one (operand rounding through ~30 convs)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@torch.no_grad()
+def test_stage_by_stage_restatement_chains_to_decode_and_negative_controls(prec):
+    """DacOracle.stage (what tests/test_dac_stage_parity_gpu.py compares each HIP kernel with) chained over all stages IS decode_latents, bit for
+    bit. Negative controls at the 44.1 kHz widths: what the per-stage bars (relative RMS of a unit's contribution to the stream <= 4e-4 in bf16 mode;
+    bf16 flips of the inner activation under a 1e-6 perturbation cost ~6e-5 there) must and do catch -
+    a residual unit whose inner activation is not rounded to bf16, a k7 conv with one tap dropped, an input slipped by one frame."""
+    import torch.nn.functional as F
+
+    spec = DA.DAC_44KHZ
+    sd = DA.make_dac_weights(spec, seed=4321)
+    o = DA.DacOracle(spec, sd, precision=prec)
+    codes = torch.randint(0, 1024, (1, 9, 6), generator=torch.Generator().manual_seed(5))
+    z = o.from_codes(codes)
+    act, raw, keep = (DA._rb(z) if prec == "bf16" else z), None, {}
+    for s in range(o.n_stages()):
+        keep[s] = (act, raw)
+        raw, act, _ = o.stage(s, act, raw)
+    n = len(spec.decoder_rates)
+    out = torch.tanh(F.conv1d(act, o.w[f"decoder.model.{n + 2}.weight"], o.w[f"decoder.model.{n + 2}.bias"], padding=3))
+    assert torch.equal(out, o.decode(codes))
+    if prec != "bf16":
+        return
+    rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())  # noqa: E731
+    for s in (6, 10, 14, 15):  # residual units of the C = 384 / 192 / 96 blocks (the fused kernels)
+        a_in, r_in = keep[s]
+        good, _, y = o.stage(s, a_in, r_in)
+        bi, k = divmod(s - 1, 4)
+        r = f"decoder.model.{bi + 1}.block.{k + 1}.block."
+        dil = (1, 3, 9)[k - 1]
+        y32 = DA.snake1d(F.conv1d(a_in, o.w[r + "1.weight"], o.w[r + "1.bias"], dilation=dil, padding=3 * dil), o.w[r + "2.alpha"])  # NOT rounded
+        unrounded = r_in + F.conv1d(y32, o.w[r + "3.weight"], o.w[r + "3.bias"])
+        w7 = o.w[r + "1.weight"].clone()
+        w7[:, :, 0] = 0  # a dropped tap
+        yt = DA._rb(DA.snake1d(F.conv1d(a_in, w7, o.w[r + "1.bias"], dilation=dil, padding=3 * dil), o.w[r + "2.alpha"]))
+        tap = r_in + F.conv1d(yt, o.w[r + "3.weight"], o.w[r + "3.bias"])
+        slip, _, _ = o.stage(s, torch.roll(a_in, 1, dims=-1), r_in)  # the halo one frame off
+        assert rel(unrounded - r_in, good - r_in) >= 3 * 4e-4, (s, rel(unrounded - r_in, good - r_in))  # measured 1.6e-3
+        assert rel(tap - r_in, good - r_in) >= 1e-2 and rel(slip - r_in, good - r_in) >= 1e-2, (s, rel(tap, good), rel(slip, good))

@@ -226,6 +226,7 @@ def _product_model_with_oracle_engine(pca: bool):
     m._get_engine = lambda B, N, Pp, L, T=0: eng
     dac = DA.DacOracle(DA.DAC_TINY, DA.make_dac_weights(DA.DAC_TINY, seed=4321))
     m.audio_encoder.decode = lambda audio_codes, audio_scales=None, **kw: types.SimpleNamespace(audio_values=dac.decode(audio_codes[0].cpu()))
+    m.audio_encoder.decode_filtered = None  # CPU stand-in codec: generate() then runs the reference's per-sample loop literally (:3627-3647)
     return m, spec, sd, eng
 
 
