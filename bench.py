@@ -464,6 +464,51 @@ def measure_dac(device, bs_list=(1, 32), with_f32: bool = True) -> dict:
     return out
 
 
+def delayed_ids_from_codes(codes: torch.Tensor, frames, K: int, L: int, bos: int, pad: int):
+    """The [B*K, L] id matrix the token loop leaves for utterances of frames[b] frames each (codebook k delayed by k columns behind the BOS
+    column, the EOS / pad id from the end of the utterance on), and the delay-pattern mask generate() applies to it."""
+    from parler_tts_amd.modeling_parler_tts import build_delay_pattern_mask
+
+    B = codes.shape[0]
+    ids = torch.full((B * K, L), pad, dtype=torch.long, device=codes.device)
+    for b in range(B):
+        n = int(frames[b])
+        for k in range(K):
+            ids[b * K + k, 1 + k: 1 + k + n] = codes[b, k, :n]
+    bos_col = torch.full((B * K, 1), bos, dtype=torch.long, device=codes.device)
+    _, pattern = build_delay_pattern_mask(bos_col, bos, pad, L, K)
+    return ids, pattern, bos_col
+
+
+def measure_ragged(model, device, bs: int = 32) -> dict:
+    """What an EOS-terminated batch pays after the token loop (modeling_parler_tts.py:3585-3647: un-delay, per-sample special-id filter, codec,
+    zero-padding): `bs` utterances whose lengths are uniform in [430, 860] frames through generate()'s own tail (`_undelay_and_decode`: one
+    filter kernel + ONE ragged codec pass) beside the fixed-length batch of 860 frames (no special ids: one plain codec call). value = audio
+    seconds produced per second of that tail; `ratio_vs_fixed` = ragged value / fixed value (1.0 = a ragged batch costs exactly its frames)."""
+    d = model.config.decoder
+    K, L, bos, pad = d.num_codebooks, NEW_TOKENS + 1, d.bos_token_id, d.pad_token_id
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(430, FRAMES + 1, (bs,), generator=g)
+    codes = torch.randint(0, 1024, (bs, K, FRAMES), generator=g).to(device)
+    out = {}
+    for name, fr in (("fixed", torch.full((bs,), FRAMES)), ("ragged", lens)):
+        ids, pattern, bos_col = delayed_ids_from_codes(codes, fr, K, L, bos, pad)
+        model._undelay_and_decode(ids, pattern, bos_col, bos, pad)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            wav, lengths = model._undelay_and_decode(ids, pattern, bos_col, bos, pad)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        assert lengths == [int(n) * 512 for n in fr], (name, lengths[:4])
+        audio = float(fr.sum()) * 512 / 44100.0
+        out[name] = {"ms": round(dt * 1e3, 2), "audio_seconds": round(audio, 1), "audio_seconds_per_sec": round(audio / dt, 1)}
+    out["frames_min_max_mean"] = [int(lens.min()), int(lens.max()), round(float(lens.float().mean()), 1)]
+    out["ratio_vs_fixed"] = round(out["ragged"]["audio_seconds_per_sec"] / out["fixed"]["audio_seconds_per_sec"], 3)
+    out["unit"] = "audio-seconds/sec of the post-loop tail (un-delay + special-id filter + codec)"
+    return out
+
+
 def _trim_roofline(r: dict) -> dict:
     return {k: r[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "bytes_per_launch", "context") if k in r}
 
@@ -483,16 +528,21 @@ def measure_fp32_parity_mode(device) -> dict:
 
 def measure_large(device) -> dict:
     """BASELINE configs[3] / configs[4] per-GPU shapes: parler-tts-large-v1 (30 layers, H 1536, F 6144; init_large_model.py:25-43),
-    bf16 with 1 utterance per GPU, then e4m3 weights with 1 and 4 utterances per GPU. Random weights drawn on the device."""
+    bf16 with 1 / 8 / 32 utterances per GPU, then e4m3 weights with 1 / 4 / 8 / 32. Random weights drawn on the device."""
     model = build_model_on_device(device, torch.bfloat16, "large")
     out = {}
-    dt = _timed_generate(model, 1, device)
-    out["bf16_bs1"] = {"value": round(AUDIO_S / dt, 3), "ms_per_step": round(dt * 1e3, 1), "roofline": _trim_roofline(measure_decode_roofline(model, 1, device, live_pmc=False))}
-    model.enable_fp8_weights()
-    for bs in (1, 4):
+
+    def point(bs):
         dt = _timed_generate(model, bs, device)
-        out[f"fp8w_bs{bs}"] = {"value": round(bs * AUDIO_S / dt, 3), "ms_per_step": round(dt * 1e3, 1),
-                               "roofline": _trim_roofline(measure_decode_roofline(model, bs, device, live_pmc=False))}
+        return {"value": round(bs * AUDIO_S / dt, 3), "ms_per_step": round(dt * 1e3, 1), "roofline": _trim_roofline(measure_decode_roofline(model, bs, device, live_pmc=False))}
+
+    for bs in (1, 8, 32):  # configs[3] is 1 utterance per GPU; 8 / 32 are the bf16 references of the e4m3 points below
+        out[f"bf16_bs{bs}"] = point(bs)
+    model.enable_fp8_weights()
+    for bs in (1, 4, 8, 32):  # configs[4] is 4 per GPU; 32 per GPU is where one-byte weights should show (GEMV step up to 8, e4m3 MFMA strips above)
+        out[f"fp8w_bs{bs}"] = point(bs)
+    for bs in (8, 32):
+        out[f"fp8w_over_bf16_step_bs{bs}"] = round(out[f"bf16_bs{bs}"]["roofline"]["us_per_launch"] / out[f"fp8w_bs{bs}"]["roofline"]["us_per_launch"], 3)
     out["unit"] = "audio-seconds/sec"
     model._engine = None
     return out
@@ -688,6 +738,11 @@ def main():
             out["dac"] = measure_dac(device)
         except Exception as e:
             out["dac"] = {"error": repr(e)[:200]}
+    if rank == 0 and world == 1 and not args.no_extras and args.model == "mini":
+        try:  # EOS-terminated batches: the per-sample tail of generate() as one filter kernel + one ragged codec pass
+            out["ragged_bs32"] = measure_ragged(model, device, 32)
+        except Exception as e:
+            out["ragged_bs32"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_extras and args.model == "mini" and args.dtype == "bf16":
         try:  # the whole-node lever: 128 utterances per GPU (the step is latency-bound at 32, utterances per step are nearly free until the KV stream dominates)
             dt = _timed_generate(model, 128, device)

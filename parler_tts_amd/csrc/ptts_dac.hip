@@ -336,13 +336,16 @@ struct ResArgs {
   float* out_raw;       // fp32 residual stream after the unit (may alias skip), or null
   void* out_act;        // activated output, bf16 (fp32 if act_f32): NOT the buffer x lives in (neighbouring tiles read x's halo rows)
   int act_f32;
+  int epi_direct;       // A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane owns 4 channels of one frame: 64-byte pieces of the stream)
 };
 
 // dynamic LDS of resunit_lds_kernel<NW>: the two slab buffers of phase A, overlaid by the y tile [128 frames][C bf16 + pad] of phase B
 // (NW = 8, C = 384: 100 KB - above the 64 KB a static __shared__ array may declare, hence dynamic for every instance)
 template <int NW> struct ResunitLds {
   static constexpr int C = NW * 3 * 16, slabs = 2 * (128 + 54) * (64 + 32), ytile = 128 * (C * 2 + 32);
-  static constexpr int bytes = slabs > ytile ? slabs : ytile;
+  static constexpr int etile = 64 * (C * 4 + 16);  // epilogue: half of the output tile as fp32 rows (16 bytes of padding: the 16 frames of one store hit 16 different bank groups)
+  static constexpr int bytes0 = slabs > ytile ? slabs : ytile;
+  static constexpr int bytes = bytes0 > etile ? bytes0 : etile;
 };
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) resunit_lds_kernel(ResArgs ra) {
@@ -490,7 +493,52 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
         acc[s][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk[s]), __builtin_bit_cast(bf16x8, bv), acc[s][f], 0, 0, 0);
     }
   }
-  // ---- phase B epilogue: + bias + residual, fp32 stream out, Snake of the unit's output
+  // ---- phase B epilogue: + bias + residual, fp32 stream out, Snake of the unit's output.
+  // Through LDS (default): a lane's accumulators are 4 channels of ONE frame, so the direct form below moves the fp32 stream in 64-byte pieces
+  // (rows C * 4 bytes apart) and ran the three fused units at 2.3-2.9 TB/s, 68 % of the batch-32 decode (profiles/r03_dac_kernels_bs32.txt).
+  // Here the output tile goes through LDS in two halves of 64 frames ([64][C fp32], rows padded by 16 bytes) and every lane then owns 16
+  // CONSECUTIVE bytes of a row: the residual read, the stream write and the activation write are whole rows (tools/epilogue_probe.hip on
+  // MI355X: 2.5-2.8 -> 3.9-5.1 TB/s with 64-frame tiles; 128-frame tiles do not pay). Same fp32 operations in the same order: bit-identical.
+  if (!ra.epi_direct) {
+    constexpr int RSE = C * 4 + 16, VPR = C / 4, NV = 64 * VPR;
+    unsigned char* et = lds;
+    __syncthreads();  // every wave has finished reading the y tile
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int s = 0; s < CSW; ++s) {
+        const int co = (strip0 + s) * 16 + q * 4;
+        const float4 bs = *reinterpret_cast<const float4*>(ra.bias1 + co);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const f32x4 av = acc[s][hh * 4 + f];
+          *reinterpret_cast<float4*>(et + (f * 16 + j) * RSE + co * 4) = make_float4(av[0] + bs.x, av[1] + bs.y, av[2] + bs.z, av[3] + bs.w);
+        }
+      }
+      __syncthreads();
+      const int r0 = t0 + hh * 64;
+      const int rows = min(64, Tv - r0);
+      const size_t base = ((size_t)b * a.Tn + r0) * C;
+#pragma unroll 4
+      for (int i = tid; i < NV; i += NT) {
+        const int rr = i / VPR, cv = i - rr * VPR;
+        if (rr >= rows) break;
+        const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
+        const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
+        const float4 sk = *reinterpret_cast<const float4*>(ra.skip + o);
+        const float4 v = make_float4(av.x + sk.x, av.y + sk.y, av.z + sk.z, av.w + sk.w);
+        if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
+        if (ra.out_act) {
+          const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + cv * 4);
+          const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+          if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
+        }
+      }
+      if (hh == 0) __syncthreads();  // the tile is rewritten by the second half
+    }
+    return;
+  }
   auto emit = [&](const f32x4 av, const int s, const int f) {
     const int jj = t0 + f * 16 + j;
     if (jj >= Tv) return;
@@ -1195,6 +1243,10 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
   r.a.x = x; r.a.Wp = c7.Wp; r.a.bias = c7.bias; r.a.alpha = c7.alpha; r.a.dil = c7.dil; r.a.pad = (c7.ksize - 1) * c7.dil / 2;
   r.a.B = B; r.a.Tin = T; r.a.Tn = T; r.a.Cin = c7.Cin; r.a.Cout = c7.Cout; r.a.ntaps = 7; r.a.nphase = 1; r.a.stride = 1;
   r.Wp1 = c1.Wp; r.bias1 = c1.bias; r.alpha1 = c1.alpha; r.skip = skip; r.out_raw = out_raw; r.out_act = out_act; r.act_f32 = act_f32 ? 1 : 0;
+  {
+    const char* ed = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process, like PTTS_DAC_NO_FUSE_RES)
+    r.epi_direct = (ed && atoi(ed)) ? 1 : 0;
+  }
   const dim3 grid((unsigned)(((T + 127) / 128) * B));
   if (c7.Cout == 384) {
     static bool attr_set = false;  // 100 KB of dynamic LDS needs the opt-in
