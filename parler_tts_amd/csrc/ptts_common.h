@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string>
+#include <atomic>
 
 #include "../../include/ptts.h"
 
@@ -45,6 +46,16 @@ struct PttsDeviceGuard {
 #define PTTS_DEVICE(dev)            \
   PttsDeviceGuard _ptts_dg(dev);    \
   if (!_ptts_dg.ok) return ptts_fail(PTTS_E_HIP, "hipSetDevice(%d) failed (%s:%d)", (int)(dev), __FILE__, __LINE__)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's function object: the opt-in is tracked per
+// (kernel instantiation, device), so a second engine on another GPU of the same process gets it too. Two threads racing
+// on the first launch both set the attribute: idempotent.
+struct PttsPerDeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  static int device() { int d = 0; (void)hipGetDevice(&d); return d < 0 ? 0 : (d > 63 ? 63 : d); }
+  bool need(int dev) const { return !((mask.load(std::memory_order_acquire) >> dev) & 1ull); }
+  void done(int dev) { mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
 
 // ---- bf16 <-> f32 (round-to-nearest-even, identical to torch's .to(bfloat16)) -------------------------
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

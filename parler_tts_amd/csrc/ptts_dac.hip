@@ -337,26 +337,30 @@ struct ResArgs {
   void* out_act;        // activated output, bf16 (fp32 if act_f32): NOT the buffer x lives in (neighbouring tiles read x's halo rows)
   int act_f32;
   int epi_direct;       // A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane owns 4 channels of one frame: 64-byte pieces of the stream)
+  int no_skip_prefetch; // A/B (PTTS_DAC_NO_SKIP_PREFETCH=1): residual rows fetched in the epilogue instead of under the k1 GEMM
 };
 
 // dynamic LDS of resunit_lds_kernel<NW>: the two slab buffers of phase A, overlaid by the y tile [128 frames][C bf16 + pad] of phase B
 // (NW = 8, C = 384: 100 KB - above the 64 KB a static __shared__ array may declare, hence dynamic for every instance)
-template <int NW> struct ResunitLds {
-  static constexpr int C = NW * 3 * 16, slabs = 2 * (128 + 54) * (64 + 32), ytile = 128 * (C * 2 + 32);
+template <int NW, int KS = 1> struct ResunitLds {
+  static constexpr int C = NW * 3 * 16, slabs = 2 * (128 + 54) * (KS * 64 + 32), ytile = 128 * (C * 2 + 32);
   static constexpr int etile = 64 * (C * 4 + 16);  // epilogue: half of the output tile as fp32 rows (16 bytes of padding: the 16 frames of one store hit 16 different bank groups)
   static constexpr int bytes0 = slabs > ytile ? slabs : ytile;
   static constexpr int bytes = bytes0 > etile ? bytes0 : etile;
 };
-template <int NW>
+// KS: 32-channel k-steps per staged chunk (1: 64-byte slab rows, the round-3 form; 2 for C >= 192: twice the bytes in flight per staging
+// round and twice the MFMA work to hide them behind - the units ran latency x concurrency-bound at ~2.7 TB/s with ~12-16 KB in flight per workgroup)
+template <int NW, int KS = 1>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) resunit_lds_kernel(ResArgs ra) {
-  constexpr int CSW = 3, FT = 8, TF = FT * 16, KS = 1, MAXHALO = 54;
+  constexpr int CSW = 3, FT = 8, TF = FT * 16, MAXHALO = 54;
   constexpr int C = NW * CSW * 16;
   constexpr int KCH = 32 * KS, RS = KS * 64 + 32, SL = KS * 4, NT = NW * 64;
   constexpr int MAXROWS = TF + MAXHALO;
   constexpr int NST = (MAXROWS * SL + NT - 1) / NT;
   constexpr int RS2 = C * 2 + 32;  // y tile row stride: an odd multiple of 32 bytes, conflict-free ds_read_b128 like the slab
   constexpr int NK1 = C / 32;      // k-steps of the k1 GEMM
-  static_assert(ResunitLds<NW>::bytes >= 2 * MAXROWS * RS && ResunitLds<NW>::bytes >= TF * RS2, "LDS size");
+  static_assert(ResunitLds<NW, KS>::bytes >= 2 * MAXROWS * RS && ResunitLds<NW, KS>::bytes >= TF * RS2, "LDS size");
+  static_assert(C % KCH == 0, "chunk width");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const ConvArgs& a = ra.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -473,6 +477,21 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   RU_PUT_ROW(2)
 #undef RU_PUT_ROW
   __syncthreads();
+  // the residual rows of the tile's first half go in flight NOW, in the epilogue's row-contiguous order (thread i owns float4 i, i + NT, ...
+  // of the [64][C] half tile): they land under the k1 GEMM instead of costing the epilogue 3-6 dependent round trips of 16 KB each
+  constexpr int VPRH = C / 4, NPT = 64 * VPRH / NT;  // float4 per row; per thread and half tile (= 12 for every NW)
+  float4 skp[NPT];
+  auto load_skip = [&](const int hh) __attribute__((always_inline)) {
+    const int r0_ = t0 + hh * 64, rows_ = min(64, Tv - r0_);
+    const float* sb_ = ra.skip + ((size_t)b * a.Tn + r0_) * C;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int i_ = tid + k * NT;
+      skp[k] = (i_ / VPRH) < rows_ ? *reinterpret_cast<const float4*>(sb_ + (size_t)i_ * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  const bool skip_pre = !ra.epi_direct && !ra.no_skip_prefetch;
+  if (skip_pre) load_skip(0);
   // ---- phase B: the k1 conv as a [C x C] GEMM over the tile; A = this wave's 3 strips of W1, B = y rows out of LDS
   const float4* W1 = reinterpret_cast<const float4*>(ra.Wp1) + (size_t)strip0 * NK1 * 64 + lane;
 #pragma unroll
@@ -519,20 +538,27 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       const int r0 = t0 + hh * 64;
       const int rows = min(64, Tv - r0);
       const size_t base = ((size_t)b * a.Tn + r0) * C;
-#pragma unroll 4
-      for (int i = tid; i < NV; i += NT) {
+      if (!skip_pre) load_skip(hh);  // A/B: all 12 loads of the half tile at once, but only now
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) {
+        const int i = tid + k * NT;
         const int rr = i / VPR, cv = i - rr * VPR;
-        if (rr >= rows) break;
-        const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
-        const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
-        const float4 sk = *reinterpret_cast<const float4*>(ra.skip + o);
-        const float4 v = make_float4(av.x + sk.x, av.y + sk.y, av.z + sk.z, av.w + sk.w);
-        if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
-        if (ra.out_act) {
-          const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + cv * 4);
-          const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
-          if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
-          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
+        const float4 sk = skp[k];
+        if (skip_pre && hh == 0) {  // the second half's residual rows, as soon as the register is free
+          const int rows1 = min(64, Tv - (t0 + 64));
+          skp[k] = rr < rows1 ? *reinterpret_cast<const float4*>(ra.skip + base + (size_t)64 * C + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (rr < rows) {
+          const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
+          const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
+          const float4 v = make_float4(av.x + sk.x, av.y + sk.y, av.z + sk.z, av.w + sk.w);
+          if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
+          if (ra.out_act) {
+            const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + cv * 4);
+            const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+            if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+            else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
+          }
         }
       }
       if (hh == 0) __syncthreads();  // the tile is rewritten by the second half
@@ -1246,18 +1272,27 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
   {
     const char* ed = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process, like PTTS_DAC_NO_FUSE_RES)
     r.epi_direct = (ed && atoi(ed)) ? 1 : 0;
+    const char* np = getenv("PTTS_DAC_NO_SKIP_PREFETCH");
+    r.no_skip_prefetch = (np && atoi(np)) ? 1 : 0;
   }
+  const char* k1e = getenv("PTTS_DAC_KS1");  // A/B: 64-byte slab rows (one 32-channel k-step per staged chunk) at every width
+  const bool ks2 = !(k1e && atoi(k1e));
   const dim3 grid((unsigned)(((T + 127) / 128) * B));
   if (c7.Cout == 384) {
-    static bool attr_set = false;  // 100 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8>::bytes);
+    static PttsPerDeviceOnce attr_once;  // 100 KB of dynamic LDS needs the opt-in
+    const int attr_dev = PttsPerDeviceOnce::device();
+    if (attr_once.need(attr_dev)) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
+      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 2>::bytes);
       if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea));
-      attr_set = true;
+      attr_once.done(attr_dev);
     }
-    hipLaunchKernelGGL((resunit_lds_kernel<8>), grid, dim3(512), ResunitLds<8>::bytes, st, r);
-  } else if (c7.Cout == 192) hipLaunchKernelGGL((resunit_lds_kernel<4>), grid, dim3(256), ResunitLds<4>::bytes, st, r);
-  else hipLaunchKernelGGL((resunit_lds_kernel<2>), grid, dim3(128), ResunitLds<2>::bytes, st, r);
+    if (ks2) hipLaunchKernelGGL((resunit_lds_kernel<8, 2>), grid, dim3(512), (ResunitLds<8, 2>::bytes), st, r);
+    else hipLaunchKernelGGL((resunit_lds_kernel<8, 1>), grid, dim3(512), (ResunitLds<8, 1>::bytes), st, r);
+  } else if (c7.Cout == 192) {
+    if (ks2) hipLaunchKernelGGL((resunit_lds_kernel<4, 2>), grid, dim3(256), (ResunitLds<4, 2>::bytes), st, r);
+    else hipLaunchKernelGGL((resunit_lds_kernel<4, 1>), grid, dim3(256), (ResunitLds<4, 1>::bytes), st, r);
+  } else hipLaunchKernelGGL((resunit_lds_kernel<2, 1>), grid, dim3(128), (ResunitLds<2, 1>::bytes), st, r);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "residual-unit launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;

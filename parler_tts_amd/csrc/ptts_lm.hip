@@ -129,12 +129,13 @@ namespace {
 
 template <typename WT, int PRO, int EPI, int MTP, bool FULL>
 int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) {
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
-  if (!attr_set) {
+  static PttsPerDeviceOnce attr_once;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
+  const int attr_dev = PttsPerDeviceOnce::device();
+  if (attr_once.need(attr_dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_once.done(attr_dev);
   }
   hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>), grid, block, sh, st, a);
   return PTTS_OK;
@@ -1033,7 +1034,7 @@ extern "C" int ptts_set_audio_prefix(ptts_engine* e, const int64_t* codes_dev, i
   return PTTS_OK;
 }
 
-static int precapture_graphs(ptts_engine* e);
+static int precapture_graphs(ptts_engine* e, int max_buckets);
 
 extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_dev, const float* prompt_dev,
                             const int32_t* prompt_mask_dev, int32_t B, int32_t N, int32_t P, int32_t sample, void* stream) {
@@ -1113,7 +1114,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   }
   e->h_ready = sample != 0;
   e->prefilled = true;
-  if (sample) PTTS_TRY(precapture_graphs(e));  // device loop ahead: its step graphs for every context bucket of this call
+  if (sample) PTTS_TRY(precapture_graphs(e, 3));  // device loop ahead: the step graphs of the next three 64-position buckets (the rest: ptts_decode_steps, ahead of the GPU)
   return PTTS_OK;
 }
 
@@ -1143,17 +1144,20 @@ static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   return PTTS_OK;
 }
 
-// Every 64-position bucket this call can reach is captured NOW, at prefill (host work that overlaps the prefill kernels already
-// enqueued), not in the middle of generation: a first long utterance or stream would otherwise stall for a capture + instantiate of
-// ~170-270 nodes every 64 frames, on the latency-critical streaming path. Graphs are cached for the engine's life, so only the first
-// call of a (batch, fold, bucket) pays. PTTS_NO_PRECAPTURE=1: capture lazily as before (A/B).
-static int precapture_graphs(ptts_engine* e) {
+// The step graphs of the next `max_buckets` 64-position buckets this call can still reach are captured AHEAD of the GPU: at prefill
+// (host work that overlaps the prefill kernels already enqueued) and again at the end of every ptts_decode_steps (behind the launches it
+// has just enqueued), never in the middle of a run of launches: a first long utterance or stream would otherwise stall for a capture +
+// instantiate of ~170-270 nodes every 64 frames, on the latency-critical streaming path. Bounded: the stock generation
+// config (max_length 2580) is ~41 buckets, three times what a call that stops on EOS needs, and all of them sat between the prefill and
+// the first decode_steps of the first call of every batch size. Graphs are cached for the engine's life, so only the first call of a
+// (batch, fold, bucket) pays. PTTS_NO_PRECAPTURE=1: capture lazily, at the launch that needs the graph (A/B).
+static int precapture_graphs(ptts_engine* e, int max_buckets) {
   static const bool off = getenv("PTTS_NO_PRECAPTURE") && atoi(getenv("PTTS_NO_PRECAPTURE"));
   if (off) return PTTS_OK;
   const int cap = e->cfg.max_ctx, saved_ub = e->kv_ub, saved_bound = e->kv_bound;
   const int last_ub = std::min(cap - 1, e->P + e->gp.max_length);  // positions the longest run of this call writes
-  int rc = PTTS_OK;
-  for (int ub = saved_ub + 1; ub <= last_ub && rc == PTTS_OK; ) {
+  int rc = PTTS_OK, done = 0;
+  for (int ub = saved_ub + 1; ub <= last_ub && rc == PTTS_OK && done < max_buckets; ++done) {
     e->kv_bound = g_no_kv_bound ? cap : std::min(cap, (ub + 1 + 63) / 64 * 64);
     rc = get_graph(e, nullptr);
     ub = e->kv_bound;  // first upper bound of the next bucket: (ub + 1 + 63) / 64 * 64 > kv_bound
@@ -1182,6 +1186,7 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
     PTTS_TRY(get_graph(e, &ex));  // cached per (batch, fold, 64-position bucket)
     PTTS_HIP(hipGraphLaunch(ex, st));
   }
+  if (n_steps > 0) PTTS_TRY(precapture_graphs(e, 2));  // the current bucket and the next one, while the GPU works through what was just enqueued
   return PTTS_OK;
 }
 

@@ -8,12 +8,13 @@ namespace {
 
 template <int PRO, int EPI, int MTP>
 int launch(const GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) {
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
-  if (!attr_set) {
+  static PttsPerDeviceOnce attr_once;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
+  const int attr_dev = PttsPerDeviceOnce::device();
+  if (attr_once.need(attr_dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<bf16_t, PRO, EPI, MTP, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e)); return -2; }
-    attr_set = true;
+    attr_once.done(attr_dev);
   }
   hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO, EPI, MTP, true, true>), grid, block, sh, st, a);
   hipError_t e = hipGetLastError();

@@ -128,13 +128,16 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
     ``dst``: rank (within ``group``) that receives the result, or ``None`` for all ranks. Returns (on the receiving ranks) a ``GenerateOutput`` with
     ``.sequences`` = waveform float32 [batch, samples] zero-padded to the longest utterance of the whole batch (on the CPU) and
     ``["audios_length"]`` = per-utterance lengths, exactly what the single-process call returns for the same batch under greedy
-    decoding; ``None`` on the other ranks. With sampling each rank draws from its own generator (torch.manual_seed per rank).
+    decoding; ``None`` on the other ranks. With sampling each rank draws from its own torch generator, advanced by the index of the shard's first
+    utterance (identical seeds on all ranks still give different shards; the draws are not those of the single-process call).
     Without an initialised process group this is ``model.generate`` (world size 1)."""
     import torch.distributed as dist
 
     from .modeling_parler_tts import GenerateOutput
 
     rank, world = _world(group)
+    if rank < 0:
+        raise ValueError("generate_sharded: this process is not a member of `group` (torch.distributed.get_rank(group) == -1)")
     K = model.config.decoder.num_codebooks
     full = dict(kwargs)
     if inputs is not None:
@@ -162,6 +165,11 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
         raise ValueError("generate_sharded: a streamer serves ONE utterance on one rank; call model.generate(streamer=...) there")
     local["return_dict_in_generate"] = True
     if hi > lo:
+        if local.get("do_sample") or (local.get("do_sample") is None and getattr(getattr(model, "generation_config", None), "do_sample", False)):
+            # sampling: generate() seeds its device sampler from torch's generator. A launcher that calls torch.manual_seed(s) identically on
+            # every rank would give every shard the SAME stream; advance the generator by the shard's first utterance index so shards differ
+            # (still deterministic for a given seed and world size; not the single-process stream - stated in the docstring)
+            torch.randint(0, 2 ** 31, (lo + 1,))
         out = model.generate(**local)
         wav = out.sequences.detach().float().cpu()
         lens = [int(x) for x in out["audios_length"]]
@@ -172,17 +180,22 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
     # ---- metadata: rows and padded width of every rank's block ------------------------------------------------------------
     backend = dist.get_backend(group)
     cdev = model.device if backend == "nccl" else torch.device("cpu")  # RCCL moves device tensors, gloo host tensors
-    meta = torch.tensor([wav.shape[0], wav.shape[1]], dtype=torch.int64, device=cdev)
+    nrs = int(full.get("num_return_sequences") or getattr(getattr(model, "generation_config", None), "num_return_sequences", 1) or 1)
+    per = shard_range(B, 0, world)[1] * max(1, nrs)  # rows of the largest shard (rank 0's): every rank knows it without a collective
+    meta = torch.zeros(2 + per, dtype=torch.int64)
+    meta[0], meta[1] = wav.shape[0], wav.shape[1]
+    if lens:
+        meta[2: 2 + len(lens)] = torch.tensor(lens, dtype=torch.int64)  # per-utterance sample counts travel as int64 (exact at any length)
+    meta = meta.to(cdev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     rows = [int(m[0]) for m in metas]
     width = max([int(m[1]) for m in metas if int(m[0]) > 0] or [1])
     max_rows = max(rows)
-    # ---- payload: one padded block per rank = [waveforms | lengths] ---------------------------------------------------------
-    block = torch.zeros(max_rows, width + 1, dtype=torch.float32)
+    # ---- payload: one padded block of waveforms per rank (an idle rank contributes an all-zero block of the common shape) --------------
+    block = torch.zeros(max_rows, width, dtype=torch.float32)
     if wav.shape[0]:
         block[: wav.shape[0], : wav.shape[1]] = wav
-        block[: wav.shape[0], width] = torch.tensor(lens, dtype=torch.float32)  # sample counts < 2^24: exact in fp32
     block = block.to(cdev)
     if dst is None:
         blocks = [torch.zeros_like(block) for _ in range(world)]
@@ -195,9 +208,8 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
             return None
     parts, all_lens = [], []
     for r in range(world):
-        b = blocks[r][: rows[r]].cpu()
-        parts.append(b[:, :width])
-        all_lens += [int(v) for v in b[:, width].tolist()]
+        parts.append(blocks[r][: rows[r]].cpu())
+        all_lens += [int(v) for v in metas[r][2: 2 + rows[r]].tolist()]
     wav_all = torch.cat(parts, dim=0)
     longest = max(all_lens) if all_lens else 0
     return GenerateOutput(sequences=wav_all[:, : max(longest, 1)], audios_length=all_lens)

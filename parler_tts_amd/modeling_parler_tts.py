@@ -247,8 +247,8 @@ def _build_uninitialised(factory):
     if hasattr(module, "tie_weights"):
         try:
             module.tie_weights()
-        except Exception:  # noqa: BLE001
-            pass
+        except Exception:  # noqa: BLE001 - a release whose tie needs the initialised path: build it the ordinary (initialised) way
+            return factory()  # never hand out a module whose tied embedding may be unallocated garbage under one of its names
     return module
 
 
@@ -545,6 +545,16 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         if strict and (missing or [k for k in unexpected if not k.startswith("text_encoder.")]):
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
         super().load_state_dict({k: v for k, v in rest.items() if k in own}, strict=False)
+        # the T5 embedding exists under two names (shared / encoder.embed_tokens); a checkpoint may hold only one. Either the two are ONE
+        # tensor (tied: loading one name filled both) or both names were in the checkpoint - otherwise one of them would keep whatever
+        # the (possibly uninitialised, init_weights=False) allocation held
+        te = getattr(self, "text_encoder", None)
+        sh, emb = getattr(te, "shared", None), getattr(getattr(te, "encoder", None), "embed_tokens", None)
+        if strict and sh is not None and emb is not None and sh.weight.data_ptr() != emb.weight.data_ptr():
+            names = [k for k in rest if k.startswith("text_encoder.") and (k.endswith("shared.weight") or k.endswith("embed_tokens.weight"))]
+            if 0 < len(names) < 2:
+                raise RuntimeError(f"text_encoder embedding is not tied (shared / encoder.embed_tokens are different tensors) and the checkpoint "
+                                   f"holds only {names}: the other copy would stay uninitialised")
         self._engine = None
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 

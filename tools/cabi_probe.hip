@@ -5,7 +5,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/cabi_probe.hip -o tools/cabi_probe \
 //         -Lparler_tts_amd -lptts_hip -Wl,-rpath,'$ORIGIN/../parler_tts_amd'
-//   tools/cabi_probe lm  <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]
+//   tools/cabi_probe lm  <batch> [large] [fp32] [fp8] [layers=<n>] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]
 //        eager=<n>: only a prefill + n EAGER decode forwards (ptts_push_tokens + ptts_step_forward), no hipGraph is captured or launched:
 //        the target of `rocprofv3 --pmc ...` passes (which crash on graph replays in this image; tools/prof_eager.py without torch),
 //        e.g. `rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- tools/cabi_probe lm 1 ctx=431 eager=24` = the bench's timed context
@@ -128,7 +128,10 @@ static int run_lm(int argc, char** argv) {
   const int dump_steps = opt(argc, argv, "steps") ? atoi(opt(argc, argv, "steps")) : 6;
   const char* tag = opt(argc, argv, "tag") ? opt(argc, argv, "tag") : "";
   const int P = opt(argc, argv, "ctx") ? atoi(opt(argc, argv, "ctx")) : 32;
-  const int H = large ? 1536 : 1024, L = large ? 30 : 24, F = large ? 6144 : 4096, NH = large ? 24 : 16, K = 9, V = 1088, NE = 64;
+  // layers=<n>: the same widths with n layers (n = 2: every weight stays in the L2s / Infinity Cache between replays, n = 8: 240 MB, Infinity
+  // Cache only): per-layer step time against the 24-layer model = what cold weights cost a dependent node
+  const int H = large ? 1536 : 1024, L = opt(argc, argv, "layers") ? atoi(opt(argc, argv, "layers")) : (large ? 30 : 24), F = large ? 6144 : 4096,
+            NH = large ? 24 : 16, K = 9, V = 1088, NE = 64;
   hipStream_t st;
   HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   ptts_config c;
