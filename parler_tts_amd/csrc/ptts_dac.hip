@@ -337,7 +337,6 @@ struct ResArgs {
   void* out_act;        // activated output, bf16 (fp32 if act_f32): NOT the buffer x lives in (neighbouring tiles read x's halo rows)
   int act_f32;
   int epi_direct;       // A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane owns 4 channels of one frame: 64-byte pieces of the stream)
-  int no_skip_prefetch; // A/B (PTTS_DAC_NO_SKIP_PREFETCH=1): residual rows fetched in the epilogue instead of under the k1 GEMM
 };
 
 // dynamic LDS of resunit_lds_kernel<NW>: the two slab buffers of phase A, overlaid by the y tile [128 frames][C bf16 + pad] of phase B
@@ -350,7 +349,11 @@ template <int NW, int KS = 1> struct ResunitLds {
 };
 // KS: 32-channel k-steps per staged chunk (1: 64-byte slab rows, the round-3 form; 2 for C >= 192: twice the bytes in flight per staging
 // round and twice the MFMA work to hide them behind - the units ran latency x concurrency-bound at ~2.7 TB/s with ~12-16 KB in flight per workgroup)
-template <int NW, int KS = 1>
+// WD: how many k-steps ahead a wave requests its weight fragments (1: two register sets, the round-3 form; 3: four sets). A k-step is 24 MFMAs
+// = 384 cycles per wave, ~770 with the SIMD's second wave interleaved: one step ahead is ~0.3 us, less than an L2 round trip - and the
+// fragments DO come from the L2 every time (a wave re-streams its 3 strips x 7 taps x C channels = 129 KB at C = 192 per tile through a
+// 32 KB L1 shared by 8 waves), so every k-step waited for its weights: MFMA pipe 23-28 % busy (profiles/r03_pmc_dac_mfma.txt).
+template <int NW, int KS = 1, int WD = 3>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) resunit_lds_kernel(ResArgs ra) {
   constexpr int CSW = 3, FT = 8, TF = FT * 16, MAXHALO = 54;
   constexpr int C = NW * CSW * 16;
@@ -369,8 +372,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   const int tile = blockIdx.x % ntile, b = blockIdx.x / ntile;
   const int strip0 = wave * CSW;
   const int cpt = C / 32, nk = a.ntaps * cpt;
-  const int nchunk = C / KCH;
-  const int NS = a.ntaps * KS;
+  constexpr int nchunk = C / KCH;
+  constexpr int NS = 7 * KS;  // k-steps per chunk (the unit's first conv is k7: run_resunit)
   const int t0 = tile * TF;
   const int Tv = valid_rows(a, b);  // ragged decode: this utterance's rows (workgroup-uniform)
   if (t0 >= Tv) return;
@@ -422,10 +425,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     const unsigned char* sb_ = (c & 1) ? slab1 : slab0;                                                                   \
     unsigned char* nb_ = (c & 1) ? slab0 : slab1;                                                                         \
     const bool more_ = c + 1 < nchunk, lastst_ = st + 1 == NS;                                                            \
-    const int nc_ = lastst_ ? c + 1 : c, ns_ = lastst_ ? 0 : st + 1;                                                      \
-    const bool next_ = nc_ < nchunk;                                                                                      \
-    if (st == 0 && more_) { RU_SLAB_FETCH(c + 1); }                                                                       \
-    RU_W_FETCH(WN, next_ ? nc_ : c, next_ ? ns_ : st);                                                                    \
+    const int gn_ = min(gi + WD, total - 1); /* unconditional (a valid re-fetch at the very end): a branch here would */   \
+    if (st == 0 && more_) { RU_SLAB_FETCH(c + 1); } /* merge into a conservative vmcnt on the MFMAs below */             \
+    RU_W_FETCH(WN, gn_ / NS, gn_ % NS);                                                                                   \
     RU_B_FETCH(bB, sb_, st, 4);                                                                                           \
     RU_MFMA_HALF(WC, bA, 0)                                                                                               \
     if (!lastst_) RU_B_FETCH(bA, sb_, st + 1, 0);                                                                         \
@@ -439,19 +441,33 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     } else {                                                                                                              \
       ++st;                                                                                                               \
     }                                                                                                                     \
+    ++gi;                                                                                                                 \
   }
-  float4 w0[CSW], w1[CSW];
+  constexpr int total = nchunk * NS;
+  float4 w0[CSW], w1[CSW], w2[CSW], w3[CSW];
   uint4 bA[4], bB[4];
   RU_W_FETCH(w0, 0, 0);
+  if constexpr (WD == 3) {
+    RU_W_FETCH(w1, (1 < total ? 1 : 0) / NS, (1 < total ? 1 : 0) % NS);
+    RU_W_FETCH(w2, (2 < total ? 2 : 0) / NS, (2 < total ? 2 : 0) % NS);
+  }
   RU_SLAB_FETCH(0);
   RU_SLAB_COMMIT(slab0);
   __syncthreads();
   RU_B_FETCH(bA, slab0, 0, 0);
-  int c = 0, st = 0;
-  const int total = nchunk * NS;
-  for (int g = 0; g < total; g += 2) {
-    RU_STEP(w0, w1)
-    if (g + 1 < total) RU_STEP(w1, w0)
+  int c = 0, st = 0, gi = 0;
+  if constexpr (WD == 3) {  // four register sets: k-step g computes out of w[g % 4] while the fragments of k-step g + 3 land in w[(g + 3) % 4]
+    for (int g = 0; g < total; g += 4) {
+      RU_STEP(w0, w3)
+      if (g + 1 < total) RU_STEP(w1, w0)
+      if (g + 2 < total) RU_STEP(w2, w1)
+      if (g + 3 < total) RU_STEP(w3, w2)
+    }
+  } else {
+    for (int g = 0; g < total; g += 2) {
+      RU_STEP(w0, w1)
+      if (g + 1 < total) RU_STEP(w1, w0)
+    }
   }
 #undef RU_STEP
 #undef RU_MFMA_HALF
@@ -477,8 +493,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   RU_PUT_ROW(2)
 #undef RU_PUT_ROW
   __syncthreads();
-  // the residual rows of the tile's first half go in flight NOW, in the epilogue's row-contiguous order (thread i owns float4 i, i + NT, ...
-  // of the [64][C] half tile): they land under the k1 GEMM instead of costing the epilogue 3-6 dependent round trips of 16 KB each
+  // the epilogue's residual rows: thread i owns float4 i, i + NT, ... of the [64][C] half tile, all 12 loads of a half in flight at once.
+  // (Requesting them BEFORE the k1 GEMM, and 64-channel staging chunks, were measured and dropped: 72.3 vs 70.2 ms per batch-32 decode,
+  // profiles/r04_experiments.txt - the units are not short of bytes in flight.)
   constexpr int VPRH = C / 4, NPT = 64 * VPRH / NT;  // float4 per row; per thread and half tile (= 12 for every NW)
   float4 skp[NPT];
   auto load_skip = [&](const int hh) __attribute__((always_inline)) {
@@ -490,8 +507,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       skp[k] = (i_ / VPRH) < rows_ ? *reinterpret_cast<const float4*>(sb_ + (size_t)i_ * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  const bool skip_pre = !ra.epi_direct && !ra.no_skip_prefetch;
-  if (skip_pre) load_skip(0);
   // ---- phase B: the k1 conv as a [C x C] GEMM over the tile; A = this wave's 3 strips of W1, B = y rows out of LDS
   const float4* W1 = reinterpret_cast<const float4*>(ra.Wp1) + (size_t)strip0 * NK1 * 64 + lane;
 #pragma unroll
@@ -538,16 +553,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       const int r0 = t0 + hh * 64;
       const int rows = min(64, Tv - r0);
       const size_t base = ((size_t)b * a.Tn + r0) * C;
-      if (!skip_pre) load_skip(hh);  // A/B: all 12 loads of the half tile at once, but only now
+      load_skip(hh);
 #pragma unroll
       for (int k = 0; k < NPT; ++k) {
         const int i = tid + k * NT;
         const int rr = i / VPR, cv = i - rr * VPR;
         const float4 sk = skp[k];
-        if (skip_pre && hh == 0) {  // the second half's residual rows, as soon as the register is free
-          const int rows1 = min(64, Tv - (t0 + 64));
-          skp[k] = rr < rows1 ? *reinterpret_cast<const float4*>(ra.skip + base + (size_t)64 * C + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         if (rr < rows) {
           const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
           const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
@@ -1272,27 +1283,28 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
   {
     const char* ed = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process, like PTTS_DAC_NO_FUSE_RES)
     r.epi_direct = (ed && atoi(ed)) ? 1 : 0;
-    const char* np = getenv("PTTS_DAC_NO_SKIP_PREFETCH");
-    r.no_skip_prefetch = (np && atoi(np)) ? 1 : 0;
   }
-  const char* k1e = getenv("PTTS_DAC_KS1");  // A/B: 64-byte slab rows (one 32-channel k-step per staged chunk) at every width
-  const bool ks2 = !(k1e && atoi(k1e));
   const dim3 grid((unsigned)(((T + 127) / 128) * B));
+  const char* wde = getenv("PTTS_DAC_WD1");  // A/B: weight fragments requested one k-step ahead (two register sets) instead of three
+  const bool wd3 = !(wde && atoi(wde));
   if (c7.Cout == 384) {
     static PttsPerDeviceOnce attr_once;  // 100 KB of dynamic LDS needs the opt-in
     const int attr_dev = PttsPerDeviceOnce::device();
     if (attr_once.need(attr_dev)) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
-      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 2>::bytes);
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
+      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
       if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea));
       attr_once.done(attr_dev);
     }
-    if (ks2) hipLaunchKernelGGL((resunit_lds_kernel<8, 2>), grid, dim3(512), (ResunitLds<8, 2>::bytes), st, r);
-    else hipLaunchKernelGGL((resunit_lds_kernel<8, 1>), grid, dim3(512), (ResunitLds<8, 1>::bytes), st, r);
+    if (wd3) hipLaunchKernelGGL((resunit_lds_kernel<8, 1, 3>), grid, dim3(512), (ResunitLds<8, 1>::bytes), st, r);
+    else hipLaunchKernelGGL((resunit_lds_kernel<8, 1, 1>), grid, dim3(512), (ResunitLds<8, 1>::bytes), st, r);
   } else if (c7.Cout == 192) {
-    if (ks2) hipLaunchKernelGGL((resunit_lds_kernel<4, 2>), grid, dim3(256), (ResunitLds<4, 2>::bytes), st, r);
-    else hipLaunchKernelGGL((resunit_lds_kernel<4, 1>), grid, dim3(256), (ResunitLds<4, 1>::bytes), st, r);
-  } else hipLaunchKernelGGL((resunit_lds_kernel<2, 1>), grid, dim3(128), (ResunitLds<2, 1>::bytes), st, r);
+    if (wd3) hipLaunchKernelGGL((resunit_lds_kernel<4, 1, 3>), grid, dim3(256), (ResunitLds<4, 1>::bytes), st, r);
+    else hipLaunchKernelGGL((resunit_lds_kernel<4, 1, 1>), grid, dim3(256), (ResunitLds<4, 1>::bytes), st, r);
+  } else {
+    if (wd3) hipLaunchKernelGGL((resunit_lds_kernel<2, 1, 3>), grid, dim3(128), (ResunitLds<2, 1>::bytes), st, r);
+    else hipLaunchKernelGGL((resunit_lds_kernel<2, 1, 1>), grid, dim3(128), (ResunitLds<2, 1>::bytes), st, r);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "residual-unit launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;

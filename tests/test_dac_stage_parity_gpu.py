@@ -8,7 +8,7 @@ is gone: stage s of the engine and of the oracle read the same tensors (the ENGI
     activation y (v_sin_f32 / summation order at a rounding boundary): each flip moves one k1-conv operand by 2^-8;
   * the bf16 activation `act` = bf16(Snake(raw)): compared through the ENGINE's raw, so only flips at that one rounding are left.
 Bars (bf16-operand mode; set from the first MI355X run x 2, record profiles/r04_parity_dac_stages.txt): relative RMS of the stage's own
-contribution to the stream (a unit's raw - raw_in; a transposed conv's raw) <= RAW_TOL;
+contribution to the stream (a unit's raw - raw_in; a transposed conv's raw) <= RAW_TOL (1.5e-4 = 3 x measured; the un-rounded-intermediate negative control is 1.6e-3);
 act: every element within one bf16 ulp (2^-7 relative) and <= ACT_FLIP of the elements different at all. The negative controls in
 tests/test_oracle_dac.py show what these bars catch: a unit whose inner activation is NOT rounded, a dropped tap, a one-frame halo slip."""
 import pytest
@@ -19,8 +19,8 @@ from oracle import dac_oracle as DA
 
 pytestmark = pytest.mark.gpu
 
-RAW_TOL = {"bf16": 4e-4, "fp32": 2e-5}
-ACT_FLIP = 5e-3
+RAW_TOL = {"bf16": 1.5e-4, "fp32": 1e-5}  # measured on MI355X: 5.2e-5 / 1.6e-6 (profiles/r04_parity_dac_stages.txt)
+ACT_FLIP = 2e-4                           # measured 2.0e-5
 
 
 def _rel(a, b):

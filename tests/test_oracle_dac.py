@@ -81,7 +81,7 @@ def test_bf16_operand_oracle_equals_port_with_rounded_conv_operands(name, T):
 @torch.no_grad()
 def test_stage_by_stage_restatement_chains_to_decode_and_negative_controls(prec):
     """DacOracle.stage (what tests/test_dac_stage_parity_gpu.py compares each HIP kernel with) chained over all stages IS decode_latents, bit for
-    bit. Negative controls at the 44.1 kHz widths: what the per-stage bars (relative RMS of a unit's contribution to the stream <= 4e-4 in bf16 mode;
+    bit. Negative controls at the 44.1 kHz widths: what the per-stage bars (relative RMS of a unit's contribution to the stream <= 1.5e-4 in bf16 mode, measured 5e-5 on MI355X;
     bf16 flips of the inner activation under a 1e-6 perturbation cost ~6e-5 there) must and do catch -
     a residual unit whose inner activation is not rounded to bf16, a k7 conv with one tap dropped, an input slipped by one frame."""
     import torch.nn.functional as F
@@ -114,5 +114,5 @@ def test_stage_by_stage_restatement_chains_to_decode_and_negative_controls(prec)
         yt = DA._rb(DA.snake1d(F.conv1d(a_in, w7, o.w[r + "1.bias"], dilation=dil, padding=3 * dil), o.w[r + "2.alpha"]))
         tap = r_in + F.conv1d(yt, o.w[r + "3.weight"], o.w[r + "3.bias"])
         slip, _, _ = o.stage(s, torch.roll(a_in, 1, dims=-1), r_in)  # the halo one frame off
-        assert rel(unrounded - r_in, good - r_in) >= 3 * 4e-4, (s, rel(unrounded - r_in, good - r_in))  # measured 1.6e-3
+        assert rel(unrounded - r_in, good - r_in) >= 8 * 1.5e-4, (s, rel(unrounded - r_in, good - r_in))  # measured 1.6e-3
         assert rel(tap - r_in, good - r_in) >= 1e-2 and rel(slip - r_in, good - r_in) >= 1e-2, (s, rel(tap, good), rel(slip, good))
