@@ -241,8 +241,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   } while (0)
 
   // One k-step: MFMAs of (chunk c, step st) with the weight fragments WC while WN receives those of the NEXT k-step (possibly the
-  // first of chunk c + 1). Two copies alternate W0 / W1 so that the prefetched registers are never copied (a copy makes the
-  // compiler wait for the loads it has just issued). The last step of a chunk commits the staged slab and holds the chunk's barrier.
+  // first of chunk c + 1). The register sets rotate (never copied: a copy makes the compiler wait for the loads it has just issued). The last step of a chunk commits the staged slab and holds the chunk's barrier.
 #define PTTS_MFMA_HALF(WC, BV, F0)                                                                                      \
   _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_)                      \
     acc[s_][(F0) + f_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WC[s_]), __builtin_bit_cast(bf16x8, BV[f_]), acc[s_][(F0) + f_], 0, 0, 0);
@@ -250,10 +249,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   {                                                                                                                     \
     const unsigned char* sb_ = slab[c & 1];                                                                               \
     const bool more_ = c + 1 < nchunk, lastst_ = st + 1 == NS;                                                            \
-    const int nc_ = lastst_ ? c + 1 : c, ns_ = lastst_ ? 0 : st + 1;                                                      \
-    const bool next_ = nc_ < nchunk; /* the prefetch is unconditional (a valid re-fetch at the very end): a branch here */  \
-    if (st == 0 && more_) { PTTS_SLAB_FETCH(c + 1); } /* would merge into a conservative vmcnt on the MFMAs below */       \
-    PTTS_W_FETCH(WN, next_ ? nc_ : c, next_ ? ns_ : st);                                                                  \
+    const int gn_ = min(gi + 3, total - 1); /* weights of k-step + 3 (resunit_lds_kernel: WD). Unconditional (a valid */    \
+    const int gc_ = gn_ / NS;               /* re-fetch at the very end): a branch here would merge into a conservative */ \
+    if (st == 0 && more_) { PTTS_SLAB_FETCH(c + 1); } /* vmcnt on the MFMAs below */                                      \
+    PTTS_W_FETCH(WN, gc_, gn_ - gc_ * NS);                                                                                \
     PTTS_B_FETCH(bB, sb_, st, 4);                                                                                         \
     PTTS_MFMA_HALF(WC, bA, 0)                                                                                             \
     if (!lastst_) PTTS_B_FETCH(bA, sb_, st + 1, 0);                                                                       \
@@ -267,19 +266,24 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     } else {                                                                                                              \
       ++st;                                                                                                               \
     }                                                                                                                     \
+    ++gi;                                                                                                                 \
   }
-  float4 w0[CSW], w1[CSW];
+  const int total = nchunk * NS;
+  float4 w0[CSW], w1[CSW], w2[CSW], w3[CSW];  // four register sets: k-step g computes out of w[g % 4] while the fragments of k-step g + 3 land
   uint4 bA[4], bB[4];
   PTTS_W_FETCH(w0, 0, 0);
+  { const int g1_ = min(1, total - 1), c1_ = g1_ / NS; PTTS_W_FETCH(w1, c1_, g1_ - c1_ * NS); }
+  { const int g2_ = min(2, total - 1), c2_ = g2_ / NS; PTTS_W_FETCH(w2, c2_, g2_ - c2_ * NS); }
   PTTS_SLAB_FETCH(0);
   PTTS_SLAB_COMMIT(0);
   __syncthreads();
   PTTS_B_FETCH(bA, slab[0], 0, 0);
-  int c = 0, st = 0;
-  const int total = nchunk * NS;
-  for (int g = 0; g < total; g += 2) {
-    PTTS_STEP(w0, w1)
+  int c = 0, st = 0, gi = 0;
+  for (int g = 0; g < total; g += 4) {
+    PTTS_STEP(w0, w3)
     if (g + 1 < total) PTTS_STEP(w1, w0)
+    if (g + 2 < total) PTTS_STEP(w2, w1)
+    if (g + 3 < total) PTTS_STEP(w3, w2)
   }
 #undef PTTS_STEP
 #undef PTTS_MFMA_HALF
