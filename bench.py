@@ -441,7 +441,7 @@ def measure_dac(device, bs_list=(1, 32), with_f32: bool = True) -> dict:
     """SURVEY.md §8(d)'s SECOND bound of the path: DAC decode is MFMA-bound. One ptts_dac_decode of bs x 860 frames (what generate() calls
     after the token loop), timed by HIP events on its launch stream; achieved = algorithmic flops (1.608 GFLOP per frame x frames x bs)
     / time, against the dense bf16 MFMA peak (2.5 PFLOP/s) in the bf16-operand mode the headline configuration runs, and against the
-    fp32 MFMA peak (157.3 TFLOP/s) in the exact-f32 parity mode. Same synthetic codec weights as the model (seed 4321)."""
+    fp32 MFMA peak (157.3 TFLOP/s) in the exact-f32 parity mode (1 and 32 utterances). Same synthetic codec weights as the model (seed 4321)."""
     from parler_tts_amd.engine import DacEngine
     from parler_tts_amd.synthetic import random_dac_state_dict
 
@@ -449,14 +449,14 @@ def measure_dac(device, bs_list=(1, 32), with_f32: bool = True) -> dict:
     fl = dac_flops_per_frame()
     out = {"bound": "mfma", "unit": "TFLOP/s", "peak_bf16": 2500.0, "peak_f32": 157.3, "flops_per_frame": fl, "frames": FRAMES,
            "kernel": "ptts_dac_decode: RVQ gather + 30 conv launches (LDS-tiled bf16 MFMA k7 / transposed convs, fused residual units, tiled final conv + tanh)"}
-    for mode, dt, peak, sizes in (("bf16", torch.bfloat16, 2500.0, bs_list), ("f32", torch.float32, 157.3, (1,) if with_f32 else ())):
+    for mode, dt, peak, sizes in (("bf16", torch.bfloat16, 2500.0, bs_list), ("f32", torch.float32, 157.3, (1, 32) if with_f32 else ())):
         if not sizes:
             continue
         eng = DacEngine(max_batch=max(sizes), max_frames=FRAMES, device=device, compute_dtype=dt)
         eng.load_state_dict(sd)
         for bs in sizes:
             codes = torch.randint(0, 1024, (bs, K_CODEBOOKS, FRAMES), generator=torch.Generator().manual_seed(7)).to(device)
-            sec = _timed_dac(eng, codes, 10 if bs == 1 else 3)
+            sec = _timed_dac(eng, codes, 10 if bs == 1 else (3 if mode == "bf16" else 2))
             ach = fl * FRAMES * bs / sec / 1e12
             out[f"{mode}_bs{bs}"] = {"ms_per_launch": round(sec * 1e3, 3), "flops_per_launch": fl * FRAMES * bs, "achieved": round(ach, 1), "peak": peak,
                                      "frac": round(ach / peak, 4), "audio_seconds_per_sec": round(bs * AUDIO_S / sec, 1)}

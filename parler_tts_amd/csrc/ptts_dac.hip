@@ -538,9 +538,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   // CONSECUTIVE bytes of a row: the residual read, the stream write and the activation write are whole rows (tools/epilogue_probe.hip on
   // MI355X: 2.5-2.8 -> 3.9-5.1 TB/s with 64-frame tiles; 128-frame tiles do not pay). Same fp32 operations in the same order: bit-identical.
   if (!ra.epi_direct) {
-    constexpr int RSE = C * 4 + 16, VPR = C / 4, NV = 64 * VPR;
+    constexpr int RSE = C * 4 + 16, VPR = C / 4;
     unsigned char* et = lds;
     __syncthreads();  // every wave has finished reading the y tile
+    // the residual rows of a half tile are requested BEFORE its accumulators go through LDS (the k1 GEMM is over: 48 registers are free), so
+    // their round trip overlaps the transposition; the second half's rows are requested as each register of the first half is consumed
+    load_skip(0);
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -555,14 +558,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       }
       __syncthreads();
       const int r0 = t0 + hh * 64;
-      const int rows = min(64, Tv - r0);
+      const int rows = min(64, Tv - r0), rows1 = min(64, Tv - (t0 + 64));
       const size_t base = ((size_t)b * a.Tn + r0) * C;
-      load_skip(hh);
 #pragma unroll
       for (int k = 0; k < NPT; ++k) {
         const int i = tid + k * NT;
         const int rr = i / VPR, cv = i - rr * VPR;
         const float4 sk = skp[k];
+        if (hh == 0) skp[k] = rr < rows1 ? *reinterpret_cast<const float4*>(ra.skip + base + (size_t)64 * C + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (rr < rows) {
           const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
           const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
