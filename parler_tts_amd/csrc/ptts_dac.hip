@@ -43,6 +43,7 @@ struct ConvArgs {
   int stride, Tn;      // input stride of a down-sampling conv (else 1); output frames per phase (Tin unless strided)
   const int* lens;     // ragged decode (ptts_dac_decode_ragged): latent frames per utterance [B] on the device, or null. Utterance b then has
   int len_mul;         // lens[b] * len_mul valid input rows (= output rows per phase): rows beyond read as the zero padding, tiles beyond exit
+  int epi_direct;      // conv_lds_kernel A/B (PTTS_DAC_CONV_EPI_DIRECT=1): the round-3 epilogue (a lane stores 4 channels of one frame)
 };
 
 // valid input rows of utterance b (buffers keep the full stride a.Tin)
@@ -291,8 +292,54 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #undef PTTS_SLAB_COMMIT
 #undef PTTS_W_FETCH
 #undef PTTS_B_FETCH
-  // epilogue: as conv_mfma_kernel (D[row = co_local = q*4 + r][col = frame j]); explicit (s, f) calls keep `acc` statically indexed
   const int Tout = a.Tn * a.nphase;
+  // epilogue through LDS (default; as resunit_lds_kernel's): the workgroup's output tile [128 frames][NW * 48 channels] goes through the slab
+  // memory in passes of EF frames as fp32 rows, and every lane then moves 16 CONSECUTIVE bytes of a row (a row of the tile = NW * 192 bytes of
+  // an output row; the rows of a transposed conv's phase are `nphase` rows apart). The direct form below stores 64-byte pieces per lane group:
+  // the transposed convs ran 45-55 % parked at 25 % MFMA busy (profiles/r04_pmc_dac_sq.txt). Same fp32 operations in the same order.
+  if (!a.epi_direct) {
+    constexpr int CW = NW * CSW * 16, RSE = CW * 4 + 16, SLB = 2 * MAXROWS * RS, VPR = CW / 4;
+    constexpr int EF0 = SLB / RSE;
+    constexpr int EF = EF0 >= 128 ? 128 : (EF0 >= 64 ? 64 : (EF0 >= 32 ? 32 : 16)), TPP = EF / 16;
+    static_assert(EF0 >= 16, "one 16-frame pass of the output tile fits the slab memory");
+    unsigned char* et = &slab[0][0];  // the last chunk's barrier has retired every slab read
+    const int c0 = blockIdx.y * CW;
+#pragma unroll
+    for (int p0 = 0; p0 < FT; p0 += TPP) {
+#pragma unroll
+      for (int s = 0; s < CSW; ++s) {
+        const float4 bs = *reinterpret_cast<const float4*>(a.bias + (strip0 + s) * 16 + q * 4);
+#pragma unroll
+        for (int f = 0; f < TPP; ++f) {
+          const f32x4 av = acc[s][p0 + f];
+          *reinterpret_cast<float4*>(et + (f * 16 + j) * RSE + ((wave * CSW + s) * 16 + q * 4) * 4) = make_float4(av[0] + bs.x, av[1] + bs.y, av[2] + bs.z, av[3] + bs.w);
+        }
+      }
+      __syncthreads();
+      const int r0 = t0 + p0 * 16, rows = min(EF, Tnv - r0);
+#pragma unroll 4
+      for (int i = tid; i < EF * VPR; i += NT) {
+        const int rr = i / VPR, cv = i - rr * VPR;
+        if (rr >= rows) break;
+        float4 v = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
+        const size_t o = ((size_t)b * Tout + (size_t)(r0 + rr) * a.nphase + ph) * a.Cout + c0 + cv * 4;
+        if (a.skip) {
+          const float4 sk = *reinterpret_cast<const float4*>(a.skip + o);
+          v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
+        }
+        if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
+        if (a.out_act) {
+          const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + cv * 4);
+          const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+          if (!a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
+        }
+      }
+      if (p0 + TPP < FT) __syncthreads();  // the tile memory is rewritten by the next pass
+    }
+    return;
+  }
+  // direct epilogue: as conv_mfma_kernel (D[row = co_local = q*4 + r][col = frame j]); explicit (s, f) calls keep `acc` statically indexed
   auto emit = [&](const f32x4 av, const int s, const int f) {
     const int jj = t0 + f * 16 + j;
     if (jj >= Tnv) return;
@@ -1214,7 +1261,12 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   static const bool no_lds = getenv("PTTS_DAC_NO_LDS") != nullptr;
   static const int lds_min_c = getenv("PTTS_DAC_LDS_MIN_C") ? atoi(getenv("PTTS_DAC_LDS_MIN_C")) : 96;
   static const bool lds_small_taps = getenv("PTTS_DAC_LDS_K1") != nullptr;
-  const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c : (lds_small_taps || (a.transposed && L.Cout >= 192));
+  static const bool last_up_direct = getenv("PTTS_DAC_LAST_UP_DIRECT") && atoi(getenv("PTTS_DAC_LAST_UP_DIRECT"));  // A/B: the last transposed conv (-> 96 channels) on the direct kernel
+  const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c : (lds_small_taps || (a.transposed && L.Cout >= (last_up_direct ? 192 : 96)));
+  {
+    const char* ced = getenv("PTTS_DAC_CONV_EPI_DIRECT");  // read per call (A/B inside one process)
+    a.epi_direct = (ced && atoi(ced)) ? 1 : 0;
+  }
   if (L.bf16 && !no_lds && lds_ok && a.stride == 1 && nstrips % 6 == 0) {
     const int nw = nstrips % 12 == 0 ? 4 : 2;
     const int halo = a.transposed ? a.ntaps - 1 : (a.ntaps - 1) * a.dil;
