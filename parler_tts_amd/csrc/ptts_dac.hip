@@ -588,9 +588,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     constexpr int RSE = C * 4 + 16, VPR = C / 4;
     unsigned char* et = lds;
     __syncthreads();  // every wave has finished reading the y tile
-    // the residual rows of a half tile are requested BEFORE its accumulators go through LDS (the k1 GEMM is over: 48 registers are free), so
-    // their round trip overlaps the transposition; the second half's rows are requested as each register of the first half is consumed
-    load_skip(0);
+    // (requesting the residual rows before the transposition, and the second half's as the first half's registers free up, measured SLOWER:
+    //  C = 96 unit 4228 -> 4735 us, profiles/r04_experiments.txt call 7; they are requested after the tile's barrier, 12 loads at once)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -605,14 +604,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       }
       __syncthreads();
       const int r0 = t0 + hh * 64;
-      const int rows = min(64, Tv - r0), rows1 = min(64, Tv - (t0 + 64));
+      const int rows = min(64, Tv - r0);
       const size_t base = ((size_t)b * a.Tn + r0) * C;
+      load_skip(hh);
 #pragma unroll
       for (int k = 0; k < NPT; ++k) {
         const int i = tid + k * NT;
         const int rr = i / VPR, cv = i - rr * VPR;
         const float4 sk = skp[k];
-        if (hh == 0) skp[k] = rr < rows1 ? *reinterpret_cast<const float4*>(ra.skip + base + (size_t)64 * C + (size_t)i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (rr < rows) {
           const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
           const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
@@ -1261,8 +1260,10 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   static const bool no_lds = getenv("PTTS_DAC_NO_LDS") != nullptr;
   static const int lds_min_c = getenv("PTTS_DAC_LDS_MIN_C") ? atoi(getenv("PTTS_DAC_LDS_MIN_C")) : 96;
   static const bool lds_small_taps = getenv("PTTS_DAC_LDS_K1") != nullptr;
-  static const bool last_up_direct = getenv("PTTS_DAC_LAST_UP_DIRECT") && atoi(getenv("PTTS_DAC_LAST_UP_DIRECT"));  // A/B: the last transposed conv (-> 96 channels) on the direct kernel
-  const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c : (lds_small_taps || (a.transposed && L.Cout >= (last_up_direct ? 192 : 96)));
+  // the last transposed conv (-> 96 channels) stays on the direct kernel: the LDS-tiled one measured the same 5.19 ms per batch-32 launch
+  // (PTTS_DAC_LAST_UP_LDS=1 selects it; profiles/r04_experiments.txt call 7)
+  static const bool last_up_lds = getenv("PTTS_DAC_LAST_UP_LDS") && atoi(getenv("PTTS_DAC_LAST_UP_LDS"));
+  const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c : (lds_small_taps || (a.transposed && L.Cout >= (last_up_lds ? 96 : 192)));
   {
     const char* ced = getenv("PTTS_DAC_CONV_EPI_DIRECT");  // read per call (A/B inside one process)
     a.epi_direct = (ced && atoi(ced)) ? 1 : 0;
