@@ -51,8 +51,11 @@ __device__ __forceinline__ int valid_rows(const ConvArgs& a, int b) { return a.l
 
 // FAST (bf16-operand mode, whose activations are rounded to bf16 anyway): v_sin_f32 on a*x / 2pi instead of the ~100-instruction
 // exact sinf - the Snake epilogue of the 42 M-element layers was ~100 us of VALU per layer (profiles/r02_dac_layers.txt).
+// inv = 1.0f / (al + 1e-9f), computed ONCE per channel at load time (inv_alpha_kernel: the same correctly rounded fp32 division the
+// epilogues evaluated per element - ~10 VALU instructions beside a sin; the Snake of the fused units was 7.3 ms of a 69 ms batch-32 decode,
+// profiles/r04_experiments.txt call 8). Stored right behind the alphas: alpha[C + c].
 template <bool FAST>
-__device__ __forceinline__ float snake_f(float x, float al) {
+__device__ __forceinline__ float snake_f(float x, float al, float inv) {
   float s;
 #ifdef PTTS_DAC_FAST_SIN
   s = __sinf(al * x);
@@ -60,7 +63,12 @@ __device__ __forceinline__ float snake_f(float x, float al) {
   if constexpr (FAST) s = __sinf(al * x);
   else s = sinf(al * x);
 #endif
-  return x + (1.0f / (al + 1e-9f)) * (s * s);
+  return x + inv * (s * s);
+}
+__device__ __forceinline__ float4 ld_inv4(const float* alpha, int C, int c) { return *reinterpret_cast<const float4*>(alpha + C + c); }
+__global__ void inv_alpha_kernel(float* __restrict__ alpha, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) alpha[C + i] = 1.0f / (alpha[i] + 1e-9f);
 }
 
 // workgroup: 4 waves = 4 consecutive 32-frame tiles; every wave owns the SAME CS 16-channel output strips (CS = 6 or 8
@@ -151,8 +159,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     }
     if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
     if (a.out_act) {
-      const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
-      const float4 sv = make_float4(snake_f<BF>(v.x, al.x), snake_f<BF>(v.y, al.y), snake_f<BF>(v.z, al.z), snake_f<BF>(v.w, al.w));
+      const float4 al = *reinterpret_cast<const float4*>(a.alpha + co), ia = ld_inv4(a.alpha, a.Cout, co);
+      const float4 sv = make_float4(snake_f<BF>(v.x, al.x, ia.x), snake_f<BF>(v.y, al.y, ia.y), snake_f<BF>(v.z, al.z, ia.z), snake_f<BF>(v.w, al.w, ia.w));
       if (BF && !a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
       else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
     }
@@ -329,8 +337,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
         }
         if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
         if (a.out_act) {
-          const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + cv * 4);
-          const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+          const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + cv * 4), ia = ld_inv4(a.alpha, a.Cout, c0 + cv * 4);
+          const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
           if (!a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
           else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
         }
@@ -353,8 +361,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     }
     if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
     if (a.out_act) {
-      const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
-      const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+      const float4 al = *reinterpret_cast<const float4*>(a.alpha + co), ia = ld_inv4(a.alpha, a.Cout, co);
+      const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
       if (!a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
       else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
     }
@@ -534,9 +542,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   auto put_y = [&](const f32x4 av, const int s, const int f) {
     const int co = (strip0 + s) * 16 + q * 4;
     const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
-    const float4 al = *reinterpret_cast<const float4*>(a.alpha + co);
+    const float4 al = *reinterpret_cast<const float4*>(a.alpha + co), ia = ld_inv4(a.alpha, C, co);
     float4 sv = make_float4(av[0] + bs.x, av[1] + bs.y, av[2] + bs.z, av[3] + bs.w);
-    if (!(ra.dbg & 8)) sv = make_float4(snake_f<true>(sv.x, al.x), snake_f<true>(sv.y, al.y), snake_f<true>(sv.z, al.z), snake_f<true>(sv.w, al.w));
+    if (!(ra.dbg & 8)) sv = make_float4(snake_f<true>(sv.x, al.x, ia.x), snake_f<true>(sv.y, al.y, ia.y), snake_f<true>(sv.z, al.z, ia.z), snake_f<true>(sv.w, al.w, ia.w));
     *reinterpret_cast<uint2*>(ytile + (f * 16 + j) * RS2 + co * 2) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
   };
 #define RU_PUT_ROW(S)                                                                                                   \
@@ -621,9 +629,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
           const float4 v = make_float4(av.x + sk.x, av.y + sk.y, av.z + sk.z, av.w + sk.w);
           if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
           if (ra.out_act) {
-            const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + cv * 4);
+            const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + cv * 4), ia = ld_inv4(ra.alpha1, C, cv * 4);
             float4 sv = v;
-            if (!(ra.dbg & 8)) sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+            if (!(ra.dbg & 8)) sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
             if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
             else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
           }
@@ -643,8 +651,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     const float4 v = make_float4(av[0] + bs.x + sk.x, av[1] + bs.y + sk.y, av[2] + bs.z + sk.z, av[3] + bs.w + sk.w);
     if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
     if (ra.out_act) {
-      const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + co);
-      const float4 sv = make_float4(snake_f<true>(v.x, al.x), snake_f<true>(v.y, al.y), snake_f<true>(v.z, al.z), snake_f<true>(v.w, al.w));
+      const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + co), ia = ld_inv4(ra.alpha1, C, co);
+      const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
       if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
       else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
     }
@@ -778,8 +786,8 @@ __global__ void conv_in_kernel(const float* __restrict__ wave, const float* __re
   }
   const size_t off = bt * C + c4 * 4;
   *reinterpret_cast<float4*>(out_raw + off) = make_float4(o[0], o[1], o[2], o[3]);
-  const float4 al = *reinterpret_cast<const float4*>(alpha + c4 * 4);
-  *reinterpret_cast<float4*>(out_act + off) = make_float4(snake_f<false>(o[0], al.x), snake_f<false>(o[1], al.y), snake_f<false>(o[2], al.z), snake_f<false>(o[3], al.w));
+  const float4 al = *reinterpret_cast<const float4*>(alpha + c4 * 4), ia = ld_inv4(alpha, C, c4 * 4);
+  *reinterpret_cast<float4*>(out_act + off) = make_float4(snake_f<false>(o[0], al.x, ia.x), snake_f<false>(o[1], al.y, ia.y), snake_f<false>(o[2], al.z, ia.z), snake_f<false>(o[3], al.w, ia.w));
 }
 
 // F.normalize(codebook) rows: c / max(||c||_2, 1e-12)
@@ -1044,7 +1052,7 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
     if (ntaps > 16) return ptts_fail(PTTS_E_UNSUPPORTED, "%s: kernel size %d unsupported", name.c_str(), k);
     PTTS_TRY(d->alloc(&L.Wp, (size_t)nphase * Cout * ntaps * Cin));
     PTTS_TRY(d->alloc(&L.bias, Cout));
-    if (!alpha_name.empty()) PTTS_TRY(d->alloc(&L.alpha, Cout));
+    if (!alpha_name.empty()) PTTS_TRY(d->alloc(&L.alpha, 2 * (size_t)Cout));  // [alpha | 1 / (alpha + 1e-9)]
     d->required.insert(name + ".weight");
     d->required.insert(name + ".bias");
     if (!alpha_name.empty()) d->required.insert(alpha_name + ".alpha");
@@ -1096,7 +1104,7 @@ extern "C" int ptts_dac_create(const ptts_dac_config* cfg, ptts_dac** out) {
     target = &d->enc_convs;
     const int n = c.num_rates;
     int dim = c.encoder_dim;
-    A(d->alloc(&d->in0_w, (size_t)dim * 7)); A(d->alloc(&d->in0_b, dim)); A(d->alloc(&d->in0_alpha, dim));
+    A(d->alloc(&d->in0_w, (size_t)dim * 7)); A(d->alloc(&d->in0_b, dim)); A(d->alloc(&d->in0_alpha, 2 * (size_t)dim));
     d->required.insert("encoder.block.0.weight"); d->required.insert("encoder.block.0.bias");
     d->required.insert("encoder.block.1.block.0.block.0.alpha");
     for (int bi = 0; bi < n; ++bi) {
@@ -1189,14 +1197,22 @@ extern "C" int ptts_dac_load_weight(ptts_dac* d, const char* name_c, const float
   if (c.encoder_dim > 0) {
     if (name == "encoder.block.0.weight") return copy(d->in0_w, (size_t)c.encoder_dim * 7);
     if (name == "encoder.block.0.bias") return copy(d->in0_b, c.encoder_dim);
-    if (name == "encoder.block.1.block.0.block.0.alpha") return copy(d->in0_alpha, c.encoder_dim);
+    if (name == "encoder.block.1.block.0.block.0.alpha") {
+      PTTS_TRY(copy(d->in0_alpha, c.encoder_dim));
+      hipLaunchKernelGGL(inv_alpha_kernel, dim3((c.encoder_dim + 255) / 256), dim3(256), 0, st, d->in0_alpha, c.encoder_dim);
+      return PTTS_OK;
+    }
   }
   std::vector<ConvLayer*> all;
   for (ConvLayer& L : d->convs) all.push_back(&L);
   for (ConvLayer& L : d->enc_convs) all.push_back(&L);
   for (ConvLayer* Lp : all) {
     ConvLayer& L = *Lp;
-    if (!L.alpha_name.empty() && name == L.alpha_name + ".alpha") return copy(L.alpha, L.Cout);
+    if (!L.alpha_name.empty() && name == L.alpha_name + ".alpha") {
+      PTTS_TRY(copy(L.alpha, L.Cout));
+      hipLaunchKernelGGL(inv_alpha_kernel, dim3((L.Cout + 255) / 256), dim3(256), 0, st, L.alpha, L.Cout);
+      return PTTS_OK;
+    }
     if (name == L.name + ".bias") return copy(L.bias, L.Cout);
     if (name == L.name + ".weight") {
       const int k = L.ksize;
