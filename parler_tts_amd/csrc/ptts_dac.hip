@@ -396,8 +396,6 @@ struct ResArgs {
   void* out_act;        // activated output, bf16 (fp32 if act_f32): NOT the buffer x lives in (neighbouring tiles read x's halo rows)
   int act_f32;
   int epi_direct;       // A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane owns 4 channels of one frame: 64-byte pieces of the stream)
-  int dbg;              // TIMING ABLATIONS ONLY (PTTS_DAC_DBG bit mask, results are wrong): 1 = no slab loads from memory, 2 = weight fragments
-                        // fetched once, 4 = no epilogue loads / stores, 8 = no Snake in either epilogue (tools/runs/r04_call8.sh)
 };
 
 // dynamic LDS of resunit_lds_kernel<NW>: the two slab buffers of phase A, overlaid by the y tile [128 frames][C bf16 + pad] of phase B
@@ -458,7 +456,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
     const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL, ti_ = t0 + o0 + r_;                              \
     stg[i_] = make_uint4(0, 0, 0, 0);                                                                                    \
-    if (idx_ < nslot && ti_ >= 0 && ti_ < Tv && !(ra.dbg & 1))                                                            \
+    if (idx_ < nslot && ti_ >= 0 && ti_ < Tv)                                                                             \
       stg[i_] = *reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * C + (size_t)(CC) * KCH) * 2 + sl_ * 16);               \
   }
 #define RU_SLAB_COMMIT(BUFP)                                                                                            \
@@ -469,7 +467,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #define RU_W_FETCH(WF, CC, S)                                                                                           \
   do {                                                                                                                  \
     const int tap_ = (S) / KS, kk_ = (S) - tap_ * KS;                                                                     \
-    if ((ra.dbg & 2) && ((CC) | (S))) break;                                                                              \
     const float4* wp_ = Wp + (size_t)(tap_ * cpt + (CC) * KS + kk_) * 64;                                                 \
     _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_) WF[s_] = wp_[(size_t)s_ * nk * 64];                               \
   } while (0)
@@ -543,8 +540,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     const int co = (strip0 + s) * 16 + q * 4;
     const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
     const float4 al = *reinterpret_cast<const float4*>(a.alpha + co), ia = ld_inv4(a.alpha, C, co);
-    float4 sv = make_float4(av[0] + bs.x, av[1] + bs.y, av[2] + bs.z, av[3] + bs.w);
-    if (!(ra.dbg & 8)) sv = make_float4(snake_f<true>(sv.x, al.x, ia.x), snake_f<true>(sv.y, al.y, ia.y), snake_f<true>(sv.z, al.z, ia.z), snake_f<true>(sv.w, al.w, ia.w));
+    const float4 sv = make_float4(snake_f<true>(av[0] + bs.x, al.x, ia.x), snake_f<true>(av[1] + bs.y, al.y, ia.y), snake_f<true>(av[2] + bs.z, al.z, ia.z),
+                                  snake_f<true>(av[3] + bs.w, al.w, ia.w));
     *reinterpret_cast<uint2*>(ytile + (f * 16 + j) * RS2 + co * 2) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
   };
 #define RU_PUT_ROW(S)                                                                                                   \
@@ -615,9 +612,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       }
       __syncthreads();
       const int r0 = t0 + hh * 64;
-      const int rows = (ra.dbg & 4) ? 0 : min(64, Tv - r0);
+      const int rows = min(64, Tv - r0);
       const size_t base = ((size_t)b * a.Tn + r0) * C;
-      if (!(ra.dbg & 4)) load_skip(hh);
+      load_skip(hh);
 #pragma unroll
       for (int k = 0; k < NPT; ++k) {
         const int i = tid + k * NT;
@@ -630,8 +627,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
           if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
           if (ra.out_act) {
             const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + cv * 4), ia = ld_inv4(ra.alpha1, C, cv * 4);
-            float4 sv = v;
-            if (!(ra.dbg & 8)) sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
+            const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
             if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
             else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
           }
@@ -1363,8 +1359,6 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
   {
     const char* ed = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process, like PTTS_DAC_NO_FUSE_RES)
     r.epi_direct = (ed && atoi(ed)) ? 1 : 0;
-    const char* dg = getenv("PTTS_DAC_DBG");
-    r.dbg = dg ? atoi(dg) : 0;
   }
   const dim3 grid((unsigned)(((T + 127) / 128) * B));
   const char* wde = getenv("PTTS_DAC_WD1");  // A/B: weight fragments requested one k-step ahead (two register sets) instead of three

@@ -3,6 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 {
+# (needs the library of commit 46a93c0: the PTTS_DAC_DBG ablation switches were removed afterwards)
 for D in 0 1 2 4 8 5 15; do PTTS_DAC_DBG=$D timeout 120 tools/cabi_probe dac 32 tag=dbg$D; done
 timeout 120 tools/cabi_probe dac 1 tag=final
 } > gpurun_out/r04_probes8.txt 2>&1
