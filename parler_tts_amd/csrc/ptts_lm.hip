@@ -87,7 +87,6 @@ struct ptts_engine {
   bool use_fo = true;                  // batch > 8 decode: engine-dtype activations in MFMA B-fragment order (PTTS_NO_FO=1: row-major, for A/B)
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
-  int attn_u16 = 0;    // decode self-attention at batch > 8 with 16 K/V row groups in flight per wave (PTTS_ATTN_U=16)
   int cross_waves = 4; // waves per cross-attention workgroup on the GEMV step: one 8-deep batch of row groups per wave covers max_enc
   // state
   long long* ids = nullptr;
@@ -262,14 +261,8 @@ int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of 
 }
 
 template <typename WT>
-int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4, int u16 = 0) {
+int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
   const dim3 grid(a.S, a.nheads, B * a.Q);
-  if (u16 && waves == 4) {
-    hipLaunchKernelGGL((attn_kernel<WT, 4, 16>), grid, dim3(256), 0, st, a);
-    hipError_t e16 = hipGetLastError();
-    if (e16 != hipSuccess) return ptts_fail(PTTS_E_HIP, "attn launch failed: %s", hipGetErrorString(e16));
-    return PTTS_OK;
-  }
   if (waves == 1) hipLaunchKernelGGL((attn_kernel<WT, 1>), grid, dim3(64), 0, st, a);
   else if (waves == 2) hipLaunchKernelGGL((attn_kernel<WT, 2>), grid, dim3(128), 0, st, a);
   else if (waves == 8) hipLaunchKernelGGL((attn_kernel<WT, 8>), grid, dim3(512), 0, st, a);
@@ -461,7 +454,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
       a.direct_out = S_used == 1 ? e->xw : nullptr; a.out_fo = fo;
       a.exact_len = (!prefill && M > 8 && e->attn_exact) ? 1 : 0;
-      PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves, (!prefill && M > 8) ? e->attn_u16 : 0)));
+      PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
       GemmArgs g = {};
@@ -823,7 +816,6 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc_bytes(&e->xw, (rows + 16) * H * es));  // + 16 rows: fragment order addresses whole 16-row tiles
   A(e->alloc_bytes(&e->xw2, std::max((rows + 16) * F, enc_rows * (size_t)H) * es));
   e->use_fo = !(getenv("PTTS_NO_FO") && atoi(getenv("PTTS_NO_FO")));
-  if (const char* ev = getenv("PTTS_ATTN_U")) e->attn_u16 = atoi(ev) == 16 ? 1 : 0;
   e->attn_exact = !(getenv("PTTS_NO_ATTN_EXACT") && atoi(getenv("PTTS_NO_ATTN_EXACT")));
   A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));

@@ -964,11 +964,9 @@ __device__ __forceinline__ void rope_apply(float (&x)[EPL], const float (&y)[EPL
 // argument: the cache capacity, or - decode steps - the host's upper bound of the context rounded up to 64 (the step graph is
 // captured once per 64-position bucket), so the speculative batch does not fetch rows no utterance can have yet (PMC: 34 MB per
 // launch at batch 32 and context 57 against 7.5 MB of live cache); validity against the lengths is applied when the data is used.
-// U: K/V row groups a wave keeps in flight per batch (8: 16 KiB per wave; 16 - decode at batch > 8, PTTS_ATTN_U=16 - 32 KiB: a 4-wave workgroup
-// covers 512 positions of bf16 cache in ONE dependent round trip instead of two)
-template <typename WT, int NW, int U = 8>
+template <typename WT, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
-  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR;
+  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8;
   __shared__ float s_o[NW][64];
   __shared__ float s_ml[NW][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -522,18 +522,6 @@ def test_long_context_split_kv_matches_oracle():
     assert worst < 3e-5, worst
 
 
-@pytest.mark.parametrize("dtype,prec,tol", [(torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)])
-def test_batched_self_attention_16_row_groups_in_flight(dtype, prec, tol, monkeypatch):
-    """PTTS_ATTN_U=16 (read at engine creation): the decode self-attention of a > 8-utterance engine keeps 16 K/V row groups per wave in flight
-    (a 4-wave workgroup covers 512 bf16 / 256 fp32 positions per dependent round trip). 12 utterances with ragged prompts, a 300-position
-    prompt so that the context crosses one batch of rows in fp32 (304..312 > 256) and sits inside one in bf16, exact-length fetch on."""
-    monkeypatch.setenv("PTTS_ATTN_U", "16")
-    spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "max_position_embeddings": 512})
-    sd = DO.make_decoder_weights(spec, seed=23)
-    err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=12, N=21, P=300, steps=8, masks=True, seed=5, max_ctx=384)
-    assert err < tol, (prec, err)
-
-
 def test_sampling_topk1_equals_greedy_and_distribution():
     spec = DO.TINY
     sd = DO.make_decoder_weights(spec, seed=5)
