@@ -428,3 +428,51 @@ def test_stream_split_device_loop_equals_per_half_runs():
     m.decode_streams = 0
     assert both.shape == (16, halves[0].shape[1]) and torch.equal(both, torch.cat(halves, dim=0))
     assert len(m._split_engines) == 2 and float(both.abs().max()) > 0
+
+
+def test_generate_eos_terminated_batch_of_8_goes_through_one_ragged_codec_pass():
+    """generate()'s per-sample tail (modeling_parler_tts.py:3615-3647) on an EOS-terminated batch of 8 with DISTINCT lengths: the ids the token
+    loop produced (captured at the hand-over) are un-delayed, filtered and decoded utterance by utterance by the ORACLE, exactly as the
+    reference's loop does; generate() itself runs ONE filter kernel + ONE ragged codec pass (DACModel.decode_filtered). Waveforms <= 1e-4 RMS,
+    lengths equal, zero padding exact. Independent of the LM's top-2 margins (whatever ids the engine chose are the ones both sides decode)."""
+    m, spec, sd, dsd = _tiny_model(seed=2, eos_gain=6.0)
+    m = m.to("cuda")
+    g = torch.Generator().manual_seed(200)
+    B = 8
+    desc = torch.randint(3, 128, (B, 9), generator=g)
+    dm = torch.ones(B, 9, dtype=torch.long)
+    dm[1, 6:] = 0
+    dm[5, 4:] = 0
+    pid = torch.randint(3, 128, (B, 5), generator=g)
+    pm = torch.ones(B, 5, dtype=torch.long)
+    pm[1, :2] = 0
+    seen, calls = {}, []
+    tail = m._undelay_and_decode
+    filt = m.audio_encoder.decode_filtered
+
+    def spy_tail(output_ids, *a, **k):
+        seen["ids"] = output_ids.detach().cpu().clone()
+        return tail(output_ids, *a, **k)
+
+    def spy_filtered(codes):
+        calls.append(tuple(codes.shape))
+        return filt(codes)
+
+    m._undelay_and_decode = spy_tail
+    m.audio_encoder.decode_filtered = spy_filtered
+    out = m.generate(input_ids=desc.cuda(), attention_mask=dm.cuda(), prompt_input_ids=pid.cuda(), prompt_attention_mask=pm.cuda(), do_sample=False,
+                     max_length=60, min_new_tokens=4, return_dict_in_generate=True)
+    wav, lens = out.sequences.cpu(), out["audios_length"]
+    assert len(calls) == 1 and calls[0][1] == B  # one ragged pass over the whole batch
+    codes = DO.undelay(seen["ids"], spec, 60)
+    orc = DA.DacOracle(DA.DAC_TINY, dsd)
+    want = []
+    for b in range(B):
+        c = DO.valid_frames(codes[b])
+        want.append(orc.decode(c[None])[0, 0] if c.shape[1] else torch.zeros(1))
+    assert len({w.shape[0] for w in want}) >= 4, [w.shape[0] for w in want]  # really ragged
+    assert wav.shape == (B, max(w.shape[0] for w in want))
+    for b in range(B):
+        assert lens[b] == want[b].shape[0], (b, lens, want[b].shape)
+        assert float((wav[b, : lens[b]] - want[b]).pow(2).mean().sqrt()) <= 1e-4
+        assert float(wav[b, lens[b]:].abs().sum()) == 0.0
