@@ -101,6 +101,9 @@ struct ptts_engine {
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
   int xattn_groups_max = 256; // largest batch that runs the fused cross block in groups of 8 (PTTS_XATTN_GROUPS_MAX; above: rows_prep + q GEMM + attention)
+  int lnproj = 0;             // decode at batch > 8: LayerNorm + projection as ONE node tiled over 64 weight rows x lnproj_g utterances instead of rows_prep + strip GEMM
+                              // (PTTS_LNPROJ: 0 off, 1 = LN1 + QKV, 2 = + LN3 + fc1 above 32 utterances, 3 = + LN3 + fc1 at 9..32 too instead of the producer-statistics prologue)
+  int lnproj_g = 8;           // utterances per workgroup of that node (PTTS_LNPROJ_G = 8 / 4)
   int xattn_g = 0;            // utterances per workgroup of the fused cross block above 8 utterances: 0 = by batch size (2 up to 32, 4 up to 64, 8 above), PTTS_XATTN_G = 8 / 4 / 2 forces one
   bool xattn_g_ok = false;    // the g < 8 instances exist for this width (Mini-v1, Large-v1)
   bool xattn_groups = true;   // the fused LN2 + cross-q + cross-attention kernel also at batch 9..32, in groups of 8 utterances (PTTS_NO_XATTN_GROUPS=1: two nodes)
@@ -280,6 +283,30 @@ int launch_prep(GemmArgs a, void* dst, hipStream_t st) {
   return PTTS_OK;
 }
 
+// LayerNorm (+ fold of pending fc2 partials) + projection, tiled over 64 weight rows x G utterances (lnproj_fused_kernel): decode at batch > 8
+template <typename WT, int EPI>
+int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st) {
+  constexpr int KT = Elem<WT>::KT;
+  const int H = p.K, g = e->lnproj_g;
+  p.invK = 1.0f / (float)H;
+  const int mg = p.M < g ? p.M : g;
+  const size_t sh = (size_t)mg * (H * sizeof(WT) + 16) + 8 * 1024;
+  const dim3 grid(p.N / 64, (p.M + g - 1) / g);
+  const bool u16 = ((H / KT) / 2) % 16 == 0;
+#define PTTS_LNPROJ_LAUNCH(UW, NF4)                                                                                   \
+  do {                                                                                                                \
+    if (g == 4) hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 4, EPI>), grid, dim3(512), sh, st, p);              \
+    else hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 8, EPI>), grid, dim3(512), sh, st, p);                    \
+  } while (0)
+  if (H == 1024 && u16) PTTS_LNPROJ_LAUNCH(16, 4);
+  else if (H == 1024) PTTS_LNPROJ_LAUNCH(8, 4);
+  else PTTS_LNPROJ_LAUNCH(8, 6);
+#undef PTTS_LNPROJ_LAUNCH
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "lnproj launch failed: %s", hipGetErrorString(err));
+  return PTTS_OK;
+}
+
 // LN -> GEMM and split-KV-combine -> GEMM: fused prologue at M <= 8 rows, prep kernel + copy staging above (the
 // redundant per-workgroup prologue is 88 % of the GEMM at M = 32: tools/phase_probe, profiles/).
 template <typename WT, int PRO, int EPI>
@@ -430,9 +457,19 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // launches on the time-to-first-token path; PTTS_NO_FO_PREFILL=1 keeps the row-major layout there for A/B)
   static const bool fo_prefill = !(getenv("PTTS_NO_FO_PREFILL") && atoi(getenv("PTTS_NO_FO_PREFILL")));
   const int fo = (e->use_fo && M > 8 && (!prefill || (fo_prefill && M <= 256))) ? 1 : 0;
+  // LayerNorm + projection as one node (lnproj_fused_kernel): decode, batch > 8, Mini / Large widths, weights in the engine dtype (e4m3 strips keep
+  // streaming bytes through the strip GEMMs)
+  const int KTf = Elem<WT>::KT;
+  const bool lnproj_ok = e->lnproj > 0 && !prefill && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
+  bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
-    {  // LN1 + fused QKV projection
+    if (lnproj_ok) {  // LN1 (+ fold of the previous fc2's partials) + fused QKV projection in one node
+      LnProjArgs p = {};
+      p.W = w.qkv; p.x = e->h; p.x_ld = H; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.K = H; p.out = e->qkv; p.out_ld = QKV; p.M = M; p.N = QKV;
+      if (fc2_pending) { p.part = e->hpart; p.S = FC2_KSPLIT; fc2_pending = false; resid_fold = true; }
+      PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st)));
+    } else {  // LN1 + fused QKV projection
       GemmArgs g = {};
       g.W = w.qkv; g.W8 = w.qkv_p8; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
       g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H; g.x_fo = fo;
@@ -460,6 +497,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       GemmArgs g = {};
       g.W = w.o; g.W8 = w.o_p8; g.wscale = w.o_sc; g.part = e->part; g.stats = e->stats; g.S = S_used; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
+      if (resid_fold) { g.fold_part = e->hpart; g.fold_S = FC2_KSPLIT; resid_fold = false; }  // the LN1 node normalised h + partials without writing it back
       if (lns) g.stats_out = e->lnstat;  // strip statistics of the new residual rows for LN2 (PRO_LNS)
       if (S_used == 1) {
         g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
@@ -531,6 +569,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       if (big) {
         g.out = reinterpret_cast<float*>(e->xw2); g.x_fo = fo; g.out_fo = fo;
         if (lns) g.lnstat = e->lnstat;
+        if (lnproj_ok && (e->lnproj >= 3 || (e->lnproj == 2 && M > 32))) {  // LN3 + fc1 + GELU in one node
+          LnProjArgs p = {};
+          p.W = w.fc1; p.x = e->h; p.x_ld = H; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.K = H; p.out = e->xw2; p.out_ld = F; p.out_fo = fo; p.M = M; p.N = F;
+          PTTS_TRY((launch_lnproj<WT, EPI_GELU_WT>(e, p, st)));
+        } else
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
         g2.x = reinterpret_cast<const float*>(e->xw2); g2.x_fo = fo;
         if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0)) {
@@ -821,6 +864,8 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
   if (const char* ev = getenv("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));
+  if (const char* ev = getenv("PTTS_LNPROJ")) e->lnproj = std::max(0, std::min(3, atoi(ev)));
+  if (const char* ev = getenv("PTTS_LNPROJ_G")) e->lnproj_g = atoi(ev) == 4 ? 4 : 8;
   e->xattn_g_ok = (H == 1024 && ((H / (c.dtype == PTTS_BF16 ? 32 : 16)) / 2) % 16 == 0) || H == 1536;
   if (const char* ev = getenv("PTTS_XATTN_G")) { const int g = atoi(ev); if (g == 2 || g == 4 || g == 8) e->xattn_g = e->xattn_g_ok ? g : 8; }
   e->xattn_groups = !(getenv("PTTS_NO_XATTN_GROUPS") && atoi(getenv("PTTS_NO_XATTN_GROUPS")));  // measured: 1386 -> 1360 us per batch-32 step (profiles/r03_experiments.txt)

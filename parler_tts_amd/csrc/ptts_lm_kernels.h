@@ -112,6 +112,8 @@ struct GemmArgs {
   int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
   int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
   int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
+  const float* fold_part;  // EPI_RESID: pending split-K partials [fold_S][M][N] of the previous fc2 that no prep kernel has added to the residual rows
+  int fold_S;              // (lnproj_fused_kernel normalised h + sum_s part[s] without writing it back): out = (out + sum_s part[s]) + acc, same order
 #ifdef PTTS_TIMING
   long long* dbg;      // phase timestamps (s_memtime) of workgroup 0 / wave 0
 #endif
@@ -643,6 +645,12 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
         } else if (EPI == EPI_RESID) {
           float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
           float4 o = mt == wave ? resid_pre : *p;
+          if (a.fold_part) {
+            for (int sp = 0; sp < a.fold_S; ++sp) {
+              const float4 u = *reinterpret_cast<const float4*>(a.fold_part + ((size_t)sp * a.M + m) * a.N + n);
+              o.x += u.x; o.y += u.y; o.z += u.z; o.w += u.w;
+            }
+          }
           o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
           *p = o;
           r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = o.w;  // the updated residual values, for the strip statistics below
@@ -1334,6 +1342,143 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
     for (int e = 0; e < EPL; ++e) res[e] = o[e] * inv;
     if (a.out_fo) reinterpret_cast<uint4*>(a.out)[fo_vec_index<WT>(b, h * 64 + c * EPL, a.K / KT)] = pack16(res, WT());
     else reinterpret_cast<uint4*>(reinterpret_cast<WT*>(a.out) + (size_t)b * a.K + h * 64)[c] = pack16(res, WT());
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// lnproj_fused_kernel (decode, batch > 8): LayerNorm [+ fold of the previous fc2's split-K partials] + a 64-row block of a projection for a
+// GROUP of G <= 8 utterances per workgroup - the front half of xattn_fused_kernel as a node of its own, for LN1 + QKV (:1020-1021, :848-850) and
+// LN3 + fc1 + GELU (:1059-1060). The strip GEMMs tile N only (16 weight rows x ALL M rows per workgroup): a LayerNorm prologue there would
+// normalise every row in every one of the N / 16 workgroups (88 % of the GEMM at M = 32, round 1), so LN1 / LN3 ran as a rows_prep node in
+// front of the GEMM: 4.9 + ~1.5 (boundary) us per layer at batch 32, 2 x 5.0 + gaps at 128. Tiled over N AND M (64 rows x G utterances, full K)
+// a workgroup normalises only its own G rows (redundant over the N / 64 row blocks: G x 4 KB each, from the L2) and re-streams its 128 KB of
+// weights once per utterance group, also from the L2: the prep node and its boundary are gone and the arithmetic per row is prep_ln_row_regs'
+// (same fold order, same one-pass shifted statistics), so the normalised rows are bit-identical to the two-node path.
+// 8 waves = 4 weight strips x 2 K halves; wave w < nb normalises row b0 + w first.
+// EPI_STORE: fp32 [M][out_ld] (QKV); EPI_GELU_WT: gelu_erf in the engine dtype, row-major or MFMA B-fragment order (fc1 -> fc2).
+// The folded residual rows are NOT written back here (N / 64 workgroups read them concurrently): the next EPI_RESID GEMM on the stream
+// (out_proj) adds the same partials in the same order (GemmArgs::fold_part).
+// ------------------------------------------------------------------------------------------------------
+struct LnProjArgs {
+  const void* W;        // packed strips [N/16][K/KT][64][16 B]
+  const float* x;       // residual stream h [M][x_ld]
+  int x_ld;
+  const float* part;    // pending split-K partials [S][M][K] fp32 of the previous fc2, or null
+  int S;
+  const float* gamma;
+  const float* beta;
+  int K;                // hidden size (= NF4 * 256)
+  float invK;
+  void* out;
+  int out_ld;
+  int out_fo;           // EPI_GELU_WT: B-fragment order for the consumer GEMM
+  int M, N;
+};
+
+template <typename WT, int UW, int NF4, int G, int EPI>
+__global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
+  constexpr int KT = Elem<WT>::KT, NWV = 8;
+  static_assert(G <= NWV, "one row per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b0 = blockIdx.y * G, nb = min(G, a.M - b0), nbmax = min(G, a.M);
+  const int row_bytes = a.K * (int)sizeof(WT) + 16;
+  char* s_x = smem_raw;                                                           // [G][row_bytes]
+  float* s_red = reinterpret_cast<float*>(smem_raw + (size_t)nbmax * row_bytes);  // [8 waves][64][4]
+  const int nfrag = a.K / KT;
+  const int strip = blockIdx.x * 4 + (wave >> 1);
+  const int per = nfrag >> 1;  // host guarantees per % UW == 0
+  const int t0 = (wave & 1) * per, t1 = t0 + per;
+  const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
+  const int q4 = lane >> 4, j = lane & 15;
+  uint4 afr[UW];
+  // ---- t = 0: the residual row (+ its pending partials, + gamma / beta) of this wave first, then - behind a rendezvous, so that no wave's row
+  // queues behind another wave's weights - the first UW weight fragments
+  if (wave < nb) {
+    const int m = b0 + wave;
+    const float* xr = a.x + (size_t)m * a.x_ld;
+    float4 v[NF4], g[NF4], bt[NF4];
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+    float4 u[4][NF4];  // S <= 4 partial rows (FC2_KSPLIT), all in flight with the row
+    if (a.part) {
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+        for (int i = 0; i < NF4; ++i)
+          u[sp][i] = *reinterpret_cast<const float4*>(a.part + ((size_t)min(sp, a.S - 1) * a.M + m) * a.K + (lane + 64 * i) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+      bt[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int uu = 0; uu < UW; ++uu) afr[uu] = ld_nt16(Wp + (size_t)(t0 + uu) * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.part) {  // h + sum_s part[s] in fixed order: prep_ln_row_regs' arithmetic
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+        if (sp < a.S) {
+#pragma unroll
+          for (int i = 0; i < NF4; ++i) { v[i].x += u[sp][i].x; v[i].y += u[sp][i].y; v[i].z += u[sp][i].z; v[i].w += u[sp][i].w; }
+        }
+    }
+    const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const float d0 = v[i].x - c, d1 = v[i].y - c, d2 = v[i].z - c, d3 = v[i].w - c;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float dm = s1 * a.invK, mean = c + dm;
+    const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+    char* row = s_x + (size_t)wave * row_bytes;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i)
+      lds_store4<WT>(row, (lane + 64 * i) * 4, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
+                     (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
+  } else {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int uu = 0; uu < UW; ++uu) afr[uu] = ld_nt16(Wp + (size_t)(t0 + uu) * 64);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  // ---- the block's 64 projection rows for the group's utterances (columns j < nb of the MFMA tile)
+  const char* brow = s_x + (size_t)min(j, nb - 1) * row_bytes + (size_t)q4 * 16;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tb = t0; tb < t1; tb += UW) {
+    if (tb != t0) {
+#pragma unroll
+      for (int uu = 0; uu < UW; ++uu) afr[uu] = ld_nt16(Wp + (size_t)(tb + uu) * 64);
+    }
+#pragma unroll
+    for (int uh = 0; uh < UW; uh += 8) {
+      uint4 bfr[8];
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) bfr[uu] = *reinterpret_cast<const uint4*>(brow + (size_t)(tb + uh + uu) * (KT * sizeof(WT)));
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) {
+        if (uu & 1) acc2 = MfmaStep<WT>::run(afr[uh + uu], bfr[uu], acc2);
+        else acc = MfmaStep<WT>::run(afr[uh + uu], bfr[uu], acc);
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(s_red + ((size_t)wave * 64 + lane) * 4) = acc + acc2;
+  __syncthreads();
+  if (wave < 4 && j < nb) {  // wave s combines the two K halves of strip s: D[row = q4*4 + e][col = utterance j]
+    const f32x4 rr = *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave) * 64 + lane) * 4) +
+                     *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave + 1) * 64 + lane) * 4);
+    const int m = b0 + j, n = (blockIdx.x * 4 + wave) * 16 + q4 * 4;
+    if (EPI == EPI_STORE) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.out_ld + n) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+    else act_store4<WT>(reinterpret_cast<WT*>(a.out), m, n, a.out_ld, a.out_fo, gelu_erf(rr[0]), gelu_erf(rr[1]), gelu_erf(rr[2]), gelu_erf(rr[3]));
   }
 }
 

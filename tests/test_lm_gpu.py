@@ -400,6 +400,27 @@ def test_fused_cross_block_with_fewer_utterances_per_workgroup(g, bsz, N, monkey
         assert err < 3e-2, (g, "large", err)
 
 
+@pytest.mark.parametrize("mode,g", [(1, 8), (2, 8), (3, 8), (3, 4)])
+@pytest.mark.parametrize("bsz", [9, 13, 32, 44, 128])
+def test_layernorm_plus_projection_as_one_node(mode, g, bsz, monkeypatch):
+    """PTTS_LNPROJ (read at engine creation): above 8 utterances LN1 + QKV (mode >= 1) and LN3 + fc1 + GELU (mode 2: above 32 utterances, mode 3: always)
+    run as ONE node tiled over 64 weight rows x g utterances (lnproj_fused_kernel) instead of rows_prep + strip GEMM; the fc2 split-K partials of the
+    previous layer are folded by the LN1 node and by the following out_proj's residual epilogue. 3 layers (two fold hand-overs), ragged groups
+    (9, 13, 44), ragged masks; Mini widths in both dtypes, Large widths in bf16."""
+    monkeypatch.setenv("PTTS_LNPROJ", str(mode))
+    monkeypatch.setenv("PTTS_LNPROJ_G", str(g))
+    spec = DO.DecoderSpec(num_hidden_layers=3, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=53)
+    for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
+        err = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=21, P=6, steps=3, masks=True, seed=bsz)
+        assert err < tol, (mode, g, bsz, prec, err)
+    if bsz == 13:
+        spec = DO.DecoderSpec(hidden_size=1536, num_attention_heads=24, ffn_dim=6144, num_hidden_layers=2, max_position_embeddings=256)
+        sd = DO.make_decoder_weights(spec, seed=77)
+        err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=10, P=5, steps=3, masks=True, seed=3)
+        assert err < 3e-2, (mode, g, "large", err)
+
+
 def test_large_v1_width_two_layers_bf16_and_fp32_batch():
     """Large-v1 widths (H=1536, 24 heads, F=6144; init_large_model.py:25-43) with 2 layers, batch 1 and 12:
     6-float4 LayerNorm rows, 6 / 12-wave K splits, the prep-kernel (M > 8) path."""
