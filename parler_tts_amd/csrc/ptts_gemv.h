@@ -3,8 +3,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { GV_LN = 0, GV_ATTN = 1, GV_COPY = 2, GV_SOFTMAX = 3 };  // SOFTMAX: per-head softmax of folded cross-attention scores (ptts_lm_kernels.h: xfold)
-enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2 };
+enum { GV_LN = 0, GV_ATTN = 1, GV_COPY = 2, GV_SOFTMAX = 3,  // SOFTMAX: per-head softmax of folded cross-attention scores (ptts_lm_kernels.h: xfold)
+       GV_ATTN2 = 4,    // combine of qkv_attn_kernel's partials: S cache splits + the new position's own slot (single utterance)
+       GV_LNP = 5 };    // LayerNorm of x + the per-head partial rows of xfold_attn_kernel (single utterance), NF4 prologue waves
+enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2,
+       GV_RESIDP = 3 };  // GV_RESID whose residual value is out + the per-head partial rows of xfold_attn_kernel, summed in GV_LNP's order
+constexpr int GV_PMAX = 24;  // partial rows (= attention heads) the GV_LNP / GV_RESIDP instances are built for
 enum { GV_F32 = 0, GV_BF16 = 1, GV_BF16_W8 = 2 };  // engine dtype of activations / weights; W8 = OCP e4m3 weights, bf16 activations
 
 constexpr int GV_MAX_ROWS = 8;  // utterances one GEMV launch serves (instances for 1, 2..4 and 5..8); above that the MFMA strip kernels take over
@@ -22,10 +26,52 @@ struct GemvArgs {
   const int* n_valid;   // GV_SOFTMAX: device-resident description length N (positions >= N carry no key)
   int ne;               // GV_SOFTMAX: positions per head in the folded layout (32 or 64)
   float* out;           // GV_STORE / GV_RESID: fp32 [M][out_ld]; GV_GELU_WT: engine dtype [M][out_ld]
+  const float* xpart;   // GV_LNP / GV_RESIDP: per-head partial rows [npart][K] / [npart][N], fp32
+  int npart;
   int x_ld, xw_ld, out_ld;
   int M, N, K, nheads;
   float invK;
 };
+
+// Single-utterance fused node: LayerNorm + this head's q / k / v rows + split-KV self-attention + KV append (qkv_attn_kernel,
+// ptts_gemv_kernels.h). Replaces the LN1+QKV node and the attention node of the GEMV step by ONE launch of nheads x (S + 3) workgroups.
+struct QkvAttnArgs {
+  const void* W;        // fused QKV projection, row-major [H + 2 * kv_heads * 64][H]: engine dtype or e4m3 bytes (W8)
+  const float* wscale;  // W8: per-row scale
+  const float* x;       // residual-stream row of the utterance, fp32 [H]
+  const float* gamma;   // self_attn_layer_norm
+  const float* beta;
+  void* kcache;         // this layer's self K / V of utterance 0: [kv_heads][cap][64] engine dtype
+  void* vcache;
+  const int* cur_len;   // device-resident column count (position of the new token = *P + cur_len[0] - 1)
+  const int* P;         // device-resident prompt length
+  const int* mask;      // prompt padding mask int32 [mask_ld] (1 = keep) or null; applies to positions < *P
+  float* part;          // [S + 1][H] unnormalised partial outputs (slot S: the new position's V row as stored in the cache)
+  float* stats;         // [S + 1][nheads][2]: (max, sumexp) in log2 units per cache split; slot S: the two half dot products of q . k_new
+  int cap, kv_bound, mask_ld;
+  int S, nheads, H, kv_heads;
+  float scale, invK;
+};
+// Single-utterance fused cross block over the folded matrices (xfold_attn_kernel): LayerNorm + the head's 64 score rows of M + per-head
+// softmax + the head's columns of U -> one partial output row per head; consumers: GV_LNP (LN3 + fc1) and GV_RESIDP (fc2).
+struct XfoldAttnArgs {
+  const void* Mw;       // folded scores matrix [nheads * 64][H], engine dtype (base-2 scale folded in)
+  const void* Uw;       // folded output matrix [H][nheads * 64], engine dtype
+  const float* x;       // residual-stream row, fp32 [H]
+  const float* gamma;   // encoder_attn_layer_norm
+  const float* beta;
+  const int* mask;      // description padding mask int32 [>= 64] (1 = keep) or null
+  const int* n_valid;   // device-resident description length
+  float* xpart;         // [nheads][H]
+  int nheads, H;
+  float invK;
+};
+int ptts_xfoldattn_launch(int mode, XfoldAttnArgs a, hipStream_t st);
+bool ptts_xfoldattn_ok(int H, int nheads, int mode);
+
+// 0 on success, -1: no instance for this width / mode, -2: launch error
+int ptts_qkvattn_launch(int mode, QkvAttnArgs a, hipStream_t st);
+bool ptts_qkvattn_ok(int H, int mode);
 
 // 0 on success, -1: no instance for this shape (the caller falls back / refuses at create time), -2: launch error
 int ptts_gemv_launch(int mode, int pro, int epi, int S, GemvArgs a, hipStream_t st);

@@ -3,4 +3,5 @@
 #define GV_W8 false
 #define GV_MULTI 1
 #define GV_FN ptts_gemv_launch_bf16
+#define GV_QA_FN ptts_qkvattn_launch_bf16
 #include "ptts_gemv_launch.inc"

@@ -2,10 +2,24 @@
 #define GV_WT float
 #define GV_W8 false
 #define GV_FN ptts_gemv_launch_f32
+#define GV_QA_FN ptts_qkvattn_launch_f32
 #include "ptts_gemv_launch.inc"
 
 int ptts_gemv_launch_bf16(int pro, int epi, int S, GemvArgs a, hipStream_t st);
 int ptts_gemv_launch_w8(int pro, int epi, int S, GemvArgs a, hipStream_t st);
+
+int ptts_qkvattn_launch_bf16(QkvAttnArgs a, hipStream_t st);
+int ptts_qkvattn_launch_w8(QkvAttnArgs a, hipStream_t st);
+
+int ptts_qkvattn_launch(int mode, QkvAttnArgs a, hipStream_t st) {
+  if (mode == GV_BF16) return ptts_qkvattn_launch_bf16(a, st);
+  if (mode == GV_BF16_W8) return ptts_qkvattn_launch_w8(a, st);
+  return ptts_qkvattn_launch_f32(a, st);
+}
+bool ptts_qkvattn_ok(int H, int mode) {
+  if (mode == GV_F32) return H == 512;
+  return H == 512 || H == 1024 || H == 1536;
+}
 
 int ptts_gemv_launch(int mode, int pro, int epi, int S, GemvArgs a, hipStream_t st) {
   if (mode == GV_BF16) return ptts_gemv_launch_bf16(pro, epi, S, a, st);

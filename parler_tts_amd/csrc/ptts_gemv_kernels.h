@@ -91,14 +91,14 @@ __device__ __forceinline__ void gv_pair_sum(float& s1, float& s2) {
 
 // prologue wave, LayerNorm of one row: row held in registers (K == NF4 * 256), shifted one-pass mean / variance
 template <typename WT, int NF4>
-__device__ __forceinline__ void gv_ln_wave(const GemvArgs& a, const float* xr, char* s_x, int lane) {
+__device__ __forceinline__ void gv_ln_row(const float* xr, const float* gamma, const float* beta, float invK, char* s_x, int lane) {
   float4 v[NF4], g[NF4], bt[NF4];
 #pragma unroll
   for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
 #pragma unroll
   for (int i = 0; i < NF4; ++i) {
-    g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
-    bt[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+    g[i] = *reinterpret_cast<const float4*>(gamma + (lane + 64 * i) * 4);
+    bt[i] = *reinterpret_cast<const float4*>(beta + (lane + 64 * i) * 4);
   }
   __builtin_amdgcn_sched_barrier(0);  // all 3 * NF4 loads are issued before the first wait (gamma / beta were sunk otherwise)
   const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
@@ -110,12 +110,17 @@ __device__ __forceinline__ void gv_ln_wave(const GemvArgs& a, const float* xr, c
     s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
   }
   gv_pair_sum(s1, s2);
-  const float dm = s1 * a.invK, mean = c + dm;
-  const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+  const float dm = s1 * invK, mean = c + dm;
+  const float rstd = rsqrtf(fmaxf(s2 * invK - dm * dm, 0.f) + 1e-5f);
 #pragma unroll
   for (int i = 0; i < NF4; ++i)
     gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
                       (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
+}
+
+template <typename WT, int NF4>
+__device__ __forceinline__ void gv_ln_wave(const GemvArgs& a, const float* xr, char* s_x, int lane) {
+  gv_ln_row<WT, NF4>(xr, a.gamma, a.beta, a.invK, s_x, lane);
 }
 
 // prologue wave, split-KV combine of one row's attention partials (attn_kernel wrote unnormalised sums + (max, sumexp) per
@@ -148,6 +153,45 @@ __device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, const float* par
       o.x += w * p[i][sp].x; o.y += w * p[i][sp].y; o.z += w * p[i][sp].z; o.w += w * p[i][sp].w;
     }
     const float inv = den > 0.f ? __frcp_rn(den) : 0.f;
+    gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+  }
+}
+
+// prologue wave, combine of qkv_attn_kernel's partials (single utterance): S cache splits as above + slot S = the new position, whose
+// base-2 score arrives as two half dot products (q . k over head dimensions 0-31 / 32-63, from two workgroups) and whose value row is
+// the partial itself (weight 1 before normalisation)
+template <typename WT, int NF4, int S>
+__device__ __forceinline__ void gv_attn2_wave(const GemvArgs& a, const float* part, const float* stats, char* s_x, int lane) {
+  float4 p[NF4][S + 1];
+  float2 st[NF4][S + 1];
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int k = (lane + 64 * i) * 4, head = k >> 6;
+#pragma unroll
+    for (int sp = 0; sp <= S; ++sp) {
+      st[i][sp] = *reinterpret_cast<const float2*>(stats + ((size_t)sp * a.nheads + head) * 2);
+      p[i][sp] = *reinterpret_cast<const float4*>(part + (size_t)sp * a.K + k);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const float m_new = st[i][S].x + st[i][S].y;
+    float mx = m_new;
+#pragma unroll
+    for (int sp = 0; sp < S; ++sp) mx = fmaxf(mx, st[i][sp].x);
+    float den = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int sp = 0; sp < S; ++sp) {
+      const float w = (st[i][sp].x == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[i][sp].x - mx);
+      den += w * st[i][sp].y;
+      o.x += w * p[i][sp].x; o.y += w * p[i][sp].y; o.z += w * p[i][sp].z; o.w += w * p[i][sp].w;
+    }
+    const float wn = __builtin_amdgcn_exp2f(m_new - mx);
+    den += wn;
+    o.x += wn * p[i][S].x; o.y += wn * p[i][S].y; o.z += wn * p[i][S].z; o.w += wn * p[i][S].w;
+    const float inv = __frcp_rn(den);  // den >= the weight of the larger of (cache maximum, new position) = 1
     gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, o.x * inv, o.y * inv, o.z * inv, o.w * inv);
   }
 }
@@ -205,6 +249,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
     if (MB == 1 || wave < a.M) {
       if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * ROW_BYTES, lane);
       else if (PRO == GV_SOFTMAX) gv_softmax_wave<WT, NF4>(a, s_x, lane);  // single utterance only
+      else if (PRO == GV_ATTN2) gv_attn2_wave<WT, NF4, S>(a, a.part, a.stats, s_x, lane);  // single utterance only
       else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
     }
     __syncthreads();
@@ -311,5 +356,213 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
     if (EPI == GV_STORE) *o = v;
     else if (EPI == GV_RESID) *o = res_pre + v;
     else gv_store<WT>(reinterpret_cast<WT*>(a.out) + (size_t)em * a.out_ld + r0 + er, gv_gelu_erf(v));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// qkv_attn_kernel (single utterance, sinusoidal positions): self_attn_layer_norm + the head's q / k / v projection rows + causal
+// self-attention over the KV arena + append of the new position, ONE launch per layer instead of two (LN1+QKV GEMV, attn_kernel).
+// Reference: modeling_parler_tts.py:1020-1021 (LayerNorm), :848-850 (projections), :880-889 (cache update), :906-914 (attention).
+//
+// The step at one utterance is a chain of dependent nodes that cost ~3.6 us each whatever they stream: what a
+// node saves is its kernel boundary and one global round trip. The attention of head h needs only the head's 64 q rows, so the
+// projection is recomputed inside every workgroup that needs it instead of being published by a node of its own:
+//   grid = nheads x (S + 3) workgroups of 1 LayerNorm wave + 8 weight waves (8 rows each, all loads of a wave in flight at once);
+//   role s < S : q rows of the head (128 KB bf16 at H = 1024; plain loads: the S + 2 workgroups of a head sit on one XCD when
+//                nheads % 8 == 0 and share them in its L2) -> q in LDS -> single-query attention over cache rows [0, pos) of split s
+//                (first batch of K/V rows requested at kernel start, before q exists) -> unnormalised partial + (max, sumexp);
+//   role S, S+1: q rows and k rows of head dimensions [0,32) / [32,64) -> half of q . k_new, K cache row of the new position;
+//   role S + 2 : the 64 v rows -> V cache row, and the row as the new position's partial (weight exp2(score - max) in the combine).
+// The combine (gv_attn2_wave, prologue of the out_proj node) merges the S + 1 slots. Dot products run in gemv_kernel's order (chunk
+// parity accumulators, one wave reduction per row): q / k / v are bit-identical to the two-node path; only the association of the
+// softmax sums differs (the new position is a slot of its own instead of a row inside a split).
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, int NCH, bool W8>
+__global__ void __launch_bounds__(576) qkv_attn_kernel(QkvAttnArgs a) {
+  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 4, NW = 8, RW = 8;
+  constexpr int NF4 = NCH * EPL / 4;
+  constexpr int ROW_BYTES = NCH * 64 * 16;                          // H * sizeof(WT)
+  constexpr int WROW_BYTES = ROW_BYTES / (W8 ? (int)sizeof(WT) : 1);  // one weight row
+  typedef typename GvDot<WT, W8>::WV WV;
+  __shared__ __attribute__((aligned(16))) char s_x[ROW_BYTES];
+  __shared__ float s_r[64];
+  __shared__ float s_o[NW][64];
+  __shared__ float s_ml[NW][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    gv_ln_row<WT, NF4>(a.x, a.gamma, a.beta, a.invK, s_x, lane);
+    __syncthreads();
+    return;
+  }
+  const int w = wave - 1;
+  const int h = blockIdx.x, role = blockIdx.y, S = a.S;
+  const int n_rep = a.nheads / a.kv_heads, kvh = h / n_rep, Hkv = a.kv_heads * 64;
+  int row0;
+  if (role < S) row0 = h * 64 + w * RW;
+  else if (role < S + 2) row0 = (w < 4 ? h * 64 : a.H + kvh * 64) + (role - S) * 32 + (w & 3) * RW;
+  else row0 = a.H + Hkv + kvh * 64 + w * RW;
+  // ---- t = 0: everything this wave will ever need from memory (bar later K/V batches of a long context) goes in flight ---------
+  WV wv[RW][NCH];
+  {
+    const char* wbase = reinterpret_cast<const char*>(a.W) + (size_t)row0 * WROW_BYTES;
+    if (row0 < a.H) {  // q rows: read by the other workgroups of this head as well
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) wv[r][c] = (reinterpret_cast<const WV*>(wbase + (size_t)r * WROW_BYTES) + lane)[c * 64];
+    } else {           // k / v rows: read once per step
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) wv[r][c] = gv_ld_nt<WV>(reinterpret_cast<const WV*>(wbase + (size_t)r * WROW_BYTES) + lane + c * 64);
+    }
+  }
+  float wsc = 1.f;
+  if (W8 && lane < RW) wsc = a.wscale[row0 + lane];
+  const int P = *a.P, cl = a.cur_len[0];
+  WT* Kc = reinterpret_cast<WT*>(a.kcache) + (size_t)kvh * a.cap * 64;
+  WT* Vc = reinterpret_cast<WT*>(a.vcache) + (size_t)kvh * a.cap * 64;
+  const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
+  const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
+  const int r = lane / LPR, c = lane % LPR;
+  const int TW = S * NW, wvid = role * NW + w;
+  uint4 kf[U], vf[U];
+  int mk[U];
+  if (role < S) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // rows at or beyond the host-known context bucket are not fetched; validity is applied when the data is used
+      const int t = (wvid + u * TW) * RPI + r;
+      const int tc = t < a.kv_bound ? t : 0;
+      kf[u] = Kb[(size_t)tc * LPR + c];
+      vf[u] = Vb[(size_t)tc * LPR + c];
+      mk[u] = (a.mask && t < a.mask_ld) ? a.mask[t] : 1;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  __syncthreads();                    // normalised row in LDS
+  // ---- the wave's 8 projection rows ---------------------------------------------------------------------------------------------
+  {
+    uint4 xv[NCH];
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) xv[cc] = *reinterpret_cast<const uint4*>(s_x + (size_t)(cc * 64 + lane) * 16);
+    float acc[RW], acc2[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) { acc[rr] = 0.f; acc2[rr] = 0.f; }
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        if (cc & 1) acc2[rr] = GvDot<WT, W8>::run(wv[rr][cc], xv[cc], acc2[rr]);
+        else acc[rr] = GvDot<WT, W8>::run(wv[rr][cc], xv[cc], acc[rr]);
+      }
+    float v = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const float t = wave_sum(acc[rr] + acc2[rr]);
+      v = lane == rr ? t : v;
+    }
+    if (lane < RW) s_r[w * RW + lane] = W8 ? v * wsc : v;
+  }
+  __syncthreads();  // the 64 projected values of this workgroup in LDS
+  const int pos = P + cl - 1;  // position of the new token; cache rows [0, pos) are in place
+  const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2 (attn_kernel)
+  if (role >= S) {
+    if (w != 0) return;
+    const bool writer = h == kvh * n_rep;  // grouped-query attention: the first query head of a group writes the shared K/V row
+    if (role < S + 2) {
+      const int half = role - S;
+      const float kd = Elem<WT>::rnd(s_r[32 + (lane & 31)]);  // the key as the cache holds it
+      const float pr = lane < 32 ? (s_r[lane] * qscale) * kd : 0.f;
+      const float dot = wave_sum(pr);
+      if (lane == 0) a.stats[((size_t)S * a.nheads + h) * 2 + half] = dot;
+      if (writer && lane < 32) gv_store<WT>(Kc + (size_t)pos * 64 + half * 32 + lane, s_r[32 + lane]);
+    } else {
+      const float vd = s_r[lane];
+      a.part[(size_t)S * a.H + h * 64 + lane] = Elem<WT>::rnd(vd);
+      if (writer) gv_store<WT>(Vc + (size_t)pos * 64 + lane, vd);
+    }
+    return;
+  }
+  // ---- role < S: single-query attention over the cache rows of this split -----------------------------------------------------------
+  float qv[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) qv[e] = s_r[c * EPL + e] * qscale;
+  const int L = pos;  // rows of the cache proper; the new position is the combine's slot S
+  const int* mrow = a.mask;
+  const int G = (L + RPI - 1) / RPI;
+  float m_run = -INFINITY, l_run = 0.f, o[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+  for (int g0 = wvid; g0 < G; g0 += TW * U) {
+    bool ok[U];
+    if (g0 != wvid) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = (g0 + u * TW) * RPI + r;
+        const int tc = t < L ? t : 0;
+        kf[u] = Kb[(size_t)tc * LPR + c];
+        vf[u] = Vb[(size_t)tc * LPR + c];
+        mk[u] = (mrow && tc < P) ? mrow[tc] : 1;
+      }
+    }
+    float sc[U], bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (g0 + u * TW) * RPI + r;
+      ok[u] = t < L && (t >= P || mk[u] != 0);
+      float kx[EPL];
+      unpack16(kf[u], kx, WT());
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kx[e], d);
+      d = group_reduce<OpSum, LPR>(d);
+      sc[u] = ok[u] ? d : -INFINITY;
+      bm = fmaxf(bm, sc[u]);
+    }
+    bm = across_groups_reduce<OpMax, LPR>(bm);
+    const float m_new = fmaxf(m_run, bm);
+    if (m_new == -INFINITY) continue;  // wave-uniform: nothing visible yet
+    const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float p = ok[u] ? __builtin_amdgcn_exp2f(sc[u] - m_new) : 0.f;
+      float vx[EPL];
+      unpack16(vf[u], vx, WT());
+      l_run += p;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(p, vx[e], o[e]) : o[e];  // masked rows may hold NaN/garbage V
+    }
+    m_run = m_new;
+  }
+  l_run = across_groups_reduce<OpSum, LPR>(l_run);
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = across_groups_reduce<OpSum, LPR>(o[e]);
+  if (r == 0) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s_o[w][c * EPL + e] = o[e];
+    if (c == 0) { s_ml[w][0] = m_run; s_ml[w][1] = l_run; }
+  }
+  __syncthreads();
+  if (w == 0) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) M = fmaxf(M, s_ml[i][0]);
+    float ov = 0.f, lv = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const float wgt = (s_ml[i][0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s_ml[i][0] - M);
+      ov += wgt * s_o[i][lane];
+      lv += wgt * s_ml[i][1];
+    }
+    a.part[(size_t)role * a.H + h * 64 + lane] = ov;
+    if (lane == 0) {
+      float* st = a.stats + ((size_t)role * a.nheads + h) * 2;
+      st[0] = M;
+      st[1] = lv;
+    }
   }
 }

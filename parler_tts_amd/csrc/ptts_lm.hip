@@ -101,8 +101,10 @@ struct ptts_engine {
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
   int xattn_groups_max = 256; // largest batch that runs the fused cross block in groups of 8 (PTTS_XATTN_GROUPS_MAX; above: rows_prep + q GEMM + attention)
-  int lnproj = 0;             // decode at batch > 8: LayerNorm + projection as ONE node tiled over 64 weight rows x lnproj_g utterances instead of rows_prep + strip GEMM
+  int lnproj = -1;            // -1 = by batch size (3 up to 40 utterances, 0 above: measured -5.3 % at 32, -3.2 % at 12, neutral at 64, +12 % at 128; profiles/r04_experiments.txt call 14). Decode at batch > 8: LayerNorm + projection as ONE node tiled over 64 weight rows x lnproj_g utterances instead of rows_prep + strip GEMM
                               // (PTTS_LNPROJ: 0 off, 1 = LN1 + QKV, 2 = + LN3 + fc1 above 32 utterances, 3 = + LN3 + fc1 at 9..32 too instead of the producer-statistics prologue)
+  bool fuse_qa = true;        // single-utterance GEMV step: LN1 + QKV rows + self-attention + append as one node (qkv_attn_kernel), PTTS_NO_FUSE_QA=1 = two nodes
+  int fuse_qa_s = 0;          // KV splits of that node: 0 = by context bucket (1 / 2 / 4 / 8 for <= 256 / 512 / 1024 / more positions), PTTS_FUSE_QA_S forces one
   int lnproj_g = 8;           // utterances per workgroup of that node (PTTS_LNPROJ_G = 8 / 4)
   int xattn_g = 0;            // utterances per workgroup of the fused cross block above 8 utterances: 0 = by batch size (2 up to 32, 4 up to 64, 8 above), PTTS_XATTN_G = 8 / 4 / 2 forces one
   bool xattn_g_ok = false;    // the g < 8 instances exist for this width (Mini-v1, Large-v1)
@@ -366,6 +368,15 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const float* rc = c.rope ? e->rope_cos : nullptr;
     const float* rs = c.rope ? e->rope_sin : nullptr;
     const int mode = c.dtype == PTTS_F32 ? GV_F32 : (e->w8 ? GV_BF16_W8 : GV_BF16);
+    // single utterance, sinusoidal positions: the two nodes of the self-attention block's first half as one (PTTS_NO_FUSE_QA=1: two nodes)
+    const bool fuse_qa = e->fuse_qa && M == 1 && !c.rope && ptts_qkvattn_ok(H, mode);
+    // KV splits of the fused node: the smallest count whose FIRST batch of row groups (8 waves x 4 groups x 8 rows = 256 positions per split,
+    // requested before q exists) covers the context bucket this graph is captured for - fewer workgroups recompute the head's q rows, and no
+    // split needs a second, dependent K/V batch (measured at context ~210 / ~460 / ~710: 2 splits 554 / 562 / 586 us per step, 4 splits
+    // 575 / 577 / 579, 8 splits 645 / 646 / 648; profiles/r04_experiments.txt call 15)
+    int S_f = 1;
+    while (S_f < 8 && S_f * 256 < e->kv_bound) S_f *= 2;
+    if (e->fuse_qa_s > 0) S_f = e->fuse_qa_s;
     auto gv = [&](int pro, int epi, int S, GemvArgs g, const char* what) -> int {
       g.M = M;
       const int rc_ = ptts_gemv_launch(mode, pro, epi, S, g, st);
@@ -375,6 +386,17 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     };
     for (int l = 0; l < c.num_layers; ++l) {
       const LayerW& w = e->L[l];
+      if (fuse_qa) {  // LN1 + the head's q / k / v rows + split-KV self-attention + append in ONE node (qkv_attn_kernel), then combine + out_proj
+        QkvAttnArgs q = {};
+        q.W = w.qkv_rm; q.wscale = w.qkv_sc; q.x = e->h; q.gamma = w.ln1_g; q.beta = w.ln1_b;
+        q.kcache = w.k_self; q.vcache = w.v_self; q.cur_len = e->cur_len; q.P = &e->dims->P; q.mask = e->prompt_mask;
+        q.part = e->part; q.stats = e->stats; q.cap = c.max_ctx; q.kv_bound = e->kv_bound; q.mask_ld = e->max_prompt;
+        q.S = S_f; q.nheads = nh; q.H = H; q.kv_heads = nkv; q.scale = scale;
+        if (ptts_qkvattn_launch(mode, q, st) != 0) return ptts_fail(PTTS_E_HIP, "qkv_attn launch failed");
+        GemvArgs g = {};
+        g.W = w.o_rm; g.wscale = w.o_sc; g.out = e->h; g.out_ld = H; g.N = H; g.K = H; g.part = e->part; g.stats = e->stats; g.nheads = nh;
+        PTTS_TRY(gv(GV_ATTN2, GV_RESID, S_f, g, "combine+out_proj"));
+      } else {
       {  // LN1 + fused QKV projection (:1020-1021, :848-850)
         GemvArgs g = {};
         g.W = w.qkv_rm; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln1_g; g.beta = w.ln1_b; g.out = e->qkv; g.out_ld = QKV; g.N = QKV; g.K = H;
@@ -396,6 +418,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         g.W = w.o_rm; g.wscale = w.o_sc; g.out = e->h; g.out_ld = H; g.N = H; g.K = H;
         if (e->S_self == 1) { g.xw = e->xw; g.xw_ld = H; PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g, "out_proj")); }
         else { g.part = e->part; g.stats = e->stats; g.nheads = nh; PTTS_TRY(gv(GV_ATTN, GV_RESID, e->S_self, g, "combine+out_proj")); }
+      }
       }
       if (e->xfold_valid && M == 1) {
         // folded cross block (xfold_*_kernel at prefill): LN2 + (K Wq) x -> base-2 scores; per-head softmax + (Wo V^T) p + residual
@@ -460,7 +483,8 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // LayerNorm + projection as one node (lnproj_fused_kernel): decode, batch > 8, Mini / Large widths, weights in the engine dtype (e4m3 strips keep
   // streaming bytes through the strip GEMMs)
   const int KTf = Elem<WT>::KT;
-  const bool lnproj_ok = e->lnproj > 0 && !prefill && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
+  const int lnproj = e->lnproj >= 0 ? e->lnproj : (M <= 40 ? 3 : 0);
+  const bool lnproj_ok = lnproj > 0 && !prefill && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
   bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
@@ -569,7 +593,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       if (big) {
         g.out = reinterpret_cast<float*>(e->xw2); g.x_fo = fo; g.out_fo = fo;
         if (lns) g.lnstat = e->lnstat;
-        if (lnproj_ok && (e->lnproj >= 3 || (e->lnproj == 2 && M > 32))) {  // LN3 + fc1 + GELU in one node
+        if (lnproj_ok && (lnproj >= 3 || (lnproj == 2 && M > 32))) {  // LN3 + fc1 + GELU in one node
           LnProjArgs p = {};
           p.W = w.fc1; p.x = e->h; p.x_ld = H; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.K = H; p.out = e->xw2; p.out_ld = F; p.out_fo = fo; p.M = M; p.N = F;
           PTTS_TRY((launch_lnproj<WT, EPI_GELU_WT>(e, p, st)));
@@ -851,8 +875,10 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->h, rows * H));
   A(e->alloc(&e->qkv, rows * 3 * H));
   A(e->alloc(&e->qc, std::max(rows, enc_rows) * H));
-  A(e->alloc(&e->part, rows * e->S_self * H));
-  A(e->alloc(&e->stats, rows * e->S_self * nh * 2));
+  A(e->alloc(&e->part, rows * e->S_self * H + (size_t)9 * H));  // + 9 rows: qkv_attn_kernel's up to 8 splits + the new position's own slot
+  A(e->alloc(&e->stats, rows * e->S_self * nh * 2 + (size_t)9 * nh * 2));
+  e->fuse_qa = !(getenv("PTTS_NO_FUSE_QA") && atoi(getenv("PTTS_NO_FUSE_QA")));
+  if (const char* ev = getenv("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
   A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));
   A(e->alloc(&e->logits, (size_t)c.max_batch * K * V));
   A(e->alloc(&e->sort_buf, 16));

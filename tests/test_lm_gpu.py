@@ -233,7 +233,8 @@ def test_mini_width_two_layers_fp32_and_bf16():
         eng.close()
 
 
-def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64, weights_fp8=False, oracle_sd=None, max_batch=None):
+def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64, weights_fp8=False, oracle_sd=None, max_batch=None,
+                              return_logits=False):
     g = torch.Generator().manual_seed(seed)
     enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
     prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
@@ -257,6 +258,8 @@ def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, se
         eng.step_forward()
         outs.append(eng.logits().cpu())
     eng.close()
+    if return_logits:
+        return outs, ref
     return max(float((a - b).abs().max()) for a, b in zip(outs, ref))
 
 
@@ -284,6 +287,42 @@ def test_single_utterance_gemv_step_long_context_all_split_counts():
     for max_ctx in (300, 1100):
         err = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=1, N=9, P=200, steps=40, masks=False, seed=3, max_ctx=max_ctx)
         assert err < 5e-5, (max_ctx, err)
+
+
+@pytest.mark.parametrize("gqa", [False, True])
+def test_fused_qkv_attention_node_single_utterance(gqa, monkeypatch):
+    """qkv_attn_kernel (single utterance, sinusoidal positions): LN1 + the head's q / k / v rows + split-KV self-attention + append as ONE
+    node, the new position as a slot of its own in the combine prologue (GV_ATTN2). fp32 at H = 512 (the widest fp32 instance): the fused
+    step against the two-node step (PTTS_NO_FUSE_QA=1) within fp32 summation noise AND both against the oracle; short context with a padded
+    prompt (2 KV splits) and a 1100-position prompt (4 splits, second K/V batch of the attention loop); grouped-query attention (one
+    writer per K/V group). bf16 at Mini and Large width (NCH 2 / 3) against the bf16 oracle."""
+    kw = dict(hidden_size=512, num_attention_heads=8, ffn_dim=1024, num_hidden_layers=3, max_position_embeddings=2048)
+    if gqa:
+        kw.update(num_key_value_heads=2, num_cross_attention_key_value_heads=2)
+    spec = DO.DecoderSpec(**kw)
+    sd = DO.make_decoder_weights(spec, seed=67)
+    for P, max_ctx, masks, steps in ((6, 300, True, 6), (1100, 1400, False, 4)):
+        runs = {}
+        for fuse in (True, False):
+            if fuse:
+                monkeypatch.delenv("PTTS_NO_FUSE_QA", raising=False)
+            else:
+                monkeypatch.setenv("PTTS_NO_FUSE_QA", "1")
+            runs[fuse], ref = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=1, N=21, P=P, steps=steps, masks=masks, seed=5, max_ctx=max_ctx,
+                                                        return_logits=True)
+        monkeypatch.delenv("PTTS_NO_FUSE_QA", raising=False)
+        ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
+        assert ab < 2e-5, (P, "fused vs two nodes", ab)
+        assert ab > 0.0, "the fused node did not run (identical logits: same kernels on both sides)"
+        for fuse in (True, False):
+            err = max(float((a - b).abs().max()) for a, b in zip(runs[fuse], ref))
+            assert err < 5e-5, (P, fuse, err)
+    if not gqa:
+        for kw2, seed, tol in ((dict(), 71, 2e-2), (dict(hidden_size=1536, num_attention_heads=24, ffn_dim=6144), 73, 3e-2)):
+            spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=2048, **kw2)
+            sd = DO.make_decoder_weights(spec, seed=seed)
+            err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=1, N=21, P=1100, steps=4, masks=False, seed=6, max_ctx=1400)
+            assert err < tol, (kw2, err)
 
 
 @pytest.mark.parametrize("bsz", [2, 3, 4, 5, 6, 8])
