@@ -156,12 +156,17 @@ def _prefilled_engine(model, bs: int, device, **gen):
 NODE_FLOOR_US = 2.13  # a dependent, trivial kernel node inside a hipGraph on MI355X (profiles/r01_sync_and_chain_probes.txt, relay chain)
 
 
-def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool):
+def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool, dtype: str = "bf16"):
     """Kernel nodes of the captured decode step (csrc/ptts_lm.hip forward<> + tail), by batch-size regime."""
-    if bs <= 8:   # GEMV step (bf16 engine): LN1+QKV, attention, combine+out_proj, [LN2+Mx, softmax+Up | LN2+q, cross-attn, out_proj], LN3+fc1, fc2
-        return (7 if folded else 8) * layers + 2
-    if bs <= 32 and hidden in (1024, 1536):  # rows_prep(LN1), QKV, attention, out_proj, fused LN2+cross-q+cross-attn (groups of 8), out_proj, LNS+fc1, fc2
-        return 8 * layers + 3
+    if bs <= 8:   # GEMV step: LN1+QKV, attention, combine+out_proj, [LN2+Mx, softmax+Up | LN2+q, cross-attn, out_proj], LN3+fc1, fc2
+        per_layer = 7 if folded else 8
+        if bs == 1 and folded and (hidden in (512, 1024, 1536) if dtype != "f32" else hidden == 512):
+            per_layer -= 1  # qkv_attn_kernel: LN1 + QKV rows + self-attention + append as one node
+            if hidden <= 1024:
+                per_layer -= 1  # xfold_attn_kernel: the folded cross block as one node of per-head partial rows
+        return per_layer * layers + 2
+    if bs <= 32 and hidden in (1024, 1536):  # LN1+QKV (lnproj), attention, combine+out_proj, fused LN2+cross-q+cross-attn, out_proj, LN3+fc1 (lnproj), fc2 split-K
+        return 7 * layers + 3
     return None
 
 
@@ -253,9 +258,9 @@ def measure_decode_roofline(model, bs: int, device, live_pmc: bool = True) -> di
            "us_per_launch": round(step_s * 1e6, 1), "bytes_per_launch": int(bytes_step), "context": lc,
            "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
     try:  # side information only: must never break the contract line
-        nodes = step_graph_nodes(bs, L, H, folded)
+        nodes = step_graph_nodes(bs, L, H, folded, "bf16" if es == 2 else "f32")
         if nodes:
-            out["kernel"] += f" ({nodes} kernel nodes)" + (f": batch <= 8 runs {7 if folded else 8} row-per-wave GEMV / attention nodes per layer + LM heads "
+            out["kernel"] += f" ({nodes} kernel nodes)" + (f": batch <= 8 runs {(nodes - 2) // L} row-per-wave GEMV / attention nodes per layer + LM heads "
                                                             "+ sampler/embed tail" if bs <= 8 else "")
             out["latency_model"] = latency_model(nodes, step_s * 1e6)
     except Exception:  # noqa: BLE001

@@ -5,10 +5,10 @@
 
 enum { GV_LN = 0, GV_ATTN = 1, GV_COPY = 2, GV_SOFTMAX = 3,  // SOFTMAX: per-head softmax of folded cross-attention scores (ptts_lm_kernels.h: xfold)
        GV_ATTN2 = 4,    // combine of qkv_attn_kernel's partials: S cache splits + the new position's own slot (single utterance)
-       GV_LNP = 5 };    // LayerNorm of x + the per-head partial rows of xfold_attn_kernel (single utterance), NF4 prologue waves
-enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2,
-       GV_RESIDP = 3 };  // GV_RESID whose residual value is out + the per-head partial rows of xfold_attn_kernel, summed in GV_LNP's order
-constexpr int GV_PMAX = 24;  // partial rows (= attention heads) the GV_LNP / GV_RESIDP instances are built for
+       GV_LNP = 5 };    // LayerNorm of (x + the per-head partial rows of xfold_attn_kernel), single utterance, one prologue wave per 256 columns;
+                        // workgroup 0 also writes the summed row to hsum (the residual operand of the fc2 node)
+enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2 };
+constexpr int GV_PMAX = 24;  // partial rows (= attention heads) the GV_LNP instances are built for
 enum { GV_F32 = 0, GV_BF16 = 1, GV_BF16_W8 = 2 };  // engine dtype of activations / weights; W8 = OCP e4m3 weights, bf16 activations
 
 constexpr int GV_MAX_ROWS = 8;  // utterances one GEMV launch serves (instances for 1, 2..4 and 5..8); above that the MFMA strip kernels take over
@@ -26,7 +26,9 @@ struct GemvArgs {
   const int* n_valid;   // GV_SOFTMAX: device-resident description length N (positions >= N carry no key)
   int ne;               // GV_SOFTMAX: positions per head in the folded layout (32 or 64)
   float* out;           // GV_STORE / GV_RESID: fp32 [M][out_ld]; GV_GELU_WT: engine dtype [M][out_ld]
-  const float* xpart;   // GV_LNP / GV_RESIDP: per-head partial rows [npart][K] / [npart][N], fp32
+  const float* resid;   // GV_RESID: the residual operand, fp32 [M][out_ld] (null = out: in-place accumulate)
+  const float* xpart;   // GV_LNP: per-head partial rows [npart][K], fp32, added to x in row order before the LayerNorm
+  float* hsum;          // GV_LNP: x + the partial rows, fp32 [K] (written by workgroup 0)
   int npart;
   int x_ld, xw_ld, out_ld;
   int M, N, K, nheads;
@@ -53,7 +55,7 @@ struct QkvAttnArgs {
   float scale, invK;
 };
 // Single-utterance fused cross block over the folded matrices (xfold_attn_kernel): LayerNorm + the head's 64 score rows of M + per-head
-// softmax + the head's columns of U -> one partial output row per head; consumers: GV_LNP (LN3 + fc1) and GV_RESIDP (fc2).
+// softmax + the head's columns of U -> one partial output row per head; consumer: GV_LNP (LN3 + fc1), which also publishes the summed row.
 struct XfoldAttnArgs {
   const void* Mw;       // folded scores matrix [nheads * 64][H], engine dtype (base-2 scale folded in)
   const void* Uw;       // folded output matrix [H][nheads * 64], engine dtype
@@ -64,8 +66,10 @@ struct XfoldAttnArgs {
   const int* n_valid;   // device-resident description length
   float* xpart;         // [nheads][H]
   int nheads, H;
+  int nur;              // rounds of output rows per workgroup (2 or 4): grid = nheads x H / (nur * rows per round)
   float invK;
 };
+// 0 on success, -1: no instance for this width / mode, -2: launch error (mode: GV_F32 / GV_BF16 - the folded matrices are never e4m3)
 int ptts_xfoldattn_launch(int mode, XfoldAttnArgs a, hipStream_t st);
 bool ptts_xfoldattn_ok(int H, int nheads, int mode);
 

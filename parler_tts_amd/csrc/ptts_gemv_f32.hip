@@ -3,6 +3,7 @@
 #define GV_W8 false
 #define GV_FN ptts_gemv_launch_f32
 #define GV_QA_FN ptts_qkvattn_launch_f32
+#define GV_XA_FN ptts_xfoldattn_launch_f32
 #include "ptts_gemv_launch.inc"
 
 int ptts_gemv_launch_bf16(int pro, int epi, int S, GemvArgs a, hipStream_t st);
@@ -17,6 +18,18 @@ int ptts_qkvattn_launch(int mode, QkvAttnArgs a, hipStream_t st) {
   return ptts_qkvattn_launch_f32(a, st);
 }
 bool ptts_qkvattn_ok(int H, int mode) {
+  if (mode == GV_F32) return H == 512;
+  return H == 512 || H == 1024 || H == 1536;
+}
+
+int ptts_xfoldattn_launch_bf16(XfoldAttnArgs a, hipStream_t st);
+int ptts_xfoldattn_launch(int mode, XfoldAttnArgs a, hipStream_t st) {
+  if (mode == GV_BF16) return ptts_xfoldattn_launch_bf16(a, st);
+  if (mode == GV_F32) return ptts_xfoldattn_launch_f32(a, st);
+  return -1;  // the folded matrices are never e4m3
+}
+bool ptts_xfoldattn_ok(int H, int nheads, int mode) {
+  if (nheads > GV_PMAX) return false;
   if (mode == GV_F32) return H == 512;
   return H == 512 || H == 1024 || H == 1536;
 }

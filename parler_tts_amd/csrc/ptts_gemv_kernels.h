@@ -196,6 +196,42 @@ __device__ __forceinline__ void gv_attn2_wave(const GemvArgs& a, const float* pa
   }
 }
 
+// prologue waves of GV_LNP (single utterance): LayerNorm of x + the npart per-head partial rows of xfold_attn_kernel. One wave per 256
+// columns (17+ rows x K fp32 do not fit one wave's registers): every wave adds the rows in order, takes its slab's shifted mean / M2,
+// the NF4 slabs are merged by the parallel-variance formula through LDS (one extra workgroup barrier, shared by the weight waves).
+// Workgroup 0 also publishes the summed row (hsum): the fc2 node's residual operand, bit-identical to what the LayerNorm saw.
+template <typename WT, int NF4>
+__device__ __forceinline__ void gv_lnp_waves(const GemvArgs& a, char* s_x, float* s_st, int wave, int lane) {
+  const int k = (wave * 64 + lane) * 4;
+  float4 v = *reinterpret_cast<const float4*>(a.x + k);
+  float4 p[GV_PMAX];
+#pragma unroll
+  for (int i = 0; i < GV_PMAX; ++i)
+    if (i < a.npart) p[i] = *reinterpret_cast<const float4*>(a.xpart + (size_t)i * a.K + k);
+  const float4 g = *reinterpret_cast<const float4*>(a.gamma + k), bt = *reinterpret_cast<const float4*>(a.beta + k);
+  __builtin_amdgcn_sched_barrier(0);  // every load of the wave is issued before the first wait
+#pragma unroll
+  for (int i = 0; i < GV_PMAX; ++i)
+    if (i < a.npart) { v.x += p[i].x; v.y += p[i].y; v.z += p[i].z; v.w += p[i].w; }
+  if (blockIdx.x == 0 && a.hsum) *reinterpret_cast<float4*>(a.hsum + k) = v;
+  const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x)));
+  const float d0 = v.x - c, d1 = v.y - c, d2 = v.z - c, d3 = v.w - c;
+  float s1 = (d0 + d1) + (d2 + d3), s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  gv_pair_sum(s1, s2);
+  const float dm = s1 * (1.0f / 256.0f);
+  if (lane == 0) { s_st[wave * 2] = c + dm; s_st[wave * 2 + 1] = fmaxf(s2 - s1 * dm, 0.f); }
+  __syncthreads();
+  float mean = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) mean += s_st[i * 2];
+  mean *= 1.0f / (float)NF4;
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) { const float dd = s_st[i * 2] - mean; m2 += s_st[i * 2 + 1] + 256.0f * dd * dd; }
+  const float rstd = rsqrtf(m2 * a.invK + 1e-5f);
+  gv_lds_store4<WT>(s_x, k, (v.x - mean) * rstd * g.x + bt.x, (v.y - mean) * rstd * g.y + bt.y, (v.z - mean) * rstd * g.z + bt.z,
+                    (v.w - mean) * rstd * g.w + bt.w);
+}
+
 // prologue wave, folded cross-attention (static description K/V folded into the projections at prefill: scores = M x, out = U p):
 // per-head softmax of the K = heads * NE base-2 scores. A head's NE scores sit in NE/4 consecutive lanes of one float4 slot
 // (16 lanes for NE = 64, 8 for NE = 32): max and sum are DPP reductions inside that lane group. Masked / absent positions get 0.
@@ -232,12 +268,14 @@ __device__ __forceinline__ void gv_softmax_wave(const GemvArgs& a, char* s_x, in
 // MB = 8 (batch 5..8): the activation chunks of MG utterances sit in registers at a time (MG * NCH <= 40 vectors), the wave's weight
 // registers are reused for every group; groups past the live batch are skipped (workgroup-uniform).
 template <typename WT, int NCH, int R, int PRO, int EPI, int S, int MB, bool W8, bool STG = false>
-__global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_kernel(GemvArgs a) {
+__global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * Elem<WT>::EPL / 4 : MB)) + 4) * 64) gemv_kernel(GemvArgs a) {
   static_assert(!STG || (PRO == GV_COPY && MB == 8), "staged activation rows: GV_COPY nodes of the 5..8-utterance instances only");
   constexpr bool HASPRO = PRO != GV_COPY;
   constexpr int EPL = Elem<WT>::EPL;
   constexpr int NF4 = NCH * EPL / 4;  // float4 per lane of one fp32 row (K / 256)
-  constexpr int NPW = HASPRO ? MB : 0;  // prologue waves
+  constexpr int NPW = PRO == GV_LNP ? NF4 : (HASPRO ? MB : 0);  // prologue waves (GV_LNP: one per 256 columns of the single row)
+  static_assert(PRO != GV_LNP || MB == 1, "GV_LNP: single utterance");
+  __shared__ float s_st[PRO == GV_LNP ? 2 * NF4 : 1];
   constexpr int MG = (MB <= 4 || MB * NCH <= 40) ? MB : ((MB / 2) * NCH <= 40 ? MB / 2 : MB / 4);  // utterances per register group
   constexpr int NG = MB / MG;
   typedef typename GvDot<WT, W8>::WV WV;
@@ -246,7 +284,9 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
   constexpr int ROW_BYTES = NCH * 64 * 16;  // K * sizeof(WT), from the template: no kernel argument is read before the branch below,
   if (HASPRO && wave < NPW) {             // so each kind of wave fetches its arguments in ONE scalar round trip (two cost ~0.12 us per node)
     __builtin_amdgcn_s_setprio(3);
-    if (MB == 1 || wave < a.M) {
+    if constexpr (PRO == GV_LNP) {
+      gv_lnp_waves<WT, NF4>(a, s_x, s_st, wave, lane);
+    } else if (MB == 1 || wave < a.M) {
       if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * ROW_BYTES, lane);
       else if (PRO == GV_SOFTMAX) gv_softmax_wave<WT, NF4>(a, s_x, lane);  // single utterance only
       else if (PRO == GV_ATTN2) gv_attn2_wave<WT, NF4, S>(a, a.part, a.stats, s_x, lane);  // single utterance only
@@ -261,7 +301,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
   const int em = lane / R, er = lane - em * R;            // epilogue role of this lane: (utterance, row) = (em, er)
   const bool elive = lane < MB * R && (MB == 1 || em < a.M) && r0 + er < a.N;
   float res_pre = 0.f, wsc = 1.f;
-  if (EPI == GV_RESID && elive) res_pre = a.out[(size_t)em * a.out_ld + r0 + er];
+  if (EPI == GV_RESID && elive) res_pre = a.resid[(size_t)em * a.out_ld + r0 + er];  // the launcher points resid at out when the caller left it null
   if (W8 && elive) wsc = a.wscale[r0 + er];
   uint4 xv[MG][NCH];
   auto load_x = [&](int g) __attribute__((always_inline)) {  // activation chunks of utterances g*MG .. g*MG + MG - 1 (absent ones clamped: computed, dropped)
@@ -306,6 +346,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : MB) + 4) * 64) gemv_ker
   }
   if (HASPRO) {
     __builtin_amdgcn_sched_barrier(0);  // the weight loads stay above the barrier
+    if (PRO == GV_LNP) __syncthreads();  // the prologue waves' slab statistics
     __syncthreads();
     load_x(0);
   }
@@ -564,5 +605,98 @@ __global__ void __launch_bounds__(576) qkv_attn_kernel(QkvAttnArgs a) {
       st[0] = M;
       st[1] = lv;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// xfold_attn_kernel (single utterance, folded cross block): encoder_attn_layer_norm + the head's 64 rows of M (base-2 scores against the
+// static description) + per-head softmax + the head's 64 columns of U for a slice of the output rows, ONE launch per layer instead of
+// two (LN2 + M x GEMV, softmax + U p + residual GEMV). Reference: modeling_parler_tts.py:1038-1052 (cross block), :906-914 (attention);
+// M = qscale K Wq and U = Wo V^T are built at prefill (ptts_lm_kernels.h: xfold_m_kernel / xfold_u_kernel).
+//
+// Same reasoning as qkv_attn_kernel: the node costs its kernel boundary + global round trip, not its bytes. Head h's softmax needs only
+// the head's 64 scores, so grid = nheads x J workgroups of 1 LayerNorm wave + 8 weight waves (8 rows of M each; the J workgroups of a head
+// sit on one XCD when nheads % 8 == 0 and share the rows in its L2); every wave finishes the head's softmax redundantly (64 values) and
+// multiplies its NUR x (64 / LPR) rows of U_h (128 / 256 contiguous bytes per row, requested at kernel start) by it. The output of the
+// block is a SUM over heads: each head's contribution goes to its own partial row xpart[h][:] and the next node's LayerNorm prologue
+// (GV_LNP) adds the rows in a fixed order - no atomics, bit-reproducible.
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, int NCH, int NUR>
+__global__ void __launch_bounds__(576) xfold_attn_kernel(XfoldAttnArgs a) {
+  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, NW = 8, RW = 8;
+  constexpr int NF4 = NCH * EPL / 4;
+  constexpr int ROW_BYTES = NCH * 64 * 16;  // H * sizeof(WT)
+  typedef typename GvDot<WT, false>::WV WV;
+  __shared__ __attribute__((aligned(16))) char s_x[ROW_BYTES];
+  __shared__ float s_r[64];
+  __shared__ __attribute__((aligned(16))) WT s_p[NW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    gv_ln_row<WT, NF4>(a.x, a.gamma, a.beta, a.invK, s_x, lane);
+    __syncthreads();
+    return;
+  }
+  const int w = wave - 1, h = blockIdx.x, j = blockIdx.y;
+  const int r = lane / LPR, c = lane % LPR;
+  // ---- t = 0: the wave's 8 rows of M_h, its NUR x RPI row segments of U_h, the mask ---------------------------------------------
+  WV wv[RW][NCH];
+  {
+    const char* wbase = reinterpret_cast<const char*>(a.Mw) + (size_t)(h * 64 + w * RW) * ROW_BYTES;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) wv[rr][cc] = (reinterpret_cast<const WV*>(wbase + (size_t)rr * ROW_BYTES) + lane)[cc * 64];
+  }
+  const int n0 = (j * NUR * NW + w) * RPI + r;  // output row of round 0; round u: + u * NW * RPI
+  const size_t KU = (size_t)a.nheads * 64;      // row pitch of U in elements
+  uint4 uf[NUR];
+#pragma unroll
+  for (int u = 0; u < NUR; ++u)
+    uf[u] = ld_nt16(reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.Uw) + (size_t)(n0 + u * NW * RPI) * KU + h * 64) + c);
+  const int mk = a.mask ? a.mask[lane] : 1;
+  const int nv = *a.n_valid;
+  __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  __syncthreads();                    // normalised row in LDS
+  {
+    uint4 xv[NCH];
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) xv[cc] = *reinterpret_cast<const uint4*>(s_x + (size_t)(cc * 64 + lane) * 16);
+    float acc[RW], acc2[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) { acc[rr] = 0.f; acc2[rr] = 0.f; }
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        if (cc & 1) acc2[rr] = GvDot<WT, false>::run(wv[rr][cc], xv[cc], acc2[rr]);
+        else acc[rr] = GvDot<WT, false>::run(wv[rr][cc], xv[cc], acc[rr]);
+      }
+    float v = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const float t = wave_sum(acc[rr] + acc2[rr]);
+      v = lane == rr ? t : v;
+    }
+    if (lane < RW) s_r[w * RW + lane] = v;
+  }
+  __syncthreads();  // the head's 64 base-2 scores in LDS
+  // ---- softmax over the description positions (lane = position), masked / absent positions weigh 0 (gv_softmax_wave's rules) ------
+  {
+    const bool valid = lane < nv && mk != 0;
+    const float sc = valid ? s_r[lane] : -INFINITY;
+    const float mx = wave_max(sc);
+    const float e = valid ? __builtin_amdgcn_exp2f(sc - mx) : 0.f;
+    const float sm = wave_sum(e);
+    const float inv = sm > 0.f ? 1.0f / sm : 0.f;
+    gv_store<WT>(&s_p[w][lane], e * inv);  // the weights enter the U product in the engine dtype (the two-node path's GV_SOFTMAX prologue)
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint4 pv = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(&s_p[w][0]) + c * 16);  // the wave's own copy: no workgroup barrier
+#pragma unroll
+  for (int u = 0; u < NUR; ++u) {
+    float d = GvDot<WT, false>::run(uf[u], pv, 0.f);
+    d = group_reduce<OpSum, LPR>(d);
+    if (c == 0) a.xpart[(size_t)h * a.H + n0 + u * NW * RPI] = d;
   }
 }

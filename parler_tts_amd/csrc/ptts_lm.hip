@@ -104,6 +104,13 @@ struct ptts_engine {
   int lnproj = -1;            // -1 = by batch size (3 up to 40 utterances, 0 above: measured -5.3 % at 32, -3.2 % at 12, neutral at 64, +12 % at 128; profiles/r04_experiments.txt call 14). Decode at batch > 8: LayerNorm + projection as ONE node tiled over 64 weight rows x lnproj_g utterances instead of rows_prep + strip GEMM
                               // (PTTS_LNPROJ: 0 off, 1 = LN1 + QKV, 2 = + LN3 + fc1 above 32 utterances, 3 = + LN3 + fc1 at 9..32 too instead of the producer-statistics prologue)
   bool fuse_qa = true;        // single-utterance GEMV step: LN1 + QKV rows + self-attention + append as one node (qkv_attn_kernel), PTTS_NO_FUSE_QA=1 = two nodes
+  int fuse_x = -1;            // single-utterance GEMV step, folded cross block: LN2 + scores + softmax + U p as one node of per-head partial rows (xfold_attn_kernel),
+                              // summed by the LN3 + fc1 node's prologue (GV_LNP). -1 = by width: on up to hidden 1024 (Mini-v1 -1 %: 566 -> 561 us per step), off
+                              // above (Large-v1 +8..17 %: every fc1 workgroup pulls 24 x 6 KB of partial rows through the L2; profiles/r04_experiments.txt
+                              // call 16); PTTS_FUSE_X=0 / 1 forces it
+  int fuse_x_nur = 2;         // rounds of output rows per workgroup of that node (PTTS_FUSE_X_NUR = 2 / 4: nheads x 8 / nheads x 4 workgroups at Mini-v1)
+  float* xpart = nullptr;     // [nheads][H] per-head partial rows of the fused cross block
+  float* h2 = nullptr;        // [H] residual row after the cross block (x + partial rows), written by the LN3 + fc1 node
   int fuse_qa_s = 0;          // KV splits of that node: 0 = by context bucket (1 / 2 / 4 / 8 for <= 256 / 512 / 1024 / more positions), PTTS_FUSE_QA_S forces one
   int lnproj_g = 8;           // utterances per workgroup of that node (PTTS_LNPROJ_G = 8 / 4)
   int xattn_g = 0;            // utterances per workgroup of the fused cross block above 8 utterances: 0 = by batch size (2 up to 32, 4 up to 64, 8 above), PTTS_XATTN_G = 8 / 4 / 2 forces one
@@ -420,7 +427,15 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         else { g.part = e->part; g.stats = e->stats; g.nheads = nh; PTTS_TRY(gv(GV_ATTN, GV_RESID, e->S_self, g, "combine+out_proj")); }
       }
       }
-      if (e->xfold_valid && M == 1) {
+      bool x_fused = false;  // the cross block left its output as per-head partial rows (summed by the LN3 + fc1 node)
+      if (e->xfold_valid && M == 1 && (e->fuse_x < 0 ? H <= 1024 : e->fuse_x != 0) && e->xfold_ne == 64 && ptts_xfoldattn_ok(H, nh, c.dtype == PTTS_F32 ? GV_F32 : GV_BF16)) {
+        // folded cross block as ONE node: LN2 + the head's rows of M + softmax + the head's columns of U -> xpart[h][:]
+        XfoldAttnArgs x = {};
+        x.Mw = w.xM; x.Uw = w.xU; x.x = e->h; x.gamma = w.ln2_g; x.beta = w.ln2_b; x.mask = e->enc_mask; x.n_valid = &e->dims->N;
+        x.xpart = e->xpart; x.nheads = nh; x.H = H; x.nur = e->fuse_x_nur;
+        if (ptts_xfoldattn_launch(c.dtype == PTTS_F32 ? GV_F32 : GV_BF16, x, st) != 0) return ptts_fail(PTTS_E_HIP, "xfold_attn launch failed");
+        x_fused = true;
+      } else if (e->xfold_valid && M == 1) {
         // folded cross block (xfold_*_kernel at prefill): LN2 + (K Wq) x -> base-2 scores; per-head softmax + (Wo V^T) p + residual
         const int K2 = nh * e->xfold_ne, gm = c.dtype == PTTS_F32 ? GV_F32 : GV_BF16;  // M / U are in the engine dtype, never e4m3
         GemvArgs g = {};
@@ -455,9 +470,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         GemvArgs g = {};
         g.W = w.fc1_rm; g.wscale = w.fc1_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln3_g; g.beta = w.ln3_b;
         g.out = reinterpret_cast<float*>(e->xw2); g.out_ld = F; g.N = F; g.K = H;
-        PTTS_TRY(gv(GV_LN, GV_GELU_WT, 1, g, "LN3+fc1"));
+        if (x_fused) { g.xpart = e->xpart; g.npart = nh; g.hsum = e->h2; PTTS_TRY(gv(GV_LNP, GV_GELU_WT, 1, g, "partial rows+LN3+fc1")); }
+        else PTTS_TRY(gv(GV_LN, GV_GELU_WT, 1, g, "LN3+fc1"));
         GemvArgs g2 = {};
         g2.W = w.fc2_rm; g2.wscale = w.fc2_sc; g2.xw = e->xw2; g2.xw_ld = F; g2.out = e->h; g2.out_ld = H; g2.N = H; g2.K = F;
+        if (x_fused) g2.resid = e->h2;  // h = (x + partial rows) + fc2(...)
         PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g2, "fc2"));
       }
     }
@@ -877,6 +894,10 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->qc, std::max(rows, enc_rows) * H));
   A(e->alloc(&e->part, rows * e->S_self * H + (size_t)9 * H));  // + 9 rows: qkv_attn_kernel's up to 8 splits + the new position's own slot
   A(e->alloc(&e->stats, rows * e->S_self * nh * 2 + (size_t)9 * nh * 2));
+  A(e->alloc(&e->xpart, (size_t)nh * H));
+  A(e->alloc(&e->h2, (size_t)H));
+  if (const char* ev = getenv("PTTS_FUSE_X")) e->fuse_x = atoi(ev) ? 1 : 0;
+  if (const char* ev = getenv("PTTS_FUSE_X_NUR")) { const int v = atoi(ev); if (v == 2 || v == 4) e->fuse_x_nur = v; }
   e->fuse_qa = !(getenv("PTTS_NO_FUSE_QA") && atoi(getenv("PTTS_NO_FUSE_QA")));
   if (const char* ev = getenv("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
   A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));

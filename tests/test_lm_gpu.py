@@ -325,6 +325,47 @@ def test_fused_qkv_attention_node_single_utterance(gqa, monkeypatch):
             assert err < tol, (kw2, err)
 
 
+@pytest.mark.parametrize("gqa", [False, True])
+def test_fused_cross_block_node_single_utterance(gqa, monkeypatch):
+    """xfold_attn_kernel (single utterance, folded cross block): LN2 + the head's rows of M + per-head softmax + the head's columns of U as ONE
+    node of per-head partial rows, summed in row order by the LN3 + fc1 node's prologue (GV_LNP), whose workgroup 0 also publishes the
+    summed row as the fc2 node's residual operand. fp32 at H = 512: the fused step (PTTS_FUSE_X=1) against the two-node step (PTTS_FUSE_X=0) within
+    fp32 summation noise AND both against the oracle, with a padded description (mask + fewer than 64 valid positions) and without, both
+    workgroup shapes (PTTS_FUSE_X_NUR = 2 / 4), grouped cross K/V heads; bf16 at Mini and Large width against the bf16 oracle (e4m3 engines
+    take the same node by default: their single-utterance tests below run it)."""
+    kw = dict(hidden_size=512, num_attention_heads=8, ffn_dim=1024, num_hidden_layers=3, max_position_embeddings=512)
+    if gqa:
+        kw.update(num_key_value_heads=2, num_cross_attention_key_value_heads=2)
+    spec = DO.DecoderSpec(**kw)
+    sd = DO.make_decoder_weights(spec, seed=79)
+    for N, masks, nur in ((21, True, 2), (64, False, 4), (37, True, 4)):
+        runs = {}
+        monkeypatch.setenv("PTTS_FUSE_X_NUR", str(nur))
+        for fuse in (True, False):
+            monkeypatch.setenv("PTTS_FUSE_X", "1" if fuse else "0")
+            runs[fuse], ref = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=1, N=N, P=6, steps=5, masks=masks, seed=7, max_ctx=64,
+                                                        return_logits=True)
+        monkeypatch.delenv("PTTS_FUSE_X", raising=False)
+        ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
+        assert ab < 2e-5, (N, "fused vs two nodes", ab)
+        assert ab > 0.0, "the fused node did not run (identical logits: same kernels on both sides)"
+        for fuse in (True, False):
+            err = max(float((a - b).abs().max()) for a, b in zip(runs[fuse], ref))
+            assert err < 5e-5, (N, fuse, err)
+    monkeypatch.delenv("PTTS_FUSE_X_NUR", raising=False)
+    if not gqa:
+        for kw2, seed, tol in ((dict(), 83, 2e-2), (dict(hidden_size=1536, num_attention_heads=24, ffn_dim=6144), 89, 3e-2)):
+            spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512, **kw2)
+            sd = DO.make_decoder_weights(spec, seed=seed)
+            monkeypatch.setenv("PTTS_FUSE_X", "1")  # off by default above hidden 1024
+            for nur in (2, 4):
+                monkeypatch.setenv("PTTS_FUSE_X_NUR", str(nur))
+                err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=1, N=45, P=9, steps=4, masks=True, seed=8, max_ctx=64)
+                assert err < tol, (kw2, nur, err)
+            monkeypatch.delenv("PTTS_FUSE_X_NUR", raising=False)
+            monkeypatch.delenv("PTTS_FUSE_X", raising=False)
+
+
 @pytest.mark.parametrize("bsz", [2, 3, 4, 5, 6, 8])
 def test_gemv_step_batch_2_to_8(bsz):
     """Batch 2..8 on the bf16 engine runs the GEMV step with every weight row read once for all utterances (MB = 4 / 8 instances:
