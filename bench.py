@@ -160,9 +160,9 @@ def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool, dtype: str
     """Kernel nodes of the captured decode step (csrc/ptts_lm.hip forward<> + tail), by batch-size regime."""
     if bs <= 8:   # GEMV step: LN1+QKV, attention, combine+out_proj, [LN2+Mx, softmax+Up | LN2+q, cross-attn, out_proj], LN3+fc1, fc2
         per_layer = 7 if folded else 8
-        if bs == 1 and folded and (hidden in (512, 1024, 1536) if dtype != "f32" else hidden == 512):
+        if bs == 1 and folded and hidden in ((512, 1024, 1536) if dtype != "f32" else (512, 1024)):
             per_layer -= 1  # qkv_attn_kernel: LN1 + QKV rows + self-attention + append as one node
-            if hidden <= 1024:
+            if hidden <= (1024 if dtype != "f32" else 512):
                 per_layer -= 1  # xfold_attn_kernel: the folded cross block as one node of per-head partial rows
         return per_layer * layers + 2
     if bs <= 32 and hidden in (1024, 1536):  # LN1+QKV (lnproj), attention, combine+out_proj, fused LN2+cross-q+cross-attn, out_proj, LN3+fc1 (lnproj), fc2 split-K

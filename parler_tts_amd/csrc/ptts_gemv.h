@@ -36,7 +36,7 @@ struct GemvArgs {
 };
 
 // Single-utterance fused node: LayerNorm + this head's q / k / v rows + split-KV self-attention + KV append (qkv_attn_kernel,
-// ptts_gemv_kernels.h). Replaces the LN1+QKV node and the attention node of the GEMV step by ONE launch of nheads x (S + 3) workgroups.
+// ptts_gemv_kernels.h). Replaces the LN1+QKV node and the attention node of the GEMV step by ONE launch of nheads x (S + 3) workgroups of 8 waves.
 struct QkvAttnArgs {
   const void* W;        // fused QKV projection, row-major [H + 2 * kv_heads * 64][H]: engine dtype or e4m3 bytes (W8)
   const float* wscale;  // W8: per-row scale
@@ -76,6 +76,7 @@ bool ptts_xfoldattn_ok(int H, int nheads, int mode);
 // 0 on success, -1: no instance for this width / mode, -2: launch error
 int ptts_qkvattn_launch(int mode, QkvAttnArgs a, hipStream_t st);
 bool ptts_qkvattn_ok(int H, int mode);
+int ptts_qkvattn_rows_per_split(int mode);  // cache positions the first K/V batch of one split covers (a second batch is a dependent round trip)
 
 // 0 on success, -1: no instance for this shape (the caller falls back / refuses at create time), -2: launch error
 int ptts_gemv_launch(int mode, int pro, int epi, int S, GemvArgs a, hipStream_t st);

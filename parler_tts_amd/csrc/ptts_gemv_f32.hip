@@ -18,9 +18,10 @@ int ptts_qkvattn_launch(int mode, QkvAttnArgs a, hipStream_t st) {
   return ptts_qkvattn_launch_f32(a, st);
 }
 bool ptts_qkvattn_ok(int H, int mode) {
-  if (mode == GV_F32) return H == 512;
+  if (mode == GV_F32) return H == 512 || H == 1024;
   return H == 512 || H == 1024 || H == 1536;
 }
+int ptts_qkvattn_rows_per_split(int mode) { return 8 * 4 * (mode == GV_F32 ? 4 : 8); }
 
 int ptts_xfoldattn_launch_bf16(XfoldAttnArgs a, hipStream_t st);
 int ptts_xfoldattn_launch(int mode, XfoldAttnArgs a, hipStream_t st) {

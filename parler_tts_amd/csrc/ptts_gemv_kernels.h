@@ -408,7 +408,9 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
 // The step at one utterance is a chain of dependent nodes that cost ~3.6 us each whatever they stream: what a
 // node saves is its kernel boundary and one global round trip. The attention of head h needs only the head's 64 q rows, so the
 // projection is recomputed inside every workgroup that needs it instead of being published by a node of its own:
-//   grid = nheads x (S + 3) workgroups of 1 LayerNorm wave + 8 weight waves (8 rows each, all loads of a wave in flight at once);
+//   grid = nheads x (S + 3) workgroups of 8 weight waves (8 rows each, all loads of a wave in flight at once; wave 0 requests the
+//   residual row + gamma / beta BEFORE its weights and normalises it while they fly: 8 waves = 2 per SIMD, 256 VGPRs each - the separate
+//   LayerNorm wave of the first version made 9, i.e. 3 on one SIMD and a 168-register ceiling that excluded fp32 at H = 1024);
 //   role s < S : q rows of the head (128 KB bf16 at H = 1024; plain loads: the S + 2 workgroups of a head sit on one XCD when
 //                nheads % 8 == 0 and share them in its L2) -> q in LDS -> single-query attention over cache rows [0, pos) of split s
 //                (first batch of K/V rows requested at kernel start, before q exists) -> unnormalised partial + (max, sumexp);
@@ -418,9 +420,9 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
 // parity accumulators, one wave reduction per row): q / k / v are bit-identical to the two-node path; only the association of the
 // softmax sums differs (the new position is a slot of its own instead of a row inside a split).
 // ------------------------------------------------------------------------------------------------------
-template <typename WT, int NCH, bool W8>
-__global__ void __launch_bounds__(576) qkv_attn_kernel(QkvAttnArgs a) {
-  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 4, NW = 8, RW = 8;
+template <typename WT, int NCH, bool W8, int U>
+__global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
+  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, NW = 8, RW = 8;
   constexpr int NF4 = NCH * EPL / 4;
   constexpr int ROW_BYTES = NCH * 64 * 16;                          // H * sizeof(WT)
   constexpr int WROW_BYTES = ROW_BYTES / (W8 ? (int)sizeof(WT) : 1);  // one weight row
@@ -429,14 +431,19 @@ __global__ void __launch_bounds__(576) qkv_attn_kernel(QkvAttnArgs a) {
   __shared__ float s_r[64];
   __shared__ float s_o[NW][64];
   __shared__ float s_ml[NW][2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave == 0) {
-    __builtin_amdgcn_s_setprio(3);
-    gv_ln_row<WT, NF4>(a.x, a.gamma, a.beta, a.invK, s_x, lane);
-    __syncthreads();
-    return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // wave 0: the LayerNorm operands first - loads return in order, so nothing it normalises waits behind its weight burst
+  float4 lv[NF4], lg[NF4], lb[NF4];
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) lv[i] = *reinterpret_cast<const float4*>(a.x + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      lg[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+      lb[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+    }
   }
-  const int w = wave - 1;
+  __builtin_amdgcn_sched_barrier(0);
   const int h = blockIdx.x, role = blockIdx.y, S = a.S;
   const int n_rep = a.nheads / a.kv_heads, kvh = h / n_rep, Hkv = a.kv_heads * 64;
   int row0;
@@ -481,6 +488,23 @@ __global__ void __launch_bounds__(576) qkv_attn_kernel(QkvAttnArgs a) {
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  if (w == 0) {  // LayerNorm of the row (gv_ln_row's arithmetic: shifted one-pass mean / variance), engine dtype into LDS
+    const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lv[0].x)));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const float d0 = lv[i].x - c0, d1 = lv[i].y - c0, d2 = lv[i].z - c0, d3 = lv[i].w - c0;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    gv_pair_sum(s1, s2);
+    const float dm = s1 * a.invK, mean = c0 + dm;
+    const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i)
+      gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, (lv[i].x - mean) * rstd * lg[i].x + lb[i].x, (lv[i].y - mean) * rstd * lg[i].y + lb[i].y,
+                        (lv[i].z - mean) * rstd * lg[i].z + lb[i].z, (lv[i].w - mean) * rstd * lg[i].w + lb[i].w);
+  }
   __syncthreads();                    // normalised row in LDS
   // ---- the wave's 8 projection rows ---------------------------------------------------------------------------------------------
   {

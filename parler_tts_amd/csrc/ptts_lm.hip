@@ -377,12 +377,12 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const int mode = c.dtype == PTTS_F32 ? GV_F32 : (e->w8 ? GV_BF16_W8 : GV_BF16);
     // single utterance, sinusoidal positions: the two nodes of the self-attention block's first half as one (PTTS_NO_FUSE_QA=1: two nodes)
     const bool fuse_qa = e->fuse_qa && M == 1 && !c.rope && ptts_qkvattn_ok(H, mode);
-    // KV splits of the fused node: the smallest count whose FIRST batch of row groups (8 waves x 4 groups x 8 rows = 256 positions per split,
+    // KV splits of the fused node: the smallest count whose FIRST batch of row groups (8 waves x 4 groups x 8 bf16 / 4 fp32 rows per split,
     // requested before q exists) covers the context bucket this graph is captured for - fewer workgroups recompute the head's q rows, and no
-    // split needs a second, dependent K/V batch (measured at context ~210 / ~460 / ~710: 2 splits 554 / 562 / 586 us per step, 4 splits
-    // 575 / 577 / 579, 8 splits 645 / 646 / 648; profiles/r04_experiments.txt call 15)
+    // split needs a second, dependent K/V batch (context ~210 / ~460 / ~710: 2 splits 554 / 562 / 586 us per step, 4 splits 575 / 577 / 579,
+    // 8 splits 645 / 646 / 648; profiles/r04_experiments.txt call 15)
     int S_f = 1;
-    while (S_f < 8 && S_f * 256 < e->kv_bound) S_f *= 2;
+    while (S_f < 8 && S_f * ptts_qkvattn_rows_per_split(mode) < e->kv_bound) S_f *= 2;
     if (e->fuse_qa_s > 0) S_f = e->fuse_qa_s;
     auto gv = [&](int pro, int epi, int S, GemvArgs g, const char* what) -> int {
       g.M = M;

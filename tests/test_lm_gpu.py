@@ -292,7 +292,7 @@ def test_single_utterance_gemv_step_long_context_all_split_counts():
 @pytest.mark.parametrize("gqa", [False, True])
 def test_fused_qkv_attention_node_single_utterance(gqa, monkeypatch):
     """qkv_attn_kernel (single utterance, sinusoidal positions): LN1 + the head's q / k / v rows + split-KV self-attention + append as ONE
-    node, the new position as a slot of its own in the combine prologue (GV_ATTN2). fp32 at H = 512 (the widest fp32 instance): the fused
+    node, the new position as a slot of its own in the combine prologue (GV_ATTN2). fp32 at H = 512 and H = 1024: the fused
     step against the two-node step (PTTS_NO_FUSE_QA=1) within fp32 summation noise AND both against the oracle; short context with a padded
     prompt (2 KV splits) and a 1100-position prompt (4 splits, second K/V batch of the attention loop); grouped-query attention (one
     writer per K/V group). bf16 at Mini and Large width (NCH 2 / 3) against the bf16 oracle."""
@@ -323,6 +323,21 @@ def test_fused_qkv_attention_node_single_utterance(gqa, monkeypatch):
             sd = DO.make_decoder_weights(spec, seed=seed)
             err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=1, N=21, P=1100, steps=4, masks=False, seed=6, max_ctx=1400)
             assert err < tol, (kw2, err)
+        # fp32 at Mini-v1 width (the bit-exact parity engine of bench.py's fp32_parity_mode): 8 weight rows x 4 KB per wave, U = 4
+        spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=2048)
+        sd = DO.make_decoder_weights(spec, seed=97)
+        for P, max_ctx, masks in ((7, 200, True), (700, 900, False)):
+            runs = {}
+            for fuse in (True, False):
+                monkeypatch.setenv("PTTS_NO_FUSE_QA", "0" if fuse else "1")
+                runs[fuse], ref = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=1, N=33, P=P, steps=4, masks=masks, seed=9, max_ctx=max_ctx,
+                                                            return_logits=True)
+            monkeypatch.delenv("PTTS_NO_FUSE_QA", raising=False)
+            ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
+            assert 0.0 < ab < 2e-5, (P, "fp32 Mini width, fused vs two nodes", ab)
+            for fuse in (True, False):
+                err = max(float((a - b).abs().max()) for a, b in zip(runs[fuse], ref))
+                assert err < 5e-5, (P, fuse, err)
 
 
 @pytest.mark.parametrize("gqa", [False, True])
