@@ -639,14 +639,14 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 // M = qscale K Wq and U = Wo V^T are built at prefill (ptts_lm_kernels.h: xfold_m_kernel / xfold_u_kernel).
 //
 // Same reasoning as qkv_attn_kernel: the node costs its kernel boundary + global round trip, not its bytes. Head h's softmax needs only
-// the head's 64 scores, so grid = nheads x J workgroups of 1 LayerNorm wave + 8 weight waves (8 rows of M each; the J workgroups of a head
+// the head's 64 scores, so grid = nheads x J workgroups of 8 weight waves (8 rows of M each; wave 0 also normalises the row; the J workgroups of a head
 // sit on one XCD when nheads % 8 == 0 and share the rows in its L2); every wave finishes the head's softmax redundantly (64 values) and
 // multiplies its NUR x (64 / LPR) rows of U_h (128 / 256 contiguous bytes per row, requested at kernel start) by it. The output of the
 // block is a SUM over heads: each head's contribution goes to its own partial row xpart[h][:] and the next node's LayerNorm prologue
 // (GV_LNP) adds the rows in a fixed order - no atomics, bit-reproducible.
 // ------------------------------------------------------------------------------------------------------
 template <typename WT, int NCH, int NUR>
-__global__ void __launch_bounds__(576) xfold_attn_kernel(XfoldAttnArgs a) {
+__global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
   constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, NW = 8, RW = 8;
   constexpr int NF4 = NCH * EPL / 4;
   constexpr int ROW_BYTES = NCH * 64 * 16;  // H * sizeof(WT)
@@ -654,14 +654,20 @@ __global__ void __launch_bounds__(576) xfold_attn_kernel(XfoldAttnArgs a) {
   __shared__ __attribute__((aligned(16))) char s_x[ROW_BYTES];
   __shared__ float s_r[64];
   __shared__ __attribute__((aligned(16))) WT s_p[NW][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave == 0) {
-    __builtin_amdgcn_s_setprio(3);
-    gv_ln_row<WT, NF4>(a.x, a.gamma, a.beta, a.invK, s_x, lane);
-    __syncthreads();
-    return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // 8 waves, all of them weight waves; wave 0 requests the LayerNorm operands first and normalises while its weights fly (qkv_attn_kernel)
+  float4 lv[NF4], lg[NF4], lb[NF4];
+  if (w == 0) {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) lv[i] = *reinterpret_cast<const float4*>(a.x + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      lg[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+      lb[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+    }
   }
-  const int w = wave - 1, h = blockIdx.x, j = blockIdx.y;
+  __builtin_amdgcn_sched_barrier(0);
+  const int h = blockIdx.x, j = blockIdx.y;
   const int r = lane / LPR, c = lane % LPR;
   // ---- t = 0: the wave's 8 rows of M_h, its NUR x RPI row segments of U_h, the mask ---------------------------------------------
   WV wv[RW][NCH];
@@ -681,6 +687,23 @@ __global__ void __launch_bounds__(576) xfold_attn_kernel(XfoldAttnArgs a) {
   const int mk = a.mask ? a.mask[lane] : 1;
   const int nv = *a.n_valid;
   __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  if (w == 0) {  // gv_ln_row's arithmetic
+    const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lv[0].x)));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const float d0 = lv[i].x - c0, d1 = lv[i].y - c0, d2 = lv[i].z - c0, d3 = lv[i].w - c0;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    gv_pair_sum(s1, s2);
+    const float dm = s1 * a.invK, mean = c0 + dm;
+    const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i)
+      gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, (lv[i].x - mean) * rstd * lg[i].x + lb[i].x, (lv[i].y - mean) * rstd * lg[i].y + lb[i].y,
+                        (lv[i].z - mean) * rstd * lg[i].z + lb[i].z, (lv[i].w - mean) * rstd * lg[i].w + lb[i].w);
+  }
   __syncthreads();                    // normalised row in LDS
   {
     uint4 xv[NCH];

@@ -111,6 +111,7 @@ struct ptts_engine {
   int fuse_x_nur = 2;         // rounds of output rows per workgroup of that node (PTTS_FUSE_X_NUR = 2 / 4: nheads x 8 / nheads x 4 workgroups at Mini-v1)
   float* xpart = nullptr;     // [nheads][H] per-head partial rows of the fused cross block
   float* h2 = nullptr;        // [H] residual row after the cross block (x + partial rows), written by the LN3 + fc1 node
+  int graph_steps = 1;        // decode steps per hipGraphLaunch inside one context bucket (PTTS_GRAPH_STEPS = 1 / 2 / 4 / 8 / 16)
   int fuse_qa_s = 0;          // KV splits of that node: 0 = by context bucket (1 / 2 / 4 / 8 for <= 256 / 512 / 1024 / more positions), PTTS_FUSE_QA_S forces one
   int lnproj_g = 8;           // utterances per workgroup of that node (PTTS_LNPROJ_G = 8 / 4)
   int xattn_g = 0;            // utterances per workgroup of the fused cross block above 8 utterances: 0 = by batch size (2 up to 32, 4 up to 64, 8 above), PTTS_XATTN_G = 8 / 4 / 2 forces one
@@ -118,7 +119,7 @@ struct ptts_engine {
   bool xattn_groups = true;   // the fused LN2 + cross-q + cross-attention kernel also at batch 9..32, in groups of 8 utterances (PTTS_NO_XATTN_GROUPS=1: two nodes)
   int kv_ub = 0;         // host-side upper bound of the self-KV positions written so far (prefill + one per decode forward)
   int kv_bound = 0;      // attention fetch bound of the next decode forward: kv_ub + 1 rounded up to 64, <= max_ctx
-  std::map<int, hipGraphExec_t> graphs;  // key: 2 * batch size + folded-cross-block flag
+  std::map<long long, hipGraphExec_t> graphs;  // key: 2 * batch size + folded-cross-block flag + context bucket + steps per launch (get_graph)
   int* host_pinned = nullptr;
 
   template <typename T> int alloc(T** p, size_t n) {
@@ -899,6 +900,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   if (const char* ev = getenv("PTTS_FUSE_X")) e->fuse_x = atoi(ev) ? 1 : 0;
   if (const char* ev = getenv("PTTS_FUSE_X_NUR")) { const int v = atoi(ev); if (v == 2 || v == 4) e->fuse_x_nur = v; }
   e->fuse_qa = !(getenv("PTTS_NO_FUSE_QA") && atoi(getenv("PTTS_NO_FUSE_QA")));
+  if (const char* ev = getenv("PTTS_GRAPH_STEPS")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->graph_steps = v; }
   if (const char* ev = getenv("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
   A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));
   A(e->alloc(&e->logits, (size_t)c.max_batch * K * V));
@@ -1212,18 +1214,23 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
 
 // The decode step (170 kernel nodes for Mini-v1 at batch <= 8) is captured ONCE per batch size on the engine's private stream
 // (capture records, it does not execute; the legacy NULL stream cannot be captured) and replayed into the caller's.
-static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
+static int get_graph(ptts_engine* e, hipGraphExec_t* out, int nsteps = 1) {
   // the node set of the step depends on the batch size and on the folded cross block; the attention fetch bound (a kernel argument)
-  // on the 64-position bucket of the context (forward<> reads it from e->kv_bound while capturing)
-  const int key = e->B * 2 + (e->xfold_valid ? 1 : 0) + 4096 * (e->kv_bound / 64);
+  // on the 64-position bucket of the context (forward<> reads it from e->kv_bound while capturing); nsteps consecutive steps of ONE
+  // bucket may share a graph (e->graph_steps: every length, position and token is device-resident, so a step is the same node list
+  // whatever its index; one hipGraphLaunch per nsteps frames instead of per frame)
+  const long long key = e->B * 2 + (e->xfold_valid ? 1 : 0) + 4096LL * (e->kv_bound / 64) + (1LL << 40) * (nsteps - 1);
   auto it = e->graphs.find(key);
   if (it != e->graphs.end()) { if (out) *out = it->second; return PTTS_OK; }
   hipGraph_t g = nullptr;
   hipStream_t st = e->own_stream;
   PTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   // decode step = layers + heads + tail; the tail embeds the column it just sampled for the NEXT replay (no embed node)
-  int rc = forward_dispatch(e, false, st, false);
-  if (rc == PTTS_OK) rc = launch_tail(e, st, true);
+  int rc = PTTS_OK;
+  for (int u = 0; u < nsteps && rc == PTTS_OK; ++u) {
+    rc = forward_dispatch(e, false, st, false);
+    if (rc == PTTS_OK) rc = launch_tail(e, st, true);
+  }
   hipError_t ce = hipStreamEndCapture(st, &g);
   if (rc != PTTS_OK) { if (g) hipGraphDestroy(g); return rc; }
   if (ce != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
@@ -1252,6 +1259,7 @@ static int precapture_graphs(ptts_engine* e, int max_buckets) {
   for (int ub = saved_ub + 1; ub <= last_ub && rc == PTTS_OK && done < max_buckets; ++done) {
     e->kv_bound = g_no_kv_bound ? cap : std::min(cap, (ub + 1 + 63) / 64 * 64);
     rc = get_graph(e, nullptr);
+    if (rc == PTTS_OK && e->graph_steps > 1 && !g_no_kv_bound) rc = get_graph(e, nullptr, e->graph_steps);
     ub = e->kv_bound;  // first upper bound of the next bucket: (ub + 1 + 63) / 64 * 64 > kv_bound
     if (g_no_kv_bound) break;
   }
@@ -1272,11 +1280,20 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
     e->h_ready = true;
     --n_steps;
   }
-  for (int i = 0; i < n_steps; ++i) {
+  const int cap = e->cfg.max_ctx;
+  for (int i = 0; i < n_steps;) {
     hipGraphExec_t ex = nullptr;
     advance_kv(e);
-    PTTS_TRY(get_graph(e, &ex));  // cached per (batch, fold, 64-position bucket)
+    // steps that follow in the same 64-position bucket share the fetch bound: graph_steps of them go out as one graph launch
+    int run = 1;
+    if (e->graph_steps > 1 && !g_no_kv_bound) {
+      while (run < e->graph_steps && i + run < n_steps && std::min(cap, (e->kv_ub + run + 1 + 63) / 64 * 64) == e->kv_bound) ++run;
+      if (run < e->graph_steps) run = 1;  // only whole groups: two graphs per bucket, not one per remainder length
+    }
+    PTTS_TRY(get_graph(e, &ex, run));  // cached per (batch, fold, 64-position bucket, steps per launch)
     PTTS_HIP(hipGraphLaunch(ex, st));
+    e->kv_ub += run - 1;
+    i += run;
   }
   if (n_steps > 0) PTTS_TRY(precapture_graphs(e, 2));  // the current bucket and the next one, while the GPU works through what was just enqueued
   return PTTS_OK;
