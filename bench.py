@@ -157,14 +157,15 @@ NODE_FLOOR_US = 2.13  # a dependent, trivial kernel node inside a hipGraph on MI
 
 
 def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool, dtype: str = "bf16"):
-    """Kernel nodes of the captured decode step (csrc/ptts_lm.hip forward<> + tail), by batch-size regime."""
-    if bs <= 8:   # GEMV step: LN1+QKV, attention, combine+out_proj, [LN2+Mx, softmax+Up | LN2+q, cross-attn, out_proj], LN3+fc1, fc2
-        per_layer = 7 if folded else 8
-        if bs == 1 and folded and hidden in ((512, 1024, 1536) if dtype != "f32" else (512, 1024)):
-            per_layer -= 1  # qkv_attn_kernel: LN1 + QKV rows + self-attention + append as one node
-            if hidden <= (1024 if dtype != "f32" else 512):
-                per_layer -= 1  # xfold_attn_kernel: the folded cross block as one node of per-head partial rows
-        return per_layer * layers + 2
+    """Kernel nodes of the captured decode step (csrc/ptts_lm.hip forward<> + tail), by batch-size regime; sinusoidal positions."""
+    if bs <= 8:   # GEMV step
+        fused_w = hidden in ((512, 1024, 1536) if dtype != "f32" else (512, 1024))  # widths the fused nodes are instantiated for
+        self_nodes = 2 if (bs == 1 and fused_w) else 3  # [qkv_attn_kernel | LN1+QKV, attention], combine + out_proj
+        if folded:  # single utterance, static cross-attention fold: [xfold_attn_kernel | LN2 + M x, softmax + U p]
+            cross_nodes = 1 if (fused_w and hidden <= (1024 if dtype != "f32" else 512)) else 2
+        else:       # [xq_attn_kernel | LN2 + q, cross-attention], out_proj
+            cross_nodes = 2 if fused_w else 3
+        return (self_nodes + cross_nodes + 2) * layers + 2  # + LN3 + fc1, fc2 per layer; + LM heads, sampler / embed tail
     if bs <= 32 and hidden in (1024, 1536):  # LN1+QKV (lnproj), attention, combine+out_proj, fused LN2+cross-q+cross-attn, out_proj, LN3+fc1 (lnproj), fc2 split-K
         return 7 * layers + 3
     return None

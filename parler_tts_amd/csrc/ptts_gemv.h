@@ -73,6 +73,28 @@ struct XfoldAttnArgs {
 int ptts_xfoldattn_launch(int mode, XfoldAttnArgs a, hipStream_t st);
 bool ptts_xfoldattn_ok(int H, int nheads, int mode);
 
+// Cross block, first half, 1..8 utterances without the static fold (xq_attn_kernel): encoder_attn_layer_norm + the head's 64 cross-q rows +
+// cross-attention against the utterance's description K / V as ONE launch of nheads x M workgroups (instead of the LN2 + q GEMV node and the
+// attention node); output = the normalised context in the engine dtype, read by the out_proj node (GV_COPY). Sinusoidal positions only
+// (RoPE rotates the cross query).
+struct XqAttnArgs {
+  const void* W;        // cross q projection, row-major [H][H]: engine dtype or e4m3 bytes (W8)
+  const float* wscale;  // W8: per-row scale
+  const float* x;       // residual rows fp32 [M][x_ld]
+  const float* gamma;   // encoder_attn_layer_norm
+  const float* beta;
+  const void* kcache;   // this layer's cross K / V: [M][kv_heads][cap][64] engine dtype
+  const void* vcache;
+  const int* mask;      // description padding mask int32 [M][mask_ld] (1 = keep) or null
+  const int* n_valid;   // device-resident description length of the call
+  void* out;            // engine dtype [M][out_ld]
+  int x_ld, out_ld, mask_ld, cap;
+  int nheads, H, kv_heads, M;
+  float scale, invK;
+};
+int ptts_xqattn_launch(int mode, XqAttnArgs a, hipStream_t st);
+bool ptts_xqattn_ok(int H, int mode);
+
 // 0 on success, -1: no instance for this width / mode, -2: launch error
 int ptts_qkvattn_launch(int mode, QkvAttnArgs a, hipStream_t st);
 bool ptts_qkvattn_ok(int H, int mode);

@@ -3,6 +3,7 @@
 #define GV_W8 false
 #define GV_FN ptts_gemv_launch_f32
 #define GV_QA_FN ptts_qkvattn_launch_f32
+#define GV_XQ_FN ptts_xqattn_launch_f32
 #define GV_XA_FN ptts_xfoldattn_launch_f32
 #include "ptts_gemv_launch.inc"
 
@@ -11,6 +12,15 @@ int ptts_gemv_launch_w8(int pro, int epi, int S, GemvArgs a, hipStream_t st);
 
 int ptts_qkvattn_launch_bf16(QkvAttnArgs a, hipStream_t st);
 int ptts_qkvattn_launch_w8(QkvAttnArgs a, hipStream_t st);
+
+int ptts_xqattn_launch_bf16(XqAttnArgs a, hipStream_t st);
+int ptts_xqattn_launch_w8(XqAttnArgs a, hipStream_t st);
+int ptts_xqattn_launch(int mode, XqAttnArgs a, hipStream_t st) {
+  if (mode == GV_BF16) return ptts_xqattn_launch_bf16(a, st);
+  if (mode == GV_BF16_W8) return ptts_xqattn_launch_w8(a, st);
+  return ptts_xqattn_launch_f32(a, st);
+}
+bool ptts_xqattn_ok(int H, int mode) { return ptts_qkvattn_ok(H, mode); }
 
 int ptts_qkvattn_launch(int mode, QkvAttnArgs a, hipStream_t st) {
   if (mode == GV_BF16) return ptts_qkvattn_launch_bf16(a, st);

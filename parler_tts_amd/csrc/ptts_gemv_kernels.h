@@ -747,3 +747,182 @@ __global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
     if (c == 0) a.xpart[(size_t)h * a.H + n0 + u * NW * RPI] = d;
   }
 }
+
+// ------------------------------------------------------------------------------------------------------
+// xq_attn_kernel (1..8 utterances, GEMV engines, no static fold, sinusoidal positions): encoder_attn_layer_norm + the head's 64 cross-q
+// projection rows + cross-attention of ONE (head, utterance) against the static description K / V - the two nodes "LN2 + q GEMV" and
+// "cross attention" of the un-folded cross block as one launch of nheads x M workgroups. Reference: modeling_parler_tts.py:1038-1047
+// (LayerNorm + attention call), :855 (q projection), :906-914 (attention). Same structure and arithmetic as qkv_attn_kernel's roles s < S
+// with one split: 8 weight waves of 8 rows (wave 0 normalises the row while its weights fly), the first batch of K / V row groups is
+// requested at kernel start, softmax in base 2 finished in the kernel (the description is short: never split). The M workgroups of a head
+// sit on one XCD (nheads % 8 == 0) and share the head's q rows in its L2.
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, int NCH, bool W8>
+__global__ void __launch_bounds__(512) xq_attn_kernel(XqAttnArgs a) {
+  constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 4, NW = 8, RW = 8;
+  constexpr int NF4 = NCH * EPL / 4;
+  constexpr int ROW_BYTES = NCH * 64 * 16;                          // H * sizeof(WT)
+  constexpr int WROW_BYTES = ROW_BYTES / (W8 ? (int)sizeof(WT) : 1);  // one weight row
+  typedef typename GvDot<WT, W8>::WV WV;
+  __shared__ __attribute__((aligned(16))) char s_x[ROW_BYTES];
+  __shared__ float s_r[64];
+  __shared__ float s_o[NW][64];
+  __shared__ float s_ml[NW][2];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.x, b = blockIdx.y;
+  float4 lv[NF4], lg[NF4], lb[NF4];
+  if (w == 0) {
+    const float* xr = a.x + (size_t)b * a.x_ld;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) lv[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      lg[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+      lb[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int row0 = h * 64 + w * RW;
+  WV wv[RW][NCH];
+  {
+    const char* wbase = reinterpret_cast<const char*>(a.W) + (size_t)row0 * WROW_BYTES;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) wv[r][c] = (reinterpret_cast<const WV*>(wbase + (size_t)r * WROW_BYTES) + lane)[c * 64];
+  }
+  float wsc = 1.f;
+  if (W8 && lane < RW) wsc = a.wscale[row0 + lane];
+  const int L = *a.n_valid;
+  const int n_rep = a.nheads / a.kv_heads, kvh = h / n_rep;
+  const uint4* Kb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64);
+  const uint4* Vb = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64);
+  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  const int r = lane / LPR, c = lane % LPR;
+  uint4 kf[U], vf[U];
+  int mk[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // positions beyond the arena are not fetched; validity against the length is applied when the data is used
+    const int t = (w + u * NW) * RPI + r;
+    const int tc = t < a.cap ? t : 0;
+    kf[u] = Kb[(size_t)tc * LPR + c];
+    vf[u] = Vb[(size_t)tc * LPR + c];
+    mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
+  }
+  __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  if (w == 0) {  // gv_ln_row's arithmetic
+    const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lv[0].x)));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const float d0 = lv[i].x - c0, d1 = lv[i].y - c0, d2 = lv[i].z - c0, d3 = lv[i].w - c0;
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    gv_pair_sum(s1, s2);
+    const float dm = s1 * a.invK, mean = c0 + dm;
+    const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i)
+      gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, (lv[i].x - mean) * rstd * lg[i].x + lb[i].x, (lv[i].y - mean) * rstd * lg[i].y + lb[i].y,
+                        (lv[i].z - mean) * rstd * lg[i].z + lb[i].z, (lv[i].w - mean) * rstd * lg[i].w + lb[i].w);
+  }
+  __syncthreads();  // normalised row in LDS
+  {
+    uint4 xv[NCH];
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) xv[cc] = *reinterpret_cast<const uint4*>(s_x + (size_t)(cc * 64 + lane) * 16);
+    float acc[RW], acc2[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) { acc[rr] = 0.f; acc2[rr] = 0.f; }
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        if (cc & 1) acc2[rr] = GvDot<WT, W8>::run(wv[rr][cc], xv[cc], acc2[rr]);
+        else acc[rr] = GvDot<WT, W8>::run(wv[rr][cc], xv[cc], acc[rr]);
+      }
+    float v = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const float t = wave_sum(acc[rr] + acc2[rr]);
+      v = lane == rr ? t : v;
+    }
+    if (lane < RW) s_r[w * RW + lane] = W8 ? v * wsc : v;
+  }
+  __syncthreads();  // the head's 64 q values in LDS
+  const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2 (attn_kernel)
+  float qv[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) qv[e] = s_r[c * EPL + e] * qscale;
+  const int G = (L + RPI - 1) / RPI;
+  float m_run = -INFINITY, l_run = 0.f, o[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+  for (int g0 = w; g0 < G; g0 += NW * U) {
+    bool ok[U];
+    if (g0 != w) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = (g0 + u * NW) * RPI + r;
+        const int tc = t < L ? t : 0;
+        kf[u] = Kb[(size_t)tc * LPR + c];
+        vf[u] = Vb[(size_t)tc * LPR + c];
+        mk[u] = mrow ? mrow[tc] : 1;
+      }
+    }
+    float sc[U], bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (g0 + u * NW) * RPI + r;
+      ok[u] = t < L && mk[u] != 0;  // cross-attention: the padding mask covers every description position
+      float kx[EPL];
+      unpack16(kf[u], kx, WT());
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kx[e], d);
+      d = group_reduce<OpSum, LPR>(d);
+      sc[u] = ok[u] ? d : -INFINITY;
+      bm = fmaxf(bm, sc[u]);
+    }
+    bm = across_groups_reduce<OpMax, LPR>(bm);
+    const float m_new = fmaxf(m_run, bm);
+    if (m_new == -INFINITY) continue;  // wave-uniform: nothing visible yet
+    const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float p = ok[u] ? __builtin_amdgcn_exp2f(sc[u] - m_new) : 0.f;
+      float vx[EPL];
+      unpack16(vf[u], vx, WT());
+      l_run += p;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(p, vx[e], o[e]) : o[e];  // masked rows may hold NaN/garbage V
+    }
+    m_run = m_new;
+  }
+  l_run = across_groups_reduce<OpSum, LPR>(l_run);
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) o[e] = across_groups_reduce<OpSum, LPR>(o[e]);
+  if (r == 0) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s_o[w][c * EPL + e] = o[e];
+    if (c == 0) { s_ml[w][0] = m_run; s_ml[w][1] = l_run; }
+  }
+  __syncthreads();
+  if (w == 0) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) M = fmaxf(M, s_ml[i][0]);
+    float ov = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const float wgt = (s_ml[i][0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s_ml[i][0] - M);
+      ov += wgt * s_o[i][lane];
+      lsum += wgt * s_ml[i][1];
+    }
+    gv_store<WT>(reinterpret_cast<WT*>(a.out) + (size_t)b * a.out_ld + h * 64 + lane, lsum > 0.f ? ov / lsum : 0.f);  // every key masked: 0 (attn_kernel)
+  }
+}

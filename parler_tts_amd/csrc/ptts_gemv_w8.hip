@@ -4,4 +4,5 @@
 #define GV_MULTI 1
 #define GV_FN ptts_gemv_launch_w8
 #define GV_QA_FN ptts_qkvattn_launch_w8
+#define GV_XQ_FN ptts_xqattn_launch_w8
 #include "ptts_gemv_launch.inc"

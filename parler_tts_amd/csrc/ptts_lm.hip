@@ -111,6 +111,7 @@ struct ptts_engine {
   int fuse_x_nur = 2;         // rounds of output rows per workgroup of that node (PTTS_FUSE_X_NUR = 2 / 4: nheads x 8 / nheads x 4 workgroups at Mini-v1)
   float* xpart = nullptr;     // [nheads][H] per-head partial rows of the fused cross block
   float* h2 = nullptr;        // [H] residual row after the cross block (x + partial rows), written by the LN3 + fc1 node
+  bool fuse_xq = true;        // GEMV step, un-folded cross block: LN2 + cross-q rows + cross-attention as one node (xq_attn_kernel), PTTS_NO_FUSE_XQ=1 = two nodes
   int graph_steps = 1;        // decode steps per hipGraphLaunch inside one context bucket (PTTS_GRAPH_STEPS = 1 / 2 / 4 / 8 / 16)
   int fuse_qa_s = 0;          // KV splits of that node: 0 = by context bucket (1 / 2 / 4 / 8 for <= 256 / 512 / 1024 / more positions), PTTS_FUSE_QA_S forces one
   int lnproj_g = 8;           // utterances per workgroup of that node (PTTS_LNPROJ_G = 8 / 4)
@@ -447,6 +448,14 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         g2.out = e->h; g2.out_ld = H; g2.N = H; g2.K = K2; g2.M = 1;
         if (ptts_gemv_launch(gm, GV_SOFTMAX, GV_RESID, 1, g2, st) != 0) return ptts_fail(PTTS_E_HIP, "gemv launch failed (softmax + folded out_proj)");
       } else {
+      if (e->fuse_xq && !c.rope && ptts_xqattn_ok(H, mode)) {
+        // LN2 + the head's cross-q rows + cross-attention of one (head, utterance) as ONE node (xq_attn_kernel): 1..8 utterances without the static fold
+        XqAttnArgs x = {};
+        x.W = w.cq_rm; x.wscale = w.cq_sc; x.x = e->h; x.x_ld = H; x.gamma = w.ln2_g; x.beta = w.ln2_b;
+        x.kcache = w.k_cross; x.vcache = w.v_cross; x.mask = e->enc_mask; x.mask_ld = c.max_enc; x.cap = c.max_enc; x.n_valid = &e->dims->N;
+        x.out = e->xw; x.out_ld = H; x.nheads = nh; x.H = H; x.kv_heads = nkc; x.M = M; x.scale = scale;
+        if (ptts_xqattn_launch(mode, x, st) != 0) return ptts_fail(PTTS_E_HIP, "xq_attn launch failed");
+      } else {
       {  // LN2 + cross q projection (:1040, :855)
         GemvArgs g = {};
         g.W = w.cq_rm; g.wscale = w.cq_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln2_g; g.beta = w.ln2_b; g.out = e->qc; g.out_ld = H; g.N = H; g.K = H;
@@ -460,6 +469,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = 1; a.nheads = nh; a.H = H; a.cross = 1;
         a.kv_heads = nkc; a.n_rep = nh / nkc; a.fused_append = 0; a.scale = scale; a.direct_out = e->xw;
         PTTS_TRY((launch_attn<WT>(a, B, st, e->cross_waves)));
+      }
       }
       {  // cross out_proj + residual (:1052)
         GemvArgs g = {};
@@ -900,6 +910,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   if (const char* ev = getenv("PTTS_FUSE_X")) e->fuse_x = atoi(ev) ? 1 : 0;
   if (const char* ev = getenv("PTTS_FUSE_X_NUR")) { const int v = atoi(ev); if (v == 2 || v == 4) e->fuse_x_nur = v; }
   e->fuse_qa = !(getenv("PTTS_NO_FUSE_QA") && atoi(getenv("PTTS_NO_FUSE_QA")));
+  e->fuse_xq = !(getenv("PTTS_NO_FUSE_XQ") && atoi(getenv("PTTS_NO_FUSE_XQ")));
   if (const char* ev = getenv("PTTS_GRAPH_STEPS")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->graph_steps = v; }
   if (const char* ev = getenv("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
   A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));

@@ -381,6 +381,44 @@ def test_fused_cross_block_node_single_utterance(gqa, monkeypatch):
             monkeypatch.delenv("PTTS_FUSE_X", raising=False)
 
 
+@pytest.mark.parametrize("bsz,gqa", [(1, False), (2, False), (3, True), (8, False)])
+def test_fused_cross_q_attention_node_gemv_step(bsz, gqa, monkeypatch):
+    """xq_attn_kernel (1..8 utterances on the GEMV step, no static fold): LN2 + the head's cross-q rows + cross-attention of one (head,
+    utterance) as ONE node. fp32 at H = 512: fused against the two-node path (PTTS_NO_FUSE_XQ=1) within fp32 summation noise and both
+    against the oracle - ragged description masks, a description longer than one K/V batch per wave (N = 300: the attention loop's
+    second batch) and longer than the fold's 64 positions at one utterance; grouped cross K/V heads. bf16 at Mini / Large width against
+    the bf16 oracle. (fp32 engines are built for one utterance: the batched cases run on the bf16 engine only.)"""
+    kw = dict(hidden_size=512, num_attention_heads=8, ffn_dim=1024, num_hidden_layers=3, max_position_embeddings=512)
+    if gqa:
+        kw.update(num_key_value_heads=2, num_cross_attention_key_value_heads=2)
+    spec = DO.DecoderSpec(**kw)
+    sd = DO.make_decoder_weights(spec, seed=101)
+    if bsz == 1:
+        for N, masks in ((80, True), (300, False)):
+            runs = {}
+            for fuse in (True, False):
+                monkeypatch.setenv("PTTS_NO_FUSE_XQ", "0" if fuse else "1")
+                runs[fuse], ref = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=1, N=N, P=6, steps=4, masks=masks, seed=11, max_ctx=64,
+                                                            return_logits=True)
+            monkeypatch.delenv("PTTS_NO_FUSE_XQ", raising=False)
+            ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
+            assert 0.0 < ab < 2e-5, (N, "fused vs two nodes", ab)
+            for fuse in (True, False):
+                err = max(float((a - b).abs().max()) for a, b in zip(runs[fuse], ref))
+                assert err < 5e-5, (N, fuse, err)
+    for kw2, seed, tol in ((dict(), 103, 2e-2), (dict(hidden_size=1536, num_attention_heads=24, ffn_dim=6144), 107, 3e-2)):
+        if gqa:
+            kw2 = dict(kw2, num_key_value_heads=4, num_cross_attention_key_value_heads=4)
+        spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512, **kw2)
+        sd = DO.make_decoder_weights(spec, seed=seed)
+        errs = {}
+        for fuse in (True, False):
+            monkeypatch.setenv("PTTS_NO_FUSE_XQ", "0" if fuse else "1")
+            errs[fuse] = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=70, P=9, steps=3, masks=True, seed=12, max_ctx=64)
+        monkeypatch.delenv("PTTS_NO_FUSE_XQ", raising=False)
+        assert errs[True] < tol and errs[False] < tol, (kw2, errs)
+
+
 @pytest.mark.parametrize("bsz", [2, 3, 4, 5, 6, 8])
 def test_gemv_step_batch_2_to_8(bsz):
     """Batch 2..8 on the bf16 engine runs the GEMV step with every weight row read once for all utterances (MB = 4 / 8 instances:
