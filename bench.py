@@ -167,7 +167,7 @@ def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool, dtype: str
             cross_nodes = 2 if fused_w else 3
         return (self_nodes + cross_nodes + 2) * layers + 2  # + LN3 + fc1, fc2 per layer; + LM heads, sampler / embed tail
     if bs <= 32 and hidden in (1024, 1536):  # LN1+QKV (lnproj), attention, combine+out_proj, fused LN2+cross-q+cross-attn, out_proj, LN3+fc1 (lnproj), fc2 split-K
-        return 7 * layers + 3
+        return 7 * layers + 3                # + heads prep (final LN), LM heads, sampler / embed tail
     return None
 
 
