@@ -141,6 +141,24 @@ struct ptts_engine {
 
 namespace {
 
+// rows of one M pass (one workgroup over blockIdx.z) of the strip GEMMs on fragment-order activations: 16, 32 or 64 (1 / 2 / 4 MFMA column tiles per
+// weight fragment). Fewer rows = more, lighter workgroups (the N = 1024 projections run on N / 16 = 64 workgroups per pass) at the price of one L2 re-read
+// of every strip per pass. Measured, us per Mini-v1 step at mid context, rows 64 / 32 / 16 (profiles/r04_experiments.txt call 25):
+//   24: 1235 / 1236 / 1191   32: 1291 / 1292 / 1241   48: 1766 / 1594 / 1554   64: 1958 / 1762 / 1828   96: 2293 / 2183 / 2272   128: 2580 / 2546 / 2713
+// -> 2..4 passes of the smallest tile: 16 rows up to 56 utterances, 32 above (PTTS_MSPLIT_ROWS forces one). Round 3 ran one 32-row pass up to 32
+// utterances and 64-row passes above.
+thread_local bool tl_decode_launches = false;  // set by forward<>: the measured policy applies to decode steps; prefill rows keep the 64-row passes
+inline int msplit_rows(int M) {
+  static const int forced = [] {
+    const char* ev = getenv("PTTS_MSPLIT_ROWS");
+    const int x = ev ? atoi(ev) : 0;
+    return (x == 16 || x == 32 || x == 64) ? x : 0;
+  }();
+  if (forced) return forced;
+  if (!tl_decode_launches) return M > 32 ? 64 : 32;  // prefill (and anything outside a decode step): as before
+  return M <= 56 ? 16 : 32;
+}
+
 template <typename WT, int PRO, int EPI, int MTP, bool FULL>
 int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) {
   static PttsPerDeviceOnce attr_once;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
@@ -183,8 +201,8 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   // strip's weights are re-streamed from L2 M/128 times instead of M/32
   // (fragment-order activations, decode at batch > 32: 64-row passes, ONE pass per workgroup via blockIdx.z - twice the workgroups and
   // half the B fragments per workgroup of a 128-row pass)
-  const bool msplit = PRO == PRO_COPY && a.x_fo && a.M > 32;
-  const int max_rows = msplit ? 64 : ((PRO == PRO_COPY && a.M > 32) ? 128 : 32);
+  const bool msplit = PRO == PRO_COPY && a.x_fo && a.M > msplit_rows(a.M);
+  const int max_rows = msplit ? msplit_rows(a.M) : ((PRO == PRO_COPY && a.M > 32) ? 128 : 32);
   int rpp = a.M < max_rows ? a.M : max_rows;
   auto tiles = [](int r) { return r > 64 ? 8 : (r > 32 ? 4 : (r > 16 ? 2 : 1)); };
   while (rpp > 1 && rpp * row_bytes + (size_t)W * tiles(rpp) * 1024 > lds_cap) --rpp;
@@ -253,9 +271,10 @@ int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of 
   if (!W) return ptts_fail(PTTS_E_INVALID, "split-K gemm K=%d", a.K);
   a.ksplit = per_split; a.frags_per_wave = per_split / W; a.invK = 1.0f / (float)a.K;
   a.out_split_stride = (long long)a.M * a.out_ld;
-  a.rows_per_pass = a.M > 32 ? 64 : a.M;  // batch > 32 (fragment-order activations only): 64-row passes over blockIdx.z
-  a.m_split = a.M > 32 ? 1 : 0;
-  const int mtp = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
+  const bool ms = a.M > msplit_rows(a.M) && a.x_fo;  // fragment-order activations only (above 32 rows splitk_ok() guarantees them)
+  a.rows_per_pass = ms ? msplit_rows(a.M) : a.M;     // passes of msplit_rows() rows over blockIdx.z
+  a.m_split = ms ? 1 : 0;
+  const int mtp = a.rows_per_pass > 32 ? 4 : (a.rows_per_pass > 16 ? 2 : 1);
   const dim3 grid(a.N / 16, FC2_KSPLIT, (a.M + a.rows_per_pass - 1) / a.rows_per_pass), block(W * 64);
   const size_t sh = (size_t)W * mtp * 1024;
   if constexpr (sizeof(WT) == 2) {
@@ -345,6 +364,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   const int Q = prefill ? e->P + 1 + e->prefill_T : 1;  // prompt positions + BOS column [+ the voice-prompt columns, run in the same pass]
   const int M = B * Q;
   const bool big = M > 8;
+  tl_decode_launches = !prefill;  // rows per M pass of the strip GEMMs (msplit_rows)
   const float scale = 1.0f / sqrtf((float)(H / nh));
 
   if (prefill) {  // cross-attention K/V of the description, once per call (:877-878 then reused :872-875)
