@@ -145,7 +145,7 @@ namespace {
 // weight fragment). Fewer rows = more, lighter workgroups (the N = 1024 projections run on N / 16 = 64 workgroups per pass) at the price of one L2 re-read
 // of every strip per pass. Measured, us per Mini-v1 step at mid context, rows 64 / 32 / 16 (profiles/r04_experiments.txt call 25):
 //   24: 1235 / 1236 / 1191   32: 1291 / 1292 / 1241   48: 1766 / 1594 / 1554   64: 1958 / 1762 / 1828   96: 2293 / 2183 / 2272   128: 2580 / 2546 / 2713
-// -> 2..4 passes of the smallest tile: 16 rows up to 56 utterances, 32 above (PTTS_MSPLIT_ROWS forces one). Round 3 ran one 32-row pass up to 32
+// -> 2..3 passes of the smallest tile: 16 rows up to 48 utterances, 32 above (56 utterances: 1764 us on 16-row passes, 60 on 32-row passes 1725; PTTS_MSPLIT_ROWS forces one). Round 3 ran one 32-row pass up to 32
 // utterances and 64-row passes above.
 thread_local bool tl_decode_launches = false;  // set by forward<>: the measured policy applies to decode steps; prefill rows keep the 64-row passes
 inline int msplit_rows(int M) {
@@ -156,7 +156,7 @@ inline int msplit_rows(int M) {
   }();
   if (forced) return forced;
   if (!tl_decode_launches) return M > 32 ? 64 : 32;  // prefill (and anything outside a decode step): as before
-  return M <= 56 ? 16 : 32;
+  return M <= 48 ? 16 : 32;
 }
 
 template <typename WT, int PRO, int EPI, int MTP, bool FULL>

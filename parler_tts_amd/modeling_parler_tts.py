@@ -645,13 +645,14 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         return es
 
     def _decode_streams(self, B: int) -> int:
-        """EXPERIMENTAL, off by default (model.decode_streams = n or PTTS_DECODE_STREAMS=n): run the batch as n independent
-        sub-batches, each on its own engine and HIP stream. Measured in round 3 at batch 32 (2 x 16: 1452 -> 1525 ms per generate(), loses:
-        a latency-bound chain does not get shorter with fewer rows) and at batch 8; kept for the >= 64-utterance operating point, where one
-        half's bandwidth-bound self-attention can overlap the other half's latency-bound GEMM chain (profiles/r04_experiments.txt)."""
+        """EXPERIMENTAL, off (model.decode_streams = n or PTTS_DECODE_STREAMS=n): run the batch as n independent sub-batches, each on its own
+        engine and HIP stream. Measured (profiles/r03_experiments.txt, r04_experiments.txt): batch 32 as 2 x 16 loses (a latency-bound chain does
+        not get shorter with fewer rows); 64 as 2 x 32 won 7.5 % while the strip GEMMs ran 64-row passes and is neutral since they run 2..3
+        lighter passes (call 26: 1690 vs 1698 ms per generate() at 64, 2137 vs 2126 at 96, 2541 vs 2534 at 128); four sub-batches are 2.7-3.3x
+        slower, and so are four or more single-utterance engines (call 20). No automatic split any more."""
         n = int(getattr(self, "decode_streams", 0) or os.environ.get("PTTS_DECODE_STREAMS", "0") or 0)
-        if n == 0:  # automatic: two sub-batches where it measured faster (64 utterances: 1929 -> 1784 ms per generate(); 128: 2643 -> 2630, neutral;
-            n = 2 if (64 <= B < 128 and B % 2 == 0 and self.device.type == "cuda") else 1  # 32: loses; four sub-batches: 2.7-3.3x slower)
+        if n == 0:
+            n = 1
         # smallest sub-batch worth its own engine: 8 by default; 4 lets batch 5..8 run as two GEMV-step sub-batches (0.84 ms at 4 utterances
         # against 1.33 ms for 8 on the MFMA strips) - to be measured with the rest (tools/experimental/run_all.sh)
         min_sub = int(getattr(self, "decode_streams_min_sub", 0) or os.environ.get("PTTS_DECODE_STREAMS_MIN_SUB", "8") or 8)

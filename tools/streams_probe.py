@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 model = bench.build_model_on_device(dev, torch.bfloat16, "mini")
 for B in [int(x) for x in (sys.argv[1:] or ["128"])]:
     for n in (1, 2, 4):
-        if B // n < 16:
+        if B // n < 16 or n > int(os.environ.get('STREAMS_PROBE_MAX_N', '4')):
             continue
         model.decode_streams = n
         model.decode_streams_min_sub = 16
