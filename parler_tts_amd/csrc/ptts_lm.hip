@@ -148,14 +148,24 @@ namespace {
 // -> 2..3 passes of the smallest tile: 16 rows up to 48 utterances, 32 above (56 utterances: 1764 us on 16-row passes, 60 on 32-row passes 1725; PTTS_MSPLIT_ROWS forces one). Round 3 ran one 32-row pass up to 32
 // utterances and 64-row passes above.
 thread_local bool tl_decode_launches = false;  // set by forward<>: the measured policy applies to decode steps; prefill rows keep the 64-row passes
-inline int msplit_rows(int M) {
+inline int msplit_rows(int M, int N = 0) {
   static const int forced = [] {
     const char* ev = getenv("PTTS_MSPLIT_ROWS");
     const int x = ev ? atoi(ev) : 0;
     return (x == 16 || x == 32 || x == 64) ? x : 0;
   }();
   if (forced) return forced;
-  if (!tl_decode_launches) return M > 32 ? 64 : 32;  // prefill (and anything outside a decode step): as before
+  // prefill rows (time-to-first-token path): the decode policy only where 64-row passes leave the projection with fewer workgroups than CUs
+  // (strips x passes < 256: the N = 1024 .. 3072 projections of a short prompt); wide projections keep the 64-row passes. Measured, prefill + first
+  // token in ms (profiles/r04_experiments.txt calls 27-28), 64-row passes | lighter everywhere | lighter where strips x passes < 128:
+  //   Mini-v1 33 rows 1.89 | 1.57 | 1.63   66 rows 2.16 | 1.95 | 2.16   101 rows 2.34 | 2.13 | 2.31   132 rows 2.75 | 2.69 | 2.73   fp32 33 rows 3.47 | 2.32 | 2.32
+  //   Large-v1 33 rows 3.17 | 3.36 | 3.17 (its 288- / 384-strip projections lose on light passes)
+  // PTTS_MSPLIT_PREFILL = 0: never, 1: everywhere, 2 (default): by workgroup count
+  static const int prefill_mode = getenv("PTTS_MSPLIT_PREFILL") ? atoi(getenv("PTTS_MSPLIT_PREFILL")) : 2;
+  if (!tl_decode_launches) {
+    const bool lighter = prefill_mode == 1 || (prefill_mode == 2 && N > 0 && (N / 16) * ((M + 63) / 64) < 256);
+    if (!lighter) return M > 32 ? 64 : 32;
+  }
   return M <= 48 ? 16 : 32;
 }
 
@@ -201,8 +211,8 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   // strip's weights are re-streamed from L2 M/128 times instead of M/32
   // (fragment-order activations, decode at batch > 32: 64-row passes, ONE pass per workgroup via blockIdx.z - twice the workgroups and
   // half the B fragments per workgroup of a 128-row pass)
-  const bool msplit = PRO == PRO_COPY && a.x_fo && a.M > msplit_rows(a.M);
-  const int max_rows = msplit ? msplit_rows(a.M) : ((PRO == PRO_COPY && a.M > 32) ? 128 : 32);
+  const bool msplit = PRO == PRO_COPY && a.x_fo && a.M > msplit_rows(a.M, a.N);
+  const int max_rows = msplit ? msplit_rows(a.M, a.N) : ((PRO == PRO_COPY && a.M > 32) ? 128 : 32);
   int rpp = a.M < max_rows ? a.M : max_rows;
   auto tiles = [](int r) { return r > 64 ? 8 : (r > 32 ? 4 : (r > 16 ? 2 : 1)); };
   while (rpp > 1 && rpp * row_bytes + (size_t)W * tiles(rpp) * 1024 > lds_cap) --rpp;
@@ -271,8 +281,8 @@ int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of 
   if (!W) return ptts_fail(PTTS_E_INVALID, "split-K gemm K=%d", a.K);
   a.ksplit = per_split; a.frags_per_wave = per_split / W; a.invK = 1.0f / (float)a.K;
   a.out_split_stride = (long long)a.M * a.out_ld;
-  const bool ms = a.M > msplit_rows(a.M) && a.x_fo;  // fragment-order activations only (above 32 rows splitk_ok() guarantees them)
-  a.rows_per_pass = ms ? msplit_rows(a.M) : a.M;     // passes of msplit_rows() rows over blockIdx.z
+  const bool ms = a.M > msplit_rows(a.M, a.N) && a.x_fo;  // fragment-order activations only (above 32 rows splitk_ok() guarantees them)
+  a.rows_per_pass = ms ? msplit_rows(a.M, a.N) : a.M;     // passes of msplit_rows() rows over blockIdx.z
   a.m_split = ms ? 1 : 0;
   const int mtp = a.rows_per_pass > 32 ? 4 : (a.rows_per_pass > 16 ? 2 : 1);
   const dim3 grid(a.N / 16, FC2_KSPLIT, (a.M + a.rows_per_pass - 1) / a.rows_per_pass), block(W * 64);
