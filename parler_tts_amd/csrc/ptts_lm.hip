@@ -166,6 +166,7 @@ inline int msplit_rows(int M, int N = 0) {
     const bool lighter = prefill_mode == 1 || (prefill_mode == 2 && N > 0 && (N / 16) * ((M + 63) / 64) < 256);
     if (!lighter) return M > 32 ? 64 : 32;
   }
+  if (N >= 8192) return M > 32 ? 64 : 32;  // the LM heads (612 strips): plenty of workgroups already - light passes cost 7.4 -> 10.6 us at 32 utterances (call 29)
   return M <= 48 ? 16 : 32;
 }
 
