@@ -167,6 +167,8 @@ inline int msplit_rows(int M, int N = 0) {
     if (!lighter) return M > 32 ? 64 : 32;
   }
   if (N >= 8192) return M > 32 ? 64 : 32;  // the LM heads (612 strips): plenty of workgroups already - light passes cost 7.4 -> 10.6 us at 32 utterances (call 29)
+  // (the wide projections - QKV, fc1, N >= 3072 - on their own pass size measured no better: 64-row passes for them cost +4 % at 48 / 64 utterances and
+  //  are within 0.5 % at 96 / 128, profiles/r04_experiments.txt call 31: one policy for every projection below 8192 rows)
   return M <= 48 ? 16 : 32;
 }
 
