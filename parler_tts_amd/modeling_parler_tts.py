@@ -653,8 +653,8 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         n = int(getattr(self, "decode_streams", 0) or os.environ.get("PTTS_DECODE_STREAMS", "0") or 0)
         if n == 0:
             n = 1
-        # smallest sub-batch worth its own engine: 8 by default; 4 lets batch 5..8 run as two GEMV-step sub-batches (0.84 ms at 4 utterances
-        # against 1.33 ms for 8 on the MFMA strips) - to be measured with the rest (tools/experimental/run_all.sh)
+        # smallest sub-batch that gets its own engine when a split is forced: 8 by default (decode_streams_min_sub / PTTS_DECODE_STREAMS_MIN_SUB lower
+        # it for probes: tools/streams_probe_small.py measured 2 x 1 at +6 %, everything else at 2..8 utterances slower than the one batched engine)
         min_sub = int(getattr(self, "decode_streams_min_sub", 0) or os.environ.get("PTTS_DECODE_STREAMS_MIN_SUB", "8") or 8)
         return n if n > 1 and B >= min_sub * n and B % n == 0 else 1
 
