@@ -302,6 +302,74 @@ def measure_ttft(model, bs: int, device, reps: int = 20) -> float:
     return ts[len(ts) // 2] * 1e3
 
 
+def measure_ttft_breakdown(model, bs: int, device, reps: int = 20) -> dict:
+    """Where the time to the first token goes: GPU time of each stage of the path `measure_ttft` times, from events
+    on the stream the work is enqueued on, p50 over `reps` calls - description encoder (modeling_parler_tts.py:3048-3097), prompt
+    embedding (:3100), HIP prefill of P + 1 positions (`_sample`'s first forward, :3564), first sampler tail (`ptts_first_token_times`) -
+    beside the p50 wall time of the whole sequence; `host_and_gaps_ms` = wall - sum of the stages (launch latency the GPU did not hide,
+    the event wait). `stock_t5_ms` = the same description through the stock transformers module replayed from a torch HIP graph (what
+    rounds 1-4 shipped), for the before / after."""
+    desc, prompt = synthetic_batch(bs, 0, device)
+    eng = model._get_engine(bs, N_DESC, N_PROMPT, NEW_TOKENS + 1)
+    eng.set_gen_params(max_length=NEW_TOKENS + 1, min_new_tokens=NEW_TOKENS)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stages = {"t5_ms": [], "prompt_embed_ms": [], "prefill_ms": [], "first_tail_ms": [], "wall_ms": []}
+    for i in range(reps + 3):
+        e = [ev() for _ in range(3)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e[0].record()
+        enc = model._encode_description(desc, None).float()
+        e[1].record()
+        pr = model.embed_prompts(prompt).float()
+        e[2].record()
+        eng.prefill(enc, None, pr, None, sample=True)
+        eng.first_token_sync()
+        wall = (time.perf_counter() - t0) * 1e3
+        tail = eng.first_tail_ms()
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record()
+        eng.prefill(enc, None, pr, None, sample=False)  # the same forward alone: no sampler tail, no fold, no graph pre-capture behind it
+        b.record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            stages["t5_ms"].append(e[0].elapsed_time(e[1]))
+            stages["prompt_embed_ms"].append(e[1].elapsed_time(e[2]))
+            stages["prefill_ms"].append(a.elapsed_time(b))
+            stages["first_tail_ms"].append(tail)
+            stages["wall_ms"].append(wall)
+    p50 = {k: sorted(v)[len(v) // 2] for k, v in stages.items()}
+    native = model.__dict__.get("_t5_engine") is not None
+    L = model.config.text_encoder.num_layers
+    out = {k: round(p50[k], 3) for k in ("t5_ms", "prompt_embed_ms", "prefill_ms", "first_tail_ms")}
+    out.update({"wall_p50_ms": round(p50["wall_ms"], 3), "bs": bs, "reps": reps,
+                "host_and_gaps_ms": round(p50["wall_ms"] - sum(p50[k] for k in ("t5_ms", "prompt_embed_ms", "prefill_ms", "first_tail_ms")), 3),
+                "t5_encoder": "native HIP (ptts_t5_encode)" if native else "stock transformers module (torch HIP graph replay)",
+                "launches": {"t5": f"2 copies + 1 hipGraph of {1 + 7 * L} kernel nodes + 1 final-norm launch" if native else "~50 per block (ATen / Tensile)",
+                             "prompt_embed": 2, "first_tail": 1}})
+    if native:  # before / after: the stock module on the same description
+        try:
+            model.use_native_text_encoder = False
+            ts = []
+            for i in range(8):
+                a, b = ev(), ev()
+                torch.cuda.synchronize()
+                a.record()
+                model._encode_description(desc, None)
+                b.record()
+                torch.cuda.synchronize()
+                if i >= 3:
+                    ts.append(a.elapsed_time(b))
+            out["stock_t5_ms"] = round(sorted(ts)[len(ts) // 2], 3)
+        except Exception as ex:  # noqa: BLE001
+            out["stock_t5_ms"] = repr(ex)[:120]
+        finally:
+            model.use_native_text_encoder = True
+            model.__dict__.pop("_enc_graphs", None)
+    return out
+
+
 def measure_ttfa(model, device, reps: int = 9, play_steps_in_s: float = 0.5) -> dict:
     """p50 time-to-first-audio (INFERENCE.md:3 "under 500 ms"): wall time from calling generate(streamer=...) in a thread
     (INFERENCE.md:130-148: play_steps = frame_rate * 0.5 s = 43 columns) to the first non-empty audio chunk in the queue:
@@ -717,6 +785,11 @@ def main():
             out["ttft_p50_ms"] = max(ttft_ranks) if ttft_ranks else round(measure_ttft(model, args.bs, device), 2)
             if ttft_ranks:
                 out["per_rank_ttft_p50_ms"] = ttft_ranks  # ttft_p50_ms = the slowest rank's p50
+            if world == 1:
+                try:
+                    out["ttft"] = measure_ttft_breakdown(model, args.bs, device)
+                except Exception as e:  # noqa: BLE001 - side information
+                    out["ttft"] = {"error": repr(e)[:200]}
         else:
             out["roofline"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a required object of the line: measured before the optional side measurements
@@ -736,6 +809,7 @@ def main():
             dt = time.perf_counter() - t0
             out["bs32"] = {"value": round(32 * AUDIO_S / dt, 2), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1),
                            "ttft_p50_ms": round(measure_ttft(model, 32, device, reps=7), 2),
+                           "ttft": measure_ttft_breakdown(model, 32, device, reps=7),
                            "roofline": measure_decode_roofline(model, 32, device)}
         except Exception as e:  # side measurement must never break the contract line
             out["bs32"] = {"error": repr(e)[:200]}

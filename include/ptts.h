@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 6
+#define PTTS_ABI_VERSION 7
 
 enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
 
@@ -40,6 +40,7 @@ enum {
 
 typedef struct ptts_engine ptts_engine; /* decoder LM engine: packed weights, KV arena, sampler state, hipGraph */
 typedef struct ptts_dac ptts_dac;       /* DAC codes -> waveform engine */
+typedef struct ptts_t5 ptts_t5;         /* T5 description encoder (ABI v7) */
 
 /* ParlerTTSDecoderConfig integers (configuration_parler_tts.py:111-172) + engine capacities. */
 typedef struct {
@@ -132,6 +133,9 @@ int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_d
  * static cross-attention fold for the decode steps) is NOT waited for. Replaces the host sync a caller of the reference would place after
  * the first `_sample` iteration (:3564). */
 int ptts_first_token_sync(ptts_engine* e);
+/* (ABI v7) Measurement hook for the time-to-first-token breakdown (bench.py `ttft`): GPU time in ms of the sampler tail of the last
+ * ptts_prefill(sample != 0), between an event recorded right before it and the first-token event. Synchronises on that event. */
+int ptts_first_token_times(ptts_engine* e, float* tail_ms);
 
 /* n_steps iterations of {embed(delay-masked last column) -> layers -> LM heads -> tail}; replayed from a
  * captured hipGraph. Steps after every row has finished are no-ops (device-side check), so callers may
@@ -219,6 +223,35 @@ int ptts_dac_debug_latents(ptts_dac* d, float** latents_dev);
  * oracle's restatement of ONE layer (dac_wrapper/modeling_dac.py:139 -> descript DecoderBlock / ResidualUnit) on identical inputs. */
 int ptts_dac_debug_decode_upto(ptts_dac* d, const int64_t* codes_dev, int32_t B, int32_t T, int32_t stage, void* stream, void** act_dev,
                                int32_t* act_is_bf16, float** raw_dev, int32_t* rows, int32_t* channels);
+
+/* ---- T5 description encoder (ABI v7) --------------------------------------------------------------------
+ * replaces the `self.text_encoder(input_ids=..., attention_mask=...)` call of generate() (modeling_parler_tts.py:3048-3097; the module is
+ * transformers' T5EncoderModel, built at :2345-2348 - google/flan-t5-large for Mini-v1 / Large-v1, training/README.md:91) on the
+ * time-to-first-token path: T5Stack.forward = shared embedding -> num_layers x [T5LayerSelfAttention, T5LayerFF (gated gelu_new)] ->
+ * final T5LayerNorm, with the bucketed relative-position bias of block 0 shared by every block. SURVEY.md section 8(f) rank 2. */
+typedef struct {
+  int32_t vocab_size, d_model, d_kv, d_ff, num_layers, num_heads; /* T5Config; d_kv must be 64, feed_forward_proj "gated-gelu" */
+  int32_t rel_buckets, rel_max_distance;                          /* relative_attention_num_buckets (32), relative_attention_max_distance (128) */
+  float layer_norm_eps;                                           /* layer_norm_epsilon (1e-6) */
+  int32_t dtype;     /* PTTS_F32 (parity mode) | PTTS_BF16 (bf16 weights and GEMM operands, fp32 accumulate / residual stream / attention) */
+  int32_t max_batch; /* descriptions per call */
+  int32_t max_len;   /* tokens per description */
+  int32_t device;
+} ptts_t5_config;
+
+int ptts_t5_create(const ptts_t5_config* cfg, ptts_t5** out);
+void ptts_t5_destroy(ptts_t5* e);
+/* One tensor by its transformers T5EncoderModel state-dict name: "shared.weight" (= "encoder.embed_tokens.weight"),
+ * "encoder.block.L.layer.0.SelfAttention.{q,k,v,o}.weight", "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+ * "encoder.block.L.layer.0.layer_norm.weight", "encoder.block.L.layer.1.DenseReluDense.{wi_0,wi_1,wo}.weight",
+ * "encoder.block.L.layer.1.layer_norm.weight", "encoder.final_layer_norm.weight". Replaces load_state_dict via from_pretrained (:2469-2488). */
+int ptts_t5_load_weight(ptts_t5* e, const char* name, const void* dev_ptr, int32_t src_dtype, const int64_t* shape, int32_t ndim, void* stream);
+int ptts_t5_weights_ready(ptts_t5* e);
+/* ids_dev int64 [B, N], mask_dev int32 [B, N] or NULL (attention_mask; 1 = keep) -> out_dev float32 [B, N, d_model] = last_hidden_state with
+ * the masked positions zeroed (:3093-3097). Replayed from one captured hipGraph per (B, N, masked?). */
+int ptts_t5_encode(ptts_t5* e, const int64_t* ids_dev, const int32_t* mask_dev, int32_t B, int32_t N, float* out_dev, void* stream);
+/* Host-only (no device): T5Attention._relative_position_bucket for the bidirectional encoder, the function the bias table is built from. */
+int32_t ptts_t5_relative_bucket(int32_t relative_position, int32_t num_buckets, int32_t max_distance);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,14 @@ class PttsGenParams(C.Structure):
     ]
 
 
+class PttsT5Config(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("d_model", C.c_int32), ("d_kv", C.c_int32), ("d_ff", C.c_int32), ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32), ("rel_buckets", C.c_int32), ("rel_max_distance", C.c_int32), ("layer_norm_eps", C.c_float),
+        ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_len", C.c_int32), ("device", C.c_int32),
+    ]
+
+
 class PttsDacConfig(C.Structure):
     _fields_ = [
         ("num_codebooks", C.c_int32), ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("latent_dim", C.c_int32),
@@ -44,7 +52,7 @@ class PttsDacConfig(C.Structure):
     ]
 
 
-ABI_VERSION = 6  # PTTS_ABI_VERSION in include/ptts.h
+ABI_VERSION = 7  # PTTS_ABI_VERSION in include/ptts.h
 
 # every symbol include/ptts.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64P = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
@@ -59,6 +67,7 @@ SYMBOLS = {
     "ptts_set_gen_params": (C.c_int, [_VP, C.POINTER(PttsGenParams)]),
     "ptts_prefill": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "ptts_first_token_sync": (C.c_int, [_VP]),
+    "ptts_first_token_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "ptts_decode_steps": (C.c_int, [_VP, _I32, _VP]),
     "ptts_state": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32), _VP]),
     "ptts_ids": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I32)]),
@@ -77,6 +86,12 @@ SYMBOLS = {
     "ptts_dac_decode_chunk": (C.c_int, [_VP, _VP, C.c_int64, _I32, _I32, _I32, _VP, C.c_int64, _I32, _I32, _VP]),
     "ptts_dac_encode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "ptts_dac_debug_latents": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "ptts_t5_create": (C.c_int, [C.POINTER(PttsT5Config), C.POINTER(_VP)]),
+    "ptts_t5_destroy": (None, [_VP]),
+    "ptts_t5_load_weight": (C.c_int, [_VP, C.c_char_p, _VP, _I32, _I64P, _I32, _VP]),
+    "ptts_t5_weights_ready": (C.c_int, [_VP]),
+    "ptts_t5_encode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _VP]),
+    "ptts_t5_relative_bucket": (C.c_int32, [_I32, _I32, _I32]),
     "ptts_dac_debug_decode_upto": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_I32)]),
 }
 

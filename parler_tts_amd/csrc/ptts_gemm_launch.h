@@ -1,0 +1,198 @@
+// Host-side launch helpers of the MFMA strip / block GEMMs and the rows_prep kernel (ptts_lm_kernels.h), shared by the decoder-LM engine
+// (ptts_lm.hip) and the T5 description encoder (ptts_t5.hip). Every function is internal to its translation unit (anonymous namespace).
+#pragma once
+#include <algorithm>
+#include <stdlib.h>
+
+#include "ptts_common.h"
+#include "ptts_lm_kernels.h"
+#include "ptts_strip_w8.h"
+
+namespace {
+
+// rows of one M pass (one workgroup over blockIdx.z) of the strip GEMMs on fragment-order activations: 16, 32 or 64 (1 / 2 / 4 MFMA column tiles per
+// weight fragment). Fewer rows = more, lighter workgroups (the N = 1024 projections run on N / 16 = 64 workgroups per pass) at the price of one L2 re-read
+// of every strip per pass. Measured, us per Mini-v1 step at mid context, rows 64 / 32 / 16 (profiles/r04_experiments.txt call 25):
+//   24: 1235 / 1236 / 1191   32: 1291 / 1292 / 1241   48: 1766 / 1594 / 1554   64: 1958 / 1762 / 1828   96: 2293 / 2183 / 2272   128: 2580 / 2546 / 2713
+// -> 2..3 passes of the smallest tile: 16 rows up to 48 utterances, 32 above (56 utterances: 1764 us on 16-row passes, 60 on 32-row passes 1725; PTTS_MSPLIT_ROWS forces one). Round 3 ran one 32-row pass up to 32
+// utterances and 64-row passes above.
+// `decode` (GemmArgs::decode, set by the caller): the measured policy applies to decode steps; prefill-sized rows keep the 64-row passes
+inline int msplit_rows(int M, int N, bool decode) {
+  static const int forced = [] {
+    const char* ev = getenv("PTTS_MSPLIT_ROWS");
+    const int x = ev ? atoi(ev) : 0;
+    return (x == 16 || x == 32 || x == 64) ? x : 0;
+  }();
+  if (forced) return forced;
+  // prefill rows (time-to-first-token path): the decode policy only where 64-row passes leave the projection with fewer workgroups than CUs
+  // (strips x passes < 256: the N = 1024 .. 3072 projections of a short prompt); wide projections keep the 64-row passes. Measured, prefill + first
+  // token in ms (profiles/r04_experiments.txt calls 27-28), 64-row passes | lighter everywhere | lighter where strips x passes < 128:
+  //   Mini-v1 33 rows 1.89 | 1.57 | 1.63   66 rows 2.16 | 1.95 | 2.16   101 rows 2.34 | 2.13 | 2.31   132 rows 2.75 | 2.69 | 2.73   fp32 33 rows 3.47 | 2.32 | 2.32
+  //   Large-v1 33 rows 3.17 | 3.36 | 3.17 (its 288- / 384-strip projections lose on light passes)
+  // PTTS_MSPLIT_PREFILL = 0: never, 1: everywhere, 2 (default): by workgroup count
+  static const int prefill_mode = getenv("PTTS_MSPLIT_PREFILL") ? atoi(getenv("PTTS_MSPLIT_PREFILL")) : 2;
+  if (!decode) {
+    const bool lighter = prefill_mode == 1 || (prefill_mode == 2 && N > 0 && (N / 16) * ((M + 63) / 64) < 256);
+    if (!lighter) return M > 32 ? 64 : 32;
+  }
+  if (N >= 8192) return M > 32 ? 64 : 32;  // the LM heads (612 strips): plenty of workgroups already - light passes cost 7.4 -> 10.6 us at 32 utterances (call 29)
+  // (the wide projections - QKV, fc1, N >= 3072 - on their own pass size measured no better: 64-row passes for them cost +4 % at 48 / 64 utterances and
+  //  are within 0.5 % at 96 / 128, profiles/r04_experiments.txt call 31: one policy for every projection below 8192 rows)
+  return M <= 48 ? 16 : 32;
+}
+
+template <typename WT, int PRO, int EPI, int MTP, bool FULL>
+int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) {
+  static PttsPerDeviceOnce attr_once;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
+  const int attr_dev = PttsPerDeviceOnce::device();
+  if (attr_once.need(attr_dev)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+    attr_once.done(attr_dev);
+  }
+  hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>), grid, block, sh, st, a);
+  return PTTS_OK;
+}
+
+template <typename WT, int PRO, int EPI>
+int launch_gemm(GemmArgs a, hipStream_t st) {
+  constexpr int KT = Elem<WT>::KT;
+  if (a.N % 16 != 0 || a.K % KT != 0) return ptts_fail(PTTS_E_INVALID, "gemm N=%d K=%d not multiples of 16/%d", a.N, a.K, KT);
+  if (PRO == PRO_LN && a.K > 64 * 4 * LN_MAX_F4) return ptts_fail(PTTS_E_UNSUPPORTED, "LayerNorm width %d > %d", a.K, 64 * 4 * LN_MAX_F4);
+  const int nfrag = a.K / KT;
+  const int wmax = (a.M > 16 ? GemmMaxThreads<PRO, 2>::value : GemmMaxThreads<PRO, 1>::value) / 64;  // MTP 2 and 8 share the 512-thread bound
+  // FULL variant: every wave owns whole 8-fragment groups (and K % 256 == 0): straight-line kernel
+  int W = 0;
+  const bool ln_ok = (PRO != PRO_LN && PRO != PRO_LNS) || a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 1536;  // ln_row<> instances
+  if (a.K % 256 == 0 && ln_ok)
+    for (int w = wmax; w >= 2; --w)
+      if (nfrag % (8 * w) == 0) { W = w; break; }
+  const bool full = W > 0;
+  if (!full) {
+    W = (nfrag + 7) / 8;
+    if (W < 2) W = 2;
+    if (W > wmax) W = wmax;
+  }
+  a.frags_per_wave = nfrag / W;
+  a.invK = 1.0f / (float)a.K;
+  // activation rows staged in LDS per pass: as many as fit beside the cross-wave reduction buffer (<= 32)
+  const size_t row_bytes = PRO == PRO_COPY ? 0 : (size_t)a.K * sizeof(WT) + 16;  // PRO_COPY reads B fragments from global
+  const size_t lds_cap = 160 * 1024 - 1024;
+  // prefill-sized M with prepared (PRO_COPY) activations: 128-row passes (8 MFMA tiles per weight fragment) so the
+  // strip's weights are re-streamed from L2 M/128 times instead of M/32
+  // (fragment-order activations, decode at batch > 32: 64-row passes, ONE pass per workgroup via blockIdx.z - twice the workgroups and
+  // half the B fragments per workgroup of a 128-row pass)
+  const bool msplit = PRO == PRO_COPY && a.x_fo && a.M > msplit_rows(a.M, a.N, a.decode != 0);
+  const int max_rows = msplit ? msplit_rows(a.M, a.N, a.decode != 0) : ((PRO == PRO_COPY && a.M > 32) ? 128 : 32);
+  int rpp = a.M < max_rows ? a.M : max_rows;
+  auto tiles = [](int r) { return r > 64 ? 8 : (r > 32 ? 4 : (r > 16 ? 2 : 1)); };
+  while (rpp > 1 && rpp * row_bytes + (size_t)W * tiles(rpp) * 1024 > lds_cap) --rpp;
+  if (rpp * row_bytes + (size_t)W * 1024 > lds_cap) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm K=%d does not fit in LDS", a.K);
+  a.rows_per_pass = rpp;
+  const int mtp = tiles(rpp);
+  const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
+  a.m_split = msplit ? 1 : 0;
+  const dim3 grid(a.N / 16, 1, msplit ? (a.M + rpp - 1) / rpp : ((EPI == EPI_KV && a.kv_layers) ? a.kv_nlayers : 1)), block(W * 64);
+  int rc;
+  if constexpr (sizeof(WT) == 2) {
+    if (a.W8 && full && a.K % 64 == 0) {  // e4m3 strips (weights_fp8): same grid / LDS, half the weight bytes; -1 = no instance, bf16 strips below
+      rc = ptts_strip_w8_launch(PRO, EPI, mtp, a, grid, block, sh, st);
+      if (rc == 0) return PTTS_OK;
+      if (rc != -1) return PTTS_E_HIP;
+    }
+  }
+  if constexpr (PRO == PRO_COPY) {
+    static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
+    // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
+    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part) {  // (pending split-K partials are folded by the strip kernel's EPI_RESID only)  // prefill-sized: register-blocked kernel, no K split
+      const int nstrips = a.N / 16;
+      const int ns = (nstrips % 4 == 0 && nstrips >= 128) ? 4 : (nstrips % 2 == 0 ? 2 : 0);  // N = 1024: 2 strips per wave keeps > 500 waves in flight
+      if (ns) {
+        const dim3 g2(nstrips / ns, (a.M + 255) / 256), b2(256);
+        if (ns == 4) hipLaunchKernelGGL((gemm_block_kernel<WT, EPI, 4>), g2, b2, 0, st, a);
+        else hipLaunchKernelGGL((gemm_block_kernel<WT, EPI, 2>), g2, b2, 0, st, a);
+        hipError_t eb = hipGetLastError();
+        if (eb != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(eb));
+        return PTTS_OK;
+      }
+    }
+    if (mtp >= 4) {
+      if (mtp == 8) rc = full ? launch_gemm_inst<WT, PRO, EPI, 8, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 8, false>(a, grid, block, sh, st);
+      else rc = full ? launch_gemm_inst<WT, PRO, EPI, 4, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 4, false>(a, grid, block, sh, st);
+      PTTS_TRY(rc);
+      hipError_t e8 = hipGetLastError();
+      if (e8 != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e8));
+      return PTTS_OK;
+    }
+  }
+  if (mtp > 2) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm: %d activation rows per pass need the PRO_COPY path", rpp);
+  if (full) rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, true>(a, grid, block, sh, st);
+  else rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, false>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, false>(a, grid, block, sh, st);
+  PTTS_TRY(rc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+// fc2 at 8 < batch <= 32 (decode): 64 strips x 128 KB of weights on 64 CUs is bound by what ONE CU can pull (~50 GB/s:
+// 12.8 us for 8 MB). Split K over blockIdx.y -> 256 workgroups x 32 KB; the partial products go to part[split][M][N] and
+// the next LayerNorm prep kernel adds them (and the residual) in a fixed order: deterministic, no atomics.
+constexpr int FC2_KSPLIT = 4;
+template <typename WT>
+bool splitk_ok(int M, int N, int K, bool fo) {
+  const int nfrag = K / Elem<WT>::KT;
+  return M > 8 && M <= (fo ? 256 : 32) && N % 16 == 0 && nfrag % (FC2_KSPLIT * 16) == 0;
+}
+template <typename WT>
+int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of partials
+  const int per_split = a.K / Elem<WT>::KT / FC2_KSPLIT;
+  int W = 0;
+  for (int w = 8; w >= 2; --w)
+    if (per_split % (8 * w) == 0) { W = w; break; }
+  if (!W) return ptts_fail(PTTS_E_INVALID, "split-K gemm K=%d", a.K);
+  a.ksplit = per_split; a.frags_per_wave = per_split / W; a.invK = 1.0f / (float)a.K;
+  a.out_split_stride = (long long)a.M * a.out_ld;
+  const bool ms = a.M > msplit_rows(a.M, a.N, a.decode != 0) && a.x_fo;  // fragment-order activations only (above 32 rows splitk_ok() guarantees them)
+  a.rows_per_pass = ms ? msplit_rows(a.M, a.N, a.decode != 0) : a.M;     // passes of msplit_rows() rows over blockIdx.z
+  a.m_split = ms ? 1 : 0;
+  const int mtp = a.rows_per_pass > 32 ? 4 : (a.rows_per_pass > 16 ? 2 : 1);
+  const dim3 grid(a.N / 16, FC2_KSPLIT, (a.M + a.rows_per_pass - 1) / a.rows_per_pass), block(W * 64);
+  const size_t sh = (size_t)W * mtp * 1024;
+  if constexpr (sizeof(WT) == 2) {
+    if (a.W8) {
+      const int r8 = ptts_strip_w8_launch(PRO_COPY, EPI_STORE, mtp, a, grid, block, sh, st);
+      if (r8 == 0) return PTTS_OK;
+      if (r8 != -1) return PTTS_E_HIP;
+    }
+  }
+  int rc = mtp == 1 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 1, true>(a, grid, block, sh, st)
+           : (mtp == 2 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 2, true>(a, grid, block, sh, st)
+                       : launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 4, true>(a, grid, block, sh, st));
+  PTTS_TRY(rc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+template <typename WT>
+int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
+  const dim3 grid(a.S, a.nheads, B * a.Q);
+  if (waves == 1) hipLaunchKernelGGL((attn_kernel<WT, 1>), grid, dim3(64), 0, st, a);
+  else if (waves == 2) hipLaunchKernelGGL((attn_kernel<WT, 2>), grid, dim3(128), 0, st, a);
+  else if (waves == 8) hipLaunchKernelGGL((attn_kernel<WT, 8>), grid, dim3(512), 0, st, a);
+  else if (waves == 16) hipLaunchKernelGGL((attn_kernel<WT, 16>), grid, dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL((attn_kernel<WT, 4>), grid, dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "attn launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+template <typename WT, int PRO>
+int launch_prep(GemmArgs a, void* dst, hipStream_t st) {
+  a.invK = 1.0f / (float)a.K;
+  hipLaunchKernelGGL((rows_prep_kernel<WT, PRO>), dim3((a.M + 3) / 4), dim3(256), 0, st, a, reinterpret_cast<WT*>(dst));
+  return PTTS_OK;
+}
+
+}  // namespace

@@ -11,6 +11,7 @@
 #include "ptts_lm_kernels.h"
 #include "ptts_gemv.h"
 #include "ptts_strip_w8.h"
+#include "ptts_gemm_launch.h"
 
 thread_local std::string g_ptts_err;
 int ptts_fail(int code, const char* fmt, ...) {
@@ -51,6 +52,7 @@ struct ptts_engine {
   hipStream_t fold_stream = nullptr;   // cross-attention folding runs here, beside the rest of the prefill
   hipEvent_t ev_kv = nullptr, ev_fold = nullptr;  // cross K/V cache written / folded matrices ready
   hipEvent_t ev_first = nullptr;                  // first token of the last prefill materialised (recorded right after the sampler tail)
+  hipEvent_t ev_tail0 = nullptr;                  // recorded right before that sampler tail (ptts_first_token_times)
   bool first_recorded = false;
   std::vector<void*> allocs;
   std::vector<LayerW> L;
@@ -121,6 +123,8 @@ struct ptts_engine {
   int kv_ub = 0;         // host-side upper bound of the self-KV positions written so far (prefill + one per decode forward)
   int kv_bound = 0;      // attention fetch bound of the next decode forward: kv_ub + 1 rounded up to 64, <= max_ctx
   std::map<long long, hipGraphExec_t> graphs;  // key: 2 * batch size + folded-cross-block flag + context bucket + steps per launch (get_graph)
+  std::map<long long, hipGraphExec_t> prefill_graphs;  // PTTS_PREFILL_GRAPH: the prefill forward of one (batch, description, prompt, voice-prompt) shape
+  bool in_capture = false;
   int* host_pinned = nullptr;
 
   template <typename T> int alloc(T** p, size_t n) {
@@ -141,190 +145,6 @@ struct ptts_engine {
 
 namespace {
 
-// rows of one M pass (one workgroup over blockIdx.z) of the strip GEMMs on fragment-order activations: 16, 32 or 64 (1 / 2 / 4 MFMA column tiles per
-// weight fragment). Fewer rows = more, lighter workgroups (the N = 1024 projections run on N / 16 = 64 workgroups per pass) at the price of one L2 re-read
-// of every strip per pass. Measured, us per Mini-v1 step at mid context, rows 64 / 32 / 16 (profiles/r04_experiments.txt call 25):
-//   24: 1235 / 1236 / 1191   32: 1291 / 1292 / 1241   48: 1766 / 1594 / 1554   64: 1958 / 1762 / 1828   96: 2293 / 2183 / 2272   128: 2580 / 2546 / 2713
-// -> 2..3 passes of the smallest tile: 16 rows up to 48 utterances, 32 above (56 utterances: 1764 us on 16-row passes, 60 on 32-row passes 1725; PTTS_MSPLIT_ROWS forces one). Round 3 ran one 32-row pass up to 32
-// utterances and 64-row passes above.
-thread_local bool tl_decode_launches = false;  // set by forward<>: the measured policy applies to decode steps; prefill rows keep the 64-row passes
-inline int msplit_rows(int M, int N = 0) {
-  static const int forced = [] {
-    const char* ev = getenv("PTTS_MSPLIT_ROWS");
-    const int x = ev ? atoi(ev) : 0;
-    return (x == 16 || x == 32 || x == 64) ? x : 0;
-  }();
-  if (forced) return forced;
-  // prefill rows (time-to-first-token path): the decode policy only where 64-row passes leave the projection with fewer workgroups than CUs
-  // (strips x passes < 256: the N = 1024 .. 3072 projections of a short prompt); wide projections keep the 64-row passes. Measured, prefill + first
-  // token in ms (profiles/r04_experiments.txt calls 27-28), 64-row passes | lighter everywhere | lighter where strips x passes < 128:
-  //   Mini-v1 33 rows 1.89 | 1.57 | 1.63   66 rows 2.16 | 1.95 | 2.16   101 rows 2.34 | 2.13 | 2.31   132 rows 2.75 | 2.69 | 2.73   fp32 33 rows 3.47 | 2.32 | 2.32
-  //   Large-v1 33 rows 3.17 | 3.36 | 3.17 (its 288- / 384-strip projections lose on light passes)
-  // PTTS_MSPLIT_PREFILL = 0: never, 1: everywhere, 2 (default): by workgroup count
-  static const int prefill_mode = getenv("PTTS_MSPLIT_PREFILL") ? atoi(getenv("PTTS_MSPLIT_PREFILL")) : 2;
-  if (!tl_decode_launches) {
-    const bool lighter = prefill_mode == 1 || (prefill_mode == 2 && N > 0 && (N / 16) * ((M + 63) / 64) < 256);
-    if (!lighter) return M > 32 ? 64 : 32;
-  }
-  if (N >= 8192) return M > 32 ? 64 : 32;  // the LM heads (612 strips): plenty of workgroups already - light passes cost 7.4 -> 10.6 us at 32 utterances (call 29)
-  // (the wide projections - QKV, fc1, N >= 3072 - on their own pass size measured no better: 64-row passes for them cost +4 % at 48 / 64 utterances and
-  //  are within 0.5 % at 96 / 128, profiles/r04_experiments.txt call 31: one policy for every projection below 8192 rows)
-  return M <= 48 ? 16 : 32;
-}
-
-template <typename WT, int PRO, int EPI, int MTP, bool FULL>
-int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) {
-  static PttsPerDeviceOnce attr_once;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
-  const int attr_dev = PttsPerDeviceOnce::device();
-  if (attr_once.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
-    attr_once.done(attr_dev);
-  }
-  hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>), grid, block, sh, st, a);
-  return PTTS_OK;
-}
-
-template <typename WT, int PRO, int EPI>
-int launch_gemm(GemmArgs a, hipStream_t st) {
-  constexpr int KT = Elem<WT>::KT;
-  if (a.N % 16 != 0 || a.K % KT != 0) return ptts_fail(PTTS_E_INVALID, "gemm N=%d K=%d not multiples of 16/%d", a.N, a.K, KT);
-  if (PRO == PRO_LN && a.K > 64 * 4 * LN_MAX_F4) return ptts_fail(PTTS_E_UNSUPPORTED, "LayerNorm width %d > %d", a.K, 64 * 4 * LN_MAX_F4);
-  const int nfrag = a.K / KT;
-  const int wmax = (a.M > 16 ? GemmMaxThreads<PRO, 2>::value : GemmMaxThreads<PRO, 1>::value) / 64;  // MTP 2 and 8 share the 512-thread bound
-  // FULL variant: every wave owns whole 8-fragment groups (and K % 256 == 0): straight-line kernel
-  int W = 0;
-  const bool ln_ok = (PRO != PRO_LN && PRO != PRO_LNS) || a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 1536;  // ln_row<> instances
-  if (a.K % 256 == 0 && ln_ok)
-    for (int w = wmax; w >= 2; --w)
-      if (nfrag % (8 * w) == 0) { W = w; break; }
-  const bool full = W > 0;
-  if (!full) {
-    W = (nfrag + 7) / 8;
-    if (W < 2) W = 2;
-    if (W > wmax) W = wmax;
-  }
-  a.frags_per_wave = nfrag / W;
-  a.invK = 1.0f / (float)a.K;
-  // activation rows staged in LDS per pass: as many as fit beside the cross-wave reduction buffer (<= 32)
-  const size_t row_bytes = PRO == PRO_COPY ? 0 : (size_t)a.K * sizeof(WT) + 16;  // PRO_COPY reads B fragments from global
-  const size_t lds_cap = 160 * 1024 - 1024;
-  // prefill-sized M with prepared (PRO_COPY) activations: 128-row passes (8 MFMA tiles per weight fragment) so the
-  // strip's weights are re-streamed from L2 M/128 times instead of M/32
-  // (fragment-order activations, decode at batch > 32: 64-row passes, ONE pass per workgroup via blockIdx.z - twice the workgroups and
-  // half the B fragments per workgroup of a 128-row pass)
-  const bool msplit = PRO == PRO_COPY && a.x_fo && a.M > msplit_rows(a.M, a.N);
-  const int max_rows = msplit ? msplit_rows(a.M, a.N) : ((PRO == PRO_COPY && a.M > 32) ? 128 : 32);
-  int rpp = a.M < max_rows ? a.M : max_rows;
-  auto tiles = [](int r) { return r > 64 ? 8 : (r > 32 ? 4 : (r > 16 ? 2 : 1)); };
-  while (rpp > 1 && rpp * row_bytes + (size_t)W * tiles(rpp) * 1024 > lds_cap) --rpp;
-  if (rpp * row_bytes + (size_t)W * 1024 > lds_cap) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm K=%d does not fit in LDS", a.K);
-  a.rows_per_pass = rpp;
-  const int mtp = tiles(rpp);
-  const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
-  a.m_split = msplit ? 1 : 0;
-  const dim3 grid(a.N / 16, 1, msplit ? (a.M + rpp - 1) / rpp : ((EPI == EPI_KV && a.kv_layers) ? a.kv_nlayers : 1)), block(W * 64);
-  int rc;
-  if constexpr (sizeof(WT) == 2) {
-    if (a.W8 && full && a.K % 64 == 0) {  // e4m3 strips (weights_fp8): same grid / LDS, half the weight bytes; -1 = no instance, bf16 strips below
-      rc = ptts_strip_w8_launch(PRO, EPI, mtp, a, grid, block, sh, st);
-      if (rc == 0) return PTTS_OK;
-      if (rc != -1) return PTTS_E_HIP;
-    }
-  }
-  if constexpr (PRO == PRO_COPY) {
-    static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
-    // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
-    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers) {  // prefill-sized: register-blocked kernel, no K split
-      const int nstrips = a.N / 16;
-      const int ns = (nstrips % 4 == 0 && nstrips >= 128) ? 4 : (nstrips % 2 == 0 ? 2 : 0);  // N = 1024: 2 strips per wave keeps > 500 waves in flight
-      if (ns) {
-        const dim3 g2(nstrips / ns, (a.M + 255) / 256), b2(256);
-        if (ns == 4) hipLaunchKernelGGL((gemm_block_kernel<WT, EPI, 4>), g2, b2, 0, st, a);
-        else hipLaunchKernelGGL((gemm_block_kernel<WT, EPI, 2>), g2, b2, 0, st, a);
-        hipError_t eb = hipGetLastError();
-        if (eb != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(eb));
-        return PTTS_OK;
-      }
-    }
-    if (mtp >= 4) {
-      if (mtp == 8) rc = full ? launch_gemm_inst<WT, PRO, EPI, 8, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 8, false>(a, grid, block, sh, st);
-      else rc = full ? launch_gemm_inst<WT, PRO, EPI, 4, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 4, false>(a, grid, block, sh, st);
-      PTTS_TRY(rc);
-      hipError_t e8 = hipGetLastError();
-      if (e8 != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e8));
-      return PTTS_OK;
-    }
-  }
-  if (mtp > 2) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm: %d activation rows per pass need the PRO_COPY path", rpp);
-  if (full) rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, true>(a, grid, block, sh, st);
-  else rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, false>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, false>(a, grid, block, sh, st);
-  PTTS_TRY(rc);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
-  return PTTS_OK;
-}
-
-// fc2 at 8 < batch <= 32 (decode): 64 strips x 128 KB of weights on 64 CUs is bound by what ONE CU can pull (~50 GB/s:
-// 12.8 us for 8 MB). Split K over blockIdx.y -> 256 workgroups x 32 KB; the partial products go to part[split][M][N] and
-// the next LayerNorm prep kernel adds them (and the residual) in a fixed order: deterministic, no atomics.
-constexpr int FC2_KSPLIT = 4;
-template <typename WT>
-bool splitk_ok(int M, int N, int K, bool fo) {
-  const int nfrag = K / Elem<WT>::KT;
-  return M > 8 && M <= (fo ? 256 : 32) && N % 16 == 0 && nfrag % (FC2_KSPLIT * 16) == 0;
-}
-template <typename WT>
-int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of partials
-  const int per_split = a.K / Elem<WT>::KT / FC2_KSPLIT;
-  int W = 0;
-  for (int w = 8; w >= 2; --w)
-    if (per_split % (8 * w) == 0) { W = w; break; }
-  if (!W) return ptts_fail(PTTS_E_INVALID, "split-K gemm K=%d", a.K);
-  a.ksplit = per_split; a.frags_per_wave = per_split / W; a.invK = 1.0f / (float)a.K;
-  a.out_split_stride = (long long)a.M * a.out_ld;
-  const bool ms = a.M > msplit_rows(a.M, a.N) && a.x_fo;  // fragment-order activations only (above 32 rows splitk_ok() guarantees them)
-  a.rows_per_pass = ms ? msplit_rows(a.M, a.N) : a.M;     // passes of msplit_rows() rows over blockIdx.z
-  a.m_split = ms ? 1 : 0;
-  const int mtp = a.rows_per_pass > 32 ? 4 : (a.rows_per_pass > 16 ? 2 : 1);
-  const dim3 grid(a.N / 16, FC2_KSPLIT, (a.M + a.rows_per_pass - 1) / a.rows_per_pass), block(W * 64);
-  const size_t sh = (size_t)W * mtp * 1024;
-  if constexpr (sizeof(WT) == 2) {
-    if (a.W8) {
-      const int r8 = ptts_strip_w8_launch(PRO_COPY, EPI_STORE, mtp, a, grid, block, sh, st);
-      if (r8 == 0) return PTTS_OK;
-      if (r8 != -1) return PTTS_E_HIP;
-    }
-  }
-  int rc = mtp == 1 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 1, true>(a, grid, block, sh, st)
-           : (mtp == 2 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 2, true>(a, grid, block, sh, st)
-                       : launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 4, true>(a, grid, block, sh, st));
-  PTTS_TRY(rc);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
-  return PTTS_OK;
-}
-
-template <typename WT>
-int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
-  const dim3 grid(a.S, a.nheads, B * a.Q);
-  if (waves == 1) hipLaunchKernelGGL((attn_kernel<WT, 1>), grid, dim3(64), 0, st, a);
-  else if (waves == 2) hipLaunchKernelGGL((attn_kernel<WT, 2>), grid, dim3(128), 0, st, a);
-  else if (waves == 8) hipLaunchKernelGGL((attn_kernel<WT, 8>), grid, dim3(512), 0, st, a);
-  else if (waves == 16) hipLaunchKernelGGL((attn_kernel<WT, 16>), grid, dim3(1024), 0, st, a);
-  else hipLaunchKernelGGL((attn_kernel<WT, 4>), grid, dim3(256), 0, st, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "attn launch failed: %s", hipGetErrorString(e));
-  return PTTS_OK;
-}
-
-template <typename WT, int PRO>
-int launch_prep(GemmArgs a, void* dst, hipStream_t st) {
-  a.invK = 1.0f / (float)a.K;
-  hipLaunchKernelGGL((rows_prep_kernel<WT, PRO>), dim3((a.M + 3) / 4), dim3(256), 0, st, a, reinterpret_cast<WT*>(dst));
-  return PTTS_OK;
-}
 
 // LayerNorm (+ fold of pending fc2 partials) + projection, tiled over 64 weight rows x G utterances (lnproj_fused_kernel): decode at batch > 8
 template <typename WT, int EPI>
@@ -377,7 +197,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   const int Q = prefill ? e->P + 1 + e->prefill_T : 1;  // prompt positions + BOS column [+ the voice-prompt columns, run in the same pass]
   const int M = B * Q;
   const bool big = M > 8;
-  tl_decode_launches = !prefill;  // rows per M pass of the strip GEMMs (msplit_rows)
+  const int dec = prefill ? 0 : 1;  // GemmArgs::decode: rows per M pass of the strip GEMMs (msplit_rows)
   const float scale = 1.0f / sqrtf((float)(H / nh));
 
   if (prefill) {  // cross-attention K/V of the description, once per call (:877-878 then reused :872-875)
@@ -395,7 +215,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       if (one_launch) { g.kv_layers = e->kv_layers; g.kv_nlayers = c.num_layers; }
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_KV>(g, st)));
     }
-    if (e->xfold_ne && B == 1) hipEventRecord(e->ev_kv, st);  // the fold (ptts_prefill) may start now, beside the layer stack
+    if (e->xfold_ne && B == 1 && !e->in_capture) hipEventRecord(e->ev_kv, st);  // the fold (ptts_prefill) may start now, beside the layer stack
   }
   if (with_embed) {
     EmbedArgs ea = {};
@@ -555,7 +375,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       if (fc2_pending) { p.part = e->hpart; p.S = FC2_KSPLIT; fc2_pending = false; resid_fold = true; }
       PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st)));
     } else {  // LN1 + fused QKV projection
-      GemmArgs g = {};
+      GemmArgs g = {}; g.decode = dec;
       g.W = w.qkv; g.W8 = w.qkv_p8; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
       g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H; g.x_fo = fo;
       if (fc2_pending) { g.part = e->hpart; g.S = FC2_KSPLIT; fc2_pending = false; }  // folded by the prep kernel (M > 8)
@@ -579,7 +399,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
-      GemmArgs g = {};
+      GemmArgs g = {}; g.decode = dec;
       g.W = w.o; g.W8 = w.o_p8; g.wscale = w.o_sc; g.part = e->part; g.stats = e->stats; g.S = S_used; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
       if (resid_fold) { g.fold_part = e->hpart; g.fold_S = FC2_KSPLIT; resid_fold = false; }  // the LN1 node normalised h + partials without writing it back
@@ -619,7 +439,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       } else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 2>), xg, dim3(512), sh, st, x);                            // hidden 512
     } else {
     {  // LN2 + cross q projection
-      GemmArgs g = {};
+      GemmArgs g = {}; g.decode = dec;
       g.W = w.cq; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln2_g; g.beta = w.ln2_b;
       g.out = e->qc; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
       if (lns) g.lnstat = e->lnstat;
@@ -638,7 +458,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     }
     }
     {  // cross out_proj + residual, activations read straight from the attention output
-      GemmArgs g = {};
+      GemmArgs g = {}; g.decode = dec;
       g.W = w.co; g.W8 = w.co_p8; g.wscale = w.co_sc; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1; g.x_fo = fo;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
       if (lns) g.stats_out = e->lnstat;  // for LN3
@@ -646,10 +466,10 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     }
     {  // LN3 + fc1 + GELU, then fc2 + residual. Above 8 rows the GELU output is written in the engine dtype so fc2
        // stages it with plain copies too.
-      GemmArgs g = {};
+      GemmArgs g = {}; g.decode = dec;
       g.W = w.fc1; g.W8 = w.fc1_p8; g.wscale = w.fc1_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln3_g; g.beta = w.ln3_b;
       g.out_ld = F; g.M = M; g.N = F; g.K = H;
-      GemmArgs g2 = {};
+      GemmArgs g2 = {}; g2.decode = dec;
       g2.W = w.fc2; g2.W8 = w.fc2_p8; g2.wscale = w.fc2_sc; g2.x_ld = F; g2.x_row_mul = 1; g2.out = e->h; g2.out_ld = H; g2.M = M; g2.N = H; g2.K = F;
       if (big) {
         g.out = reinterpret_cast<float*>(e->xw2); g.x_fo = fo; g.out_fo = fo;
@@ -679,7 +499,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // (the final LayerNorm + LM heads as one lnproj_fused_kernel node at 9..40 utterances measured neutral to +0.6 %: the 20 MB of head weights are
   //  re-read once per group of 8 utterances - profiles/r04_experiments.txt call 23; the rows_prep + strip GEMM pair stays)
   {  // final LayerNorm + all K LM heads as one [K*V, H] projection, last position of each utterance only
-    GemmArgs g = {};
+    GemmArgs g = {}; g.decode = dec;
     g.W = e->heads; g.W8 = e->heads_p8; g.wscale = e->heads_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = Q; g.x_row_off = Q - 1; g.gamma = e->lnf_g; g.beta = e->lnf_b;
     g.out = e->logits; g.out_ld = c.num_codebooks * c.vocab_size; g.M = B; g.N = c.num_codebooks * c.vocab_size; g.K = H;
     g.x_fo = (e->use_fo && B > 8 && (!prefill || (fo_prefill && B <= 256))) ? 1 : 0;
@@ -803,7 +623,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   auto fail = [&](int r) { ptts_engine_destroy(e); return r; };
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate failed"));
   if (hipStreamCreateWithFlags(&e->fold_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_kv, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_fold, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_first, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&e->ev_fold, hipEventDisableTiming) != hipSuccess || hipEventCreate(&e->ev_first) != hipSuccess || hipEventCreate(&e->ev_tail0) != hipSuccess)
     return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate / hipEventCreate failed"));
   const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size, nh = c.num_heads;
   const size_t es = e->esize;
@@ -986,6 +806,7 @@ extern "C" void ptts_engine_destroy(ptts_engine* e) {
   PttsDeviceGuard _dg(e->cfg.device);
   hipDeviceSynchronize();
   for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : e->prefill_graphs) hipGraphExecDestroy(kv.second);
   for (void* p : e->allocs) hipFree(p);
   if (e->host_pinned) hipHostFree(e->host_pinned);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
@@ -993,6 +814,7 @@ extern "C" void ptts_engine_destroy(ptts_engine* e) {
   if (e->ev_kv) hipEventDestroy(e->ev_kv);
   if (e->ev_fold) hipEventDestroy(e->ev_fold);
   if (e->ev_first) hipEventDestroy(e->ev_first);
+  if (e->ev_tail0) hipEventDestroy(e->ev_tail0);
   delete e;
 }
 
@@ -1223,7 +1045,41 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
     e->prefill_T = T;
   }
   e->xfold_valid = false;  // the prefill itself (and anything before the fold below) runs the un-folded cross-attention
-  const int rc_fwd = forward_dispatch(e, true, st);
+  // The prefill forward (~290 launches of 4-8 us kernels for one utterance) replayed from ONE captured graph per (batch, description, prompt,
+  // voice-prompt) shape: every operand is an engine-owned buffer and every per-call value (lengths, masks) is device-resident, so the
+  // launch list is a pure function of the shape. PTTS_PREFILL_GRAPH=0 launches eagerly (A/B).
+  static const bool prefill_graph = !(getenv("PTTS_PREFILL_GRAPH") && !atoi(getenv("PTTS_PREFILL_GRAPH")));
+  int rc_fwd = PTTS_OK;
+  if (prefill_graph) {
+    const long long key = (long long)B | ((long long)N << 12) | ((long long)P << 28) | ((long long)e->prefill_T << 44);
+    auto it = e->prefill_graphs.find(key);
+    hipGraphExec_t ex = nullptr;
+    if (it != e->prefill_graphs.end()) {
+      ex = it->second;
+    } else {
+      hipGraph_t g = nullptr;
+      PTTS_HIP(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+      e->in_capture = true;
+      rc_fwd = forward_dispatch(e, true, e->own_stream);
+      e->in_capture = false;
+      hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
+      if (rc_fwd != PTTS_OK) { if (g) hipGraphDestroy(g); e->prefill_T = 0; return rc_fwd; }
+      if (ce != hipSuccess) { e->prefill_T = 0; return ptts_fail(PTTS_E_HIP, "hipStreamEndCapture(prefill) failed: %s", hipGetErrorString(ce)); }
+      hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+      hipGraphDestroy(g);
+      if (ie != hipSuccess) { e->prefill_T = 0; return ptts_fail(PTTS_E_HIP, "hipGraphInstantiate(prefill) failed: %s", hipGetErrorString(ie)); }
+      if (e->prefill_graphs.size() >= 32) {  // bounded: a server cycling through many prompt lengths re-captures instead of growing
+        for (auto& kv : e->prefill_graphs) hipGraphExecDestroy(kv.second);
+        e->prefill_graphs.clear();
+      }
+      e->prefill_graphs[key] = ex;
+    }
+    hipError_t le = hipGraphLaunch(ex, st);
+    if (le != hipSuccess) { e->prefill_T = 0; return ptts_fail(PTTS_E_HIP, "hipGraphLaunch(prefill) failed: %s", hipGetErrorString(le)); }
+    if (e->xfold_ne && B == 1) hipEventRecord(e->ev_kv, st);
+  } else {
+    rc_fwd = forward_dispatch(e, true, st);
+  }
   e->prefill_T = 0;
   PTTS_TRY(rc_fwd);
   e->kv_ub = P + 1 + (batched ? T : 0);  // self-KV positions written by this pass
@@ -1234,7 +1090,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
     advance_kv(e);
     PTTS_TRY(forward_dispatch(e, false, st, true));
   }
-  if (sample) PTTS_TRY(launch_tail(e, st, true));  // also embeds the sampled column for the first decode step
+  if (sample) { PTTS_HIP(hipEventRecord(e->ev_tail0, st)); PTTS_TRY(launch_tail(e, st, true)); }  // also embeds the sampled column for the first decode step
   e->first_recorded = false;
   if (sample) { PTTS_HIP(hipEventRecord(e->ev_first, st)); e->first_recorded = true; }
   if (e->xfold_ne && B == 1) {
@@ -1350,6 +1206,15 @@ extern "C" int ptts_first_token_sync(ptts_engine* e) {
   PTTS_CHECK(e->prefilled && e->first_recorded, PTTS_E_INVALID, "ptts_first_token_sync: no sampling prefill to wait for");
   PTTS_DEVICE(e->cfg.device);
   PTTS_HIP(hipEventSynchronize(e->ev_first));
+  return PTTS_OK;
+}
+
+extern "C" int ptts_first_token_times(ptts_engine* e, float* tail_ms) {
+  PTTS_CHECK(e && tail_ms, PTTS_E_INVALID, "null argument");
+  PTTS_CHECK(e->prefilled && e->first_recorded, PTTS_E_INVALID, "ptts_first_token_times: no sampling prefill to report on");
+  PTTS_DEVICE(e->cfg.device);
+  PTTS_HIP(hipEventSynchronize(e->ev_first));
+  PTTS_HIP(hipEventElapsedTime(tail_ms, e->ev_tail0, e->ev_first));
   return PTTS_OK;
 }
 

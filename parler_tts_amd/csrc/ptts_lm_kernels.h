@@ -72,13 +72,17 @@ __global__ void convert_kernel(const ST* __restrict__ src, DT* __restrict__ dst,
 //   EPI_RESID : out += acc (residual stream, :1034/:1052/:1064)
 //   EPI_KV    : scatter into the cross-attention K/V cache [b][head][t][64] (:877-878, cached :872-875)
 // ------------------------------------------------------------------------------------------------------
-enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2, PRO_COPY = 3, PRO_LNS = 4 };  // PRO_COPY: x already in the engine dtype (prep kernel)
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2, PRO_COPY = 3, PRO_LNS = 4, PRO_RMS = 5 };  // PRO_COPY: x already in the engine dtype (prep kernel)
+// PRO_RMS (rows_prep_kernel only; T5 description encoder, ptts_t5.hip): T5LayerNorm = x * rsqrt(mean(x^2) + eps) * weight - no mean, no bias
 // PRO_LNS (8 < M <= 32): LayerNorm whose row statistics come from the PRODUCER of the residual stream. The EPI_RESID GEMM
 // that wrote h also wrote, per (row, 16-column strip), the strip mean and the strip sum of squared deviations
 // (`stats_out`); the consumer combines the K/16 strip partials per row (Chan's pairwise update, exact and cancellation
 // free) with 3 DPP steps for 8 rows at once, so the per-workgroup prologue is loads + one fma per element: no reduction
 // over K, and the separate rows_prep_kernel node (25 % of the batch-32 step in round 1) disappears.
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3, EPI_GELU_WT = 4 };  // _WT: output in the engine dtype
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3, EPI_GELU_WT = 4, EPI_GATE_WT = 5 };  // _WT: output in the engine dtype
+// EPI_GATE_WT (T5 gated-GELU feed-forward, ptts_t5.hip): the packed matrix interleaves the rows of wi_0 and wi_1 (row 2i = wi_0[i], row 2i + 1 =
+// wi_1[i]), so a lane's 4 accumulator rows are (u, v, u', v') of two output features: out[m][n / 2 .. n / 2 + 1] = gelu_new(u) * v in the engine dtype,
+// row-major [M][N / 2] or B-fragment order - the gate never leaves the registers of the GEMM that produced both halves.
 
 struct KvLayer { const void* W; void* k; void* v; };  // one layer's operands of the batched cross K/V projection (EPI_KV over blockIdx.z)
 
@@ -111,7 +115,10 @@ struct GemmArgs {
   int kv_nlayers;            // of EVERY layer in one launch (24 launches of ~8 us sat on the time-to-first-token path); null = W / kcache / vcache
   int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
   int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
+  int decode;          // host-side launch policy only: 1 = a decode-step GEMM (light M passes, msplit_rows), 0 = prefill-sized rows
   int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
+  float rms_eps;       // PRO_RMS: T5Config.layer_norm_epsilon
+  const int* row_keep; // PRO_RMS: [M] int32 or null; rows with 0 are written as zeros (masked description positions, modeling_parler_tts.py:3093-3097)
   const float* fold_part;  // EPI_RESID: pending split-K partials [fold_S][M][N] of the previous fc2 that no prep kernel has added to the residual rows
   int fold_S;              // (lnproj_fused_kernel normalised h + sum_s part[s] without writing it back): out = (out + sum_s part[s]) + acc, same order
 #ifdef PTTS_TIMING
@@ -196,6 +203,20 @@ template <typename A> __device__ __forceinline__ long long* ptts_dbg_of(const A&
 template <> __device__ __forceinline__ long long* ptts_dbg_of<GemmArgs>(const GemmArgs& a) { return a.dbg; }
 #endif
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// transformers NewGELUActivation ("gelu_new", T5 v1.1 / flan-t5 gated-gelu): 0.5 x (1 + tanh(sqrt(2 / pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_new(float x) { return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * (x * x * x)))); }
+// two consecutive engine-dtype elements (k % 2 == 0) of row m: row-major [M][K] or fragment order
+template <typename WT> __device__ __forceinline__ void act_store2(WT* base, int m, int k, int K, int fo, float a, float b);
+template <> __device__ __forceinline__ void act_store2<float>(float* base, int m, int k, int K, int fo, float a, float b) {
+  float2* p = fo ? reinterpret_cast<float2*>(reinterpret_cast<float4*>(base) + fo_vec_index<float>(m, k & ~3, K / Elem<float>::KT)) + ((k >> 1) & 1)
+                 : reinterpret_cast<float2*>(base + (size_t)m * K + k);
+  *p = make_float2(a, b);
+}
+template <> __device__ __forceinline__ void act_store2<bf16_t>(bf16_t* base, int m, int k, int K, int fo, float a, float b) {
+  uint32_t* p = fo ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(base) + fo_vec_index<bf16_t>(m, k & ~7, K / Elem<bf16_t>::KT)) + ((k >> 1) & 3)
+                   : reinterpret_cast<uint32_t*>(base + (size_t)m * K + k);
+  *p = pack_bf16x2(a, b);
+}
 
 // ---- activation staging ---------------------------------------------------------------------------------
 // The rows of one pass are brought into LDS ONCE per workgroup, already in their final form (LayerNorm applied /
@@ -642,6 +663,8 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
               make_float4(gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
         } else if (EPI == EPI_GELU_WT) {
           act_store4<WT>(reinterpret_cast<WT*>(a.out), m, n, a.out_ld, a.out_fo, gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
+        } else if (EPI == EPI_GATE_WT) {  // rows n .. n + 3 of the interleaved matrix = (wi_0, wi_1) of features n / 2, n / 2 + 1
+          act_store2<WT>(reinterpret_cast<WT*>(a.out), m, n >> 1, a.out_ld, a.out_fo, gelu_new(r[0]) * r[1], gelu_new(r[2]) * r[3]);
         } else if (EPI == EPI_RESID) {
           float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
           float4 o = mt == wave ? resid_pre : *p;
@@ -702,6 +725,8 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int m, int n,
     WT* o = reinterpret_cast<WT*>(a.out) + (size_t)m * a.out_ld + n;
 #pragma unroll
     for (int e = 0; e < 4; ++e) store_from_f32<WT>(o + e, gelu_erf(r[e]));
+  } else if (EPI == EPI_GATE_WT) {
+    act_store2<WT>(reinterpret_cast<WT*>(a.out), m, n >> 1, a.out_ld, 0, gelu_new(r[0]) * r[1], gelu_new(r[2]) * r[3]);
   } else if (EPI == EPI_RESID) {
     float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
     float4 o = *p;
@@ -828,11 +853,54 @@ __device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* d
                    (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
 }
 
+// T5LayerNorm (transformers modeling_t5.py T5LayerNorm.forward): variance = mean(x^2) in fp32, x * rsqrt(variance + eps), then * weight.
+// NF4 > 0: K == NF4 * 256, the row lives in registers (one round trip); NF4 == 0: any K % 4 == 0, two passes over the (L2-resident) row.
+template <typename WT, int NF4>
+__device__ __forceinline__ void prep_rms_row(const GemmArgs& a, int m, WT* dst, int lane) {
+  const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
+  const bool keep = !a.row_keep || a.row_keep[m] != 0;
+  if constexpr (NF4 > 0) {
+    float4 v[NF4], g[NF4];
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    ss = wave_sum(ss);
+    const float rstd = keep ? rsqrtf(ss * a.invK + a.rms_eps) : 0.f;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i)
+      act_store4<WT>(dst, m, (lane + 64 * i) * 4, a.K, a.out_fo, (v[i].x * rstd) * g[i].x, (v[i].y * rstd) * g[i].y, (v[i].z * rstd) * g[i].z, (v[i].w * rstd) * g[i].w);
+  } else {
+    float ss = 0.f;
+    for (int k = lane * 4; k < a.K; k += 256) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + k);
+      ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+    }
+    ss = wave_sum(ss);
+    const float rstd = keep ? rsqrtf(ss * a.invK + a.rms_eps) : 0.f;
+    for (int k = lane * 4; k < a.K; k += 256) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + k);
+      const float4 g = *reinterpret_cast<const float4*>(a.gamma + k);
+      act_store4<WT>(dst, m, k, a.K, a.out_fo, (t.x * rstd) * g.x, (t.y * rstd) * g.y, (t.z * rstd) * g.z, (t.w * rstd) * g.w);
+    }
+  }
+}
+
 template <typename WT, int PRO>
 __global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restrict__ dst) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= a.M) return;
+  if constexpr (PRO == PRO_RMS) {
+    if (a.K == 1024) prep_rms_row<WT, 4>(a, m, dst, lane);
+    else if (a.K == 512) prep_rms_row<WT, 2>(a, m, dst, lane);
+    else if (a.K == 768) prep_rms_row<WT, 3>(a, m, dst, lane);
+    else prep_rms_row<WT, 0>(a, m, dst, lane);
+    return;
+  }
   if (PRO == PRO_LN && a.K == 1024) { prep_ln_row_regs<WT, 4>(a, m, dst, lane); return; }  // Mini-v1
   if (PRO == PRO_LN && a.K == 1536) { prep_ln_row_regs<WT, 6>(a, m, dst, lane); return; }  // Large-v1
   if (PRO == PRO_LN) {

@@ -158,6 +158,12 @@ class DecoderEngine:
         time-to-first-token; work the prefill enqueued behind the sampler tail (cross-attention fold) is not waited for."""
         N.check(self.lib.ptts_first_token_sync(self._h), "ptts_first_token_sync")
 
+    def first_tail_ms(self) -> float:
+        """GPU time of the sampler tail of the last sampling ``prefill`` (``ptts_first_token_times``; synchronises on the first-token event)."""
+        ms = C.c_float()
+        N.check(self.lib.ptts_first_token_times(self._h, C.byref(ms)), "ptts_first_token_times")
+        return float(ms.value)
+
     def set_audio_prefix(self, codes: Optional[torch.Tensor]):
         """Voice prompt for the NEXT ``prefill``: un-delayed audio codes int64 [B, K, T] (or [B*K, T]); ``None`` clears it."""
         if codes is None or codes.shape[-1] == 0:
@@ -233,6 +239,86 @@ class DecoderEngine:
             if fin:
                 break
         return self.ids()
+
+
+class T5Engine:
+    """Owner of a ``ptts_t5``: the description encoder (transformers ``T5EncoderModel``, gated-gelu, d_kv 64) on MI355X.
+    Replaces the ``self.text_encoder(...)`` call of generate() (modeling_parler_tts.py:3048-3097) on the time-to-first-token path."""
+
+    def __init__(self, *, vocab_size: int, d_model: int, d_kv: int, d_ff: int, num_layers: int, num_heads: int,
+                 relative_attention_num_buckets: int = 32, relative_attention_max_distance: int = 128, layer_norm_epsilon: float = 1e-6,
+                 dtype: torch.dtype = torch.bfloat16, max_batch: int = 1, max_len: int = 64, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise N.NativeLibraryError("T5Engine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = N.load_library()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"engine dtype must be float32 or bfloat16, got {dtype}")
+        self.dtype, self.d_model, self.max_batch, self.max_len = dtype, d_model, max_batch, max_len
+        self.cfg = N.PttsT5Config(vocab_size, d_model, d_kv, d_ff, num_layers, num_heads, relative_attention_num_buckets,
+                                  relative_attention_max_distance, float(layer_norm_epsilon),
+                                  N.PTTS_BF16 if dtype == torch.bfloat16 else N.PTTS_F32, max_batch, max_len, self.device.index or 0)
+        self._h = C.c_void_p()
+        N.check(self.lib.ptts_t5_create(C.byref(self.cfg), C.byref(self._h)), "ptts_t5_create")
+
+    @staticmethod
+    def supports(config) -> bool:
+        """True for the T5 configurations the HIP encoder implements (flan-t5 / T5 v1.1 shapes: gated gelu_new feed-forward, d_kv 64)."""
+        return (getattr(config, "model_type", None) == "t5" and getattr(config, "d_kv", 0) == 64 and bool(getattr(config, "is_gated_act", False))
+                and getattr(config, "dense_act_fn", None) == "gelu_new" and config.d_model % 32 == 0 and config.d_ff % 32 == 0)
+
+    @classmethod
+    def from_config(cls, config, **kw) -> "T5Engine":
+        return cls(vocab_size=config.vocab_size, d_model=config.d_model, d_kv=config.d_kv, d_ff=config.d_ff, num_layers=config.num_layers,
+                   num_heads=config.num_heads, relative_attention_num_buckets=config.relative_attention_num_buckets,
+                   relative_attention_max_distance=getattr(config, "relative_attention_max_distance", 128),
+                   layer_norm_epsilon=config.layer_norm_epsilon, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.ptts_t5_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
+        """``sd``: transformers ``T5EncoderModel`` names (``shared.weight``, ``encoder.block.N....``), optionally under ``prefix``
+        (``"text_encoder."`` for a ParlerTTSForConditionalGeneration checkpoint)."""
+        for k, v in sd.items():
+            if not k.startswith(prefix):
+                continue
+            name = k[len(prefix):]
+            if not (name.startswith("encoder.") or name == "shared.weight"):
+                continue
+            t = v.detach()
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                t = t.float()
+            t = t.to(self.device).contiguous()
+            dt = N.PTTS_BF16 if t.dtype == torch.bfloat16 else N.PTTS_F32
+            N.check(self.lib.ptts_t5_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, _shape_arr(t), t.dim(), _stream_ptr(device=self.device)),
+                    f"ptts_t5_load_weight({name})")
+            torch.cuda.current_stream(self.device).synchronize()  # the engine re-packs asynchronously; `t` must stay alive until then
+        N.check(self.lib.ptts_t5_weights_ready(self._h), "ptts_t5_weights_ready")
+
+    def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """input_ids int64 [B, N], attention_mask [B, N] or None -> float32 [B, N, d_model]: ``last_hidden_state`` with the masked
+        positions zeroed (what generate() hands to the decoder, :3093-3097). Asynchronous on the current stream of the engine's device."""
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [batch, tokens], got {tuple(input_ids.shape)}")
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        B, Nn = ids.shape
+        mk = attention_mask.to(self.device, torch.int32).contiguous() if attention_mask is not None else None
+        if mk is not None and mk.shape != ids.shape:
+            raise ValueError(f"attention_mask {tuple(mk.shape)} does not match input_ids {tuple(ids.shape)}")
+        out = torch.empty(B, Nn, self.d_model, dtype=torch.float32, device=self.device)
+        N.check(self.lib.ptts_t5_encode(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(mk.data_ptr()) if mk is not None else C.c_void_p(), B, Nn,
+                                        C.c_void_p(out.data_ptr()), _stream_ptr(device=self.device)), "ptts_t5_encode")
+        self._keep = (ids, mk)  # consumed asynchronously by the enqueued copies
+        return out
 
 
 class DacEngine:

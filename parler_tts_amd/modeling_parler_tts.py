@@ -21,7 +21,7 @@ from torch import nn
 
 from .configuration_parler_tts import DACConfig, ParlerTTSConfig, ParlerTTSDecoderConfig
 from .dac_wrapper import DACModel
-from .engine import DecoderEngine
+from .engine import DecoderEngine, T5Engine
 from .generation_extras import active_extras, build_processors, build_stopping_criteria, check_generation_mode, check_model_kwargs
 from .logits_processors import ParlerTTSLogitsProcessor
 
@@ -614,6 +614,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
     def _engine(self, value):
         if value is None:
             self.__dict__["_engines"] = {}
+            t5 = self.__dict__.pop("_t5_engine", None)  # the description encoder's packed weight copy goes with them
+            if t5 is not None:
+                t5.close()
             for e in self.__dict__.get("_split_engines") or []:  # the stream-split loop's engines hold packed copies of the same weights
                 e.close()
             self.__dict__["_split_engines"], self.__dict__["_split_key"] = [], None
@@ -667,11 +670,40 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             enc = enc * attention_mask[..., None]
         return enc
 
+    def _get_t5_engine(self, B: int, N: int) -> Optional[T5Engine]:
+        """The HIP description encoder for this model's text encoder, or None when the text encoder is not a T5 the engine implements
+        (then the stock module runs, as SURVEY.md section 2 row 8 scopes it) or ``use_native_text_encoder`` is off (A/B, parity tests).
+        Capacities grow-only; the packed weight copy (0.68 GB for flan-t5-large in bf16) is dropped with the decoder engines."""
+        if not getattr(self, "use_native_text_encoder", True) or os.environ.get("PTTS_NO_NATIVE_T5", "0") not in ("", "0"):
+            return None
+        cfg = getattr(self.text_encoder, "config", None)
+        if cfg is None or not T5Engine.supports(cfg) or self.dtype not in (torch.float32, torch.bfloat16):
+            return None
+        e = self.__dict__.get("_t5_engine")
+        if e is None or e.device != self.device or e.dtype != self.dtype or e.max_batch < B or e.max_len < N:
+            caps = dict(max_batch=B, max_len=max(N, 16))
+            if e is not None:
+                caps = dict(max_batch=max(B, e.max_batch), max_len=max(caps["max_len"], e.max_len))
+                self.__dict__.pop("_t5_engine").close()
+            e = T5Engine.from_config(cfg, dtype=self.dtype, device=self.device, **caps)
+            e.load_state_dict(self.text_encoder.state_dict())
+            self.__dict__["_t5_engine"] = e
+        return e
+
     def _encode_description(self, input_ids, attention_mask):
-        """:3048-3097 — T5 encoder (third-party, stock PyTorch-ROCm), optional enc_to_dec_proj, masked positions zeroed.
-        The encoder is ~360 tiny launches (13 ms eager at 64 tokens, launch-bound, on the time-to-first-token path), so
-        on a HIP device it is captured once per (batch, length, masked?) into a torch HIP graph and replayed (~3 ms).
-        Any capture failure falls back to the eager call (same arithmetic either way)."""
+        """:3048-3097 — T5 encoder, optional enc_to_dec_proj, masked positions zeroed. On a HIP device the encoder is the native one
+        (``ptts_t5_encode``: 7 kernel nodes per block in one captured hipGraph). A text encoder the HIP
+        engine does not implement runs as the stock module (~360 tiny launches, 13 ms eager at 64 tokens), captured once per
+        (batch, length, masked?) into a torch HIP graph and replayed (~3-5 ms); a capture failure there falls back to the eager call."""
+        if input_ids.device.type == "cuda":
+            t5 = self._get_t5_engine(int(input_ids.shape[0]), int(input_ids.shape[1]))
+            if t5 is not None:
+                enc = t5.encode(input_ids, attention_mask)  # fp32, masked positions already zero
+                if hasattr(self, "enc_to_dec_proj"):
+                    enc = self.enc_to_dec_proj(enc.to(self.dtype))
+                    if attention_mask is not None:
+                        enc = enc * attention_mask[..., None]
+                return enc
         if input_ids.device.type != "cuda" or not getattr(self, "use_encoder_graph", True):
             return self._encode_description_eager(input_ids, attention_mask)
         key = (tuple(input_ids.shape), attention_mask is not None, self.dtype, input_ids.device)

@@ -23,11 +23,11 @@ def test_exports_every_declared_symbol():
     N, lib = _lib()
     hdr = open(os.path.join(ROOT, "include", "ptts.h")).read()
     declared = set(re.findall(r"\b(ptts_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"ptts_engine", "ptts_dac"}
+    declared -= {"ptts_engine", "ptts_dac", "ptts_t5"}
     assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ptts_abi_version() == N.ABI_VERSION == 6
+    assert lib.ptts_abi_version() == N.ABI_VERSION == 7
 
 
 def test_invalid_config_is_value_error_not_crash():
@@ -64,6 +64,10 @@ def test_engines_refuse_to_run_without_gpu():
         DecoderEngine(hidden_size=128, num_layers=1, num_heads=2, ffn_dim=256, num_codebooks=9, vocab_size=1088, max_positions=64)
     with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
         DacEngine()
+    from parler_tts_amd.engine import T5Engine
+
+    with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+        T5Engine(vocab_size=100, d_model=128, d_kv=64, d_ff=256, num_layers=1, num_heads=2)
 
 
 def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_binding(tmp_path):
@@ -83,14 +87,16 @@ def test_header_is_plain_c_and_struct_layouts_match_the_ctypes_binding(tmp_path)
     src = tmp_path / "abi.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ptts.h"\n'
                    'int main(void) {\n'
-                   '  printf("%d %zu %zu %zu %zu %zu %zu\\n", PTTS_ABI_VERSION, sizeof(ptts_config), sizeof(ptts_gen_params), sizeof(ptts_dac_config),\n'
-                   '         offsetof(ptts_config, rope_theta), offsetof(ptts_gen_params, seed), offsetof(ptts_dac_config, compute_dtype));\n'
+                   '  printf("%d %zu %zu %zu %zu %zu %zu %zu %zu\\n", PTTS_ABI_VERSION, sizeof(ptts_config), sizeof(ptts_gen_params), sizeof(ptts_dac_config),\n'
+                   '         offsetof(ptts_config, rope_theta), offsetof(ptts_gen_params, seed), offsetof(ptts_dac_config, compute_dtype),\n'
+                   '         sizeof(ptts_t5_config), offsetof(ptts_t5_config, layer_norm_eps));\n'
                    '  return 0;\n}\n')
     exe = tmp_path / "abi"
     subprocess.check_call([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert [int(x) for x in out] == [N.ABI_VERSION, C.sizeof(N.PttsConfig), C.sizeof(N.PttsGenParams), C.sizeof(N.PttsDacConfig),
-                                     N.PttsConfig.rope_theta.offset, N.PttsGenParams.seed.offset, N.PttsDacConfig.compute_dtype.offset]
+                                     N.PttsConfig.rope_theta.offset, N.PttsGenParams.seed.offset, N.PttsDacConfig.compute_dtype.offset,
+                                     C.sizeof(N.PttsT5Config), N.PttsT5Config.layer_norm_eps.offset]
 
 
 def test_torch_free_cxx_client_of_the_header_builds_and_links(tmp_path):
