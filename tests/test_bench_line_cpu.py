@@ -143,6 +143,7 @@ def test_main_prints_one_contract_line_with_everything_stubbed(monkeypatch, caps
     monkeypatch.setattr(bench, "measure_large", lambda device: {"bf16_bs1": {"value": 9.0}})
     monkeypatch.setattr(bench, "measure_ttft", lambda model, bs, device, reps=20: 9.0)
     monkeypatch.setattr(bench, "measure_ttfa", lambda model, device: {"ttfa_p50_ms": 37.0})
+    monkeypatch.setattr(bench, "measure_ttft_breakdown", lambda model, bs, device, reps=20: {"t5_ms": 1.0, "prefill_ms": 1.5, "bs": bs})
     monkeypatch.setattr(bench, "measure_sampling_step", lambda model, bs, device: {"ratio_sampling_over_greedy": 1.04})
     monkeypatch.setattr(bench, "cpu_baseline", lambda: {"value": 0.15, "unit": "audio-seconds/sec", "cores": 4, "kind": "port", "sample": "stub"})
     bench.main()
@@ -155,6 +156,7 @@ def test_main_prints_one_contract_line_with_everything_stubbed(monkeypatch, caps
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
     assert j["unit"] == "audio-seconds/sec" and j["dtype"] == "bf16" and "workload" in j["config"] and "model" not in j["config"]
     assert j["cpu_baseline"]["kind"] == "port" and j["gpu_over_cpu"] == round(j["value"] / 0.15, 1)
+    assert j["ttft"] == {"t5_ms": 1.0, "prefill_ms": 1.5, "bs": 1} and j["bs32"]["ttft"]["bs"] == 32
     assert j["bs32"]["roofline"]["bound"] == "hbm" and j["streaming"] == {"ttfa_p50_ms": 37.0} and j["sampling"]["ratio_sampling_over_greedy"] == 1.04
     assert "watchdog" not in j
     assert j["bs128"]["roofline"] == {"achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None} and j["bs128"]["unit"] == "audio-seconds/sec"
