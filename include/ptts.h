@@ -133,9 +133,11 @@ int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t* enc_mask_d
  * static cross-attention fold for the decode steps) is NOT waited for. Replaces the host sync a caller of the reference would place after
  * the first `_sample` iteration (:3564). */
 int ptts_first_token_sync(ptts_engine* e);
-/* (ABI v7) Measurement hook for the time-to-first-token breakdown (bench.py `ttft`): GPU time in ms of the sampler tail of the last
- * ptts_prefill(sample != 0), between an event recorded right before it and the first-token event. Synchronises on that event. */
-int ptts_first_token_times(ptts_engine* e, float* tail_ms);
+/* (ABI v7) Measurement hook for the time-to-first-token breakdown (bench.py `ttft`), last ptts_prefill(sample != 0): GPU time in ms from the
+ * moment the stream reached the call's first piece of work to the start of the sampler tail (prefill_ms: staging copies + the P + 1-position
+ * forward, as it ran IN SEQUENCE behind whatever the caller enqueued before), and of the tail itself up to the first-token event (tail_ms).
+ * Synchronises on that event. */
+int ptts_first_token_times(ptts_engine* e, float* prefill_ms, float* tail_ms);
 
 /* n_steps iterations of {embed(delay-masked last column) -> layers -> LM heads -> tail}; replayed from a
  * captured hipGraph. Steps after every row has finished are no-ops (device-side check), so callers may

@@ -67,7 +67,7 @@ SYMBOLS = {
     "ptts_set_gen_params": (C.c_int, [_VP, C.POINTER(PttsGenParams)]),
     "ptts_prefill": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "ptts_first_token_sync": (C.c_int, [_VP]),
-    "ptts_first_token_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "ptts_first_token_times": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ptts_decode_steps": (C.c_int, [_VP, _I32, _VP]),
     "ptts_state": (C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32), _VP]),
     "ptts_ids": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I32)]),

@@ -53,6 +53,7 @@ struct ptts_engine {
   hipEvent_t ev_kv = nullptr, ev_fold = nullptr;  // cross K/V cache written / folded matrices ready
   hipEvent_t ev_first = nullptr;                  // first token of the last prefill materialised (recorded right after the sampler tail)
   hipEvent_t ev_tail0 = nullptr;                  // recorded right before that sampler tail (ptts_first_token_times)
+  hipEvent_t ev_pre0 = nullptr;                   // recorded when the stream reaches the last ptts_prefill's first piece of work
   bool first_recorded = false;
   std::vector<void*> allocs;
   std::vector<LayerW> L;
@@ -365,7 +366,10 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // streaming bytes through the strip GEMMs)
   const int KTf = Elem<WT>::KT;
   const int lnproj = e->lnproj >= 0 ? e->lnproj : (M <= 40 ? 3 : 0);
-  const bool lnproj_ok = lnproj > 0 && !prefill && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
+  // (prefill rows of one short prompt, M <= 40, on the same fused node: PTTS_LNPROJ_PREFILL=1 - three rows_prep nodes less per layer on the
+  //  time-to-first-token path)
+  static const bool lnproj_prefill = getenv("PTTS_LNPROJ_PREFILL") && atoi(getenv("PTTS_LNPROJ_PREFILL"));
+  const bool lnproj_ok = lnproj > 0 && (!prefill || lnproj_prefill) && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
   bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
@@ -438,6 +442,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 6, 8>), xg, dim3(512), sh, st, x);
       } else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 2>), xg, dim3(512), sh, st, x);                            // hidden 512
     } else {
+    if (prefill && lnproj_ok) {  // LN2 + cross q projection as one node
+      LnProjArgs p = {};
+      p.W = w.cq; p.x = e->h; p.x_ld = H; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.K = H; p.out = e->qc; p.out_ld = H; p.M = M; p.N = H;
+      PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st)));
+    } else
     {  // LN2 + cross q projection
       GemmArgs g = {}; g.decode = dec;
       g.W = w.cq; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln2_g; g.beta = w.ln2_b;
@@ -623,7 +632,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   auto fail = [&](int r) { ptts_engine_destroy(e); return r; };
   if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate failed"));
   if (hipStreamCreateWithFlags(&e->fold_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_kv, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_fold, hipEventDisableTiming) != hipSuccess || hipEventCreate(&e->ev_first) != hipSuccess || hipEventCreate(&e->ev_tail0) != hipSuccess)
+      hipEventCreateWithFlags(&e->ev_fold, hipEventDisableTiming) != hipSuccess || hipEventCreate(&e->ev_first) != hipSuccess || hipEventCreate(&e->ev_tail0) != hipSuccess || hipEventCreate(&e->ev_pre0) != hipSuccess)
     return fail(ptts_fail(PTTS_E_HIP, "hipStreamCreate / hipEventCreate failed"));
   const int H = c.hidden_size, F = c.ffn_dim, K = c.num_codebooks, V = c.vocab_size, nh = c.num_heads;
   const size_t es = e->esize;
@@ -815,6 +824,7 @@ extern "C" void ptts_engine_destroy(ptts_engine* e) {
   if (e->ev_fold) hipEventDestroy(e->ev_fold);
   if (e->ev_first) hipEventDestroy(e->ev_first);
   if (e->ev_tail0) hipEventDestroy(e->ev_tail0);
+  if (e->ev_pre0) hipEventDestroy(e->ev_pre0);
   delete e;
 }
 
@@ -1014,6 +1024,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   hipStream_t st = pick_stream(e, stream);
   const int H = c.hidden_size, K = c.num_codebooks;
   e->B = B; e->N = N; e->P = P;
+  if (sample) PTTS_HIP(hipEventRecord(e->ev_pre0, st));
   // per-call device params travel as kernel arguments (no host staging buffer to keep alive)
   {
     DevDims hd; hd.P = P; hd.N = N; hd.max_length = e->gp.max_length;
@@ -1047,8 +1058,10 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   e->xfold_valid = false;  // the prefill itself (and anything before the fold below) runs the un-folded cross-attention
   // The prefill forward (~290 launches of 4-8 us kernels for one utterance) replayed from ONE captured graph per (batch, description, prompt,
   // voice-prompt) shape: every operand is an engine-owned buffer and every per-call value (lengths, masks) is device-resident, so the
-  // launch list is a pure function of the shape. PTTS_PREFILL_GRAPH=0 launches eagerly (A/B).
-  static const bool prefill_graph = !(getenv("PTTS_PREFILL_GRAPH") && !atoi(getenv("PTTS_PREFILL_GRAPH")));
+  // launch list is a pure function of the shape. Measured (profiles/r05_experiments.txt call 1): time to the first token 2.420 ms with the
+  // graph, 2.401 ms with eager launches - behind the description encoder's 1 ms of GPU time the host is ahead of the GPU either way, and a
+  // graph costs a capture + instantiate per new (batch, description, prompt) shape. OFF by default; PTTS_PREFILL_GRAPH=1 enables it (A/B).
+  static const bool prefill_graph = getenv("PTTS_PREFILL_GRAPH") && atoi(getenv("PTTS_PREFILL_GRAPH"));
   int rc_fwd = PTTS_OK;
   if (prefill_graph) {
     const long long key = (long long)B | ((long long)N << 12) | ((long long)P << 28) | ((long long)e->prefill_T << 44);
@@ -1209,11 +1222,12 @@ extern "C" int ptts_first_token_sync(ptts_engine* e) {
   return PTTS_OK;
 }
 
-extern "C" int ptts_first_token_times(ptts_engine* e, float* tail_ms) {
-  PTTS_CHECK(e && tail_ms, PTTS_E_INVALID, "null argument");
+extern "C" int ptts_first_token_times(ptts_engine* e, float* prefill_ms, float* tail_ms) {
+  PTTS_CHECK(e && prefill_ms && tail_ms, PTTS_E_INVALID, "null argument");
   PTTS_CHECK(e->prefilled && e->first_recorded, PTTS_E_INVALID, "ptts_first_token_times: no sampling prefill to report on");
   PTTS_DEVICE(e->cfg.device);
   PTTS_HIP(hipEventSynchronize(e->ev_first));
+  PTTS_HIP(hipEventElapsedTime(prefill_ms, e->ev_pre0, e->ev_tail0));
   PTTS_HIP(hipEventElapsedTime(tail_ms, e->ev_tail0, e->ev_first));
   return PTTS_OK;
 }

@@ -158,11 +158,12 @@ class DecoderEngine:
         time-to-first-token; work the prefill enqueued behind the sampler tail (cross-attention fold) is not waited for."""
         N.check(self.lib.ptts_first_token_sync(self._h), "ptts_first_token_sync")
 
-    def first_tail_ms(self) -> float:
-        """GPU time of the sampler tail of the last sampling ``prefill`` (``ptts_first_token_times``; synchronises on the first-token event)."""
-        ms = C.c_float()
-        N.check(self.lib.ptts_first_token_times(self._h, C.byref(ms)), "ptts_first_token_times")
-        return float(ms.value)
+    def first_token_times(self) -> Tuple[float, float]:
+        """(prefill_ms, tail_ms): GPU time of the last sampling ``prefill`` as it ran in sequence on its stream - staging + forward up to
+        the sampler tail, and the tail itself (``ptts_first_token_times``; synchronises on the first-token event)."""
+        pre, tail = C.c_float(), C.c_float()
+        N.check(self.lib.ptts_first_token_times(self._h, C.byref(pre), C.byref(tail)), "ptts_first_token_times")
+        return float(pre.value), float(tail.value)
 
     def set_audio_prefix(self, codes: Optional[torch.Tensor]):
         """Voice prompt for the NEXT ``prefill``: un-delayed audio codes int64 [B, K, T] (or [B*K, T]); ``None`` clears it."""
