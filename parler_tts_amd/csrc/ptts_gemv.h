@@ -52,6 +52,7 @@ struct QkvAttnArgs {
   float* stats;         // [S + 1][nheads][2]: (max, sumexp) in log2 units per cache split; slot S: the two half dot products of q . k_new
   int cap, kv_bound, mask_ld;
   int S, nheads, H, kv_heads;
+  int M, x_ld;          // utterances (grid.z) and the row pitch of x; part / stats hold M x (S + 1) slots, the caches M x kv_heads heads
   float scale, invK;
 };
 // Single-utterance fused cross block over the folded matrices (xfold_attn_kernel): LayerNorm + the head's 64 score rows of M + per-head

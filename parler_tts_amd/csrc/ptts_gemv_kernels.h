@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
     } else if (MB == 1 || wave < a.M) {
       if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * ROW_BYTES, lane);
       else if (PRO == GV_SOFTMAX) gv_softmax_wave<WT, NF4>(a, s_x, lane);  // single utterance only
-      else if (PRO == GV_ATTN2) gv_attn2_wave<WT, NF4, S>(a, a.part, a.stats, s_x, lane);  // single utterance only
+      else if (PRO == GV_ATTN2) gv_attn2_wave<WT, NF4, S>(a, a.part + (size_t)wave * (S + 1) * a.K, a.stats + (size_t)wave * (S + 1) * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
       else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
     }
     __syncthreads();
@@ -434,9 +434,11 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // wave 0: the LayerNorm operands first - loads return in order, so nothing it normalises waits behind its weight burst
   float4 lv[NF4], lg[NF4], lb[NF4];
+  const int b = blockIdx.z;  // utterance (round 5: 2..8 utterances run the same node, one grid slice each)
   if (w == 0) {
+    const float* xr = a.x + (size_t)b * a.x_ld;
 #pragma unroll
-    for (int i = 0; i < NF4; ++i) lv[i] = *reinterpret_cast<const float4*>(a.x + (lane + 64 * i) * 4);
+    for (int i = 0; i < NF4; ++i) lv[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
       lg[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   WV wv[RW][NCH];
   {
     const char* wbase = reinterpret_cast<const char*>(a.W) + (size_t)row0 * WROW_BYTES;
-    if (row0 < a.H) {  // q rows: read by the other workgroups of this head as well
+    if (row0 < a.H || a.M > 1) {  // q rows: read by the other workgroups of this head as well (k / v rows too when several utterances share them)
 #pragma unroll
       for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -468,9 +470,12 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   }
   float wsc = 1.f;
   if (W8 && lane < RW) wsc = a.wscale[row0 + lane];
-  const int P = *a.P, cl = a.cur_len[0];
-  WT* Kc = reinterpret_cast<WT*>(a.kcache) + (size_t)kvh * a.cap * 64;
-  WT* Vc = reinterpret_cast<WT*>(a.vcache) + (size_t)kvh * a.cap * 64;
+  const int P = *a.P, cl = a.cur_len[b];
+  WT* Kc = reinterpret_cast<WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
+  WT* Vc = reinterpret_cast<WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
+  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  float* part = a.part + (size_t)b * (S + 1) * a.H;              // this utterance's S + 1 slots
+  float* stats = a.stats + (size_t)b * (S + 1) * a.nheads * 2;
   const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
   const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
   const int r = lane / LPR, c = lane % LPR;
@@ -484,7 +489,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       const int tc = t < a.kv_bound ? t : 0;
       kf[u] = Kb[(size_t)tc * LPR + c];
       vf[u] = Vb[(size_t)tc * LPR + c];
-      mk[u] = (a.mask && t < a.mask_ld) ? a.mask[t] : 1;
+      mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
@@ -540,11 +545,11 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       const float kd = Elem<WT>::rnd(s_r[32 + (lane & 31)]);  // the key as the cache holds it
       const float pr = lane < 32 ? (s_r[lane] * qscale) * kd : 0.f;
       const float dot = wave_sum(pr);
-      if (lane == 0) a.stats[((size_t)S * a.nheads + h) * 2 + half] = dot;
+      if (lane == 0) stats[((size_t)S * a.nheads + h) * 2 + half] = dot;
       if (writer && lane < 32) gv_store<WT>(Kc + (size_t)pos * 64 + half * 32 + lane, s_r[32 + lane]);
     } else {
       const float vd = s_r[lane];
-      a.part[(size_t)S * a.H + h * 64 + lane] = Elem<WT>::rnd(vd);
+      part[(size_t)S * a.H + h * 64 + lane] = Elem<WT>::rnd(vd);
       if (writer) gv_store<WT>(Vc + (size_t)pos * 64 + lane, vd);
     }
     return;
@@ -554,7 +559,6 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
   for (int e = 0; e < EPL; ++e) qv[e] = s_r[c * EPL + e] * qscale;
   const int L = pos;  // rows of the cache proper; the new position is the combine's slot S
-  const int* mrow = a.mask;
   const int G = (L + RPI - 1) / RPI;
   float m_run = -INFINITY, l_run = 0.f, o[EPL];
 #pragma unroll
@@ -623,9 +627,9 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       ov += wgt * s_o[i][lane];
       lv += wgt * s_ml[i][1];
     }
-    a.part[(size_t)role * a.H + h * 64 + lane] = ov;
+    part[(size_t)role * a.H + h * 64 + lane] = ov;
     if (lane == 0) {
-      float* st = a.stats + ((size_t)role * a.nheads + h) * 2;
+      float* st = stats + ((size_t)role * a.nheads + h) * 2;
       st[0] = M;
       st[1] = lv;
     }

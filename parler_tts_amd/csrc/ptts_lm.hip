@@ -106,6 +106,7 @@ struct ptts_engine {
   int xattn_groups_max = 256; // largest batch that runs the fused cross block in groups of 8 (PTTS_XATTN_GROUPS_MAX; above: rows_prep + q GEMM + attention)
   int lnproj = -1;            // -1 = by batch size (3 up to 40 utterances, 0 above: measured -5.3 % at 32, -3.2 % at 12, neutral at 64, +12 % at 128; profiles/r04_experiments.txt call 14). Decode at batch > 8: LayerNorm + projection as ONE node tiled over 64 weight rows x lnproj_g utterances instead of rows_prep + strip GEMM
                               // (PTTS_LNPROJ: 0 off, 1 = LN1 + QKV, 2 = + LN3 + fc1 above 32 utterances, 3 = + LN3 + fc1 at 9..32 too instead of the producer-statistics prologue)
+  bool fuse_qa_multi = true;  // the same node at 2..8 utterances, one grid slice per utterance (round 5; PTTS_FUSE_QA_MULTI=0: single utterance only)
   bool fuse_qa = true;        // single-utterance GEMV step: LN1 + QKV rows + self-attention + append as one node (qkv_attn_kernel), PTTS_NO_FUSE_QA=1 = two nodes
   int fuse_x = -1;            // single-utterance GEMV step, folded cross block: LN2 + scores + softmax + U p as one node of per-head partial rows (xfold_attn_kernel),
                               // summed by the LN3 + fc1 node's prologue (GV_LNP). -1 = by width: on up to hidden 1024 (Mini-v1 -1 %: 566 -> 561 us per step), off
@@ -152,6 +153,7 @@ template <typename WT, int EPI>
 int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st) {
   constexpr int KT = Elem<WT>::KT;
   const int H = p.K, g = e->lnproj_g;
+  if (g == 16 && p.part) return ptts_fail(PTTS_E_UNSUPPORTED, "lnproj: the 16-row instance does not fold split-K partials");
   p.invK = 1.0f / (float)H;
   const int mg = p.M < g ? p.M : g;
   const size_t sh = (size_t)mg * (H * sizeof(WT) + 16) + 8 * 1024;
@@ -159,7 +161,8 @@ int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st) {
   const bool u16 = ((H / KT) / 2) % 16 == 0;
 #define PTTS_LNPROJ_LAUNCH(UW, NF4)                                                                                   \
   do {                                                                                                                \
-    if (g == 4) hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 4, EPI>), grid, dim3(512), sh, st, p);              \
+    if (g == 16) hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 16, EPI>), grid, dim3(512), sh, st, p);            \
+    else if (g == 4) hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 4, EPI>), grid, dim3(512), sh, st, p);         \
     else hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 8, EPI>), grid, dim3(512), sh, st, p);                    \
   } while (0)
   if (H == 1024 && u16) PTTS_LNPROJ_LAUNCH(16, 4);
@@ -232,14 +235,16 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const float* rs = c.rope ? e->rope_sin : nullptr;
     const int mode = c.dtype == PTTS_F32 ? GV_F32 : (e->w8 ? GV_BF16_W8 : GV_BF16);
     // single utterance, sinusoidal positions: the two nodes of the self-attention block's first half as one (PTTS_NO_FUSE_QA=1: two nodes)
-    const bool fuse_qa = e->fuse_qa && M == 1 && !c.rope && ptts_qkvattn_ok(H, mode);
+    // (round 5: 2..8 utterances too - one grid slice per utterance, the slices of a head share its weight rows in the L2; PTTS_FUSE_QA_MULTI=0: one only)
+    const bool fuse_qa = e->fuse_qa && (M == 1 || (e->fuse_qa_multi && mode != GV_F32)) && !c.rope && ptts_qkvattn_ok(H, mode);
     // KV splits of the fused node: the smallest count whose FIRST batch of row groups (8 waves x 4 groups x 8 bf16 / 4 fp32 rows per split,
     // requested before q exists) covers the context bucket this graph is captured for - fewer workgroups recompute the head's q rows, and no
     // split needs a second, dependent K/V batch (context ~210 / ~460 / ~710: 2 splits 554 / 562 / 586 us per step, 4 splits 575 / 577 / 579,
     // 8 splits 645 / 646 / 648; profiles/r04_experiments.txt call 15)
     int S_f = 1;
-    while (S_f < 8 && S_f * ptts_qkvattn_rows_per_split(mode) < e->kv_bound) S_f *= 2;
-    if (e->fuse_qa_s > 0) S_f = e->fuse_qa_s;
+    const int S_cap = M == 1 ? 8 : (M <= 4 ? 4 : 2);  // the combine prologue of the out_proj node holds S + 1 slots per lane: 12-wave workgroups (5..8 utterances) fit 2 splits
+    while (S_f < S_cap && S_f * ptts_qkvattn_rows_per_split(mode) < e->kv_bound) S_f *= 2;
+    if (e->fuse_qa_s > 0) S_f = std::min(e->fuse_qa_s, S_cap);
     auto gv = [&](int pro, int epi, int S, GemvArgs g, const char* what) -> int {
       g.M = M;
       const int rc_ = ptts_gemv_launch(mode, pro, epi, S, g, st);
@@ -254,7 +259,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         q.W = w.qkv_rm; q.wscale = w.qkv_sc; q.x = e->h; q.gamma = w.ln1_g; q.beta = w.ln1_b;
         q.kcache = w.k_self; q.vcache = w.v_self; q.cur_len = e->cur_len; q.P = &e->dims->P; q.mask = e->prompt_mask;
         q.part = e->part; q.stats = e->stats; q.cap = c.max_ctx; q.kv_bound = e->kv_bound; q.mask_ld = e->max_prompt;
-        q.S = S_f; q.nheads = nh; q.H = H; q.kv_heads = nkv; q.scale = scale;
+        q.S = S_f; q.nheads = nh; q.H = H; q.kv_heads = nkv; q.scale = scale; q.M = M; q.x_ld = H;
         if (ptts_qkvattn_launch(mode, q, st) != 0) return ptts_fail(PTTS_E_HIP, "qkv_attn launch failed");
         GemvArgs g = {};
         g.W = w.o_rm; g.wscale = w.o_sc; g.out = e->h; g.out_ld = H; g.N = H; g.K = H; g.part = e->part; g.stats = e->stats; g.nheads = nh;
@@ -490,7 +495,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         } else
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
         g2.x = reinterpret_cast<const float*>(e->xw2); g2.x_fo = fo;
-        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0)) {
+        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0) && !(lnproj_ok && e->lnproj_g == 16)) {
           g2.out = e->hpart;  // h += sum of the partials happens in the next layer's LN1 prep kernel
           PTTS_TRY((launch_gemm_splitk<WT>(g2, st)));
           fc2_pending = true;
@@ -767,13 +772,16 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->h, rows * H));
   A(e->alloc(&e->qkv, rows * 3 * H));
   A(e->alloc(&e->qc, std::max(rows, enc_rows) * H));
-  A(e->alloc(&e->part, rows * e->S_self * H + (size_t)9 * H));  // + 9 rows: qkv_attn_kernel's up to 8 splits + the new position's own slot
-  A(e->alloc(&e->stats, rows * e->S_self * nh * 2 + (size_t)9 * nh * 2));
+  // qkv_attn_kernel: up to 8 splits + the new position's own slot for one utterance, up to 4 + 1 for each of 2..8
+  const size_t part_rows = std::max(rows * (size_t)e->S_self, (size_t)c.max_batch * 5) + 9;
+  A(e->alloc(&e->part, part_rows * H));
+  A(e->alloc(&e->stats, part_rows * nh * 2));
   A(e->alloc(&e->xpart, (size_t)nh * H));
   A(e->alloc(&e->h2, (size_t)H));
   if (const char* ev = getenv("PTTS_FUSE_X")) e->fuse_x = atoi(ev) ? 1 : 0;
   if (const char* ev = getenv("PTTS_FUSE_X_NUR")) { const int v = atoi(ev); if (v == 2 || v == 4) e->fuse_x_nur = v; }
   e->fuse_qa = !(getenv("PTTS_NO_FUSE_QA") && atoi(getenv("PTTS_NO_FUSE_QA")));
+  e->fuse_qa_multi = !(getenv("PTTS_FUSE_QA_MULTI") && !atoi(getenv("PTTS_FUSE_QA_MULTI")));
   e->fuse_xq = !(getenv("PTTS_NO_FUSE_XQ") && atoi(getenv("PTTS_NO_FUSE_XQ")));
   if (const char* ev = getenv("PTTS_GRAPH_STEPS")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->graph_steps = v; }
   if (const char* ev = getenv("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
@@ -789,7 +797,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
   if (const char* ev = getenv("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));
   if (const char* ev = getenv("PTTS_LNPROJ")) e->lnproj = std::max(0, std::min(3, atoi(ev)));
-  if (const char* ev = getenv("PTTS_LNPROJ_G")) e->lnproj_g = atoi(ev) == 4 ? 4 : 8;
+  if (const char* ev = getenv("PTTS_LNPROJ_G")) e->lnproj_g = atoi(ev) == 4 ? 4 : (atoi(ev) == 16 ? 16 : 8);
   e->xattn_g_ok = (H == 1024 && ((H / (c.dtype == PTTS_BF16 ? 32 : 16)) / 2) % 16 == 0) || H == 1536;
   if (const char* ev = getenv("PTTS_XATTN_G")) { const int g = atoi(ev); if (g == 2 || g == 4 || g == 8) e->xattn_g = e->xattn_g_ok ? g : 8; }
   e->xattn_groups = !(getenv("PTTS_NO_XATTN_GROUPS") && atoi(getenv("PTTS_NO_XATTN_GROUPS")));  // measured: 1386 -> 1360 us per batch-32 step (profiles/r03_experiments.txt)

@@ -1443,10 +1443,13 @@ struct LnProjArgs {
   int M, N;
 };
 
+// G = 16 (round 5): two rows per wave (rows w and w + 8, both in flight), all 16 columns of the MFMA tile in use - half the weight re-reads of
+// G = 8 per utterance (the L2 traffic of the strip GEMM it replaces at 64..128 utterances). No split-K fold in that instance (a.part must be
+// null: the host runs fc2 un-split beside it).
 template <typename WT, int UW, int NF4, int G, int EPI>
 __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
   constexpr int KT = Elem<WT>::KT, NWV = 8;
-  static_assert(G <= NWV, "one row per wave");
+  static_assert(G <= 2 * NWV, "at most two rows per wave");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b0 = blockIdx.y * G, nb = min(G, a.M - b0), nbmax = min(G, a.M);
@@ -1460,6 +1463,52 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
   const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
   const int q4 = lane >> 4, j = lane & 15;
   uint4 afr[UW];
+  if constexpr (G > NWV) {  // two rows per wave, no pending partials
+    if (wave < nb) {
+      const bool two = wave + NWV < nb;
+      const float* xr0 = a.x + (size_t)(b0 + wave) * a.x_ld;
+      const float* xr1 = a.x + (size_t)(b0 + (two ? wave + NWV : wave)) * a.x_ld;
+      float4 v0[NF4], v1[NF4], g[NF4], bt[NF4];
+#pragma unroll
+      for (int i = 0; i < NF4; ++i) { v0[i] = *reinterpret_cast<const float4*>(xr0 + (lane + 64 * i) * 4); v1[i] = *reinterpret_cast<const float4*>(xr1 + (lane + 64 * i) * 4); }
+#pragma unroll
+      for (int i = 0; i < NF4; ++i) {
+        g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
+        bt[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int uu = 0; uu < UW; ++uu) afr[uu] = ld_nt16(Wp + (size_t)(t0 + uu) * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      auto norm_row = [&](float4 (&v)[NF4], char* row) __attribute__((always_inline)) {  // prep_ln_row_regs' arithmetic
+        const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+          const float d0 = v[i].x - c, d1 = v[i].y - c, d2 = v[i].z - c, d3 = v[i].w - c;
+          s1 += (d0 + d1) + (d2 + d3);
+          s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const float dm = s1 * a.invK, mean = c + dm;
+        const float rstd = rsqrtf(fmaxf(s2 * a.invK - dm * dm, 0.f) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NF4; ++i)
+          lds_store4<WT>(row, (lane + 64 * i) * 4, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
+                         (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
+      };
+      norm_row(v0, s_x + (size_t)wave * row_bytes);
+      if (two) norm_row(v1, s_x + (size_t)(wave + NWV) * row_bytes);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int uu = 0; uu < UW; ++uu) afr[uu] = ld_nt16(Wp + (size_t)(t0 + uu) * 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
   // ---- t = 0: the residual row (+ its pending partials, + gamma / beta) of this wave first, then - behind a rendezvous, so that no wave's row
   // queues behind another wave's weights - the first UW weight fragments
   if (wave < nb) {

@@ -341,6 +341,34 @@ def test_fused_qkv_attention_node_single_utterance(gqa, monkeypatch):
 
 
 @pytest.mark.parametrize("gqa", [False, True])
+@pytest.mark.parametrize("bsz", [2, 3, 8])
+def test_fused_qkv_attention_node_two_to_eight_utterances(bsz, gqa, monkeypatch):
+    """qkv_attn_kernel with one grid slice per utterance (round 5): 2..8 utterances run LN1 + q / k / v rows + split-KV self-attention + append
+    as ONE node, combined per utterance by the out_proj node's GV_ATTN2 prologue (instances for 2..4 and 5..8 utterances). bf16 (the fp32
+    engine serves one utterance on this path): the fused step against the two-node step (PTTS_FUSE_QA_MULTI=0) AND both against the bf16 oracle,
+    ragged description / prompt masks, a short context (1 split) and a 600-position prompt (4 splits at <= 4 utterances, 2 above: second K/V
+    batch of the attention loop), grouped-query attention (one writer per K/V group and utterance)."""
+    kw = dict(num_hidden_layers=2, max_position_embeddings=2048)
+    if gqa:
+        kw.update(num_key_value_heads=4, num_cross_attention_key_value_heads=2)
+    spec = DO.DecoderSpec(**kw)
+    sd = DO.make_decoder_weights(spec, seed=83)
+    for P, max_ctx, steps in ((6, 200, 5), (600, 800, 3)):
+        runs = {}
+        for fuse in (True, False):
+            monkeypatch.setenv("PTTS_FUSE_QA_MULTI", "1" if fuse else "0")
+            runs[fuse], ref = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=P, steps=steps, masks=True, seed=11 + bsz, max_ctx=max_ctx,
+                                                        return_logits=True)
+        monkeypatch.delenv("PTTS_FUSE_QA_MULTI", raising=False)
+        ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
+        assert ab > 0.0, "the fused node did not run at this batch size (identical logits: same kernels on both sides)"
+        assert ab < 2e-2, (bsz, P, "fused vs two nodes", ab)
+        for fuse in (True, False):
+            err = max(float((a - b).abs().max()) for a, b in zip(runs[fuse], ref))
+            assert err < 2e-2, (bsz, P, fuse, err)
+
+
+@pytest.mark.parametrize("gqa", [False, True])
 def test_fused_cross_block_node_single_utterance(gqa, monkeypatch):
     """xfold_attn_kernel (single utterance, folded cross block): LN2 + the head's rows of M + per-head softmax + the head's columns of U as ONE
     node of per-head partial rows, summed in row order by the LN3 + fc1 node's prologue (GV_LNP), whose workgroup 0 also publishes the
