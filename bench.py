@@ -160,14 +160,14 @@ def step_graph_nodes(bs: int, layers: int, hidden: int, folded: bool, dtype: str
     """Kernel nodes of the captured decode step (csrc/ptts_lm.hip forward<> + tail), by batch-size regime; sinusoidal positions."""
     if bs <= 8:   # GEMV step
         fused_w = hidden in ((512, 1024, 1536) if dtype != "f32" else (512, 1024))  # widths the fused nodes are instantiated for
-        self_nodes = 2 if (bs == 1 and fused_w) else 3  # [qkv_attn_kernel | LN1+QKV, attention], combine + out_proj
+        self_nodes = 2 if (bs <= 3 and fused_w) else 3  # [qkv_attn_kernel (up to 3 utterances) | LN1+QKV, attention], combine + out_proj
         if folded:  # single utterance, static cross-attention fold: [xfold_attn_kernel | LN2 + M x, softmax + U p]
             cross_nodes = 1 if (fused_w and hidden <= (1024 if dtype != "f32" else 512)) else 2
         else:       # [xq_attn_kernel | LN2 + q, cross-attention], out_proj
             cross_nodes = 2 if fused_w else 3
         return (self_nodes + cross_nodes + 2) * layers + 2  # + LN3 + fc1, fc2 per layer; + LM heads, sampler / embed tail
-    if bs <= 32 and hidden in (1024, 1536):  # LN1+QKV (lnproj), attention, combine+out_proj, fused LN2+cross-q+cross-attn, out_proj, LN3+fc1 (lnproj), fc2 split-K
-        return 7 * layers + 3                # + heads prep (final LN), LM heads, sampler / embed tail
+    if hidden in (1024, 1536):  # LN1+QKV (lnproj: 8 / 16 utterances per workgroup), attention, combine+out_proj, fused LN2+cross-q+cross-attn, out_proj, LN3+fc1 (lnproj), fc2
+        return 7 * layers + 3   # + heads prep (final LN), LM heads, sampler / embed tail
     return None
 
 
@@ -241,12 +241,15 @@ def measure_decode_roofline(model, bs: int, device, live_pmc: bool = True) -> di
     es = 2 if model.dtype == torch.bfloat16 else 4
     # e4m3 weights are streamed as bytes at EVERY batch size (GEMV step up to 8 utterances, e4m3 MFMA strips above: DESIGN.md §4.1 / §4.2)
     ws = 1 if getattr(model, "decoder_weights_fp8", False) else es
-    bytes_step = w_step * ws + bs * 2 * L * H * (lc + N_DESC) * es + bs * (Kc * H * es + Kc * V * 4)
+    # e4m3 self-attention cache (opt-in, engines of more than 8 utterances): 64 bytes + one fp32 scale per (head, position) row of 64 values
+    kv8 = bool(getattr(model, "decoder_kv_fp8", False)) and bs > 8
+    kv_es = (1.0 + 4.0 / 64.0) if kv8 else es
+    bytes_step = int(w_step * ws + bs * 2 * L * H * (lc * kv_es + N_DESC * es) + bs * (Kc * H * es + Kc * V * 4))
     achieved = bytes_step / step_s / 1e9
     traffic, tnote = None, "PMC pass not available for this configuration"
     pmc = os.path.join(ROOT, "profiles", f"r03_pmc_step_bs{bs}.json")  # the same two passes, committed (context ~455), when the live ones are off / fail
     live = measure_traffic_live(bs, lc) if (LIVE_PMC and live_pmc and es == 2 and H == 1024 and L == 24 and ws == 2 and bs <= 32) else None
-    if live is not None or (es == 2 and H == 1024 and os.path.exists(pmc)):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
+    if live is not None or (es == 2 and H == 1024 and not kv8 and os.path.exists(pmc)):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
         j = live if live is not None else json.load(open(pmc))
         traffic = int(j["traffic_bytes_per_step"])
         tnote = (f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~{j.get('algorithmic_mb', '?')} MB). Every weight "
@@ -260,6 +263,10 @@ def measure_decode_roofline(model, bs: int, device, live_pmc: bool = True) -> di
            "frac_of_measured_copy_6.29TBps": round(achieved / 6290.0, 4)}
     try:  # side information only: must never break the contract line
         nodes = step_graph_nodes(bs, L, H, folded, "bf16" if es == 2 else "f32")
+        real = int(eng.graph_nodes()) if hasattr(eng, "graph_nodes") else 0  # the captured step graph's own node count (ptts_debug_graph_nodes)
+        if real > 0:
+            out["graph_nodes_counted"] = real
+            nodes = real
         if nodes:
             out["kernel"] += f" ({nodes} kernel nodes)" + (f": batch <= 8 runs {(nodes - 2) // L} row-per-wave GEMV / attention nodes per layer + LM heads "
                                                             "+ sampler/embed tail" if bs <= 8 else "")
@@ -843,6 +850,20 @@ def main():
                 model.__dict__["_engines"].pop(key).close()
         except Exception as e:
             out["bs128"] = {"error": repr(e)[:200]}
+        try:  # opt-in numerics mode: e4m3 self-attention KV cache (ptts_config::kv_fp8), the lever SURVEY.md section 8(d) names for the bandwidth-bound third of the step
+            model.enable_fp8_kv_cache(True)
+            dt = _timed_generate(model, 128, device)
+            out["bs128_kv8"] = {"value": round(128 * AUDIO_S / dt, 2), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1),
+                                "roofline": _trim_roofline(measure_decode_roofline(model, 128, device, live_pmc=False)),
+                                "note": "opt-in: e4m3 self-attention cache rows + one power-of-two scale per (utterance, head, position); parity vs the oracle "
+                                        "with the same quantiser (tests/test_lm_gpu.py::test_e4m3_kv_cache_mode); never the default"}
+        except Exception as e:
+            out["bs128_kv8"] = {"error": repr(e)[:200]}
+        finally:
+            try:
+                model.enable_fp8_kv_cache(False)
+            except Exception:  # noqa: BLE001
+                pass
     if rank == 0 and world == 1 and not args.no_extras and args.bs == 1:
         try:
             out["streaming"] = measure_ttfa(model, device)

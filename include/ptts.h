@@ -69,6 +69,10 @@ typedef struct {
                                  row (ptts_load_weight_fp8) at EVERY batch size: the GEMV step up to 8 utterances, e4m3 MFMA strips above
                                  (converted to bf16 in registers). Only the prefill and the cross-attention q projection inside the fused
                                  cross block read the exact bf16 dequantisation */
+  int32_t kv_fp8;             /* (ABI v7) 1 (dtype PTTS_BF16, max_batch > 8 only): the self-attention KV cache holds OCP e4m3 bytes with one power-of-two
+                                 scale per (utterance, K/V head, position), quantised when a row is appended. Opt-in numerics mode - the reference has no
+                                 quantised cache on this path (modeling_parler_tts.py:3497-3501 raises) - for 64+ utterances per GPU, where the K/V
+                                 stream is the bandwidth-bound third of a step */
 } ptts_config;
 
 /* Generation parameters: the subset of GenerationConfig that generate() consumes (:3395-3552). */
@@ -163,6 +167,9 @@ int ptts_step_forward(ptts_engine* e, void* stream);
 int ptts_logits(ptts_engine* e, float** logits_dev);
 int ptts_push_tokens(ptts_engine* e, const int64_t* tokens_dev, const int32_t* finished_dev, void* stream);
 
+/* (ABI v7) Kernel nodes per decode step of the step graph captured last (0 before the first capture): what the `latency_model` of bench.py counts,
+ * and how the tests check that a fused node really is in the step. */
+int ptts_debug_graph_nodes(ptts_engine* e, int32_t* nodes);
 /* Debug / parity probes: residual stream after the last forward, fp32 [rows, H]. */
 int ptts_debug_hidden(ptts_engine* e, float** hidden_dev, int32_t* rows);
 

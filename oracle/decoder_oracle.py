@@ -332,7 +332,12 @@ class DecoderOracle:
             if spec.rope_embeddings:
                 q = q * cos + _rotate_half(q) * sin  # :858-859
                 k = k * cos + _rotate_half(k) * sin  # :880-882
-            k, v = self._act(k), self._act(v)  # bf16 mode: KV cache holds bf16
+            if getattr(self, "kv_fp8", False):  # the product's opt-in e4m3 self-attention cache (ptts_config::kv_fp8): quantised from the fp32 rows
+                from .fp8_oracle import quantize_kv_rows
+
+                k, v = quantize_kv_rows(k), quantize_kv_rows(v)
+            else:
+                k, v = self._act(k), self._act(v)  # bf16 mode: KV cache holds bf16
             if self.k_self[i] is None:
                 self.k_self[i], self.v_self[i] = k, v
             else:

@@ -33,6 +33,19 @@ def quantize_rows(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return round_to_e4m3((w / scale[:, None]).clamp(-E4M3_MAX, E4M3_MAX)) * scale[:, None], scale
 
 
+def quantize_kv_rows(x: torch.Tensor) -> torch.Tensor:
+    """The e4m3 self-attention cache of the product's kv_fp8 mode (csrc/ptts_lm_kernels.h: kv8_row_scale / kv8_pack8), restated: every row of 64
+    head dimensions (last axis) gets ONE power-of-two scale 2^ceil(log2(max|x| / 448)) - taken from the exponent of max|x| / 448, exactly as the
+    kernel does (frexp: a power of two keeps its own exponent, anything above rounds up) - and its values are rounded to e4m3 (nearest, ties
+    to even). Returns the dequantised rows (what attention sees for EVERY position, the newest included)."""
+    x = x.float()
+    amax = x.abs().amax(dim=-1, keepdim=True)
+    m, e = torch.frexp(amax / E4M3_MAX)  # amax / 448 = m * 2^e, m in [0.5, 1)
+    ce = torch.where(m == 0.5, e - 1, e)
+    scale = torch.where(amax > 0, torch.exp2(ce.float()), torch.ones_like(amax))
+    return round_to_e4m3(x / scale) * scale
+
+
 FP8_MATRICES = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "encoder_attn.q_proj",
                 "encoder_attn.out_proj", ".fc1.", ".fc2.")
 

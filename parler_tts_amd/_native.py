@@ -25,7 +25,7 @@ class PttsConfig(C.Structure):
         ("rope_theta", C.c_float), ("pad_token_id", C.c_int32), ("eos_token_id", C.c_int32), ("bos_token_id", C.c_int32),
         ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_ctx", C.c_int32), ("max_enc", C.c_int32),
         ("max_prompt", C.c_int32), ("device", C.c_int32), ("num_kv_heads", C.c_int32), ("num_cross_kv_heads", C.c_int32),
-        ("weights_fp8", C.c_int32),
+        ("weights_fp8", C.c_int32), ("kv_fp8", C.c_int32),
     ]
 
 
@@ -75,6 +75,7 @@ SYMBOLS = {
     "ptts_logits": (C.c_int, [_VP, C.POINTER(_VP)]),
     "ptts_push_tokens": (C.c_int, [_VP, _VP, _VP, _VP]),
     "ptts_debug_hidden": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_I32)]),
+    "ptts_debug_graph_nodes": (C.c_int, [_VP, C.POINTER(_I32)]),
     "ptts_set_audio_prefix": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
     "ptts_dac_create": (C.c_int, [C.POINTER(PttsDacConfig), C.POINTER(_VP)]),
     "ptts_dac_destroy": (None, [_VP]),

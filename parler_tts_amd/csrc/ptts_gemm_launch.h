@@ -178,6 +178,17 @@ int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of 
 template <typename WT>
 int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
   const dim3 grid(a.S, a.nheads, B * a.Q);
+  if (a.kscale) {  // e4m3 self-attention cache (ptts_config::kv_fp8): bf16 engine, 4 waves per workgroup
+    if constexpr (sizeof(WT) == 2) {
+      if (waves != 4) return ptts_fail(PTTS_E_UNSUPPORTED, "kv_fp8: the attention kernel is built for 4 waves per workgroup (PTTS_ATTN_WAVES=%d)", waves);
+      hipLaunchKernelGGL((attn_kernel<WT, 4, true>), grid, dim3(256), 0, st, a);
+      hipError_t e8 = hipGetLastError();
+      if (e8 != hipSuccess) return ptts_fail(PTTS_E_HIP, "attn launch failed: %s", hipGetErrorString(e8));
+      return PTTS_OK;
+    } else {
+      return ptts_fail(PTTS_E_UNSUPPORTED, "kv_fp8 needs the bf16 engine");
+    }
+  }
   if (waves == 1) hipLaunchKernelGGL((attn_kernel<WT, 1>), grid, dim3(64), 0, st, a);
   else if (waves == 2) hipLaunchKernelGGL((attn_kernel<WT, 2>), grid, dim3(128), 0, st, a);
   else if (waves == 8) hipLaunchKernelGGL((attn_kernel<WT, 8>), grid, dim3(512), 0, st, a);

@@ -32,6 +32,7 @@ struct LayerW {
   void *qkv = nullptr, *o = nullptr, *cq = nullptr, *ckv = nullptr, *co = nullptr, *fc1 = nullptr, *fc2 = nullptr;
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr, *ln3_g = nullptr, *ln3_b = nullptr;
   void *k_self = nullptr, *v_self = nullptr, *k_cross = nullptr, *v_cross = nullptr;
+  float *ks_self = nullptr, *vs_self = nullptr;  // kv_fp8 engines: one power-of-two scale per (utterance, K/V head, position) of the e4m3 self cache
   // row-major [N][K] copies in the engine dtype for the single-utterance GEMV step (ptts_gemv_kernels.h); null = path off
   void *qkv_rm = nullptr, *o_rm = nullptr, *cq_rm = nullptr, *co_rm = nullptr, *fc1_rm = nullptr, *fc2_rm = nullptr;
   // weights_fp8: the row-major copies hold OCP e4m3 bytes, one power-of-two scale per output row
@@ -104,8 +105,11 @@ struct ptts_engine {
   bool prefilled = false;
   bool h_ready = false;  // residual-stream input of the next decode step already embedded by the last tail
   int xattn_groups_max = 256; // largest batch that runs the fused cross block in groups of 8 (PTTS_XATTN_GROUPS_MAX; above: rows_prep + q GEMM + attention)
-  int lnproj = -1;            // -1 = by batch size (3 up to 40 utterances, 0 above: measured -5.3 % at 32, -3.2 % at 12, neutral at 64, +12 % at 128; profiles/r04_experiments.txt call 14). Decode at batch > 8: LayerNorm + projection as ONE node tiled over 64 weight rows x lnproj_g utterances instead of rows_prep + strip GEMM
+  int lnproj = -1;            // -1 = on (3) at every batch size above 8: 8 utterances per workgroup up to 40 (round 4: -5.3 % at 32, -3.2 % at 12; neutral at 64, +12 % at 128
+                              // with 8 per workgroup), 16 per workgroup above (round 5, profiles/r05_experiments.txt call 2: 48 / 64 / 96 / 128 utterances -9.7 / -6.6 / -2.3 / -5.1 % per step). Decode at batch > 8: LayerNorm + projection as ONE node tiled over 64 weight rows x lnproj_g utterances instead of rows_prep + strip GEMM
                               // (PTTS_LNPROJ: 0 off, 1 = LN1 + QKV, 2 = + LN3 + fc1 above 32 utterances, 3 = + LN3 + fc1 at 9..32 too instead of the producer-statistics prologue)
+  int fuse_qa_max = 3;        // largest batch that runs it (PTTS_FUSE_QA_MAX = 1..8)
+  int last_graph_nodes = 0;   // kernel nodes of the step graph captured last (ptts_debug_graph_nodes)
   bool fuse_qa_multi = true;  // the same node at 2..8 utterances, one grid slice per utterance (round 5; PTTS_FUSE_QA_MULTI=0: single utterance only)
   bool fuse_qa = true;        // single-utterance GEMV step: LN1 + QKV rows + self-attention + append as one node (qkv_attn_kernel), PTTS_NO_FUSE_QA=1 = two nodes
   int fuse_x = -1;            // single-utterance GEMV step, folded cross block: LN2 + scores + softmax + U p as one node of per-head partial rows (xfold_attn_kernel),
@@ -118,7 +122,7 @@ struct ptts_engine {
   bool fuse_xq = true;        // GEMV step, un-folded cross block: LN2 + cross-q rows + cross-attention as one node (xq_attn_kernel), PTTS_NO_FUSE_XQ=1 = two nodes
   int graph_steps = 1;        // decode steps per hipGraphLaunch inside one context bucket (PTTS_GRAPH_STEPS = 1 / 2 / 4 / 8 / 16)
   int fuse_qa_s = 0;          // KV splits of that node: 0 = by context bucket (1 / 2 / 4 / 8 for <= 256 / 512 / 1024 / more positions), PTTS_FUSE_QA_S forces one
-  int lnproj_g = 8;           // utterances per workgroup of that node (PTTS_LNPROJ_G = 8 / 4)
+  int lnproj_g = 0;           // utterances per workgroup of that node: 0 = by batch size (8 up to 40 utterances, 16 above), PTTS_LNPROJ_G = 4 / 8 / 16 forces one
   int xattn_g = 0;            // utterances per workgroup of the fused cross block above 8 utterances: 0 = by batch size (2 up to 32, 4 up to 64, 8 above), PTTS_XATTN_G = 8 / 4 / 2 forces one
   bool xattn_g_ok = false;    // the g < 8 instances exist for this width (Mini-v1, Large-v1)
   bool xattn_groups = true;   // the fused LN2 + cross-q + cross-attention kernel also at batch 9..32, in groups of 8 utterances (PTTS_NO_XATTN_GROUPS=1: two nodes)
@@ -150,9 +154,9 @@ namespace {
 
 // LayerNorm (+ fold of pending fc2 partials) + projection, tiled over 64 weight rows x G utterances (lnproj_fused_kernel): decode at batch > 8
 template <typename WT, int EPI>
-int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st) {
+int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st, int g) {
   constexpr int KT = Elem<WT>::KT;
-  const int H = p.K, g = e->lnproj_g;
+  const int H = p.K;
   if (g == 16 && p.part) return ptts_fail(PTTS_E_UNSUPPORTED, "lnproj: the 16-row instance does not fold split-K partials");
   p.invK = 1.0f / (float)H;
   const int mg = p.M < g ? p.M : g;
@@ -236,7 +240,10 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const int mode = c.dtype == PTTS_F32 ? GV_F32 : (e->w8 ? GV_BF16_W8 : GV_BF16);
     // single utterance, sinusoidal positions: the two nodes of the self-attention block's first half as one (PTTS_NO_FUSE_QA=1: two nodes)
     // (round 5: 2..8 utterances too - one grid slice per utterance, the slices of a head share its weight rows in the L2; PTTS_FUSE_QA_MULTI=0: one only)
-    const bool fuse_qa = e->fuse_qa && (M == 1 || (e->fuse_qa_multi && mode != GV_F32)) && !c.rope && ptts_qkvattn_ok(H, mode);
+    // measured, Mini-v1 us per step at contexts ~210 / ~460 / ~710, fused | two nodes (profiles/r05_experiments.txt call 2): 2 utterances 720 / 756 / 791 |
+    // 769 / 777 / 791; 3: 741 / 788 / 862 | 780 / 796 / 821; 4: 777 / 864 / 923 | 803 / 832 / 862; 8: 966 / 1010 / 1068 | 907 / 965 / 1023 (the slices of
+    // a head re-read its q / k / v rows from the L2 once per utterance and split): on up to fuse_qa_max utterances (3), PTTS_FUSE_QA_MAX forces a bound
+    const bool fuse_qa = e->fuse_qa && (M == 1 || (e->fuse_qa_multi && M <= e->fuse_qa_max && mode != GV_F32)) && !c.rope && ptts_qkvattn_ok(H, mode);
     // KV splits of the fused node: the smallest count whose FIRST batch of row groups (8 waves x 4 groups x 8 bf16 / 4 fp32 rows per split,
     // requested before q exists) covers the context bucket this graph is captured for - fewer workgroups recompute the head's q rows, and no
     // split needs a second, dependent K/V batch (context ~210 / ~460 / ~710: 2 splits 554 / 562 / 586 us per step, 4 splits 575 / 577 / 579,
@@ -370,11 +377,13 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // LayerNorm + projection as one node (lnproj_fused_kernel): decode, batch > 8, Mini / Large widths, weights in the engine dtype (e4m3 strips keep
   // streaming bytes through the strip GEMMs)
   const int KTf = Elem<WT>::KT;
-  const int lnproj = e->lnproj >= 0 ? e->lnproj : (M <= 40 ? 3 : 0);
-  // (prefill rows of one short prompt, M <= 40, on the same fused node: PTTS_LNPROJ_PREFILL=1 - three rows_prep nodes less per layer on the
-  //  time-to-first-token path)
-  static const bool lnproj_prefill = getenv("PTTS_LNPROJ_PREFILL") && atoi(getenv("PTTS_LNPROJ_PREFILL"));
-  const bool lnproj_ok = lnproj > 0 && (!prefill || lnproj_prefill) && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
+  const int lnproj = e->lnproj >= 0 ? e->lnproj : 3;
+  // utterances per workgroup of that node: 8 (one row per wave) up to 40, 16 (two rows per wave, the whole MFMA tile, half the weight re-reads) above
+  const int lnproj_g = e->lnproj_g > 0 ? e->lnproj_g : (M <= 40 ? 8 : 16);
+  // (round 5: the prefill rows of a short prompt, 8 < M <= 40, run the same fused nodes - three rows_prep nodes less per layer on the
+  //  time-to-first-token path: prefill 1.41 -> 1.29 ms, first token 2.41 -> 2.28 ms at 33 rows, profiles/r05_experiments.txt call 2; PTTS_LNPROJ_PREFILL=0: off)
+  static const bool lnproj_prefill = !(getenv("PTTS_LNPROJ_PREFILL") && !atoi(getenv("PTTS_LNPROJ_PREFILL")));
+  const bool lnproj_ok = lnproj > 0 && (!prefill || (lnproj_prefill && M <= 40)) && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
   bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
@@ -382,7 +391,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       LnProjArgs p = {};
       p.W = w.qkv; p.x = e->h; p.x_ld = H; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.K = H; p.out = e->qkv; p.out_ld = QKV; p.M = M; p.N = QKV;
       if (fc2_pending) { p.part = e->hpart; p.S = FC2_KSPLIT; fc2_pending = false; resid_fold = true; }
-      PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st)));
+      PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st, lnproj_g)));
     } else {  // LN1 + fused QKV projection
       GemmArgs g = {}; g.decode = dec;
       g.W = w.qkv; g.W8 = w.qkv_p8; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
@@ -391,6 +400,15 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
     if (prefill) {
+      bool done8 = false;
+      if constexpr (sizeof(WT) == 2) {
+        if (w.ks_self) {
+          hipLaunchKernelGGL((kv_append_kernel<WT, true>), dim3(Q, nkv, B), dim3(64), 0, st, e->qkv + H, e->qkv + H + Hkv, QKV, w.k_self, w.v_self, c.max_ctx,
+                             Q, nkv, c.rope ? e->rope_cos : nullptr, c.rope ? e->rope_sin : nullptr, w.ks_self, w.vs_self);
+          done8 = true;
+        }
+      }
+      if (!done8)
       hipLaunchKernelGGL((kv_append_kernel<WT>), dim3(Q, nkv, B), dim3(64), 0, st, e->qkv + H, e->qkv + H + Hkv, QKV, w.k_self,
                          w.v_self, c.max_ctx, Q, nkv, c.rope ? e->rope_cos : nullptr, c.rope ? e->rope_sin : nullptr);
     }
@@ -403,6 +421,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
       a.part = e->part; a.stats = e->stats; a.S = S_used; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
+      a.kscale = w.ks_self; a.vscale = w.vs_self;
       a.direct_out = S_used == 1 ? e->xw : nullptr; a.out_fo = fo;
       a.exact_len = (!prefill && M > 8 && e->attn_exact) ? 1 : 0;
       PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
@@ -450,7 +469,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     if (prefill && lnproj_ok) {  // LN2 + cross q projection as one node
       LnProjArgs p = {};
       p.W = w.cq; p.x = e->h; p.x_ld = H; p.gamma = w.ln2_g; p.beta = w.ln2_b; p.K = H; p.out = e->qc; p.out_ld = H; p.M = M; p.N = H;
-      PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st)));
+      PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st, lnproj_g)));
     } else
     {  // LN2 + cross q projection
       GemmArgs g = {}; g.decode = dec;
@@ -491,11 +510,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         if (lnproj_ok && (lnproj >= 3 || (lnproj == 2 && M > 32))) {  // LN3 + fc1 + GELU in one node
           LnProjArgs p = {};
           p.W = w.fc1; p.x = e->h; p.x_ld = H; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.K = H; p.out = e->xw2; p.out_ld = F; p.out_fo = fo; p.M = M; p.N = F;
-          PTTS_TRY((launch_lnproj<WT, EPI_GELU_WT>(e, p, st)));
+          PTTS_TRY((launch_lnproj<WT, EPI_GELU_WT>(e, p, st, lnproj_g)));
         } else
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
         g2.x = reinterpret_cast<const float*>(e->xw2); g2.x_fo = fo;
-        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0) && !(lnproj_ok && e->lnproj_g == 16)) {
+        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0) && !(lnproj_ok && lnproj_g == 16)) {  // (the 16-row LN1 node does not fold partials: fc2 runs un-split beside it)
           g2.out = e->hpart;  // h += sum of the partials happens in the next layer's LN1 prep kernel
           PTTS_TRY((launch_gemm_splitk<WT>(g2, st)));
           fc2_pending = true;
@@ -656,6 +675,10 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   if (e->use_gemv && !c.rope && c.max_enc <= 64 && ptts_gemv_k_ok(nh * 64, gmode) && !(getenv("PTTS_NO_XFOLD") && atoi(getenv("PTTS_NO_XFOLD"))))
     e->xfold_ne = 64;
   e->w8_strips = e->w8 && !e->use_gemv && !(getenv("PTTS_NO_W8_STRIPS") && atoi(getenv("PTTS_NO_W8_STRIPS")));
+  if (c.kv_fp8 && (c.dtype != PTTS_BF16 || e->use_gemv)) {
+    ptts_engine_destroy(e);
+    return ptts_fail(PTTS_E_UNSUPPORTED, "kv_fp8 (e4m3 self-attention cache) needs the bf16 engine created for more than %d utterances (the MFMA strip step)", GV_MAX_ROWS);
+  }
   if (e->w8 && (c.dtype != PTTS_BF16 || H % 512 || F % 512 || H > 2048)) {
     ptts_engine_destroy(e);
     return ptts_fail(PTTS_E_UNSUPPORTED, "weights_fp8 needs the bf16 engine and hidden / ffn sizes that are multiples of 512 (hidden <= 2048)");
@@ -694,8 +717,9 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
     }
     A(e->alloc(&w.ln1_g, H)); A(e->alloc(&w.ln1_b, H)); A(e->alloc(&w.ln2_g, H)); A(e->alloc(&w.ln2_b, H));
     A(e->alloc(&w.ln3_g, H)); A(e->alloc(&w.ln3_b, H));
-    const size_t kvs = (size_t)c.max_batch * e->nkv * c.max_ctx * 64 * es, kvc = (size_t)c.max_batch * e->nkc * c.max_enc * 64 * es;
+    const size_t kvs = (size_t)c.max_batch * e->nkv * c.max_ctx * 64 * (c.kv_fp8 ? 1 : es), kvc = (size_t)c.max_batch * e->nkc * c.max_enc * 64 * es;
     A(e->alloc_bytes(&w.k_self, kvs)); A(e->alloc_bytes(&w.v_self, kvs));
+    if (c.kv_fp8) { A(e->alloc(&w.ks_self, (size_t)c.max_batch * e->nkv * c.max_ctx)); A(e->alloc(&w.vs_self, (size_t)c.max_batch * e->nkv * c.max_ctx)); }
     A(e->alloc_bytes(&w.k_cross, kvc)); A(e->alloc_bytes(&w.v_cross, kvc));
     char nm[160];
     const char* mats[] = {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "encoder_attn.q_proj",
@@ -782,6 +806,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   if (const char* ev = getenv("PTTS_FUSE_X_NUR")) { const int v = atoi(ev); if (v == 2 || v == 4) e->fuse_x_nur = v; }
   e->fuse_qa = !(getenv("PTTS_NO_FUSE_QA") && atoi(getenv("PTTS_NO_FUSE_QA")));
   e->fuse_qa_multi = !(getenv("PTTS_FUSE_QA_MULTI") && !atoi(getenv("PTTS_FUSE_QA_MULTI")));
+  if (const char* ev = getenv("PTTS_FUSE_QA_MAX")) e->fuse_qa_max = std::max(1, std::min(GV_MAX_ROWS, atoi(ev)));
   e->fuse_xq = !(getenv("PTTS_NO_FUSE_XQ") && atoi(getenv("PTTS_NO_FUSE_XQ")));
   if (const char* ev = getenv("PTTS_GRAPH_STEPS")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->graph_steps = v; }
   if (const char* ev = getenv("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
@@ -797,7 +822,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
   if (const char* ev = getenv("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));
   if (const char* ev = getenv("PTTS_LNPROJ")) e->lnproj = std::max(0, std::min(3, atoi(ev)));
-  if (const char* ev = getenv("PTTS_LNPROJ_G")) e->lnproj_g = atoi(ev) == 4 ? 4 : (atoi(ev) == 16 ? 16 : 8);
+  if (const char* ev = getenv("PTTS_LNPROJ_G")) e->lnproj_g = atoi(ev) == 4 ? 4 : (atoi(ev) == 16 ? 16 : (atoi(ev) == 8 ? 8 : 0));
   e->xattn_g_ok = (H == 1024 && ((H / (c.dtype == PTTS_BF16 ? 32 : 16)) / 2) % 16 == 0) || H == 1536;
   if (const char* ev = getenv("PTTS_XATTN_G")) { const int g = atoi(ev); if (g == 2 || g == 4 || g == 8) e->xattn_g = e->xattn_g_ok ? g : 8; }
   e->xattn_groups = !(getenv("PTTS_NO_XATTN_GROUPS") && atoi(getenv("PTTS_NO_XATTN_GROUPS")));  // measured: 1386 -> 1360 us per batch-32 step (profiles/r03_experiments.txt)
@@ -1158,6 +1183,10 @@ static int get_graph(ptts_engine* e, hipGraphExec_t* out, int nsteps = 1) {
   if (rc != PTTS_OK) { if (g) hipGraphDestroy(g); return rc; }
   if (ce != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
   hipGraphExec_t ex = nullptr;
+  {
+    size_t nn = 0;
+    if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) e->last_graph_nodes = (int)(nn / (size_t)nsteps);
+  }
   hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
   if (ie != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
@@ -1288,6 +1317,12 @@ extern "C" int ptts_push_tokens(ptts_engine* e, const int64_t* tokens_dev, const
                      e->ids_ld, e->cur_len, e->unfinished, e->has_eos, e->B, e->cfg.num_codebooks, e->cfg.eos_token_id);
   hipLaunchKernelGGL(bump_len_kernel, dim3((e->B + 255) / 256), dim3(256), 0, st, e->cur_len, e->B);
   e->h_ready = false;
+  return PTTS_OK;
+}
+
+extern "C" int ptts_debug_graph_nodes(ptts_engine* e, int32_t* nodes) {
+  PTTS_CHECK(e && nodes, PTTS_E_INVALID, "null argument");
+  *nodes = e->last_graph_nodes;
   return PTTS_OK;
 }
 

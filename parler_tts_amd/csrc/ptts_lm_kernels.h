@@ -977,6 +977,8 @@ struct AttnArgs {
   int fused_append;
   float scale;
   int out_fo;          // direct_out in MFMA B-fragment order (fo_vec_index) instead of row-major [rows][H]
+  float* kscale;       // (KV8 instances) e4m3 self-attention cache: kcache / vcache hold 64 bytes per row and these one power-of-two scale per
+  float* vscale;       // (utterance, K/V head, position): [B][kv_heads][cap] fp32, written at append like the rows; null = engine-dtype cache
   int exact_len;       // decode self-attention at batch > 8: wait for the device-resident length (one scalar round trip) and fetch only the
                        // rows this utterance has, instead of everything below kv_bound (the 64-position bucket: up to 63 unused rows per
                        // (utterance, head), ~7-13 % of the K/V bytes at mid context; at batch 1..8 the extra round trip costs more than it saves)
@@ -1040,8 +1042,38 @@ __device__ __forceinline__ void rope_apply(float (&x)[EPL], const float (&y)[EPL
 // argument: the cache capacity, or - decode steps - the host's upper bound of the context rounded up to 64 (the step graph is
 // captured once per 64-position bucket), so the speculative batch does not fetch rows no utterance can have yet (PMC: 34 MB per
 // launch at batch 32 and context 57 against 7.5 MB of live cache); validity against the lengths is applied when the data is used.
-template <typename WT, int NW>
+// ---- opt-in e4m3 self-attention cache (ptts_config::kv_fp8, engines of more than GV_MAX_ROWS utterances; round 5) -----------------------------
+// At 64+ utterances the K/V stream is the bandwidth-bound third of the step and already runs at 6+ TB/s: only fewer bytes
+// move it. A cache row is stored as 64 OCP e4m3 bytes + ONE power-of-two fp32 scale per (utterance, K/V head, position), quantised when the row
+// is appended (from the fp32 projection, after RoPE): scale = 2^ceil(log2(max|x| / 448)), q = rne_e4m3(x / scale). Attention converts the bytes
+// in registers (v_cvt_pk_f32_fp8) and applies the scales to the score / the probability, so every position - the new one included - is seen
+// exactly as the cache holds it. NOT a reference mode (modeling_parler_tts.py:3497-3501 raises on quantised caches): its own oracle leg
+// (oracle/fp8_oracle.py: quantize_kv_rows), its own tolerance, never the default.
+__device__ __forceinline__ float kv8_row_scale(float amax) {  // 2^ceil(log2(amax / 448)), 1 for an all-zero row
+  if (!(amax > 0.f)) return 1.f;
+  int e;
+  const float m = frexpf(amax / 448.0f, &e);  // amax / 448 = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.0f, m == 0.5f ? e - 1 : e);
+}
+__device__ __forceinline__ uint2 kv8_pack8(const float (&x)[8], float inv_scale) {
+  int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0] * inv_scale, x[1] * inv_scale, 0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2] * inv_scale, x[3] * inv_scale, w0, true);
+  int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4] * inv_scale, x[5] * inv_scale, 0, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * inv_scale, x[7] * inv_scale, w1, true);
+  return make_uint2((unsigned)w0, (unsigned)w1);
+}
+__device__ __forceinline__ void kv8_unpack8(const uint2& v, float (&o)[8]) {
+  const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+  const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+  o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1]; o[4] = c[0]; o[5] = c[1]; o[6] = d[0]; o[7] = d[1];
+}
+template <bool KV8> struct KvVec { typedef uint4 T; };
+template <> struct KvVec<true> { typedef uint2 T; };
+
+template <typename WT, int NW, bool KV8 = false>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
+  static_assert(!KV8 || sizeof(WT) == 2, "e4m3 cache: bf16 engine (8 elements per lane)");
+  typedef typename KvVec<KV8>::T KVV;
   constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8;
   __shared__ float s_o[NW][64];
   __shared__ float s_ml[NW][2];
@@ -1062,12 +1094,16 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     load_chunk_raw<EPL>(a.knew + (size_t)row * a.kv_ld + kvh * 64, c * EPL, a.cos != nullptr, kk, ky);
     load_chunk_raw<EPL>(a.vnew + (size_t)row * a.kv_ld + kvh * 64, c * EPL, false, vv, vy);
   }
-  WT* Kc = reinterpret_cast<WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
-  WT* Vc = reinterpret_cast<WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
-  const uint4* Kb = reinterpret_cast<const uint4*>(Kc);
-  const uint4* Vb = reinterpret_cast<const uint4*>(Vc);
+  // row pitch of the cache: 64 elements of WT, or 64 bytes (KV8)
+  char* Kc = reinterpret_cast<char*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64 * (KV8 ? 1 : sizeof(WT));
+  char* Vc = reinterpret_cast<char*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64 * (KV8 ? 1 : sizeof(WT));
+  const KVV* Kb = reinterpret_cast<const KVV*>(Kc);
+  const KVV* Vb = reinterpret_cast<const KVV*>(Vc);
+  float* Ks = KV8 ? a.kscale + ((size_t)b * a.kv_heads + kvh) * a.cap : nullptr;
+  float* Vs = KV8 ? a.vscale + ((size_t)b * a.kv_heads + kvh) * a.cap : nullptr;
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
-  uint4 kf[U], vf[U];
+  KVV kf[U], vf[U];
+  float ksc[KV8 ? U : 1], vsc[KV8 ? U : 1];
   int mk[U];
   // exact_len: self-attention decode, rows [0, P + cur_len - 1) are in the cache; the row of the new position comes from registers
   const int fetch_bound = a.exact_len ? min(a.kv_bound, P + cl - 1) : a.kv_bound;
@@ -1077,6 +1113,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     const int tc = t < fetch_bound ? t : 0;
     kf[u] = Kb[(size_t)tc * LPR + c];
     vf[u] = Vb[(size_t)tc * LPR + c];
+    if constexpr (KV8) { ksc[u] = Ks[tc]; vsc[u] = Vs[tc]; }
     mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
   }
   // ---- lengths known from here on -------------------------------------------------------------------------------------
@@ -1084,14 +1121,31 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   const int L = a.cross ? Nenc : pos + 1;
   const int mask_len = a.cross ? L : P;
   rope_apply<EPL>(qv, qy, c * EPL, a.cos, a.sin, (size_t)pos);
-  uint4 knew_p = make_uint4(0, 0, 0, 0), vnew_p = make_uint4(0, 0, 0, 0);
+  KVV knew_p = KVV(), vnew_p = KVV();
+  float ks_new = 1.f, vs_new = 1.f;
   if (a.fused_append) {
     rope_apply<EPL>(kk, ky, c * EPL, a.cos, a.sin, (size_t)pos);
-    knew_p = pack16(kk, WT());
-    vnew_p = pack16(vv, WT());
-    if (s == 0 && w == 0 && r == 0 && h == kvh * a.n_rep) {  // single writer of the new cache row (first query head of the group)
-      reinterpret_cast<uint4*>(Kc + (size_t)pos * 64)[c] = knew_p;
-      reinterpret_cast<uint4*>(Vc + (size_t)pos * 64)[c] = vnew_p;
+    const bool writer = s == 0 && w == 0 && r == 0 && h == kvh * a.n_rep;  // single writer of the new cache row (first query head of the group)
+    if constexpr (KV8) {
+      float ka = 0.f, va = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) { ka = fmaxf(ka, fabsf(kk[e])); va = fmaxf(va, fabsf(vv[e])); }
+      ks_new = kv8_row_scale(group_reduce<OpMax, LPR>(ka));  // the row's 64 values sit in the LPR lanes of this row group
+      vs_new = kv8_row_scale(group_reduce<OpMax, LPR>(va));
+      knew_p = kv8_pack8(kk, 1.0f / ks_new);  // reciprocal of a power of two: exact
+      vnew_p = kv8_pack8(vv, 1.0f / vs_new);
+      if (writer) {
+        reinterpret_cast<uint2*>(Kc + (size_t)pos * 64)[c] = knew_p;
+        reinterpret_cast<uint2*>(Vc + (size_t)pos * 64)[c] = vnew_p;
+        if (c == 0) { Ks[pos] = ks_new; Vs[pos] = vs_new; }
+      }
+    } else {
+      knew_p = pack16(kk, WT());
+      vnew_p = pack16(vv, WT());
+      if (writer) {
+        reinterpret_cast<uint4*>(Kc + (size_t)pos * 64 * sizeof(WT))[c] = knew_p;
+        reinterpret_cast<uint4*>(Vc + (size_t)pos * 64 * sizeof(WT))[c] = vnew_p;
+      }
     }
   }
   // softmax in base 2: log2(e) is folded into the query scale, every exponential is ONE v_exp_f32 (expf is a ~15-instruction
@@ -1115,6 +1169,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
         const int tc = t < L ? t : 0;
         kf[u] = Kb[(size_t)tc * LPR + c];
         vf[u] = Vb[(size_t)tc * LPR + c];
+        if constexpr (KV8) { ksc[u] = Ks[tc]; vsc[u] = Vs[tc]; }
         mk[u] = (mrow && tc < mask_len) ? mrow[tc] : 1;
       }
     }
@@ -1123,13 +1178,18 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     for (int u = 0; u < U; ++u) {
       const int t = (g0 + u * TW) * RPI + r;
       ok[u] = t < L && (t >= mask_len || mk[u] != 0);
-      if (a.fused_append && t == pos) { kf[u] = knew_p; vf[u] = vnew_p; }
+      if (a.fused_append && t == pos) {
+        kf[u] = knew_p; vf[u] = vnew_p;
+        if constexpr (KV8) { ksc[u] = ks_new; vsc[u] = vs_new; }
+      }
       float kx[EPL];
-      unpack16(kf[u], kx, WT());
+      if constexpr (KV8) kv8_unpack8(kf[u], kx);
+      else unpack16(kf[u], kx, WT());
       float d = 0.f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) d = fmaf(qv[e], kx[e], d);
       d = group_reduce<OpSum, LPR>(d);
+      if constexpr (KV8) d *= ksc[u];
       sc[u] = ok[u] ? d : -INFINITY;
       bm = fmaxf(bm, sc[u]);
     }
@@ -1144,10 +1204,12 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     for (int u = 0; u < U; ++u) {
       const float p = ok[u] ? __builtin_amdgcn_exp2f(sc[u] - m_new) : 0.f;
       float vx[EPL];
-      unpack16(vf[u], vx, WT());
+      if constexpr (KV8) kv8_unpack8(vf[u], vx);
+      else unpack16(vf[u], vx, WT());
       l_run += p;
+      const float pv = KV8 ? p * vsc[KV8 ? u : 0] : p;  // the value row's scale rides on the probability
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(p, vx[e], o[e]) : o[e];  // masked rows may hold NaN/garbage V
+      for (int e = 0; e < EPL; ++e) o[e] = ok[u] ? fmaf(pv, vx[e], o[e]) : o[e];  // masked rows may hold NaN/garbage V
     }
     m_run = m_new;
   }
@@ -1675,9 +1737,10 @@ __global__ void __launch_bounds__(64) xfold_u_kernel(const FoldLayer* __restrict
 }
 
 // prefill: write all Q new K/V rows (RoPE on k) into the self cache.  grid (Q, heads, B), 64 threads
-template <typename WT>
+template <typename WT, bool KV8 = false>
 __global__ void kv_append_kernel(const float* __restrict__ knew, const float* __restrict__ vnew, int kv_ld, void* kcache,
-                                 void* vcache, int cap, int Q, int nheads, const float* cos, const float* sin) {
+                                 void* vcache, int cap, int Q, int nheads, const float* cos, const float* sin, float* kscale = nullptr,
+                                 float* vscale = nullptr) {
   const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
   const int row = b * Q + qi, pos = qi;
   const float* kr = knew + (size_t)row * kv_ld + h * 64;
@@ -1686,9 +1749,20 @@ __global__ void kv_append_kernel(const float* __restrict__ knew, const float* __
     const float other = d < 32 ? -kr[d + 32] : kr[d - 32];
     kx = kx * cos[(size_t)pos * 64 + d] + other * sin[(size_t)pos * 64 + d];
   }
+  const float vx = vnew[(size_t)row * kv_ld + h * 64 + d];
   const size_t off = (((size_t)b * nheads + h) * cap + pos) * 64 + d;
-  store_from_f32<WT>(reinterpret_cast<WT*>(kcache) + off, kx);
-  store_from_f32<WT>(reinterpret_cast<WT*>(vcache) + off, vnew[(size_t)row * kv_ld + h * 64 + d]);
+  if constexpr (KV8) {  // e4m3 cache rows: one wave = one row, scale from the row's maximum (attn_kernel's quantiser)
+    const float ks = kv8_row_scale(wave_max(fabsf(kx))), vs = kv8_row_scale(wave_max(fabsf(vx)));
+    reinterpret_cast<uint8_t*>(kcache)[off] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(kx * (1.0f / ks), 0.f, 0, false) & 0xff);
+    reinterpret_cast<uint8_t*>(vcache)[off] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(vx * (1.0f / vs), 0.f, 0, false) & 0xff);
+    if (d == 0) {
+      kscale[((size_t)b * nheads + h) * cap + pos] = ks;
+      vscale[((size_t)b * nheads + h) * cap + pos] = vs;
+    }
+  } else {
+    store_from_f32<WT>(reinterpret_cast<WT*>(kcache) + off, kx);
+    store_from_f32<WT>(reinterpret_cast<WT*>(vcache) + off, vx);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------

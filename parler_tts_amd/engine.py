@@ -42,7 +42,7 @@ class DecoderEngine:
                  pad_token_id: int = 1024, eos_token_id: int = 1024, bos_token_id: int = 1025,
                  dtype: torch.dtype = torch.bfloat16, max_batch: int = 1, max_ctx: int = 2700, max_enc: int = 256,
                  max_prompt: int = 128, device: Optional[torch.device] = None, num_kv_heads: int = 0, num_cross_kv_heads: int = 0,
-                 weights_fp8: bool = False):
+                 weights_fp8: bool = False, kv_fp8: bool = False):
         if not torch.cuda.is_available():
             raise N.NativeLibraryError("DecoderEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = N.load_library()
@@ -55,8 +55,9 @@ class DecoderEngine:
         self.cfg = N.PttsConfig(hidden_size, num_layers, num_heads, ffn_dim, num_codebooks, vocab_size, max_positions, int(rope),
                                 float(rope_theta), pad_token_id, eos_token_id, bos_token_id,
                                 N.PTTS_BF16 if dtype == torch.bfloat16 else N.PTTS_F32, max_batch, max_ctx, max_enc, max_prompt,
-                                self.device.index or 0, int(num_kv_heads or 0), int(num_cross_kv_heads or 0), int(bool(weights_fp8)))
+                                self.device.index or 0, int(num_kv_heads or 0), int(num_cross_kv_heads or 0), int(bool(weights_fp8)), int(bool(kv_fp8)))
         self.weights_fp8 = bool(weights_fp8)
+        self.kv_fp8 = bool(kv_fp8)
         if self.weights_fp8 and dtype != torch.bfloat16:
             raise ValueError("weights_fp8 needs the bfloat16 engine (e4m3 weights, bf16 activations)")
         self._h = C.c_void_p()
@@ -164,6 +165,12 @@ class DecoderEngine:
         pre, tail = C.c_float(), C.c_float()
         N.check(self.lib.ptts_first_token_times(self._h, C.byref(pre), C.byref(tail)), "ptts_first_token_times")
         return float(pre.value), float(tail.value)
+
+    def graph_nodes(self) -> int:
+        """Kernel nodes per decode step of the step graph captured last (``ptts_debug_graph_nodes``)."""
+        n = C.c_int32()
+        N.check(self.lib.ptts_debug_graph_nodes(self._h, C.byref(n)), "ptts_debug_graph_nodes")
+        return int(n.value)
 
     def set_audio_prefix(self, codes: Optional[torch.Tensor]):
         """Voice prompt for the NEXT ``prefill``: un-delayed audio codes int64 [B, K, T] (or [B*K, T]); ``None`` clears it."""

@@ -568,6 +568,16 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         self._engine = None
         return self
 
+    def enable_fp8_kv_cache(self, enabled: bool = True):
+        """Opt-in e4m3 self-attention KV cache for engines of more than 8 utterances (``ptts_config::kv_fp8``): 64 bytes + one power-of-two
+        scale per (utterance, head, position) instead of 128 bytes, for 64+ utterances per GPU where the K/V stream bounds a third of the step.
+        Not a reference feature (the reference raises on quantised caches, modeling_parler_tts.py:3497-3501): outputs are those of the model with
+        a quantised cache, checked against the oracle applying the SAME quantiser (oracle/fp8_oracle.py: quantize_kv_rows). Smaller batches
+        keep the bf16 cache."""
+        self.decoder_kv_fp8 = bool(enabled)
+        self._engine = None
+        return self
+
     def _get_engine(self, B: int, N: int, P: int, max_length: int, T: int = 0) -> DecoderEngine:
         """T = voice-prompt frames: the prefill runs the P prompt positions, the BOS column and the T given columns in one pass."""
         dev, dt = self.device, self.dtype
@@ -583,7 +593,11 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         # GEMV step up to 8 utterances; MFMA strips only - bf16 or e4m3 - above). So a single-utterance call must not land on an engine
         # sized for 32, and a server that alternates between a wide batch and a long single utterance must not re-pack the weights and
         # re-capture the step graphs on every call. Each resident engine costs its own weight copies (~0.7-1.5 GB for Mini-v1).
-        key = (dev, dt, fp8, "b<=4" if B <= 4 else ("b<=8" if B <= 8 else "b>8"))
+        kv8_on = bool(getattr(self, "decoder_kv_fp8", False))
+        if kv8_on and dt != torch.bfloat16:
+            raise NotImplementedError("decoder_kv_fp8 needs the model in bfloat16 (e4m3 cache rows, bf16 activations)")
+        kv8 = kv8_on and B > 8  # the GEMV step of up to 8 utterances keeps the bf16 cache
+        key = (dev, dt, (fp8, kv8_on), "b<=4" if B <= 4 else ("b<=8" if B <= 8 else "b>8"))
         engines = self.__dict__.setdefault("_engines", {})
         e = engines.get(key)
         if e is None or e.cfg.max_batch < B or e.cfg.max_enc < N or e.cfg.max_prompt < P + 1 + T or e.cfg.max_ctx < P + max_length:
@@ -598,7 +612,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                               num_codebooks=d.num_codebooks, vocab_size=d.vocab_size, max_positions=d.max_position_embeddings,
                               rope=d.rope_embeddings, rope_theta=d.rope_theta, pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id,
                               bos_token_id=d.bos_token_id, dtype=dt, device=dev, num_kv_heads=d.num_key_value_heads,
-                              num_cross_kv_heads=d.num_cross_attention_key_value_heads, weights_fp8=fp8, **caps)
+                              num_cross_kv_heads=d.num_cross_attention_key_value_heads, weights_fp8=fp8, kv_fp8=kv8, **caps)
             e.load_state_dict(self.decoder.state_dict())
             engines[key] = e
         self.__dict__["_engine_last"] = e

@@ -35,7 +35,7 @@ def spec_from_gold(arr, **kw):
                           rope_embeddings=bool(rope), **kw)
 
 
-def make_engine(spec, sd, dtype=torch.float32, max_batch=2, max_ctx=128, max_enc=32, max_prompt=16, weights_fp8=False):
+def make_engine(spec, sd, dtype=torch.float32, max_batch=2, max_ctx=128, max_enc=32, max_prompt=16, weights_fp8=False, kv_fp8=False):
     from parler_tts_amd.engine import DecoderEngine
 
     eng = DecoderEngine(hidden_size=spec.hidden_size, num_layers=spec.num_hidden_layers, num_heads=spec.num_attention_heads,
@@ -43,7 +43,7 @@ def make_engine(spec, sd, dtype=torch.float32, max_batch=2, max_ctx=128, max_enc
                         max_positions=spec.max_position_embeddings, rope=spec.rope_embeddings, rope_theta=spec.rope_theta,
                         pad_token_id=spec.pad_token_id, eos_token_id=spec.eos_token_id, bos_token_id=spec.bos_token_id, dtype=dtype,
                         max_batch=max_batch, max_ctx=max_ctx, max_enc=max_enc, max_prompt=max_prompt,
-                        num_kv_heads=spec.kv_heads, num_cross_kv_heads=spec.cross_kv_heads, weights_fp8=weights_fp8)
+                        num_kv_heads=spec.kv_heads, num_cross_kv_heads=spec.cross_kv_heads, weights_fp8=weights_fp8, kv_fp8=kv_fp8)
     eng.load_state_dict(sd)
     return eng
 

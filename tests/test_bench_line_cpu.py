@@ -72,7 +72,8 @@ def test_step_graph_node_counts_follow_the_forward_structure():
     assert bench.step_graph_nodes(4, 30, 1536, False) == 212 and bench.step_graph_nodes(8, 24, 1024, False) == 170  # 2..8 utterances: xq_attn_kernel, 7 per layer
     assert bench.step_graph_nodes(8, 24, 2048, False) == 194
     assert bench.step_graph_nodes(32, 24, 1024, False) == 171 and bench.step_graph_nodes(32, 24, 512, False) is None  # 7 nodes per layer + heads prep / heads / tail
-    assert bench.step_graph_nodes(64, 24, 1024, False) is None
+    assert bench.step_graph_nodes(64, 24, 1024, False) == 171 and bench.step_graph_nodes(128, 30, 1536, False) == 213  # round 5: the 16-row LayerNorm + projection nodes above 40 utterances
+    assert bench.step_graph_nodes(2, 24, 1024, False) == 146 and bench.step_graph_nodes(3, 24, 1024, False) == 146  # round 5: fused self-attention node up to 3 utterances
 
 
 def test_live_pmc_result_replaces_the_committed_pass_and_failures_fall_back(monkeypatch):

@@ -234,7 +234,7 @@ def test_mini_width_two_layers_fp32_and_bf16():
 
 
 def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, seed, max_ctx=64, weights_fp8=False, oracle_sd=None, max_batch=None,
-                              return_logits=False):
+                              return_logits=False, kv_fp8=False, oracle_kv_fp8=None):
     g = torch.Generator().manual_seed(seed)
     enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
     prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
@@ -246,10 +246,11 @@ def _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz, N, P, steps, masks, se
         enc = enc * enc_mask[..., None]
     step_ids = torch.randint(0, 1024, (steps, bsz * spec.num_codebooks), generator=g)
     orc = DO.DecoderOracle(spec, oracle_sd if oracle_sd is not None else sd, precision=prec)
+    orc.kv_fp8 = kv_fp8 if oracle_kv_fp8 is None else oracle_kv_fp8
     ref = [orc.forward(torch.full((bsz * 9, 1), 1025), enc, enc_mask, prompt, prompt_mask)[:, -1]]
     for s in range(steps):
         ref.append(orc.forward(step_ids[s][:, None])[:, -1])
-    eng = make_engine(spec, sd, dtype, max_batch=max_batch or bsz, max_ctx=max_ctx, max_enc=max(N, 16), max_prompt=P + 1, weights_fp8=weights_fp8)
+    eng = make_engine(spec, sd, dtype, max_batch=max_batch or bsz, max_ctx=max_ctx, max_enc=max(N, 16), max_prompt=P + 1, weights_fp8=weights_fp8, kv_fp8=kv_fp8)
     eng.set_gen_params(max_length=16)
     eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
     outs = [eng.logits().cpu()]
@@ -343,29 +344,91 @@ def test_fused_qkv_attention_node_single_utterance(gqa, monkeypatch):
 @pytest.mark.parametrize("gqa", [False, True])
 @pytest.mark.parametrize("bsz", [2, 3, 8])
 def test_fused_qkv_attention_node_two_to_eight_utterances(bsz, gqa, monkeypatch):
-    """qkv_attn_kernel with one grid slice per utterance (round 5): 2..8 utterances run LN1 + q / k / v rows + split-KV self-attention + append
-    as ONE node, combined per utterance by the out_proj node's GV_ATTN2 prologue (instances for 2..4 and 5..8 utterances). bf16 (the fp32
-    engine serves one utterance on this path): the fused step against the two-node step (PTTS_FUSE_QA_MULTI=0) AND both against the bf16 oracle,
-    ragged description / prompt masks, a short context (1 split) and a 600-position prompt (4 splits at <= 4 utterances, 2 above: second K/V
-    batch of the attention loop), grouped-query attention (one writer per K/V group and utterance)."""
+    """qkv_attn_kernel with one grid slice per utterance (round 5): 2..8 utterances can run LN1 + q / k / v rows + split-KV self-attention +
+    append as ONE node, combined per utterance by the out_proj node's GV_ATTN2 prologue (instances for 2..4 and 5..8 utterances). Default: up
+    to 3 utterances (measured); PTTS_FUSE_QA_MAX=8 here so the 5..8 instances are covered too. bf16 (the fp32 engine serves one utterance on
+    this path): the fused step against the two-node step (PTTS_FUSE_QA_MULTI=0) AND both against the bf16 oracle, ragged description / prompt
+    masks, a short context (1 split) and a 600-position prompt (4 splits at <= 4 utterances, 2 above: second K/V batch of the attention
+    loop), grouped-query attention (one writer per K/V group and utterance). That the fused node really is in the step is read off the
+    captured graph: one kernel node less per layer (ptts_debug_graph_nodes) - in bf16 the two variants can agree to the last bit."""
     kw = dict(num_hidden_layers=2, max_position_embeddings=2048)
     if gqa:
         kw.update(num_key_value_heads=4, num_cross_attention_key_value_heads=2)
     spec = DO.DecoderSpec(**kw)
     sd = DO.make_decoder_weights(spec, seed=83)
+    monkeypatch.setenv("PTTS_FUSE_QA_MAX", "8")
     for P, max_ctx, steps in ((6, 200, 5), (600, 800, 3)):
         runs = {}
         for fuse in (True, False):
             monkeypatch.setenv("PTTS_FUSE_QA_MULTI", "1" if fuse else "0")
             runs[fuse], ref = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=P, steps=steps, masks=True, seed=11 + bsz, max_ctx=max_ctx,
                                                         return_logits=True)
-        monkeypatch.delenv("PTTS_FUSE_QA_MULTI", raising=False)
         ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
-        assert ab > 0.0, "the fused node did not run at this batch size (identical logits: same kernels on both sides)"
         assert ab < 2e-2, (bsz, P, "fused vs two nodes", ab)
         for fuse in (True, False):
             err = max(float((a - b).abs().max()) for a, b in zip(runs[fuse], ref))
             assert err < 2e-2, (bsz, P, fuse, err)
+    # node count of the captured step: 6 nodes per layer fused (qkv_attn, combine + out_proj, xq_attn, cross out_proj, LN3 + fc1, fc2), 7 otherwise
+    g = torch.Generator().manual_seed(1)
+    enc, prompt = torch.randn(bsz, 9, spec.hidden_size, generator=g), torch.randn(bsz, 4, spec.hidden_size, generator=g)
+    nodes = {}
+    for fuse in (True, False):
+        monkeypatch.setenv("PTTS_FUSE_QA_MULTI", "1" if fuse else "0")
+        eng = make_engine(spec, sd, torch.bfloat16, max_batch=bsz, max_ctx=64, max_enc=16, max_prompt=5)
+        eng.set_gen_params(max_length=12, min_new_tokens=11)
+        eng.prefill(enc, None, prompt, None, sample=True)
+        eng.decode_steps(2)
+        nodes[fuse] = eng.graph_nodes()
+        eng.close()
+    assert nodes[False] == 7 * spec.num_hidden_layers + 2 and nodes[True] == 6 * spec.num_hidden_layers + 2, nodes
+
+
+def test_fused_qkv_attention_default_bound_is_three_utterances():
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=256)
+    sd = DO.make_decoder_weights(spec, seed=5)
+    g = torch.Generator().manual_seed(2)
+    for bsz, per_layer in ((1, 5), (2, 6), (3, 6), (4, 7)):
+        enc, prompt = torch.randn(bsz, 9, spec.hidden_size, generator=g), torch.randn(bsz, 4, spec.hidden_size, generator=g)
+        eng = make_engine(spec, sd, torch.bfloat16, max_batch=bsz, max_ctx=64, max_enc=16, max_prompt=5)
+        eng.set_gen_params(max_length=12, min_new_tokens=11)
+        eng.prefill(enc, None, prompt, None, sample=True)
+        eng.decode_steps(2)
+        assert eng.graph_nodes() == per_layer * spec.num_hidden_layers + 2, (bsz, eng.graph_nodes())
+        eng.close()
+
+
+@pytest.mark.parametrize("bsz", [12, 40, 70])
+def test_e4m3_kv_cache_mode(bsz):
+    """ptts_config::kv_fp8 (opt-in, engines of more than 8 utterances): the self-attention cache holds e4m3 rows + one power-of-two scale per
+    (utterance, head, position), quantised at append - by kv_append_kernel for the prefill rows, by attn_kernel's fused append at decode.
+    Teacher-forced logits against the bf16 oracle applying the SAME quantiser (oracle/fp8_oracle.py: quantize_kv_rows) within the bf16
+    tolerance; the mode is really on (logits differ from the bf16-cache engine) and the quantiser is the right one (the engine is closer to the
+    quantised oracle than to the plain one). Ragged masks; 70 utterances = the 16-row LayerNorm + projection nodes, exact-length K/V fetch."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=29)
+    kw = dict(bsz=bsz, N=13, P=5, steps=4, masks=True, seed=7, max_ctx=64, return_logits=True)
+    q_out, q_ref = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", kv_fp8=True, **kw)
+    p_out, p_ref = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", kv_fp8=False, **kw)
+    err_q = max(float((a - b).abs().max()) for a, b in zip(q_out, q_ref))
+    err_cross = max(float((a - b).abs().max()) for a, b in zip(q_out, p_ref))
+    on = max(float((a - b).abs().max()) for a, b in zip(q_out, p_out))
+    model = max(float((a - b).abs().max()) for a, b in zip(q_ref, p_ref))
+    from helpers import log_parity
+
+    log_parity(f"[e4m3 KV cache, {bsz} utterances] max |dlogit| vs the quantised-cache oracle {err_q:.2e}; vs the bf16-cache oracle {err_cross:.2e}; "
+               f"engine kv8 vs engine bf16 cache {on:.2e}; oracle kv8 vs oracle bf16 cache {model:.2e}", "r05_parity_kv8.txt")
+    assert err_q < 2e-2, err_q
+    assert on > 1e-3, "kv_fp8 engine produced the bf16-cache logits: the mode is not on"
+    assert err_q < err_cross, (err_q, err_cross)
+
+
+def test_e4m3_kv_cache_needs_the_wide_bf16_engine():
+    spec = DO.DecoderSpec(num_hidden_layers=1, max_position_embeddings=128)
+    sd = DO.make_decoder_weights(spec, seed=1)
+    with pytest.raises(NotImplementedError, match="kv_fp8"):
+        make_engine(spec, sd, torch.bfloat16, max_batch=4, kv_fp8=True)
+    with pytest.raises(NotImplementedError, match="kv_fp8"):
+        make_engine(spec, sd, torch.float32, max_batch=16, kv_fp8=True)
 
 
 @pytest.mark.parametrize("gqa", [False, True])

@@ -5,7 +5,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/cabi_probe.hip -o tools/cabi_probe \
 //         -Lparler_tts_amd -lptts_hip -Wl,-rpath,'$ORIGIN/../parler_tts_amd'
-//   tools/cabi_probe lm  <batch> [large] [fp32] [fp8] [layers=<n>] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]
+//   tools/cabi_probe lm  <batch> [large] [fp32] [fp8] [kv8] [layers=<n>] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]
 //        eager=<n>: only a prefill + n EAGER decode forwards (ptts_push_tokens + ptts_step_forward), no hipGraph is captured or launched:
 //        the target of `rocprofv3 --pmc ...` passes (which crash on graph replays in this image; tools/prof_eager.py without torch),
 //        e.g. `rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- tools/cabi_probe lm 1 ctx=431 eager=24` = the bench's timed context
@@ -140,6 +140,7 @@ static int run_lm(int argc, char** argv) {
   c.rope = 0; c.rope_theta = 10000.f; c.pad_token_id = 1024; c.eos_token_id = 1024; c.bos_token_id = 1025;
   c.dtype = fp32 ? PTTS_F32 : PTTS_BF16; c.max_batch = B; c.max_ctx = P + 908; c.max_enc = NE; c.max_prompt = P + 8; c.device = 0;
   c.weights_fp8 = fp8 ? 1 : 0;
+  c.kv_fp8 = opt(argc, argv, "kv8") != nullptr ? 1 : 0;  // e4m3 self-attention cache (engines of more than 8 utterances)
   ptts_engine* e = nullptr;
   const double t_create = now_s();
   PT(ptts_engine_create(&c, &e));
