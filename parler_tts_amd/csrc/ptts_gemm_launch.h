@@ -38,7 +38,9 @@ inline int msplit_rows(int M, int N, bool decode) {
   if (N >= 8192) return M > 32 ? 64 : 32;  // the LM heads (612 strips): plenty of workgroups already - light passes cost 7.4 -> 10.6 us at 32 utterances (call 29)
   // (the wide projections - QKV, fc1, N >= 3072 - on their own pass size measured no better: 64-row passes for them cost +4 % at 48 / 64 utterances and
   //  are within 0.5 % at 96 / 128, profiles/r04_experiments.txt call 31: one policy for every projection below 8192 rows)
-  return M <= 48 ? 16 : 32;
+  // round 5 (the LayerNorm + projection nodes took QKV / fc1 off the strips above 40 utterances, fc2 runs un-split there): rows 16 / 32 / 64 at
+  //   64: 1597 / 1671 / 1839   96: 2227 / 2157 / 2322   128: 2516 / 2444 / 2608 us per step (profiles/r05_experiments.txt call 3) -> 16 rows up to 64 utterances
+  return M <= 64 ? 16 : 32;
 }
 
 template <typename WT, int PRO, int EPI, int MTP, bool FULL>

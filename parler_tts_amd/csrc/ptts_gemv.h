@@ -11,6 +11,25 @@ enum { GV_STORE = 0, GV_RESID = 1, GV_GELU_WT = 2 };
 constexpr int GV_PMAX = 24;  // partial rows (= attention heads) the GV_LNP instances are built for
 enum { GV_F32 = 0, GV_BF16 = 1, GV_BF16_W8 = 2 };  // engine dtype of activations / weights; W8 = OCP e4m3 weights, bf16 activations
 
+// ---- measurement build only (-DPTTS_TIMING: tools/build_stamps.sh -> tools/stamps/, never the product library) --------------------------------
+// Every node of the single-utterance step stamps s_memtime at its phases into dbg[3 sampled workgroups][16] (first / middle / last workgroup of
+// the launch; lane 0 of the wave named at the call site). One global counter: stamps of different kernels of the same replay compare directly
+// (entry-to-entry = kernel boundary + the phases in between). VERDICT r04 item 5; report: profiles/r05_node_stamps.txt.
+#ifdef PTTS_TIMING
+#define GV_DBG_FIELDS long long* dbg;
+#define GV_STAMP(a, idx)                                                                                                   \
+  do {                                                                                                                     \
+    if ((a).dbg && (threadIdx.x & 63) == 0) {                                                                              \
+      const unsigned nb_ = gridDim.x * gridDim.y * gridDim.z, lb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      const int slot_ = lb_ == 0 ? 0 : (lb_ == nb_ / 2 ? 1 : (lb_ == nb_ - 1 ? 2 : -1));                                   \
+      if (slot_ >= 0) (a).dbg[slot_ * 16 + (idx)] = __builtin_amdgcn_s_memtime();                                          \
+    }                                                                                                                      \
+  } while (0)
+#else
+#define GV_DBG_FIELDS
+#define GV_STAMP(a, idx) do { } while (0)
+#endif
+
 constexpr int GV_MAX_ROWS = 8;  // utterances one GEMV launch serves (instances for 1, 2..4 and 5..8); above that the MFMA strip kernels take over
 
 struct GemvArgs {
@@ -33,6 +52,7 @@ struct GemvArgs {
   int x_ld, xw_ld, out_ld;
   int M, N, K, nheads;
   float invK;
+  GV_DBG_FIELDS
 };
 
 // Single-utterance fused node: LayerNorm + this head's q / k / v rows + split-KV self-attention + KV append (qkv_attn_kernel,
@@ -54,6 +74,7 @@ struct QkvAttnArgs {
   int S, nheads, H, kv_heads;
   int M, x_ld;          // utterances (grid.z) and the row pitch of x; part / stats hold M x (S + 1) slots, the caches M x kv_heads heads
   float scale, invK;
+  GV_DBG_FIELDS
 };
 // Single-utterance fused cross block over the folded matrices (xfold_attn_kernel): LayerNorm + the head's 64 score rows of M + per-head
 // softmax + the head's columns of U -> one partial output row per head; consumer: GV_LNP (LN3 + fc1), which also publishes the summed row.
@@ -69,6 +90,7 @@ struct XfoldAttnArgs {
   int nheads, H;
   int nur;              // rounds of output rows per workgroup (2 or 4): grid = nheads x H / (nur * rows per round)
   float invK;
+  GV_DBG_FIELDS
 };
 // 0 on success, -1: no instance for this width / mode, -2: launch error (mode: GV_F32 / GV_BF16 - the folded matrices are never e4m3)
 int ptts_xfoldattn_launch(int mode, XfoldAttnArgs a, hipStream_t st);

@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
   extern __shared__ __attribute__((aligned(16))) char s_x[];  // HASPRO: the prepared rows, engine dtype [MB][K]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int ROW_BYTES = NCH * 64 * 16;  // K * sizeof(WT), from the template: no kernel argument is read before the branch below,
+  if (wave == 0 || wave == NPW) GV_STAMP(a, wave == 0 ? 0 : 2);  // entry: wave 0 (a prologue wave when the node has one), first weight wave
   if (HASPRO && wave < NPW) {             // so each kind of wave fetches its arguments in ONE scalar round trip (two cost ~0.12 us per node)
     __builtin_amdgcn_s_setprio(3);
     if constexpr (PRO == GV_LNP) {
@@ -292,6 +293,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
       else if (PRO == GV_ATTN2) gv_attn2_wave<WT, NF4, S>(a, a.part + (size_t)wave * (S + 1) * a.K, a.stats + (size_t)wave * (S + 1) * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
       else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
     }
+    if (wave == 0) GV_STAMP(a, 1);  // prologue: operands landed, row prepared, LDS stores issued
     __syncthreads();
     return;
   }
@@ -344,10 +346,12 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
       load_x(0);
     }
   }
+  if (wave == NPW) GV_STAMP(a, 3);  // every load of this weight wave issued
   if (HASPRO) {
     __builtin_amdgcn_sched_barrier(0);  // the weight loads stay above the barrier
     if (PRO == GV_LNP) __syncthreads();  // the prologue waves' slab statistics
     __syncthreads();
+    if (wave == NPW) GV_STAMP(a, 4);  // prepared row available (barrier passed)
     load_x(0);
   }
   // e4m3 weights serving several utterances: convert each weight chunk to packed bf16 ONCE and run the bf16 dot products on it
@@ -391,6 +395,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
       }
     }
   }
+  if (wave == NPW) GV_STAMP(a, 5);  // weights landed, dot products and wave reductions done
   if (elive) {
     if (W8) v *= wsc;
     float* o = a.out + (size_t)em * a.out_ld + r0 + er;
@@ -398,6 +403,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
     else if (EPI == GV_RESID) *o = res_pre + v;
     else gv_store<WT>(reinterpret_cast<WT*>(a.out) + (size_t)em * a.out_ld + r0 + er, gv_gelu_erf(v));
   }
+  if (wave == NPW) GV_STAMP(a, 6);  // store issued
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -435,6 +441,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   // wave 0: the LayerNorm operands first - loads return in order, so nothing it normalises waits behind its weight burst
   float4 lv[NF4], lg[NF4], lb[NF4];
   const int b = blockIdx.z;  // utterance (round 5: 2..8 utterances run the same node, one grid slice each)
+  if (w == 0) GV_STAMP(a, 0);  // entry
   if (w == 0) {
     const float* xr = a.x + (size_t)b * a.x_ld;
 #pragma unroll
@@ -493,6 +500,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  if (w == 0) GV_STAMP(a, 1);  // every load issued
   if (w == 0) {  // LayerNorm of the row (gv_ln_row's arithmetic: shifted one-pass mean / variance), engine dtype into LDS
     const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lv[0].x)));
     float s1 = 0.f, s2 = 0.f;
@@ -510,6 +518,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, (lv[i].x - mean) * rstd * lg[i].x + lb[i].x, (lv[i].y - mean) * rstd * lg[i].y + lb[i].y,
                         (lv[i].z - mean) * rstd * lg[i].z + lb[i].z, (lv[i].w - mean) * rstd * lg[i].w + lb[i].w);
   }
+  if (w == 0) GV_STAMP(a, 2);         // residual row landed, normalised, in LDS
   __syncthreads();                    // normalised row in LDS
   // ---- the wave's 8 projection rows ---------------------------------------------------------------------------------------------
   {
@@ -534,6 +543,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
     }
     if (lane < RW) s_r[w * RW + lane] = W8 ? v * wsc : v;
   }
+  if (w == 0) GV_STAMP(a, 3);  // weight rows landed, 8 dot products + reductions done
   __syncthreads();  // the 64 projected values of this workgroup in LDS
   const int pos = P + cl - 1;  // position of the new token; cache rows [0, pos) are in place
   const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2 (attn_kernel)
@@ -610,6 +620,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
   l_run = across_groups_reduce<OpSum, LPR>(l_run);
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] = across_groups_reduce<OpSum, LPR>(o[e]);
+  if (w == 0) GV_STAMP(a, 4);  // K / V rows landed, attention loop of this wave done
   if (r == 0) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) s_o[w][c * EPL + e] = o[e];
@@ -627,6 +638,7 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
       ov += wgt * s_o[i][lane];
       lv += wgt * s_ml[i][1];
     }
+    GV_STAMP(a, 5);  // cross-wave combine done, stores next
     part[(size_t)role * a.H + h * 64 + lane] = ov;
     if (lane == 0) {
       float* st = stats + ((size_t)role * a.nheads + h) * 2;
@@ -661,6 +673,7 @@ __global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // 8 waves, all of them weight waves; wave 0 requests the LayerNorm operands first and normalises while its weights fly (qkv_attn_kernel)
   float4 lv[NF4], lg[NF4], lb[NF4];
+  if (w == 0) GV_STAMP(a, 0);  // entry
   if (w == 0) {
 #pragma unroll
     for (int i = 0; i < NF4; ++i) lv[i] = *reinterpret_cast<const float4*>(a.x + (lane + 64 * i) * 4);
@@ -691,6 +704,7 @@ __global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
   const int mk = a.mask ? a.mask[lane] : 1;
   const int nv = *a.n_valid;
   __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  if (w == 0) GV_STAMP(a, 1);  // every load issued
   if (w == 0) {  // gv_ln_row's arithmetic
     const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lv[0].x)));
     float s1 = 0.f, s2 = 0.f;
@@ -708,6 +722,7 @@ __global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
       gv_lds_store4<WT>(s_x, (lane + 64 * i) * 4, (lv[i].x - mean) * rstd * lg[i].x + lb[i].x, (lv[i].y - mean) * rstd * lg[i].y + lb[i].y,
                         (lv[i].z - mean) * rstd * lg[i].z + lb[i].z, (lv[i].w - mean) * rstd * lg[i].w + lb[i].w);
   }
+  if (w == 0) GV_STAMP(a, 2);         // residual row landed, normalised, in LDS
   __syncthreads();                    // normalised row in LDS
   {
     uint4 xv[NCH];
@@ -731,6 +746,7 @@ __global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
     }
     if (lane < RW) s_r[w * RW + lane] = v;
   }
+  if (w == 0) GV_STAMP(a, 3);  // rows of M landed, 8 dot products + reductions done
   __syncthreads();  // the head's 64 base-2 scores in LDS
   // ---- softmax over the description positions (lane = position), masked / absent positions weigh 0 (gv_softmax_wave's rules) ------
   {
@@ -750,6 +766,7 @@ __global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
     d = group_reduce<OpSum, LPR>(d);
     if (c == 0) a.xpart[(size_t)h * a.H + n0 + u * NW * RPI] = d;
   }
+  if (w == 0) GV_STAMP(a, 5);  // softmax, U rows landed, partial row stores issued
 }
 
 // ------------------------------------------------------------------------------------------------------

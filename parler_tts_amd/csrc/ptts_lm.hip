@@ -132,6 +132,9 @@ struct ptts_engine {
   std::map<long long, hipGraphExec_t> prefill_graphs;  // PTTS_PREFILL_GRAPH: the prefill forward of one (batch, description, prompt, voice-prompt) shape
   bool in_capture = false;
   int* host_pinned = nullptr;
+#ifdef PTTS_TIMING
+  long long* dbg_stamps = nullptr;  // measurement build: [layers + 1][5 nodes][3 workgroups][16] s_memtime stamps of the single-utterance step (ptts_debug_stamps)
+#endif
 
   template <typename T> int alloc(T** p, size_t n) {
     void* v = nullptr;
@@ -259,6 +262,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       if (rc_ != 0) return ptts_fail(PTTS_E_HIP, "gemv launch failed (%s)", what);
       return PTTS_OK;
     };
+#ifdef PTTS_TIMING
+#define PTTS_DBG_NODE(args, l_, k_) (args).dbg = (e->dbg_stamps && M == 1) ? e->dbg_stamps + ((size_t)(l_) * 5 + (k_)) * 48 : nullptr
+#else
+#define PTTS_DBG_NODE(args, l_, k_) do { } while (0)
+#endif
     for (int l = 0; l < c.num_layers; ++l) {
       const LayerW& w = e->L[l];
       if (fuse_qa) {  // LN1 + the head's q / k / v rows + split-KV self-attention + append in ONE node (qkv_attn_kernel), then combine + out_proj
@@ -267,9 +275,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         q.kcache = w.k_self; q.vcache = w.v_self; q.cur_len = e->cur_len; q.P = &e->dims->P; q.mask = e->prompt_mask;
         q.part = e->part; q.stats = e->stats; q.cap = c.max_ctx; q.kv_bound = e->kv_bound; q.mask_ld = e->max_prompt;
         q.S = S_f; q.nheads = nh; q.H = H; q.kv_heads = nkv; q.scale = scale; q.M = M; q.x_ld = H;
+        PTTS_DBG_NODE(q, l, 0);
         if (ptts_qkvattn_launch(mode, q, st) != 0) return ptts_fail(PTTS_E_HIP, "qkv_attn launch failed");
         GemvArgs g = {};
         g.W = w.o_rm; g.wscale = w.o_sc; g.out = e->h; g.out_ld = H; g.N = H; g.K = H; g.part = e->part; g.stats = e->stats; g.nheads = nh;
+        PTTS_DBG_NODE(g, l, 1);
         PTTS_TRY(gv(GV_ATTN2, GV_RESID, S_f, g, "combine+out_proj"));
       } else {
       {  // LN1 + fused QKV projection (:1020-1021, :848-850)
@@ -301,6 +311,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         XfoldAttnArgs x = {};
         x.Mw = w.xM; x.Uw = w.xU; x.x = e->h; x.gamma = w.ln2_g; x.beta = w.ln2_b; x.mask = e->enc_mask; x.n_valid = &e->dims->N;
         x.xpart = e->xpart; x.nheads = nh; x.H = H; x.nur = e->fuse_x_nur;
+        PTTS_DBG_NODE(x, l, 2);
         if (ptts_xfoldattn_launch(c.dtype == PTTS_F32 ? GV_F32 : GV_BF16, x, st) != 0) return ptts_fail(PTTS_E_HIP, "xfold_attn launch failed");
         x_fused = true;
       } else if (e->xfold_valid && M == 1) {
@@ -347,17 +358,20 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         GemvArgs g = {};
         g.W = w.fc1_rm; g.wscale = w.fc1_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln3_g; g.beta = w.ln3_b;
         g.out = reinterpret_cast<float*>(e->xw2); g.out_ld = F; g.N = F; g.K = H;
+        PTTS_DBG_NODE(g, l, 3);
         if (x_fused) { g.xpart = e->xpart; g.npart = nh; g.hsum = e->h2; PTTS_TRY(gv(GV_LNP, GV_GELU_WT, 1, g, "partial rows+LN3+fc1")); }
         else PTTS_TRY(gv(GV_LN, GV_GELU_WT, 1, g, "LN3+fc1"));
         GemvArgs g2 = {};
         g2.W = w.fc2_rm; g2.wscale = w.fc2_sc; g2.xw = e->xw2; g2.xw_ld = F; g2.out = e->h; g2.out_ld = H; g2.N = H; g2.K = F;
         if (x_fused) g2.resid = e->h2;  // h = (x + partial rows) + fc2(...)
+        PTTS_DBG_NODE(g2, l, 4);
         PTTS_TRY(gv(GV_COPY, GV_RESID, 1, g2, "fc2"));
       }
     }
     GemvArgs g = {};  // final LayerNorm + all K LM heads (:1632, :1917-1960)
     g.W = e->heads_rm; g.wscale = e->heads_sc; g.x = e->h; g.x_ld = H; g.gamma = e->lnf_g; g.beta = e->lnf_b; g.out = e->logits;
     g.out_ld = c.num_codebooks * c.vocab_size; g.N = c.num_codebooks * c.vocab_size; g.K = H;
+    PTTS_DBG_NODE(g, c.num_layers, 0);
     PTTS_TRY(gv(GV_LN, GV_STORE, 1, g, "final LN + LM heads"));
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "forward launch failed: %s", hipGetErrorString(err));
@@ -836,6 +850,14 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc(&e->dims, 1)); A(e->alloc(&e->gen, 1));
 #undef A
   if (hipHostMalloc((void**)&e->host_pinned, ((size_t)c.max_batch * K + 16) * 4) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipHostMalloc failed"));
+#ifdef PTTS_TIMING
+  {
+    const size_t n = (size_t)(c.num_layers + 1) * 5 * 48;
+    rc = e->alloc(&e->dbg_stamps, n);
+    if (rc != PTTS_OK) return fail(rc);
+    hipMemset(e->dbg_stamps, 0, n * sizeof(long long));
+  }
+#endif
   ptts_gen_params gp = {};
   gp.max_length = c.max_ctx; gp.temperature = 1.f; gp.top_p = 1.f; gp.use_eos_gate = 1;
   e->gp = gp;
@@ -1319,6 +1341,16 @@ extern "C" int ptts_push_tokens(ptts_engine* e, const int64_t* tokens_dev, const
   e->h_ready = false;
   return PTTS_OK;
 }
+
+#ifdef PTTS_TIMING
+// measurement build only: the stamp buffer [layers + 1][5][3][16] (device memory) of the last replayed single-utterance step
+extern "C" int ptts_debug_stamps(ptts_engine* e, long long** stamps_dev, int32_t* layers) {
+  PTTS_CHECK(e && stamps_dev && layers, PTTS_E_INVALID, "null argument");
+  *stamps_dev = e->dbg_stamps;
+  *layers = e->cfg.num_layers;
+  return PTTS_OK;
+}
+#endif
 
 extern "C" int ptts_debug_graph_nodes(ptts_engine* e, int32_t* nodes) {
   PTTS_CHECK(e && nodes, PTTS_E_INVALID, "null argument");

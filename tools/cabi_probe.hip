@@ -22,6 +22,7 @@
 // TFLOP/s at 1.608 GFLOP per frame.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -111,6 +112,9 @@ struct Filler {
 };
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#ifdef PTTS_STAMPS
+static int report_stamps(ptts_engine* e, hipStream_t st, double step_us);  // measurement build (tools/build_stamps.sh)
+#endif
 
 static const char* opt(int argc, char** argv, const char* key) {  // "key=value" -> value, bare "key" -> "", absent -> nullptr
   const size_t n = strlen(key);
@@ -274,9 +278,79 @@ static int run_lm(int argc, char** argv) {
          tag, large ? " large" : "", fp32 ? " fp32" : "", fp8 ? " fp8" : "", B, us[0], us[1], us[2], wb / 1e6, wb / 1e6 / us[1], ttft1 * 1e3, ttft2 * 1e3,
          (t_loaded - t_create) * 1e3, cur);
   fflush(stdout);
+#ifdef PTTS_STAMPS
+  if (B == 1) {
+    PT(ptts_decode_steps(e, 4, st));
+    HIPCHK(hipStreamSynchronize(st));
+    report_stamps(e, st, us[2]);
+  }
+#endif
   ptts_engine_destroy(e);
   return 0;
 }
+
+#ifdef PTTS_STAMPS
+// Measurement build (tools/build_stamps.sh: the library compiled with -DPTTS_TIMING): the s_memtime stamps every node of the single-utterance step
+// left in its last replay -> per node the phases inside the kernel, per edge the time from the producer's last store to the consumer's entry.
+extern "C" int ptts_debug_stamps(ptts_engine* e, long long** stamps_dev, int32_t* layers);
+__global__ void stamp_now_kernel(long long* p) { *p = __builtin_amdgcn_s_memtime(); }
+static int report_stamps(ptts_engine* e, hipStream_t st, double step_us) {
+  long long* dev = nullptr;
+  int32_t nl = 0;
+  PT(ptts_debug_stamps(e, &dev, &nl));
+  // tick rate of s_memtime: two stamps 20 ms apart, timed by HIP events on the same stream
+  long long* tk = nullptr;
+  HIPCHK(hipMalloc(&tk, 16));
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  stamp_now_kernel<<<1, 1, 0, st>>>(tk); HIPCHK(hipEventRecord(a, st)); HIPCHK(hipStreamSynchronize(st));
+  const double w0 = now_s();
+  while (now_s() - w0 < 0.02) {}
+  stamp_now_kernel<<<1, 1, 0, st>>>(tk + 1); HIPCHK(hipEventRecord(b, st)); HIPCHK(hipStreamSynchronize(st));
+  long long t2[2];
+  HIPCHK(hipMemcpy(t2, tk, 16, hipMemcpyDeviceToHost));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  const double tpu = (double)(t2[1] - t2[0]) / (ms * 1e3);  // ticks per microsecond
+  std::vector<long long> h((size_t)(nl + 1) * 5 * 48);
+  HIPCHK(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
+  auto S = [&](int l, int k, int slot, int idx) { return h[(((size_t)l * 5 + k) * 3 + slot) * 16 + idx]; };
+  const char* names[5] = {"qkv_attn (LN1 + q/k/v rows + self-attention + append)", "combine + out_proj + residual", "xfold_attn (LN2 + M rows + softmax + U columns)",
+                          "partial rows + LN3 + fc1 + GELU", "fc2 + residual"};
+  printf("[node stamps] s_memtime runs at %.1f ticks / us (calibrated over %.1f ms); step = %.1f us by HIP events; layers averaged: 2 .. %d\n", tpu, ms, step_us, nl - 2);
+  // first / last stamp of a node over the sampled workgroups
+  auto first_entry = [&](int l, int k) { long long m = 0; for (int s = 0; s < 3; ++s) for (int i : {0, 2}) { const long long v = S(l, k, s, i); if (v && (!m || v < m)) m = v; } return m; };
+  auto last_stamp = [&](int l, int k) { long long m = 0; for (int s = 0; s < 3; ++s) for (int i = 0; i < 16; ++i) m = std::max(m, S(l, k, s, i)); return m; };
+  const int l0 = 2, l1 = nl - 2;
+  double tot_in = 0, tot_gap = 0;
+  for (int k = 0; k < 5; ++k) {
+    double in_kernel = 0, gap = 0, ph[16] = {0};
+    int cnt[16] = {0}, n = 0;
+    for (int l = l0; l <= l1; ++l) {
+      const long long e0 = first_entry(l, k), e1 = last_stamp(l, k);
+      const int kn = (k + 1) % 5, ln = k == 4 ? l + 1 : l;
+      const long long en = first_entry(ln, kn);
+      if (!e0 || !e1 || !en) continue;
+      in_kernel += (double)(e1 - e0) / tpu; gap += (double)(en - e1) / tpu; ++n;
+      for (int i = 1; i < 8; ++i) {  // phases of the FIRST sampled workgroup, relative to its own entry (weight wave: idx 2 when present)
+        const long long v = S(l, k, 0, i), base = (i >= 3 && S(l, k, 0, 2)) ? S(l, k, 0, 2) : S(l, k, 0, 0);
+        if (v && base) { ph[i] += (double)(v - base) / tpu; ++cnt[i]; }
+      }
+    }
+    if (!n) { printf("[node stamps] node %d: no stamps\n", k); continue; }
+    tot_in += in_kernel / n; tot_gap += gap / n;
+    printf("[node stamps] node %d %-58s first entry -> last sampled stamp %.2f us | last stamp -> next node's first entry %.2f us | workgroup 0 phases (us from its entry):", k,
+           names[k], in_kernel / n, gap / n);
+    for (int i = 1; i < 8; ++i) if (cnt[i]) printf(" s%d=%.2f", i, ph[i] / cnt[i]);
+    printf("\n");
+  }
+  printf("[node stamps] per layer: in-kernel %.2f us + boundaries %.2f us = %.2f us (x %d layers = %.1f us of the %.1f us step); a boundary = %.2f us on average\n", tot_in,
+         tot_gap, tot_in + tot_gap, nl, (tot_in + tot_gap) * nl, step_us, tot_gap / 5);
+  printf("[node stamps] stamp legend - qkv_attn / xfold_attn (wave 0): s1 loads issued, s2 row normalised, s3 projection rows done, s4 attention loop done, s5 combine done; "
+         "GEMV nodes: s1 prologue wave done (row prepared), s3 weight wave: loads issued, s4 barrier passed, s5 dot products + reductions done, s6 store issued\n");
+  return 0;
+}
+#endif
 
 static int run_dac(int argc, char** argv) {
   const int B = atoi(argv[2]);
