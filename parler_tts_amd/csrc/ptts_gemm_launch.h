@@ -57,6 +57,47 @@ int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t 
   return PTTS_OK;
 }
 
+// prefill-sized rows on the LDS-tiled kernel (gemm_tile_kernel): the largest tile that still gives every CU a workgroup
+template <typename WT, int EPI, int BNS, int BMT>
+int launch_gemm_tile_inst(const GemmArgs& a, hipStream_t st) {
+  constexpr size_t sh = (size_t)2 * (BNS + BMT) * 2 * 64 * 16;
+  static PttsPerDeviceOnce attr_once;
+  const int attr_dev = PttsPerDeviceOnce::device();
+  if (attr_once.need(attr_dev)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<WT, EPI, BNS, BMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+    attr_once.done(attr_dev);
+  }
+  const dim3 grid(a.N / (16 * BNS), (a.M + BMT * 16 - 1) / (BMT * 16));
+  hipLaunchKernelGGL((gemm_tile_kernel<WT, EPI, BNS, BMT>), grid, dim3(256), sh, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+// -1 = shape not served (the caller keeps the register-blocked kernel)
+template <typename WT, int EPI>
+int launch_gemm_tile(const GemmArgs& a, hipStream_t st) {
+  static const int mode = getenv("PTTS_GEMM_TILE") ? atoi(getenv("PTTS_GEMM_TILE")) : 1;  // 0: off (gemm_block_kernel), 1: by workgroup count, 88 / 48 / 84 / 44: force a tile
+  const int nstrips = a.N / 16, nfrag = a.K / Elem<WT>::KT;
+  if (!mode || nstrips % 4 || nfrag % 2 || a.K % Elem<WT>::KT) return -1;
+  auto wgs = [&](int bns, int bmt) { return (nstrips / bns) * ((a.M + bmt * 16 - 1) / (bmt * 16)); };
+  int pick = 44;
+  if (mode == 1) {
+    if (nstrips % 8 == 0 && wgs(8, 8) >= 224) pick = 88;
+    else if (wgs(4, 8) >= 224) pick = 48;
+    else if (nstrips % 8 == 0 && wgs(8, 4) >= 224) pick = 84;
+  } else {
+    pick = mode;
+    if ((pick == 88 || pick == 84) && nstrips % 8) pick = pick == 88 ? 48 : 44;
+  }
+  switch (pick) {
+    case 88: return launch_gemm_tile_inst<WT, EPI, 8, 8>(a, st);
+    case 48: return launch_gemm_tile_inst<WT, EPI, 4, 8>(a, st);
+    case 84: return launch_gemm_tile_inst<WT, EPI, 8, 4>(a, st);
+    default: return launch_gemm_tile_inst<WT, EPI, 4, 4>(a, st);
+  }
+}
+
 template <typename WT, int PRO, int EPI>
 int launch_gemm(GemmArgs a, hipStream_t st) {
   constexpr int KT = Elem<WT>::KT;
@@ -107,6 +148,10 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   if constexpr (PRO == PRO_COPY) {
     static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
     // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
+    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part && !a.stats_out && !a.W8) {  // LDS-tiled kernel first (round 5)
+      const int rt = launch_gemm_tile<WT, EPI>(a, st);
+      if (rt != -1) return rt;
+    }
     if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part) {  // (pending split-K partials are folded by the strip kernel's EPI_RESID only)  // prefill-sized: register-blocked kernel, no K split
       const int nstrips = a.N / 16;
       const int ns = (nstrips % 4 == 0 && nstrips >= 128) ? 4 : (nstrips % 2 == 0 ? 2 : 0);  // N = 1024: 2 strips per wave keeps > 500 waves in flight
@@ -198,6 +243,21 @@ int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
   else hipLaunchKernelGGL((attn_kernel<WT, 4>), grid, dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "attn launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+// prefill attention, tiled (prefill_attn_kernel): 8 query rows per workgroup; Q = a.Q rows per utterance, output in a.direct_out
+template <typename WT>
+int launch_prefill_attn(const AttnArgs& a, int B, hipStream_t st) {
+  const dim3 grid((a.Q + 7) / 8, a.nheads, B);
+  if (a.kscale) {
+    if constexpr (sizeof(WT) == 2) hipLaunchKernelGGL((prefill_attn_kernel<WT, true>), grid, dim3(256), 0, st, a);
+    else return ptts_fail(PTTS_E_UNSUPPORTED, "kv_fp8 needs the bf16 engine");
+  } else {
+    hipLaunchKernelGGL((prefill_attn_kernel<WT, false>), grid, dim3(256), 0, st, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "prefill attention launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
 }
 

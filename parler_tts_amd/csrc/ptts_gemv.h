@@ -12,9 +12,11 @@ constexpr int GV_PMAX = 24;  // partial rows (= attention heads) the GV_LNP inst
 enum { GV_F32 = 0, GV_BF16 = 1, GV_BF16_W8 = 2 };  // engine dtype of activations / weights; W8 = OCP e4m3 weights, bf16 activations
 
 // ---- measurement build only (-DPTTS_TIMING: tools/build_stamps.sh -> tools/stamps/, never the product library) --------------------------------
-// Every node of the single-utterance step stamps s_memtime at its phases into dbg[3 sampled workgroups][16] (first / middle / last workgroup of
-// the launch; lane 0 of the wave named at the call site). One global counter: stamps of different kernels of the same replay compare directly
-// (entry-to-entry = kernel boundary + the phases in between). VERDICT r04 item 5; report: profiles/r05_node_stamps.txt.
+// Every node of the single-utterance step stamps the device-wide constant-rate counter (wall_clock64 = s_memrealtime, 100 MHz: 10 ns) at its phases
+// into dbg[3 sampled workgroups][16] (first / middle / last workgroup of the launch; lane 0 of the wave named at the call site). s_memtime is NOT
+// usable here: it counts shader cycles PER XCD with unrelated offsets (first attempt, call 4: negative intervals between workgroups of different
+// XCDs). One global counter: stamps of different kernels of the same replay compare directly (entry-to-entry = kernel boundary + the phases in
+// between). VERDICT r04 item 5; report: profiles/r05_node_stamps.txt.
 #ifdef PTTS_TIMING
 #define GV_DBG_FIELDS long long* dbg;
 #define GV_STAMP(a, idx)                                                                                                   \
@@ -22,7 +24,7 @@ enum { GV_F32 = 0, GV_BF16 = 1, GV_BF16_W8 = 2 };  // engine dtype of activation
     if ((a).dbg && (threadIdx.x & 63) == 0) {                                                                              \
       const unsigned nb_ = gridDim.x * gridDim.y * gridDim.z, lb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
       const int slot_ = lb_ == 0 ? 0 : (lb_ == nb_ / 2 ? 1 : (lb_ == nb_ - 1 ? 2 : -1));                                   \
-      if (slot_ >= 0) (a).dbg[slot_ * 16 + (idx)] = __builtin_amdgcn_s_memtime();                                          \
+      if (slot_ >= 0) (a).dbg[slot_ * 16 + (idx)] = (long long)wall_clock64();                                          \
     }                                                                                                                      \
   } while (0)
 #else

@@ -398,6 +398,8 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   //  time-to-first-token path: prefill 1.41 -> 1.29 ms, first token 2.41 -> 2.28 ms at 33 rows, profiles/r05_experiments.txt call 2; PTTS_LNPROJ_PREFILL=0: off)
   static const bool lnproj_prefill = !(getenv("PTTS_LNPROJ_PREFILL") && !atoi(getenv("PTTS_LNPROJ_PREFILL")));
   const bool lnproj_ok = lnproj > 0 && (!prefill || (lnproj_prefill && M <= 40)) && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
+  // prefill attention on the tiled kernel (8 query rows per workgroup share the K / V tile; PTTS_PREFILL_ATTN=0: one workgroup per query row, attn_kernel)
+  const bool prefill_attn = !(getenv("PTTS_PREFILL_ATTN") && !atoi(getenv("PTTS_PREFILL_ATTN")));
   bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
@@ -438,7 +440,8 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.kscale = w.ks_self; a.vscale = w.vs_self;
       a.direct_out = S_used == 1 ? e->xw : nullptr; a.out_fo = fo;
       a.exact_len = (!prefill && M > 8 && e->attn_exact) ? 1 : 0;
-      PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
+      if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st)));
+      else PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
       GemmArgs g = {}; g.decode = dec;
@@ -501,7 +504,8 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.kv_heads = nkc; a.n_rep = nh / nkc;
       a.fused_append = 0; a.scale = scale;
       a.direct_out = e->xw; a.out_fo = fo;  // the description is short: never split, softmax finished in the attention kernel
-      PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->cross_waves)));  // decode: as few waves as cover the description (no LDS combine at 1)
+      if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st)));
+      else PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->cross_waves)));  // decode: as few waves as cover the description (no LDS combine at 1)
     }
     }
     {  // cross out_proj + residual, activations read straight from the attention output

@@ -799,6 +799,98 @@ __global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// gemm_tile_kernel (round 5): prefill-sized M (> 256 rows: 32 utterances x 33 prompt positions, 32 descriptions x 64 tokens in the T5 encoder) is
+// COMPUTE-bound, and gemm_block_kernel above feeds its MFMAs straight from L1 / L2: 0.5 KB of operand loads per MFMA against a 64 B/clk L1 - it ran
+// the batch-32 prefill at ~70 and the T5 encoder at ~215 TFLOP/s (profiles/r05_experiments.txt call 4). This one is the classic LDS-tiled form:
+// a workgroup owns BNS weight strips x BMT row tiles (128 x 128 outputs at 8 x 8) over the whole K; per stage of two k fragments every thread copies
+// its share of the A tile (weights, already in fragment order: contiguous 1 KiB pieces) and of the B tile (engine-dtype rows, 128 contiguous bytes
+// per row, re-ordered to fragment order on the way into LDS) global -> registers -> LDS, double-buffered with ONE barrier per stage; the 2 x 2 waves
+// each hold (BNS / 2) x (BMT / 2) accumulator tiles and read every fragment as one conflict-free ds_read_b128 per lane. No K split: deterministic.
+// Epilogues: gemm_store_tile (store / residual / GELU / gated GELU / cross K-V scatter).
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, int EPI, int BNS, int BMT>
+__global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
+  constexpr int KT = Elem<WT>::KT;
+  constexpr int NS = BNS / 2, MT = BMT / 2;              // strips / row tiles per wave
+  constexpr int ACH = BNS / 2, BCH = BMT / 2;            // 16-byte pieces per thread and stage (BNS * 128 / 256, BMT * 128 / 256)
+  constexpr int STAGE = (BNS + BMT) * 2 * 64;            // uint4 per LDS stage: [BNS strips][2 frags][64] + [BMT tiles][2 frags][64]
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint4* sm = reinterpret_cast<uint4*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 1, wm = wave >> 1;
+  const int q = lane >> 4, j = lane & 15;
+  const int strip0 = blockIdx.x * BNS, m0 = blockIdx.y * BMT * 16;
+  const int nfrag = a.K / KT, nstage = nfrag >> 1;       // host guarantees an even fragment count
+  const uint4* gA[ACH];
+  const uint4* gB[BCH];
+  int sA[ACH], sB[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const int ca = tid + 256 * i, strip = ca >> 7, frag = (ca >> 6) & 1, ln = ca & 63;
+    gA[i] = reinterpret_cast<const uint4*>(a.W) + ((size_t)(strip0 + strip) * nfrag + frag) * 64 + ln;
+    sA[i] = (strip * 2 + frag) * 64 + ln;
+  }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int cb = tid + 256 * i, rl = cb >> 3, kc = cb & 7;  // row of the tile, 16-byte piece of the stage's 2 * KT elements
+    const int row = min(m0 + rl, a.M - 1);                    // clamped rows are computed and dropped
+    gB[i] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.x) + (size_t)(row * a.x_row_mul + a.x_row_off) * a.x_ld) + kc;
+    sB[i] = BNS * 128 + ((rl >> 4) * 2 + (kc >> 2)) * 64 + (kc & 3) * 16 + (rl & 15);
+  }
+  f32x4 acc[NS][MT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 ra[ACH], rb[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) ra[i] = gA[i][0];
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) rb[i] = gB[i][0];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) sm[sA[i]] = ra[i];
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) sm[sB[i]] = rb[i];
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    if (more) {  // next stage's pieces in flight under this stage's MFMAs
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) ra[i] = gA[i][(size_t)(st + 1) * 128];  // two fragments = 128 uint4 further along the strip
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) rb[i] = gB[i][(size_t)(st + 1) * 8];    // two fragments = 8 pieces further along the row
+    }
+    const uint4* cur = sm + (st & 1) * STAGE;
+#pragma unroll
+    for (int frag = 0; frag < 2; ++frag) {
+      uint4 af[NS], bf[MT];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = cur[((wn * NS + s) * 2 + frag) * 64 + lane];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = cur[BNS * 128 + ((wm * MT + mt) * 2 + frag) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[s][mt] = MfmaStep<WT>::run(af[s], bf[mt], acc[s][mt]);
+    }
+    if (more) {
+      uint4* nxt = sm + ((st + 1) & 1) * STAGE;  // read last in stage st - 1: every wave has passed that stage's barrier
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) nxt[sA[i]] = ra[i];
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) nxt[sB[i]] = rb[i];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + (wm * MT + mt) * 16 + j;
+      if (m < a.M) gemm_store_tile<WT, EPI>(a, m, (strip0 + wn * NS + s) * 16 + q * 4, acc[s][mt]);  // D[row = q*4 + r][col = j]
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // rows_prep_kernel: for M > 8 rows (batch 32, prefill) the LayerNorm / split-KV combine is computed ONCE here
 // (one wave per row) into an engine-dtype [M][K] buffer that the GEMM then stages with plain 16-byte copies
 // (PRO_COPY). At M <= 8 the fused prologues win (one graph node less: 1.58 us + a latency chain).
@@ -1248,6 +1340,123 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       st[0] = M;
       st[1] = lv;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// prefill_attn_kernel (round 5): the attention of the PREFILL (Q = P + 1 [+ voice-prompt] positions per utterance, K/V of at most a few tiles),
+// self (causal, prompt padding mask) and cross (description mask), as a tiled kernel: one workgroup = 8 consecutive query rows of one
+// (utterance, head), 4 waves x 2 queries; the K / V rows of a 64-position tile are read from the cache ONCE per workgroup into LDS (fp32, as the
+// cache holds them: engine dtype or e4m3 x row scale) and shared by the 8 queries; lane = key for the scores, lane = head dimension for P V;
+// online softmax in base 2 across tiles. attn_kernel ran one workgroup per QUERY ROW here, every one re-reading the utterance's K / V rows:
+// 16 896 workgroups and 89 us per launch at 32 utterances x 33 positions, 48 launches = 4.3 of the 10.6 ms of that prefill
+// (profiles/r04_step_bf16_bs32_v2.txt). Same semantics as attn_kernel with S = 1 (masked keys carry no weight; a row without a visible key
+// yields 0; RoPE on q, also in the cross block - quirk :858 vs :880); output = the normalised context in the engine dtype (direct_out).
+// Reference: modeling_parler_tts.py:906-914 (SDPA), :1474-1501 / :1553-1562 (masks).
+// ------------------------------------------------------------------------------------------------------
+template <typename WT, bool KV8 = false>
+__global__ void __launch_bounds__(256) prefill_attn_kernel(AttnArgs a) {
+  static_assert(!KV8 || sizeof(WT) == 2, "e4m3 cache: bf16 engine");
+  constexpr int QW = 2, QB = 4 * QW, EPL = Elem<WT>::EPL;
+  __shared__ float sK[64 * 65];
+  __shared__ __attribute__((aligned(16))) float sV[64 * 64];
+  __shared__ float sQ[QB][64];
+  __shared__ float sP[QB][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * QB;
+  const int kvh = h / a.n_rep;
+  const int P = a.dims->P;
+  const int Lmax = a.cross ? a.dims->N : min(i0 + QB, a.Q);  // keys any query of this workgroup can see (self: causal, position = row index)
+  const int mask_len = a.cross ? Lmax : P;
+  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2 (attn_kernel)
+  for (int e = tid; e < QB * 64; e += 256) {  // the workgroup's query rows, RoPE-rotated at their own position, pre-scaled
+    const int qi = e >> 6, d = e & 63, i = min(i0 + qi, a.Q - 1);
+    const float* qr = a.q + (size_t)(b * a.Q + i) * a.q_ld + h * 64;
+    float v = qr[d];
+    if (a.cos) {
+      const float other = d < 32 ? -qr[d + 32] : qr[d - 32];
+      v = v * a.cos[(size_t)i * 64 + d] + other * a.sin[(size_t)i * 64 + d];
+    }
+    sQ[qi][d] = v * qscale;
+  }
+  const char* Kc = reinterpret_cast<const char*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64 * (KV8 ? 1 : sizeof(WT));
+  const char* Vc = reinterpret_cast<const char*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64 * (KV8 ? 1 : sizeof(WT));
+  const float* Ks = KV8 ? a.kscale + ((size_t)b * a.kv_heads + kvh) * a.cap : nullptr;
+  const float* Vs = KV8 ? a.vscale + ((size_t)b * a.kv_heads + kvh) * a.cap : nullptr;
+  float m_run[QW], l_run[QW], o[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) { m_run[q] = -INFINITY; l_run[q] = 0.f; o[q] = 0.f; }
+  for (int j0 = 0; j0 < Lmax; j0 += 64) {
+    __syncthreads();  // the previous tile is consumed (first pass: sQ is visible)
+    // stage the tile: 64 rows x 8 pieces of 8 elements per matrix, one piece per (thread, pass)
+    for (int e = tid; e < 64 * 8; e += 256) {
+      const int r = e >> 3, c8 = e & 7, j = j0 + r;
+      float kx[8], vx[8];
+      if (j < Lmax) {
+        if constexpr (KV8) {
+          const float ks = Ks[j], vs = Vs[j];
+          kv8_unpack8(reinterpret_cast<const uint2*>(Kc + (size_t)j * 64)[c8], kx);
+          kv8_unpack8(reinterpret_cast<const uint2*>(Vc + (size_t)j * 64)[c8], vx);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { kx[i] *= ks; vx[i] *= vs; }
+        } else {
+          const WT* kr = reinterpret_cast<const WT*>(Kc) + (size_t)j * 64 + c8 * 8;
+          const WT* vr = reinterpret_cast<const WT*>(Vc) + (size_t)j * 64 + c8 * 8;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { kx[i] = Elem<WT>::ld(kr + i); vx[i] = Elem<WT>::ld(vr + i); }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kx[i] = 0.f; vx[i] = 0.f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sK[r * 65 + c8 * 8 + i] = kx[i]; sV[r * 64 + c8 * 8 + i] = vx[i]; }
+    }
+    __syncthreads();
+    const int j = j0 + lane;
+    const int mk = (mrow && j < mask_len && j < a.mask_ld) ? mrow[j] : 1;
+    float s[QW];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) s[q] = 0.f;
+    for (int d = 0; d < 64; ++d) {
+      const float kd = sK[lane * 65 + d];
+#pragma unroll
+      for (int q = 0; q < QW; ++q) s[q] = fmaf(sQ[w * QW + q][d], kd, s[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      const int i = i0 + w * QW + q;                 // query row = position (prefill)
+      const int L = a.cross ? Lmax : min(i, a.Q - 1) + 1;
+      const bool ok = j < L && (j >= mask_len || mk != 0);
+      const float sc = ok ? s[q] : -INFINITY;
+      const float m_new = fmaxf(m_run[q], wave_max(sc));
+      float p = 0.f, alpha = 1.f;
+      if (m_new != -INFINITY) {  // wave-uniform
+        alpha = m_run[q] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run[q] - m_new);
+        p = ok ? __builtin_amdgcn_exp2f(sc - m_new) : 0.f;
+      }
+      l_run[q] = l_run[q] * alpha + wave_sum(p);
+      o[q] *= alpha;
+      m_run[q] = m_new;
+      sP[w * QW + q][lane] = p;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < 64; ++jj) {
+      const float v = sV[jj * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < QW; ++q) o[q] = fmaf(sP[w * QW + q][jj], v, o[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const int i = i0 + w * QW + q;
+    if (i >= a.Q) continue;
+    const int row = b * a.Q + i, kcol = h * 64 + lane;
+    WT* dst = reinterpret_cast<WT*>(a.direct_out);
+    if (a.out_fo) dst += fo_vec_index<WT>(row, kcol & ~(EPL - 1), a.H / Elem<WT>::KT) * EPL + (kcol & (EPL - 1));
+    else dst += (size_t)row * a.H + kcol;
+    store_from_f32<WT>(dst, l_run[q] > 0.f ? o[q] / l_run[q] : 0.f);
   }
 }
 

@@ -397,6 +397,29 @@ def test_fused_qkv_attention_default_bound_is_three_utterances():
         eng.close()
 
 
+@pytest.mark.parametrize("rope", [False, True])
+def test_prefill_attention_tiled_kernel_vs_one_workgroup_per_row(rope, monkeypatch):
+    """prefill_attn_kernel (round 5: 8 query rows per workgroup share the K / V tile; default) against attn_kernel's one-workgroup-per-row
+    prefill (PTTS_PREFILL_ATTN=0) and both against the oracle: 70 prompt positions (two key tiles, causal boundary inside a tile), ragged
+    prompt / description masks incl. a fully padded prompt head, grouped-query attention, RoPE (q rotated in both blocks, cross keys not),
+    fp32 and bf16; 3 utterances (M = 213 rows) and 9 (M = 639: block GEMMs, row-major activations)."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512, rope_embeddings=rope, num_key_value_heads=4, num_cross_attention_key_value_heads=2)
+    sd = DO.make_decoder_weights(spec, seed=53)
+    for bsz in (3, 9):
+        for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
+            runs = {}
+            for tiled in (True, False):
+                monkeypatch.setenv("PTTS_PREFILL_ATTN", "1" if tiled else "0")
+                runs[tiled], ref = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=70, P=70, steps=1, masks=True, seed=17, max_ctx=128, return_logits=True)
+            monkeypatch.delenv("PTTS_PREFILL_ATTN", raising=False)
+            for tiled in (True, False):
+                err = max(float((a - b).abs().max()) for a, b in zip(runs[tiled], ref))
+                assert err < tol, (bsz, prec, "tiled" if tiled else "per row", err)
+            if dtype == torch.float32:
+                ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
+                assert 0.0 < ab < 2e-5, (bsz, "tiled vs per-row prefill attention", ab)
+
+
 @pytest.mark.parametrize("bsz", [12, 40, 70])
 def test_e4m3_kv_cache_mode(bsz):
     """ptts_config::kv_fp8 (opt-in, engines of more than 8 utterances): the self-attention cache holds e4m3 rows + one power-of-two scale per

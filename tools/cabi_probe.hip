@@ -290,10 +290,10 @@ static int run_lm(int argc, char** argv) {
 }
 
 #ifdef PTTS_STAMPS
-// Measurement build (tools/build_stamps.sh: the library compiled with -DPTTS_TIMING): the s_memtime stamps every node of the single-utterance step
+// Measurement build (tools/build_stamps.sh: the library compiled with -DPTTS_TIMING): the wall_clock64 stamps every node of the single-utterance step
 // left in its last replay -> per node the phases inside the kernel, per edge the time from the producer's last store to the consumer's entry.
 extern "C" int ptts_debug_stamps(ptts_engine* e, long long** stamps_dev, int32_t* layers);
-__global__ void stamp_now_kernel(long long* p) { *p = __builtin_amdgcn_s_memtime(); }
+__global__ void stamp_now_kernel(long long* p) { *p = (long long)wall_clock64(); }
 static int report_stamps(ptts_engine* e, hipStream_t st, double step_us) {
   long long* dev = nullptr;
   int32_t nl = 0;
@@ -317,7 +317,10 @@ static int report_stamps(ptts_engine* e, hipStream_t st, double step_us) {
   auto S = [&](int l, int k, int slot, int idx) { return h[(((size_t)l * 5 + k) * 3 + slot) * 16 + idx]; };
   const char* names[5] = {"qkv_attn (LN1 + q/k/v rows + self-attention + append)", "combine + out_proj + residual", "xfold_attn (LN2 + M rows + softmax + U columns)",
                           "partial rows + LN3 + fc1 + GELU", "fc2 + residual"};
-  printf("[node stamps] s_memtime runs at %.1f ticks / us (calibrated over %.1f ms); step = %.1f us by HIP events; layers averaged: 2 .. %d\n", tpu, ms, step_us, nl - 2);
+  int khz = 0;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+  printf("[node stamps] wall_clock64 runs at %.2f ticks / us (calibrated over %.1f ms; hipDeviceAttributeWallClockRate %d kHz); step = %.1f us by HIP events; layers averaged: 2 .. %d\n",
+         tpu, ms, khz, step_us, nl - 2);
   // first / last stamp of a node over the sampled workgroups
   auto first_entry = [&](int l, int k) { long long m = 0; for (int s = 0; s < 3; ++s) for (int i : {0, 2}) { const long long v = S(l, k, s, i); if (v && (!m || v < m)) m = v; } return m; };
   auto last_stamp = [&](int l, int k) { long long m = 0; for (int s = 0; s < 3; ++s) for (int i = 0; i < 16; ++i) m = std::max(m, S(l, k, s, i)); return m; };
