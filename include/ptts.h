@@ -181,8 +181,10 @@ typedef struct {
   int32_t num_rates;
   int32_t rates[8];
   int32_t compute_dtype; /* PTTS_F32: exact-f32 MFMA and exact sinf (parity, RMS <= 1e-4); PTTS_BF16: bf16 MFMA operands and bf16
-                            activations between layers, fp32 accumulate / bias / residual stream, Snake's sin on v_sin_f32 (waveform
-                            within 3 % RMS of the fp32 oracle: measured 1.7 %) */
+                            activations between layers, fp32 accumulate / bias / residual stream, Snake's sin on v_sin_f32. Contract of the
+                            bf16 mode: every decoder stage within 2e-4 relative RMS of the bf16-operand oracle on IDENTICAL inputs (measured
+                            3-5e-5, tests/test_dac_stage_parity_gpu.py) and the whole decode within 2e-2 of that oracle end to end (measured
+                            9.8e-3 at 860 frames: the floor of any bf16 evaluation of this stack, profiles/r04_dac_bf16_sensitivity.txt) */
   int32_t max_batch, max_frames;
   int32_t device;
   int32_t encoder_dim;   /* 0: decode only; > 0: also build the encoder (descript default 64) for ptts_dac_encode */

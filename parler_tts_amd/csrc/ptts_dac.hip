@@ -47,7 +47,7 @@ struct ConvArgs {
 };
 
 // valid input rows of utterance b (buffers keep the full stride a.Tin)
-__device__ __forceinline__ int valid_rows(const ConvArgs& a, int b) { return a.lens ? min(a.Tin, a.lens[b] * a.len_mul) : a.Tin; }
+__device__ __forceinline__ int valid_rows(const ConvArgs& a, int b) { return a.lens ? min(a.Tin, max(a.lens[b], 0) * a.len_mul) : a.Tin; }  // lengths clamped to [0, T]
 
 // FAST (bf16-operand mode, whose activations are rounded to bf16 anyway): v_sin_f32 on a*x / 2pi instead of the ~100-instruction
 // exact sinf - the Snake epilogue of the 42 M-element layers was ~100 us of VALU per layer (profiles/r02_dac_layers.txt).

@@ -180,8 +180,12 @@ def generate_sharded(model, inputs=None, dst=0, group=None, **kwargs):
     # ---- metadata: rows and padded width of every rank's block ------------------------------------------------------------
     backend = dist.get_backend(group)
     cdev = model.device if backend == "nccl" else torch.device("cpu")  # RCCL moves device tensors, gloo host tensors
-    nrs = int(full.get("num_return_sequences") or getattr(getattr(model, "generation_config", None), "num_return_sequences", 1) or 1)
-    per = shard_range(B, 0, world)[1] * max(1, nrs)  # rows of the largest shard (rank 0's): every rank knows it without a collective
+    # rows of the largest block: taken from what generate() RETURNED on every rank (one tiny max-all-reduce), not recomputed from the arguments -
+    # a `generation_config=` object carrying num_return_sequences, or any other expansion of the batch, would otherwise leave one rank with more rows
+    # than the metadata tensor holds: a shape error on that rank only, and the others hanging in the all_gather
+    per_t = torch.tensor([len(lens)], dtype=torch.int64, device=cdev)
+    dist.all_reduce(per_t, op=dist.ReduceOp.MAX, group=group)
+    per = int(per_t.item())
     meta = torch.zeros(2 + per, dtype=torch.int64)
     meta[0], meta[1] = wav.shape[0], wav.shape[1]
     if lens:

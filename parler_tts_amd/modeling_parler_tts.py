@@ -649,6 +649,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             for e in es:
                 e.close()
             es = []
+            for e in self.__dict__.get("_engines", {}).values():  # the single-engine cache holds another packed copy of the same weights (+ its KV arena)
+                e.close()
+            self.__dict__["_engines"] = {}
             for _ in range(n):
                 e = DecoderEngine(hidden_size=d.hidden_size, num_layers=d.num_hidden_layers, num_heads=d.num_attention_heads, ffn_dim=d.ffn_dim,
                                   num_codebooks=d.num_codebooks, vocab_size=d.vocab_size, max_positions=d.max_position_embeddings,
@@ -666,7 +669,9 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         engine and HIP stream. Measured (profiles/r03_experiments.txt, r04_experiments.txt): batch 32 as 2 x 16 loses (a latency-bound chain does
         not get shorter with fewer rows); 64 as 2 x 32 won 7.5 % while the strip GEMMs ran 64-row passes and is neutral since they run 2..3
         lighter passes (call 26: 1690 vs 1698 ms per generate() at 64, 2137 vs 2126 at 96, 2541 vs 2534 at 128); four sub-batches are 2.7-3.3x
-        slower, and so are four or more single-utterance engines (call 20). No automatic split any more."""
+        slower, and so are four or more single-utterance engines (call 20). No automatic split any more.
+        Greedy outputs equal the single-engine run (tests/test_generate_glue_cpu.py, tests/test_generate_gpu.py); with do_sample=True sub-batch i draws
+        from seed + i, so the samples differ from the single-engine run of the same torch seed (still deterministic for a given seed and split)."""
         n = int(getattr(self, "decode_streams", 0) or os.environ.get("PTTS_DECODE_STREAMS", "0") or 0)
         if n == 0:
             n = 1
