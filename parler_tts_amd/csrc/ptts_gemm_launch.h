@@ -148,6 +148,8 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   if constexpr (PRO == PRO_COPY) {
     static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
     // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
+    static const int xcd_swz = !(getenv("PTTS_GEMM_XCD") && !atoi(getenv("PTTS_GEMM_XCD")));
+    a.xcd_swz = xcd_swz;
     if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part && !a.stats_out && !a.W8) {  // LDS-tiled kernel first (round 5)
       const int rt = launch_gemm_tile<WT, EPI>(a, st);
       if (rt != -1) return rt;

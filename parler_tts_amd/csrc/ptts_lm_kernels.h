@@ -115,6 +115,7 @@ struct GemmArgs {
   int kv_nlayers;            // of EVERY layer in one launch (24 launches of ~8 us sat on the time-to-first-token path); null = W / kcache / vcache
   int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
   int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
+  int xcd_swz;         // gemm_block_kernel / gemm_tile_kernel: XCD-aware tile order (xcd_tile_order), set by launch_gemm (PTTS_GEMM_XCD=0: launch order)
   int decode;          // host-side launch policy only: 1 = a decode-step GEMM (light M passes, msplit_rows), 0 = prefill-sized rows
   int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
   float rms_eps;       // PRO_RMS: T5Config.layer_norm_epsilon
@@ -744,13 +745,38 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int m, int n,
   }
 }
 
+// XCD-aware tile order for the 2-D grids of the prefill-sized GEMMs (round 5). The dispatcher places workgroup b (x fastest) on XCD b % 8, each
+// XCD with its own 4 MiB L2: in launch order the 8 neighbours that share a weight panel sit on 8 different L2s and every XCD streams EVERY panel
+// of both operands (measured: the batch-32 T5 GEMMs moved ~200 MB per launch at ~3 TB/s - L2-miss bound). Remapped, XCD x owns one contiguous
+// (RN x RM) region of the tile grid (RN * RM = 8), so a panel is fetched by ONE XCD. Bijective; grids it cannot split evenly keep launch order
+// (a speed choice only: the placement itself is not guaranteed by the runtime).
+__device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int swz) {
+  const int NB = gridDim.x, MB = gridDim.y, total = NB * MB;
+  bx = blockIdx.x; by = blockIdx.y;
+  if (!swz || total % 8) return;
+  int RM = 2, RN = 4;
+  if (MB % 2 || NB % 4) {
+    if (NB % 8 == 0) { RM = 1; RN = 8; }
+    else if (MB % 4 == 0 && NB % 2 == 0) { RM = 4; RN = 2; }
+    else if (MB % 8 == 0) { RM = 8; RN = 1; }
+    else return;
+  }
+  const int lin = by * NB + bx, xcd = lin & 7, slot = lin >> 3;
+  const int nbr = NB / RN, mbr = MB / RM;  // tiles per region along N / M: slot runs over nbr * mbr = total / 8 of them
+  bx = (xcd % RN) * nbr + slot % nbr;
+  by = (xcd / RN) * mbr + slot / nbr;
+  (void)mbr;
+}
+
 template <typename WT, int EPI, int NS>
 __global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
   constexpr int KT = Elem<WT>::KT, MT = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, j = lane & 15;
-  const int strip0 = blockIdx.x * NS;
-  const int m0 = (blockIdx.y * 4 + wave) * (16 * MT);
+  int bx, by;
+  xcd_tile_order(bx, by, a.xcd_swz);
+  const int strip0 = bx * NS;
+  const int m0 = (by * 4 + wave) * (16 * MT);
   if (m0 >= a.M) return;
   const int nfrag = a.K / KT;
   const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip0 * nfrag * 64 + lane;
@@ -808,32 +834,49 @@ __global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
 // each hold (BNS / 2) x (BMT / 2) accumulator tiles and read every fragment as one conflict-free ds_read_b128 per lane. No K split: deterministic.
 // Epilogues: gemm_store_tile (store / residual / GELU / gated GELU / cross K-V scatter).
 // ------------------------------------------------------------------------------------------------------
+// (staging registers and fragments are ext_vector values, not HIP's uint4 struct: arrays of the struct type assigned under the loop's conditions were
+//  kept in scratch memory by the compiler - every global load followed by a scratch store, i.e. no prefetch at all: the 131 TFLOP/s of call 5)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <typename WT> __device__ __forceinline__ f32x4 mfma_step_v(const u32x4_t& a, const u32x4_t& b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mfma_step_v<bf16_t>(const u32x4_t& a, const u32x4_t& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma_step_v<float>(const u32x4_t& a, const u32x4_t& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  return c;
+}
+
 template <typename WT, int EPI, int BNS, int BMT>
 __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
   constexpr int KT = Elem<WT>::KT;
   constexpr int NS = BNS / 2, MT = BMT / 2;              // strips / row tiles per wave
   constexpr int ACH = BNS / 2, BCH = BMT / 2;            // 16-byte pieces per thread and stage (BNS * 128 / 256, BMT * 128 / 256)
-  constexpr int STAGE = (BNS + BMT) * 2 * 64;            // uint4 per LDS stage: [BNS strips][2 frags][64] + [BMT tiles][2 frags][64]
+  constexpr int STAGE = (BNS + BMT) * 2 * 64;            // 16-byte slots per LDS stage: [BNS strips][2 frags][64] + [BMT tiles][2 frags][64]
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  uint4* sm = reinterpret_cast<uint4*>(smem_raw);
+  u32x4_t* sm = reinterpret_cast<u32x4_t*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 1, wm = wave >> 1;
   const int q = lane >> 4, j = lane & 15;
-  const int strip0 = blockIdx.x * BNS, m0 = blockIdx.y * BMT * 16;
+  int bx, by;
+  xcd_tile_order(bx, by, a.xcd_swz);
+  const int strip0 = bx * BNS, m0 = by * BMT * 16;
   const int nfrag = a.K / KT, nstage = nfrag >> 1;       // host guarantees an even fragment count
-  const uint4* gA[ACH];
-  const uint4* gB[BCH];
+  const u32x4_t* gA[ACH];
+  const u32x4_t* gB[BCH];
   int sA[ACH], sB[BCH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
     const int ca = tid + 256 * i, strip = ca >> 7, frag = (ca >> 6) & 1, ln = ca & 63;
-    gA[i] = reinterpret_cast<const uint4*>(a.W) + ((size_t)(strip0 + strip) * nfrag + frag) * 64 + ln;
+    gA[i] = reinterpret_cast<const u32x4_t*>(a.W) + ((size_t)(strip0 + strip) * nfrag + frag) * 64 + ln;
     sA[i] = (strip * 2 + frag) * 64 + ln;
   }
 #pragma unroll
   for (int i = 0; i < BCH; ++i) {
     const int cb = tid + 256 * i, rl = cb >> 3, kc = cb & 7;  // row of the tile, 16-byte piece of the stage's 2 * KT elements
     const int row = min(m0 + rl, a.M - 1);                    // clamped rows are computed and dropped
-    gB[i] = reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.x) + (size_t)(row * a.x_row_mul + a.x_row_off) * a.x_ld) + kc;
+    gB[i] = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const WT*>(a.x) + (size_t)(row * a.x_row_mul + a.x_row_off) * a.x_ld) + kc;
     sB[i] = BNS * 128 + ((rl >> 4) * 2 + (kc >> 2)) * 64 + (kc & 3) * 16 + (rl & 15);
   }
   f32x4 acc[NS][MT];
@@ -841,46 +884,50 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint4 ra[ACH], rb[BCH];
-#pragma unroll
-  for (int i = 0; i < ACH; ++i) ra[i] = gA[i][0];
-#pragma unroll
-  for (int i = 0; i < BCH; ++i) rb[i] = gB[i][0];
-#pragma unroll
-  for (int i = 0; i < ACH; ++i) sm[sA[i]] = ra[i];
-#pragma unroll
-  for (int i = 0; i < BCH; ++i) sm[sB[i]] = rb[i];
+  // register staging TWO stages ahead (two register sets): a stage's pieces have two stages of MFMA work (and the other resident workgroups') to arrive
+  u32x4_t ra0[ACH], rb0[BCH], ra1[ACH], rb1[BCH];
+#define PTTS_TILE_FETCH(stg, ra, rb)                                                                                          \
+  do {                                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < ACH; ++i) ra[i] = gA[i][(size_t)(stg) * 128]; /* two fragments = 128 slots along the strip */ \
+    _Pragma("unroll") for (int i = 0; i < BCH; ++i) rb[i] = gB[i][(size_t)(stg) * 8];   /* two fragments = 8 pieces along the row */   \
+  } while (0)
+#define PTTS_TILE_COMMIT(stg, ra, rb)                                                \
+  do {                                                                               \
+    u32x4_t* dst_ = sm + ((stg) & 1) * STAGE;                                        \
+    _Pragma("unroll") for (int i = 0; i < ACH; ++i) dst_[sA[i]] = ra[i];             \
+    _Pragma("unroll") for (int i = 0; i < BCH; ++i) dst_[sB[i]] = rb[i];             \
+  } while (0)
+#define PTTS_TILE_COMPUTE(stg)                                                                                                  \
+  do {                                                                                                                          \
+    const u32x4_t* cur_ = sm + ((stg) & 1) * STAGE;                                                                             \
+    _Pragma("unroll") for (int frag = 0; frag < 2; ++frag) {                                                                    \
+      u32x4_t af[NS], bf[MT];                                                                                                   \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) af[s] = cur_[((wn * NS + s) * 2 + frag) * 64 + lane];                      \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) bf[mt] = cur_[BNS * 128 + ((wm * MT + mt) * 2 + frag) * 64 + lane];     \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s)                                                                            \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mfma_step_v<WT>(af[s], bf[mt], acc[s][mt]);              \
+    }                                                                                                                           \
+  } while (0)
+  PTTS_TILE_FETCH(0, ra0, rb0);
+  if (nstage > 1) PTTS_TILE_FETCH(1, ra1, rb1);
+  PTTS_TILE_COMMIT(0, ra0, rb0);
   __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const bool more = st + 1 < nstage;
-    if (more) {  // next stage's pieces in flight under this stage's MFMAs
-#pragma unroll
-      for (int i = 0; i < ACH; ++i) ra[i] = gA[i][(size_t)(st + 1) * 128];  // two fragments = 128 uint4 further along the strip
-#pragma unroll
-      for (int i = 0; i < BCH; ++i) rb[i] = gB[i][(size_t)(st + 1) * 8];    // two fragments = 8 pieces further along the row
-    }
-    const uint4* cur = sm + (st & 1) * STAGE;
-#pragma unroll
-    for (int frag = 0; frag < 2; ++frag) {
-      uint4 af[NS], bf[MT];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) af[s] = cur[((wn * NS + s) * 2 + frag) * 64 + lane];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) bf[mt] = cur[BNS * 128 + ((wm * MT + mt) * 2 + frag) * 64 + lane];
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[s][mt] = MfmaStep<WT>::run(af[s], bf[mt], acc[s][mt]);
-    }
-    if (more) {
-      uint4* nxt = sm + ((st + 1) & 1) * STAGE;  // read last in stage st - 1: every wave has passed that stage's barrier
-#pragma unroll
-      for (int i = 0; i < ACH; ++i) nxt[sA[i]] = ra[i];
-#pragma unroll
-      for (int i = 0; i < BCH; ++i) nxt[sB[i]] = rb[i];
-    }
+  // stage st computes from LDS buffer st & 1; set (st & 1) is free again (its stage-st pieces were committed at the end of stage st - 1): it takes
+  // stage st + 2; the other set holds stage st + 1, committed into the other buffer (last read in stage st - 1, behind that stage's barrier)
+  for (int st = 0; st < nstage; st += 2) {
+    if (st + 2 < nstage) PTTS_TILE_FETCH(st + 2, ra0, rb0);
+    PTTS_TILE_COMPUTE(st);
+    if (st + 1 < nstage) PTTS_TILE_COMMIT(st + 1, ra1, rb1);
+    __syncthreads();
+    if (st + 1 >= nstage) break;
+    if (st + 3 < nstage) PTTS_TILE_FETCH(st + 3, ra1, rb1);
+    PTTS_TILE_COMPUTE(st + 1);
+    if (st + 2 < nstage) PTTS_TILE_COMMIT(st + 2, ra0, rb0);
     __syncthreads();
   }
+#undef PTTS_TILE_FETCH
+#undef PTTS_TILE_COMMIT
+#undef PTTS_TILE_COMPUTE
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
