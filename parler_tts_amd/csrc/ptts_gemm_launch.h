@@ -81,12 +81,13 @@ int launch_gemm_tile(const GemmArgs& a, hipStream_t st) {
   const int nstrips = a.N / 16, nfrag = a.K / Elem<WT>::KT;
   if (!mode || nstrips % 4 || nfrag % 2 || a.K % Elem<WT>::KT) return -1;
   auto wgs = [&](int bns, int bmt) { return (nstrips / bns) * ((a.M + bmt * 16 - 1) / (bmt * 16)); };
+  // measured (profiles/r05_experiments.txt call 6, time to the first token at 32 utterances = T5 on 2048 rows + prefill on 1056 rows, ms):
+  //   register-blocked kernel 13.41 | tiles 8x8 14.38, 4x8 12.94, 8x4 11.57, 4x4 11.43 -> the SMALLEST tile: three workgroups per CU hide the
+  //   staging latency that two stages of register prefetch do not (the loop is still latency-bound: ~250 TFLOP/s); larger tiles need an
+  //   asynchronous global->LDS ring (next step)
   int pick = 44;
-  if (mode == 1) {
-    if (nstrips % 8 == 0 && wgs(8, 8) >= 224) pick = 88;
-    else if (wgs(4, 8) >= 224) pick = 48;
-    else if (nstrips % 8 == 0 && wgs(8, 4) >= 224) pick = 84;
-  } else {
+  (void)wgs;
+  if (mode != 1) {
     pick = mode;
     if ((pick == 88 || pick == 84) && nstrips % 8) pick = pick == 88 ? 48 : 44;
   }
