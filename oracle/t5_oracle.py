@@ -89,9 +89,12 @@ def gelu_new(x: torch.Tensor) -> torch.Tensor:
 
 
 class T5Oracle:
-    def __init__(self, spec: T5Spec, sd: Dict[str, torch.Tensor], precision: str = "fp32"):
+    def __init__(self, spec: T5Spec, sd: Dict[str, torch.Tensor], precision: str = "fp32", fold_norm: bool = False):
+        """``fold_norm``: where the bf16 engine rounds at <= 256 rows (csrc/ptts_t5.hip): T5LayerNorm commutes with the projection, so every norm
+        but block 0's first one feeds the GEMM the rounded g o x and scales the product by rstd afterwards (same algebra; in bf16 a
+        different - equivalent - rounding point; in fp32 a re-association)."""
         assert precision in ("fp32", "bf16")
-        self.spec, self.bf = spec, precision == "bf16"
+        self.spec, self.bf, self.fold = spec, precision == "bf16", fold_norm
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         if "shared.weight" not in self.sd:
             self.sd["shared.weight"] = self.sd["encoder.embed_tokens.weight"]
@@ -127,18 +130,26 @@ class T5Oracle:
             ext = (1.0 - attention_mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
             bias = bias + ext
         nl = sp.num_layers if upto is None else upto
+        def normed_proj(hh, wname, mats, folded):
+            """[x @ W.T for W in mats] with x = layer_norm(hh): the plain order, or the engine's folded one (operand g o h rounded, product * rstd)."""
+            w = sd[wname]
+            if not folded:
+                x = self._r(self._norm(hh, w))
+                return [x @ sd[m].T for m in mats]
+            rstd = torch.rsqrt(hh.pow(2).mean(-1, keepdim=True) + sp.layer_norm_epsilon)
+            x = self._r(hh * w)
+            return [(x @ sd[m].T) * rstd for m in mats]
+
         for l in range(nl):
             p = f"encoder.block.{l}."
-            x = self._r(self._norm(h, sd[p + "layer.0.layer_norm.weight"]))
-            q = (x @ sd[p + "layer.0.SelfAttention.q.weight"].T).view(B, N, H, dk).transpose(1, 2)
-            k = (x @ sd[p + "layer.0.SelfAttention.k.weight"].T).view(B, N, H, dk).transpose(1, 2)
-            v = (x @ sd[p + "layer.0.SelfAttention.v.weight"].T).view(B, N, H, dk).transpose(1, 2)
+            q, k, v = [t.view(B, N, H, dk).transpose(1, 2) for t in normed_proj(
+                h, p + "layer.0.layer_norm.weight", [p + f"layer.0.SelfAttention.{n}.weight" for n in "qkv"], self.fold and l > 0)]
             scores = q @ k.transpose(2, 3) + bias
             pr = torch.softmax(scores, dim=-1)
             ctx = self._r((pr @ v).transpose(1, 2).reshape(B, N, H * dk))
             h = h + ctx @ sd[p + "layer.0.SelfAttention.o.weight"].T
-            x = self._r(self._norm(h, sd[p + "layer.1.layer_norm.weight"]))
-            ff = self._r(gelu_new(x @ sd[p + "layer.1.DenseReluDense.wi_0.weight"].T) * (x @ sd[p + "layer.1.DenseReluDense.wi_1.weight"].T))
+            u, g_ = normed_proj(h, p + "layer.1.layer_norm.weight", [p + "layer.1.DenseReluDense.wi_0.weight", p + "layer.1.DenseReluDense.wi_1.weight"], self.fold)
+            ff = self._r(gelu_new(u) * g_)
             h = h + ff @ sd[p + "layer.1.DenseReluDense.wo.weight"].T
         if upto is not None:
             return h

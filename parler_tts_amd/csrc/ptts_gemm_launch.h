@@ -135,7 +135,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   if (rpp * row_bytes + (size_t)W * 1024 > lds_cap) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm K=%d does not fit in LDS", a.K);
   a.rows_per_pass = rpp;
   const int mtp = tiles(rpp);
-  const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024;
+  const size_t sh = rpp * row_bytes + (size_t)W * mtp * 1024 + 256;  // + rstd of the pass's rows (rs_part consumers)
   a.m_split = msplit ? 1 : 0;
   const dim3 grid(a.N / 16, 1, msplit ? (a.M + rpp - 1) / rpp : ((EPI == EPI_KV && a.kv_layers) ? a.kv_nlayers : 1)), block(W * 64);
   int rc;

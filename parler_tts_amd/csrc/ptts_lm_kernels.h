@@ -118,7 +118,17 @@ struct GemmArgs {
   int xcd_swz;         // gemm_block_kernel / gemm_tile_kernel: XCD-aware tile order (xcd_tile_order), set by launch_gemm (PTTS_GEMM_XCD=0: launch order)
   int decode;          // host-side launch policy only: 1 = a decode-step GEMM (light M passes, msplit_rows), 0 = prefill-sized rows
   int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
-  float rms_eps;       // PRO_RMS: T5Config.layer_norm_epsilon
+  // T5 RMSNorm folded into the GEMMs around it (ptts_t5.hip, <= 256 rows; strip kernel only). T5LayerNorm has no mean and no bias, so it commutes with
+  // the projection: W (g o x * rstd) = rstd * (W (g o x)). The PRODUCER of the residual rows (EPI_RESID with nx_out) also writes the next GEMM's
+  // operand g o h in the engine dtype and the per-strip sums of h^2; the CONSUMER (EPI_STORE / EPI_GATE_WT with rs_part) sums a row's rs_n partials
+  // once per workgroup, in a fixed order, while its weights stream, and scales its accumulators by rstd[m]: no rows_prep node, no extra pass over h.
+  const float* rs_part;  // consumer: [M][rs_n] per-strip sums of squares of the un-normalised rows, or null
+  int rs_n;
+  float rs_invD;         // 1 / d_model
+  void* nx_out;          // producer (EPI_RESID): engine-dtype [M][N] (row-major or fragment order by out_fo) = updated residual row * nx_gamma, or null
+  const float* nx_gamma; // [N]
+  float* ss_out;         // producer: [M][N/16] sum of squares of the updated residual row over this strip's 16 columns
+  float rms_eps;       // PRO_RMS / rs_part: T5Config.layer_norm_epsilon
   const int* row_keep; // PRO_RMS: [M] int32 or null; rows with 0 are written as zeros (masked description positions, modeling_parler_tts.py:3093-3097)
   const float* fold_part;  // EPI_RESID: pending split-K partials [fold_S][M][N] of the previous fc2 that no prep kernel has added to the residual rows
   int fold_S;              // (lnproj_fused_kernel normalised h + sum_s part[s] without writing it back): out = (out + sum_s part[s]) + acc, same order
@@ -543,9 +553,24 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
 
   const int m_first = (PRO == PRO_COPY && a.m_split) ? (int)blockIdx.z * a.rows_per_pass : 0;
   const int m_last = (PRO == PRO_COPY && a.m_split) ? min(a.M, m_first + a.rows_per_pass) : a.M;
+  float* s_rstd = s_red + (size_t)W * MTP * 256;  // [rows_per_pass <= 64] (rs_part consumers; the launch reserves 256 bytes behind the reduction buffer)
   for (int m0 = m_first; m0 < m_last; m0 += a.rows_per_pass) {
     const int nrows = min(a.rows_per_pass, a.M - m0);
     PTTS_STAMP(PTTS_DBG(a), 0);
+    if (PRO == PRO_COPY && (EPI == EPI_STORE || EPI == EPI_GATE_WT) && a.rs_part) {
+      // rstd of this pass's rows: 4 lanes per row, each a quarter of the rs_n strip partials (requested before the weights), fixed summation order
+      for (int r0 = 0; r0 < nrows; r0 += (int)(blockDim.x >> 2)) {
+        const int r = r0 + (int)(threadIdx.x >> 2), part = threadIdx.x & 3, per = a.rs_n >> 2;
+        float s = 0.f;
+        if (r < nrows) {
+          const float* pp = a.rs_part + (size_t)(m0 + r) * a.rs_n + part * per;
+          for (int i = 0; i < per; ++i) s += pp[i];
+        }
+        s += dpp_mov<0xB1>(s);  // lanes 4k .. 4k + 3: quad_perm [1,0,3,2], then [2,3,0,1]
+        s += dpp_mov<0x4E>(s);
+        if (r < nrows && part == 0) s_rstd[r] = rsqrtf(s * a.rs_invD + a.rms_eps);
+      }
+    }
     // 0. EPI_RESID: the residual values this wave will update are fetched now, not after the reduction (one cold
     //    round trip off the tail of the kernel)
     float4 resid_pre = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -656,6 +681,10 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
       const int mloc = mt * 16 + j;
       const int m = m0 + mloc;
       const int n = strip * 16 + q * 4;  // D[row = (l>>4)*4 + r][col = l&15]
+      if (PRO == PRO_COPY && (EPI == EPI_STORE || EPI == EPI_GATE_WT) && a.rs_part && mloc < nrows) {
+        const float rs = s_rstd[mloc];
+        r[0] *= rs; r[1] *= rs; r[2] *= rs; r[3] *= rs;
+      }
       if (mloc < nrows) {
         if (EPI == EPI_STORE) {
           *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(r[0], r[1], r[2], r[3]);
@@ -700,6 +729,15 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
         float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         m2 = swap32_reduce<OpSum>(swap16_reduce<OpSum>(m2));
         if (q == 0 && mloc < nrows) reinterpret_cast<float2*>(a.stats_out)[(size_t)m * (a.N >> 4) + strip] = make_float2(mean, m2);
+      }
+      if (EPI == EPI_RESID && a.nx_out) {  // T5: the next GEMM's operand g o h and this strip's share of sum(h^2) (every lane takes part in the swaps)
+        if (mloc < nrows) {
+          const float4 g = *reinterpret_cast<const float4*>(a.nx_gamma + n);
+          act_store4<WT>(reinterpret_cast<WT*>(a.nx_out), m, n, a.N, a.out_fo, r[0] * g.x, r[1] * g.y, r[2] * g.z, r[3] * g.w);
+        }
+        float ss = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+        ss = swap32_reduce<OpSum>(swap16_reduce<OpSum>(ss));
+        if (q == 0 && mloc < nrows) a.ss_out[(size_t)m * (a.N >> 4) + strip] = ss;
       }
     }
     PTTS_STAMP(PTTS_DBG(a), 5);

@@ -182,6 +182,8 @@ struct ptts_t5 {
   bool bias_built = false;
   // scratch + static inputs of the captured graphs
   float *h = nullptr, *qkv = nullptr;
+  float* ss = nullptr;     // [rows][d_model / 16] per-strip sums of squares of the residual rows (RMSNorm folded into the GEMMs, <= 256 rows)
+  bool use_fold = true;
   void *xw = nullptr, *ctx = nullptr, *ff = nullptr;
   long long* ids = nullptr;
   int* mask = nullptr;
@@ -274,6 +276,7 @@ extern "C" int ptts_t5_create(const ptts_t5_config* cfg, ptts_t5** out) {
   const size_t rows = (size_t)e->rows;
   A(e->alloc(&e->h, rows * D));
   A(e->alloc(&e->qkv, rows * 3 * I));
+  A(e->alloc(&e->ss, rows * (size_t)(D / 16) + 64));
   A(e->alloc_bytes(&e->xw, (rows + 16) * D * es));   // + 16 rows: fragment order addresses whole 16-row tiles
   A(e->alloc_bytes(&e->ctx, (rows + 16) * I * es));
   A(e->alloc_bytes(&e->ff, (rows + 16) * F * es));
@@ -282,6 +285,7 @@ extern "C" int ptts_t5_create(const ptts_t5_config* cfg, ptts_t5** out) {
 #undef A
   e->use_fo = !(getenv("PTTS_T5_NO_FO") && atoi(getenv("PTTS_T5_NO_FO")));
   e->use_graph = !(getenv("PTTS_T5_NO_GRAPH") && atoi(getenv("PTTS_T5_NO_GRAPH")));
+  e->use_fold = D % 64 == 0 && !(getenv("PTTS_T5_NO_FOLD") && atoi(getenv("PTTS_T5_NO_FOLD")));  // (a row's d_model / 16 partials are summed by 4 lanes)
   *out = e;
   return PTTS_OK;
 }
@@ -334,13 +338,20 @@ int t5_forward(ptts_t5* e, int B, int N, bool has_mask, hipStream_t st) {
     p.x = e->h; p.x_ld = D; p.x_row_mul = 1; p.gamma = gamma; p.M = M; p.K = D; p.out_fo = fo; p.rms_eps = c.layer_norm_eps;
     return launch_prep<WT, PRO_RMS>(p, e->xw, st);
   };
+  // <= 256 rows (the strip kernels): T5LayerNorm folded into the GEMMs around it - it has no mean and no bias, so W (g o x * rstd) = rstd * W (g o x):
+  // the o / wo GEMMs' residual epilogues write the next GEMM's operand g o h and per-strip sums of h^2, the q|k|v and wi GEMMs scale their
+  // accumulators by rstd (GemmArgs::rs_part / nx_out). 7 -> 5 nodes per block; block 0's first norm keeps its rows_prep node (PTTS_T5_NO_FOLD=1: all do)
+  const bool fold = e->use_fold && M <= 256;
+  auto consume = [&](GemmArgs& g) { g.rs_part = e->ss; g.rs_n = D / 16; g.rs_invD = 1.0f / (float)D; g.rms_eps = c.layer_norm_eps; };
+  auto produce = [&](GemmArgs& g, const float* gamma) { g.nx_out = e->xw; g.nx_gamma = gamma; g.ss_out = e->ss; g.out_fo = fo; };
   for (int l = 0; l < c.num_layers; ++l) {
     const T5Layer& w = e->L[l];
-    PTTS_TRY(prep(w.ln1));  // T5LayerSelfAttention: normed = layer_norm(hidden)
+    if (!fold || l == 0) PTTS_TRY(prep(w.ln1));  // T5LayerSelfAttention: normed = layer_norm(hidden)
     {
       GemmArgs g = {};
       g.W = w.qkv; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = D; g.x_row_mul = 1; g.x_fo = fo;
       g.out = e->qkv; g.out_ld = 3 * I; g.M = M; g.N = 3 * I; g.K = D;
+      if (fold && l > 0) consume(g);
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_STORE>(g, st)));
     }
     {
@@ -353,19 +364,22 @@ int t5_forward(ptts_t5* e, int B, int N, bool has_mask, hipStream_t st) {
       GemmArgs g = {};
       g.W = w.o; g.x = reinterpret_cast<const float*>(e->ctx); g.x_ld = I; g.x_row_mul = 1; g.x_fo = fo;
       g.out = e->h; g.out_ld = D; g.M = M; g.N = D; g.K = I;
+      if (fold) produce(g, w.ln2);
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
     }
-    PTTS_TRY(prep(w.ln2));  // T5LayerFF: hidden + wo(gelu_new(wi_0 x) * wi_1 x)
+    if (!fold) PTTS_TRY(prep(w.ln2));  // T5LayerFF: hidden + wo(gelu_new(wi_0 x) * wi_1 x)
     {
       GemmArgs g = {};
       g.W = w.wi; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = D; g.x_row_mul = 1; g.x_fo = fo;
       g.out = reinterpret_cast<float*>(e->ff); g.out_ld = F; g.out_fo = fo; g.M = M; g.N = 2 * F; g.K = D;
+      if (fold) consume(g);
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_GATE_WT>(g, st)));
     }
     {
       GemmArgs g = {};
       g.W = w.wo; g.x = reinterpret_cast<const float*>(e->ff); g.x_ld = F; g.x_row_mul = 1; g.x_fo = fo;
       g.out = e->h; g.out_ld = D; g.M = M; g.N = D; g.K = F;
+      if (fold && l + 1 < c.num_layers) produce(g, e->L[l + 1].ln1);
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
     }
   }

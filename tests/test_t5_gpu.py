@@ -79,7 +79,7 @@ def test_mini_widths_bf16_vs_bf16_oracle(B, N):
         mask[1, N - N // 3:] = 0
     eng = make_t5(spec, sd, dtype=torch.bfloat16, max_batch=B, max_len=N)
     out = eng.encode(ids.cuda(), mask.cuda()).cpu()
-    ref16 = TO.T5Oracle(spec, sd, precision="bf16").encode(ids, mask)
+    ref16 = TO.T5Oracle(spec, sd, precision="bf16", fold_norm=B * N <= 256).encode(ids, mask)  # <= 256 rows: the engine folds the norms into the GEMMs
     ref32 = TO.T5Oracle(spec, sd).encode(ids, mask)
     r16, r32, model = rel_rms(out, ref16), rel_rms(out, ref32), rel_rms(ref16, ref32)
     log_parity(f"[t5 bf16 B={B} N={N}] relative RMS vs bf16 oracle {r16:.2e}, vs fp32 oracle {r32:.2e} (bf16 oracle vs fp32: {model:.2e})", LOG)
@@ -99,7 +99,7 @@ def test_full_depth_flan_t5_large_shape():
     log_parity(f"[t5 fp32 24 blocks] max |d| {err:.2e}, relative RMS {r:.2e}", LOG)
     assert r <= 2e-5
     out = make_t5(spec, sd, dtype=torch.bfloat16, max_batch=1, max_len=64).encode(ids.cuda(), None).cpu()
-    ref16 = TO.T5Oracle(spec, sd, precision="bf16").encode(ids, None)
+    ref16 = TO.T5Oracle(spec, sd, precision="bf16", fold_norm=True).encode(ids, None)
     r16, r32, model = rel_rms(out, ref16), rel_rms(out, ref), rel_rms(ref16, ref)
     log_parity(f"[t5 bf16 24 blocks] relative RMS vs bf16 oracle {r16:.2e}, vs fp32 {r32:.2e} (bf16 oracle vs fp32 {model:.2e})", LOG)
     assert r16 <= 1e-2 and r32 <= 1.5 * model + 1e-4
@@ -124,6 +124,34 @@ def test_graph_replay_equals_eager_and_repeats():
     assert torch.equal(eager.encode(ids1), a1)
     ref = TO.T5Oracle(spec, sd).encode(ids1.cpu(), None)
     assert float((a1.cpu() - ref).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("dtype,prec", [(torch.float32, "fp32"), (torch.bfloat16, "bf16")])
+def test_norm_folded_into_the_gemms_vs_rows_prep_nodes(dtype, prec):
+    """<= 256 rows: T5LayerNorm folded into the GEMMs around it (the o / wo residual epilogues emit g o h and per-strip sums of squares, the q|k|v and
+    wi GEMMs scale their accumulators by rstd; default) against the rows_prep node in front of every GEMM (PTTS_T5_NO_FOLD=1), each against the oracle
+    that rounds where it rounds; 3 blocks (block 0's first norm is never folded), ragged masks, 3 x 40 = 120 rows."""
+    spec = TO.T5Spec(vocab_size=300, d_model=1024, d_kv=64, d_ff=2816, num_layers=3, num_heads=16)
+    sd = TO.make_t5_weights(spec, seed=13)
+    g = torch.Generator().manual_seed(14)
+    ids = torch.randint(0, 300, (3, 40), generator=g)
+    mask = torch.ones(3, 40, dtype=torch.long)
+    mask[0, 33:] = 0
+    mask[2, :7] = 0
+    outs = {}
+    for fold in (True, False):
+        os.environ["PTTS_T5_NO_FOLD"] = "0" if fold else "1"
+        try:
+            eng = make_t5(spec, sd, dtype=dtype, max_batch=3, max_len=40)
+        finally:
+            del os.environ["PTTS_T5_NO_FOLD"]
+        outs[fold] = eng.encode(ids.cuda(), mask.cuda()).cpu()
+        ref = TO.T5Oracle(spec, sd, precision=prec, fold_norm=fold).encode(ids, mask)
+        r = rel_rms(outs[fold], ref)
+        log_parity(f"[t5 {prec} norm {'folded' if fold else 'rows_prep'}] relative RMS vs its oracle {r:.2e}", LOG)
+        assert r <= (1e-5 if prec == "fp32" else 3e-3), (fold, r)
+    ab = rel_rms(outs[True], outs[False])
+    assert 0.0 < ab <= (1e-5 if prec == "fp32" else 1e-2), ab  # the folded nodes really ran, and re-associate / re-round only
 
 
 def test_capacity_and_name_errors():
