@@ -557,20 +557,6 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   for (int m0 = m_first; m0 < m_last; m0 += a.rows_per_pass) {
     const int nrows = min(a.rows_per_pass, a.M - m0);
     PTTS_STAMP(PTTS_DBG(a), 0);
-    if (PRO == PRO_COPY && (EPI == EPI_STORE || EPI == EPI_GATE_WT) && a.rs_part) {
-      // rstd of this pass's rows: 4 lanes per row, each a quarter of the rs_n strip partials (requested before the weights), fixed summation order
-      for (int r0 = 0; r0 < nrows; r0 += (int)(blockDim.x >> 2)) {
-        const int r = r0 + (int)(threadIdx.x >> 2), part = threadIdx.x & 3, per = a.rs_n >> 2;
-        float s = 0.f;
-        if (r < nrows) {
-          const float* pp = a.rs_part + (size_t)(m0 + r) * a.rs_n + part * per;
-          for (int i = 0; i < per; ++i) s += pp[i];
-        }
-        s += dpp_mov<0xB1>(s);  // lanes 4k .. 4k + 3: quad_perm [1,0,3,2], then [2,3,0,1]
-        s += dpp_mov<0x4E>(s);
-        if (r < nrows && part == 0) s_rstd[r] = rsqrtf(s * a.rs_invD + a.rms_eps);
-      }
-    }
     // 0. EPI_RESID: the residual values this wave will update are fetched now, not after the reduction (one cold
     //    round trip off the tail of the kernel)
     float4 resid_pre = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -608,6 +594,20 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
       __syncthreads();
     } else {
       issue_w(1);
+    }
+    if (PRO == PRO_COPY && (EPI == EPI_STORE || EPI == EPI_GATE_WT) && a.rs_part) {
+      // rstd of this pass's rows: 4 lanes per row, each a quarter of the rs_n strip partials (requested right behind the first weight fragments: call 7 - requested BEFORE them the round trip sat in front of the weight stream and ate what the removed rows_prep nodes saved), fixed summation order
+      for (int r0 = 0; r0 < nrows; r0 += (int)(blockDim.x >> 2)) {
+        const int r = r0 + (int)(threadIdx.x >> 2), part = threadIdx.x & 3, per = a.rs_n >> 2;
+        float s = 0.f;
+        if (r < nrows) {
+          const float* pp = a.rs_part + (size_t)(m0 + r) * a.rs_n + part * per;
+          for (int i = 0; i < per; ++i) s += pp[i];
+        }
+        s += dpp_mov<0xB1>(s);  // lanes 4k .. 4k + 3: quad_perm [1,0,3,2], then [2,3,0,1]
+        s += dpp_mov<0x4E>(s);
+        if (r < nrows && part == 0) s_rstd[r] = rsqrtf(s * a.rs_invD + a.rms_eps);
+      }
     }
     PTTS_STAMP(PTTS_DBG(a), 3);
     // 3. MFMA over this wave's K slice; B fragments come from LDS (rows beyond nrows are clamped: their output

@@ -167,6 +167,14 @@ def _sharded_generate_worker(rank, world, port, q):
         grp = dist.new_group([0, 1])
         sub = generate_sharded(m, dst=1, group=grp, **kw)  # an explicit group, result on ITS rank 1
         one = generate_sharded(m, dst=0, input_ids=desc[:1], prompt_input_ids=prompt_ids[:1], do_sample=False, max_length=24, min_new_tokens=3)  # rank 1 idles
+        # num_return_sequences carried by a `generation_config=` OBJECT (not a kwarg): every rank returns twice the rows of its slice; the block size of
+        # the gather comes from what generate() returned (sized from the arguments, one rank overflowed its metadata and the others hung)
+        import copy
+
+        gc2 = copy.deepcopy(m.generation_config)
+        gc2.num_return_sequences, gc2.do_sample, gc2.max_length, gc2.min_new_tokens = 2, True, 24, 3  # (transformers rejects greedy + num_return_sequences > 1)
+        kw2 = dict(input_ids=desc, attention_mask=mask, prompt_input_ids=prompt_ids, generation_config=gc2)
+        nrs = generate_sharded(m, dst=0, **kw2)
         single = m.generate(return_dict_in_generate=True, **kw) if rank == 0 else None
         single1 = m.generate(return_dict_in_generate=True, input_ids=desc[:1], prompt_input_ids=prompt_ids[:1], do_sample=False, max_length=24,
                              min_new_tokens=3) if rank == 0 else None
@@ -178,6 +186,7 @@ def _sharded_generate_worker(rank, world, port, q):
             ok = ok and one is not None and list(one["audios_length"]) == list(single1["audios_length"]) and torch.equal(one.sequences, single1.sequences.float().cpu())
             ok = ok and len(set(single["audios_length"])) > 1  # the case really is ragged
             ok = ok and sub is None
+            ok = ok and nrs is not None and nrs.sequences.shape[0] == 6 and len(nrs["audios_length"]) == 6  # (sampled: shards draw their own streams)
         else:
             ok = res[0] is None and res[None] is not None and one is None
             ok = ok and sub is not None and list(sub["audios_length"]) == res[None][1] and torch.equal(sub.sequences, res[None][0])
