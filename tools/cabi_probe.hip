@@ -10,6 +10,7 @@
 //        the target of `rocprofv3 --pmc ...` passes (which crash on graph replays in this image; tools/prof_eager.py without torch),
 //        e.g. `rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- tools/cabi_probe lm 1 ctx=431 eager=24` = the bench's timed context
 //   tools/cabi_probe dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>] [dump=<file>]
+//   tools/cabi_probe t5  <batch> [tokens=<n>] [layers=<n>] [fp32] [reps=<n>] [tag=<text>]   (round 5: the T5 description encoder, ptts_t5_*)
 //   tools/cabi_probe cmp <file a> <file b>
 //   (environment knobs as for tools/step_probe2.py: PTTS_NO_GEMV, PTTS_GEMV_ROWS, PTTS_GEMV_STAGE, PTTS_NO_FO, PTTS_DAC_NO_FUSE_RES ...)
 //
@@ -518,13 +519,81 @@ static int run_cmp(const char* pa, const char* pb) {
   return (mx == 0 && nan == 0 && first_id < 0 && a.id_cols == b.id_cols) ? 0 : 4;
 }
 
+// T5 description encoder (ABI v7: ptts_t5_*) at flan-t5-large widths, synthetic weights filled on the device, loaded by their transformers names
+static int run_t5(int argc, char** argv) {
+  const int B = atoi(argv[2]);
+  const int N = opt(argc, argv, "tokens") ? atoi(opt(argc, argv, "tokens")) : 64;
+  const int L = opt(argc, argv, "layers") ? atoi(opt(argc, argv, "layers")) : 24;
+  const int reps = opt(argc, argv, "reps") ? atoi(opt(argc, argv, "reps")) : 50;
+  const bool fp32 = opt(argc, argv, "fp32") != nullptr;
+  const char* tag = opt(argc, argv, "tag") ? opt(argc, argv, "tag") : "";
+  const int V = 32128, D = 1024, F = 2816, NH = 16;
+  hipStream_t st;
+  HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  ptts_t5_config c;
+  memset(&c, 0, sizeof c);
+  c.vocab_size = V; c.d_model = D; c.d_kv = 64; c.d_ff = F; c.num_layers = L; c.num_heads = NH; c.rel_buckets = 32; c.rel_max_distance = 128;
+  c.layer_norm_eps = 1e-6f; c.dtype = fp32 ? PTTS_F32 : PTTS_BF16; c.max_batch = B; c.max_len = N; c.device = 0;
+  ptts_t5* e = nullptr;
+  PT(ptts_t5_create(&c, &e));
+  Filler f;
+  f.st = st;
+  auto load = [&](const std::string& name, std::vector<int64_t> shape, float std, float mean) {
+    size_t n = 1;
+    for (int64_t s : shape) n *= (size_t)s;
+    PT(ptts_t5_load_weight(e, name.c_str(), f.get(n, std, mean), PTTS_F32, shape.data(), (int32_t)shape.size(), st));
+  };
+  load("shared.weight", {V, D}, 1.0f, 0.f);
+  load("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", {32, NH}, 0.1f, 0.f);
+  load("encoder.final_layer_norm.weight", {D}, 0.f, 1.f);
+  for (int l = 0; l < L; ++l) {
+    const std::string p = "encoder.block." + std::to_string(l) + ".";
+    load(p + "layer.0.SelfAttention.q.weight", {D, D}, 0.004f, 0.f);
+    for (const char* m : {"k", "v", "o"}) load(p + "layer.0.SelfAttention." + m + ".weight", {D, D}, 0.03f, 0.f);
+    load(p + "layer.0.layer_norm.weight", {D}, 0.f, 1.f);
+    load(p + "layer.1.DenseReluDense.wi_0.weight", {F, D}, 0.03f, 0.f);
+    load(p + "layer.1.DenseReluDense.wi_1.weight", {F, D}, 0.03f, 0.f);
+    load(p + "layer.1.DenseReluDense.wo.weight", {D, F}, 0.02f, 0.f);
+    load(p + "layer.1.layer_norm.weight", {D}, 0.f, 1.f);
+  }
+  PT(ptts_t5_weights_ready(e));
+  long long* ids = nullptr;
+  float* out = nullptr;
+  HIPCHK(hipMalloc(&ids, (size_t)B * N * 8));
+  HIPCHK(hipMalloc(&out, (size_t)B * N * D * 4));
+  fill_codes_kernel<<<dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st>>>(ids, (size_t)B * N, 31u, V);
+  for (int i = 0; i < 3; ++i) PT(ptts_t5_encode(e, (const int64_t*)ids, nullptr, B, N, out, st));  // first call captures the graph
+  HIPCHK(hipStreamSynchronize(st));
+  hipEvent_t ev0, ev1;
+  HIPCHK(hipEventCreate(&ev0));
+  HIPCHK(hipEventCreate(&ev1));
+  HIPCHK(hipEventRecord(ev0, st));
+  for (int i = 0; i < reps; ++i) PT(ptts_t5_encode(e, (const int64_t*)ids, nullptr, B, N, out, st));
+  HIPCHK(hipEventRecord(ev1, st));
+  HIPCHK(hipEventSynchronize(ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+  ms /= reps;
+  std::vector<float> h((size_t)N * D);
+  HIPCHK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
+  double ss = 0;
+  for (float v : h) ss += (double)v * v;
+  const double flops = 2.0 * B * N * L * (4.0 * D * D + 3.0 * D * F);
+  printf("[cabi_probe t5 %s%s] B=%d tokens=%d layers=%d: %.3f ms per encode = %.1f TFLOP/s (projection flops only; weights %.0f MB); rms of the first utterance's "
+         "output %.4f\n", tag, fp32 ? " fp32" : "", B, N, L, ms, flops / ms / 1e9, (double)L * (4.0 * D * D + 3.0 * D * F) * (fp32 ? 4 : 2) / 1e6, std::sqrt(ss / h.size()));
+  ptts_t5_destroy(e);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "cmp")) return run_cmp(argv[2], argv[3]);
-  if (argc < 3 || (strcmp(argv[1], "lm") && strcmp(argv[1], "dac"))) {
-    fprintf(stderr, "usage: %s lm <batch> [large] [fp32] [fp8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]\n"
-                    "       %s dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>] [dump=<file>]\n       %s cmp <file a> <file b>\n", argv[0], argv[0], argv[0]);
+  if (argc < 3 || (strcmp(argv[1], "lm") && strcmp(argv[1], "dac") && strcmp(argv[1], "t5"))) {
+    fprintf(stderr, "usage: %s lm <batch> [large] [fp32] [fp8] [kv8] [ctx=<prompt positions>] [tag=<text>] [dump=<file> [steps=<n>]] [eager=<n>]\n"
+                    "       %s dac <batch> [frames=<n>] [f32] [reps=<n>] [tag=<text>] [dump=<file>]\n"
+                    "       %s t5 <batch> [tokens=<n>] [layers=<n>] [fp32] [reps=<n>] [tag=<text>]\n       %s cmp <file a> <file b>\n", argv[0], argv[0], argv[0], argv[0]);
     return 1;
   }
   if (ptts_abi_version() != PTTS_ABI_VERSION) { fprintf(stderr, "libptts_hip.so has ABI %d, the header %d\n", ptts_abi_version(), PTTS_ABI_VERSION); return 1; }
+  if (!strcmp(argv[1], "t5")) return run_t5(argc, argv);
   return !strcmp(argv[1], "lm") ? run_lm(argc, argv) : run_dac(argc, argv);
 }
