@@ -248,6 +248,12 @@ class DacOracle:
             return raw, rb(snake1d(raw, w[f"{d}{bi + 2}.block.0.alpha"])), y
         return raw, snake1d(raw, w[f"{d}{n + 1}.alpha"]), y  # feeds the fp32 final conv: not rounded
 
+    def final_stage(self, act_in: torch.Tensor) -> torch.Tensor:
+        """The last step of decode_latents on a GIVEN input: Conv1d(C → 1, k7, pad 3) + tanh of the fp32 activation the last residual unit
+        hands over (stage n_stages() - 1's act_out). fp32 in both precisions, like decode_latents."""
+        w, d, n = self.w, "decoder.model.", len(self.spec.decoder_rates)
+        return torch.tanh(F.conv1d(act_in, w[f"{d}{n + 2}.weight"], w[f"{d}{n + 2}.bias"], padding=3))
+
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
         """codes [B, K, T] → waveform [B, 1, hop·T]  (DACModel.decode, modeling_dac.py:138-139)."""
         return self.decode_latents(self.from_codes(codes))

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <string.h>
 #include <string>
 #include <atomic>
 
@@ -56,6 +57,31 @@ struct PttsPerDeviceOnce {
   bool need(int dev) const { return !((mask.load(std::memory_order_acquire) >> dev) & 1ull); }
   void done(int dev) { mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
+
+// ---- kernel-argument preload (gfx950) ---------------------------------------------------------------------------------------------
+// A wave's first instructions are s_load of its kernel arguments: one scalar round trip before the first global load can be addressed.
+// gfx950's command processor can instead write the first 14 argument dwords of a dispatch into user SGPRs before the first wave starts
+// (LLVM: -mllvm -amdgpu-kernarg-preload-count=14, set in __graft_entry__.build), but only for arguments the kernel takes as SCALARS - a
+// by-value struct stays behind s_load. Measured on a chain of dependent GEMV nodes: -0.075 us per node (profiles/r05_experiments.txt call 9).
+// The nodes of the decode step therefore take the fields in the first 56 bytes of their argument struct A as scalar parameters of their own
+// types (pointers stay pointers: re-assembled from integers they would lose their address space and every load would become a flat_load)
+// and the rest of A as KTail<A>; A's fields are ordered so that everything a wave needs to address its FIRST loads sits in those 56 bytes.
+// Per struct (ptts_gemv.h): <A>_KPARAMS = the parameter list, <A>_KJOIN(a) re-assembles `A a` in registers (SROA: preloaded SGPRs + the
+// tail's s_loads, no memory), ptts_klaunch(kernel, ..., a) splits it on the host.
+typedef unsigned long long ptts_u64;
+template <typename A> struct KTail {
+  static_assert(sizeof(A) > 56 && sizeof(A) % 8 == 0, "argument struct: more than the 56 preloaded bytes, a multiple of 8");
+  ptts_u64 w[(sizeof(A) - 56) / 8];
+};
+// A tail field first used by the EPILOGUE (the output pointer) would be fetched by an s_load right in front of the store - a scalar round trip at
+// the end of the node's critical path. PTTS_KTOUCH(v), placed behind the wave's load burst, makes the compiler fetch it there, in the burst's shadow.
+#define PTTS_KTOUCH(v) asm volatile("" ::"s"(v))
+#define PTTS_KTAIL_JOIN(A, a) __builtin_memcpy(reinterpret_cast<char*>(&a) + 56, &kt_, sizeof(kt_))
+template <typename A> inline KTail<A> ptts_ktail(const A& a) {
+  KTail<A> t;
+  memcpy(&t, reinterpret_cast<const char*>(&a) + 56, sizeof(t));
+  return t;
+}
 
 // ---- bf16 <-> f32 (round-to-nearest-even, identical to torch's .to(bfloat16)) -------------------------
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

@@ -135,7 +135,7 @@ __device__ __forceinline__ void gv_attn_wave(const GemvArgs& a, const float* par
 #pragma unroll
     for (int sp = 0; sp < S; ++sp) {
       st[i][sp] = *reinterpret_cast<const float2*>(stats + ((size_t)sp * a.nheads + head) * 2);
-      p[i][sp] = *reinterpret_cast<const float4*>(part + (size_t)sp * a.K + k);
+      p[i][sp] = *reinterpret_cast<const float4*>(part + (size_t)sp * (NF4 * 256) + k);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first exp
@@ -170,7 +170,7 @@ __device__ __forceinline__ void gv_attn2_wave(const GemvArgs& a, const float* pa
 #pragma unroll
     for (int sp = 0; sp <= S; ++sp) {
       st[i][sp] = *reinterpret_cast<const float2*>(stats + ((size_t)sp * a.nheads + head) * 2);
-      p[i][sp] = *reinterpret_cast<const float4*>(part + (size_t)sp * a.K + k);
+      p[i][sp] = *reinterpret_cast<const float4*>(part + (size_t)sp * (NF4 * 256) + k);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -207,7 +207,7 @@ __device__ __forceinline__ void gv_lnp_waves(const GemvArgs& a, char* s_x, float
   float4 p[GV_PMAX];
 #pragma unroll
   for (int i = 0; i < GV_PMAX; ++i)
-    if (i < a.npart) p[i] = *reinterpret_cast<const float4*>(a.xpart + (size_t)i * a.K + k);
+    if (i < a.npart) p[i] = *reinterpret_cast<const float4*>(a.part + (size_t)i * (NF4 * 256) + k);
   const float4 g = *reinterpret_cast<const float4*>(a.gamma + k), bt = *reinterpret_cast<const float4*>(a.beta + k);
   __builtin_amdgcn_sched_barrier(0);  // every load of the wave is issued before the first wait
 #pragma unroll
@@ -268,7 +268,8 @@ __device__ __forceinline__ void gv_softmax_wave(const GemvArgs& a, char* s_x, in
 // MB = 8 (batch 5..8): the activation chunks of MG utterances sit in registers at a time (MG * NCH <= 40 vectors), the wave's weight
 // registers are reused for every group; groups past the live batch are skipped (workgroup-uniform).
 template <typename WT, int NCH, int R, int PRO, int EPI, int S, int MB, bool W8, bool STG = false>
-__global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * Elem<WT>::EPL / 4 : MB)) + 4) * 64) gemv_kernel(GemvArgs a) {
+__global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * Elem<WT>::EPL / 4 : MB)) + 4) * 64) gemv_kernel(GemvArgs_KPARAMS) {
+  GemvArgs_KJOIN(a)
   static_assert(!STG || (PRO == GV_COPY && MB == 8), "staged activation rows: GV_COPY nodes of the 5..8-utterance instances only");
   constexpr bool HASPRO = PRO != GV_COPY;
   constexpr int EPL = Elem<WT>::EPL;
@@ -288,10 +289,12 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
     if constexpr (PRO == GV_LNP) {
       gv_lnp_waves<WT, NF4>(a, s_x, s_st, wave, lane);
     } else if (MB == 1 || wave < a.M) {
-      if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (size_t)wave * a.x_ld, s_x + (size_t)wave * ROW_BYTES, lane);
+      constexpr int KK = NF4 * 256;              // = a.K
+      const size_t pw = MB == 1 ? 0 : wave;      // single utterance: no tail argument (x_ld) in front of the row's loads
+      if (PRO == GV_LN) gv_ln_wave<WT, NF4>(a, a.x + (MB == 1 ? 0 : pw * a.x_ld), s_x + pw * ROW_BYTES, lane);
       else if (PRO == GV_SOFTMAX) gv_softmax_wave<WT, NF4>(a, s_x, lane);  // single utterance only
-      else if (PRO == GV_ATTN2) gv_attn2_wave<WT, NF4, S>(a, a.part + (size_t)wave * (S + 1) * a.K, a.stats + (size_t)wave * (S + 1) * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
-      else gv_attn_wave<WT, NF4, S>(a, a.part + (size_t)wave * S * a.K, a.stats + (size_t)wave * S * a.nheads * 2, s_x + (size_t)wave * ROW_BYTES, lane);
+      else if (PRO == GV_ATTN2) gv_attn2_wave<WT, NF4, S>(a, a.part + pw * (S + 1) * KK, a.stats + pw * (S + 1) * a.nheads * 2, s_x + pw * ROW_BYTES, lane);
+      else gv_attn_wave<WT, NF4, S>(a, a.part + pw * S * KK, a.stats + pw * S * a.nheads * 2, s_x + pw * ROW_BYTES, lane);
     }
     if (wave == 0) GV_STAMP(a, 1);  // prologue: operands landed, row prepared, LDS stores issued
     __syncthreads();
@@ -303,8 +306,7 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
   const int em = lane / R, er = lane - em * R;            // epilogue role of this lane: (utterance, row) = (em, er)
   const bool elive = lane < MB * R && (MB == 1 || em < a.M) && r0 + er < a.N;
   float res_pre = 0.f, wsc = 1.f;
-  if (EPI == GV_RESID && elive) res_pre = a.resid[(size_t)em * a.out_ld + r0 + er];  // the launcher points resid at out when the caller left it null
-  if (W8 && elive) wsc = a.wscale[r0 + er];
+  if (EPI == GV_RESID && elive) res_pre = a.resid[(MB == 1 ? 0 : (size_t)em * a.out_ld) + r0 + er];  // the launcher points resid at out when the caller left it null
   uint4 xv[MG][NCH];
   auto load_x = [&](int g) __attribute__((always_inline)) {  // activation chunks of utterances g*MG .. g*MG + MG - 1 (absent ones clamped: computed, dropped)
 #pragma unroll
@@ -328,6 +330,11 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) wv[r][c] = gv_ld_nt<WV>(wp + c * 64);
   }
+  // the tail arguments (one s_load) are first needed HERE, behind the burst: the row scales now, the output pointer in the epilogue
+  __builtin_amdgcn_sched_barrier(0);
+  if (W8 && elive) wsc = a.wscale[r0 + er];
+  PTTS_KTOUCH(a.out);
+  PTTS_KTOUCH(a.out_ld);
   if constexpr (STG) {
     {
       constexpr int PER_ROW = NCH * 64, TOT = MB * PER_ROW / 256;  // 16-byte vectors per row / per thread over the MB rows
@@ -427,7 +434,8 @@ __global__ void __launch_bounds__(((PRO == GV_COPY ? 0 : (PRO == GV_LNP ? NCH * 
 // softmax sums differs (the new position is a slot of its own instead of a row inside a split).
 // ------------------------------------------------------------------------------------------------------
 template <typename WT, int NCH, bool W8, int U>
-__global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
+__global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs_KPARAMS) {
+  QkvAttnArgs_KJOIN(a)
   constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, NW = 8, RW = 8;
   constexpr int NF4 = NCH * EPL / 4;
   constexpr int ROW_BYTES = NCH * 64 * 16;                          // H * sizeof(WT)
@@ -662,7 +670,8 @@ __global__ void __launch_bounds__(512) qkv_attn_kernel(QkvAttnArgs a) {
 // (GV_LNP) adds the rows in a fixed order - no atomics, bit-reproducible.
 // ------------------------------------------------------------------------------------------------------
 template <typename WT, int NCH, int NUR>
-__global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
+__global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs_KPARAMS) {
+  XfoldAttnArgs_KJOIN(a)
   constexpr int EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, NW = 8, RW = 8;
   constexpr int NF4 = NCH * EPL / 4;
   constexpr int ROW_BYTES = NCH * 64 * 16;  // H * sizeof(WT)
@@ -701,9 +710,11 @@ __global__ void __launch_bounds__(512) xfold_attn_kernel(XfoldAttnArgs a) {
 #pragma unroll
   for (int u = 0; u < NUR; ++u)
     uf[u] = ld_nt16(reinterpret_cast<const uint4*>(reinterpret_cast<const WT*>(a.Uw) + (size_t)(n0 + u * NW * RPI) * KU + h * 64) + c);
-  const int mk = a.mask ? a.mask[lane] : 1;
   const int nv = *a.n_valid;
+  const int mk = a.mask ? a.mask[lane] : 1;
   __builtin_amdgcn_sched_barrier(0);  // the loads stay above the barrier
+  PTTS_KTOUCH(nv);       // the dependent scalar load and the epilogue's tail arguments are fetched here, in the shadow of the burst
+  PTTS_KTOUCH(a.xpart);
   if (w == 0) GV_STAMP(a, 1);  // every load issued
   if (w == 0) {  // gv_ln_row's arithmetic
     const float c0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lv[0].x)));

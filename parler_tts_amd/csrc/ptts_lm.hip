@@ -359,7 +359,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         g.W = w.fc1_rm; g.wscale = w.fc1_sc; g.x = e->h; g.x_ld = H; g.gamma = w.ln3_g; g.beta = w.ln3_b;
         g.out = reinterpret_cast<float*>(e->xw2); g.out_ld = F; g.N = F; g.K = H;
         PTTS_DBG_NODE(g, l, 3);
-        if (x_fused) { g.xpart = e->xpart; g.npart = nh; g.hsum = e->h2; PTTS_TRY(gv(GV_LNP, GV_GELU_WT, 1, g, "partial rows+LN3+fc1")); }
+        if (x_fused) { g.part = e->xpart; g.npart = nh; g.hsum = e->h2; PTTS_TRY(gv(GV_LNP, GV_GELU_WT, 1, g, "partial rows+LN3+fc1")); }
         else PTTS_TRY(gv(GV_LN, GV_GELU_WT, 1, g, "LN3+fc1"));
         GemvArgs g2 = {};
         g2.W = w.fc2_rm; g2.wscale = w.fc2_sc; g2.xw = e->xw2; g2.xw_ld = F; g2.out = e->h; g2.out_ld = H; g2.N = H; g2.K = F;
@@ -586,9 +586,16 @@ int fold_cross(ptts_engine* e, hipStream_t st) {
   const ptts_config& c = e->cfg;
   const int H = c.hidden_size, nh = c.num_heads, NE = e->xfold_ne, n_rep = nh / e->nkc, L = c.num_layers;
   const float qscale = 1.44269504088896340736f / sqrtf((float)(H / nh));
-  hipLaunchKernelGGL((xfold_m_kernel<WT, W8>), dim3((H / 8 + 63) / 64, NE, L * nh), dim3(64), 0, st, e->fold_layers, nh, H, NE, c.max_enc, n_rep,
-                     e->dims, qscale);
-  hipLaunchKernelGGL((xfold_u_kernel<WT, W8>), dim3((nh * NE + 63) / 64, H, L), dim3(64), 0, st, e->fold_layers, H, NE, nh, c.max_enc, n_rep, e->dims);
+  // tiled kernels (round 5; bit-identical to the row kernels, PTTS_FOLD_TILED=0 selects those for A/B)
+  static const bool tiled = !(getenv("PTTS_FOLD_TILED") && !atoi(getenv("PTTS_FOLD_TILED")));
+  if (tiled && H % 64 == 0 && NE <= 64) {
+    hipLaunchKernelGGL((xfold_tile_kernel<WT, W8, false>), dim3(H / 64, nh, L), dim3(256), 0, st, e->fold_layers, nh, H, NE, c.max_enc, n_rep, e->dims, qscale);
+    hipLaunchKernelGGL((xfold_tile_kernel<WT, W8, true>), dim3(H / 64, nh, L), dim3(256), 0, st, e->fold_layers, nh, H, NE, c.max_enc, n_rep, e->dims, qscale);
+  } else {
+    hipLaunchKernelGGL((xfold_m_kernel<WT, W8>), dim3((H / 8 + 63) / 64, NE, L * nh), dim3(64), 0, st, e->fold_layers, nh, H, NE, c.max_enc, n_rep,
+                       e->dims, qscale);
+    hipLaunchKernelGGL((xfold_u_kernel<WT, W8>), dim3((nh * NE + 63) / 64, H, L), dim3(64), 0, st, e->fold_layers, H, NE, nh, c.max_enc, n_rep, e->dims);
+  }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "cross-attention fold launch failed: %s", hipGetErrorString(err));
   return PTTS_OK;

@@ -2030,6 +2030,76 @@ __global__ void __launch_bounds__(64) xfold_u_kernel(const FoldLayer* __restrict
   store_from_f32<WT>(reinterpret_cast<WT*>(fl.U) + (size_t)o * heads * NE + col, acc);
 }
 
+// The same two products, tiled (round 5): the kernels above re-read their second operand once per output row - xfold_u_kernel the head's V rows
+// for each of the H output rows (438 us for the 24 layers of Mini-v1), xfold_m_kernel the head's 64 rows of Wq for each of the NE positions
+// (141 us). Here a workgroup owns a 64 x 64 output tile of one (layer, head): both operands ([64][64 head dimensions]) go through LDS once,
+// transposed to [d][i] / [d][j], and a thread accumulates a 4 x 4 patch with ONE fmaf chain per output in ascending d - the order (and therefore
+// every bit) of the kernels above. IS_U: out = U, i = output row o (tile index blockIdx.x), j = position n; else out = M, i = position n,
+// j = input feature k (tile index blockIdx.x). grid (H / 64, heads, layers), 256 threads; H % 64 == 0.
+template <typename WT, bool W8, bool IS_U>
+__global__ void __launch_bounds__(256) xfold_tile_kernel(const FoldLayer* __restrict__ layers, int nheads, int H, int NE, int cap, int n_rep,
+                                                         const DevDims* dims, float qscale) {
+  constexpr int LD = 68;  // row pitch in floats: 16-byte aligned rows for the float4 reads
+  __shared__ __attribute__((aligned(16))) float At[64 * LD];
+  __shared__ __attribute__((aligned(16))) float Bt[64 * LD];
+  const int tid = threadIdx.x, t0 = blockIdx.x * 64, h = blockIdx.y;
+  const FoldLayer fl = layers[blockIdx.z];
+  const int N = dims->N;
+  const WT* kv = reinterpret_cast<const WT*>(IS_U ? fl.vcache : fl.kcache) + (size_t)(h / n_rep) * cap * 64;
+  float* const kvt = IS_U ? Bt : At;  // the cache rows are the j operand of U and the i operand of M
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = tid & 63, d0 = (r * 4 + (tid >> 6)) * 8;  // consecutive lanes = consecutive rows: conflict-free transposed stores
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (row < NE && row < N) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = Elem<WT>::ld(kv + (size_t)row * 64 + d0 + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kvt[(d0 + e) * LD + row] = v[e];
+    float w[8];
+    if constexpr (IS_U) {  // Wo row t0 + row, head dimensions d0 .. d0 + 7 of head h
+      RmRow<WT, W8>::ld8(fl.wo, fl.wo_sc, t0 + row, H, h * 64 + d0, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) At[(d0 + e) * LD + row] = w[e];
+    } else {               // Wq row h * 64 + row (= head dimension d), input features t0 + d0 .. + 7
+      RmRow<WT, W8>::ld8(fl.wq, fl.wq_sc, h * 64 + row, H, t0 + d0, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Bt[row * LD + d0 + e] = w[e];
+    }
+  }
+  __syncthreads();
+  const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+#pragma unroll 8
+  for (int d = 0; d < 64; ++d) {
+    const float4 av = *reinterpret_cast<const float4*>(At + d * LD + i0), bv = *reinterpret_cast<const float4*>(Bt + d * LD + j0);
+    const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(aa[a], bb[b], acc[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if constexpr (IS_U) {
+        const int o = t0 + i0 + a, n = j0 + b;
+        if (n < NE) store_from_f32<WT>(reinterpret_cast<WT*>(fl.U) + (size_t)o * nheads * NE + h * NE + n, n < N ? acc[a][b] : 0.f);
+      } else {
+        const int n = i0 + a, k = t0 + j0 + b;
+        if (n < NE) store_from_f32<WT>(reinterpret_cast<WT*>(fl.M) + ((size_t)h * NE + n) * H + k, (n < N ? acc[a][b] : 0.f) * qscale);
+      }
+    }
+}
+
 // prefill: write all Q new K/V rows (RoPE on k) into the self cache.  grid (Q, heads, B), 64 threads
 template <typename WT, bool KV8 = false>
 __global__ void kv_append_kernel(const float* __restrict__ knew, const float* __restrict__ vnew, int kv_ld, void* kcache,

@@ -86,7 +86,15 @@ def test_every_stage_matches_the_oracle_on_identical_inputs(mode, fuse, monkeypa
             if mode == "bf16":
                 check(frac <= ACT_FLIP, mode, fuse, s, "act flips", frac)
         prev_act, prev_raw = act, raw
-    log_parity(f"[dac stages {mode} fused={fuse}] {orc.n_stages()} stages, {B} x {T} frames: worst raw-stream relative RMS {worst_raw:.2e}, "
+    # the last kernel of the decode - Conv1d(C -> 1, k7) + tanh (conv_out_tanh_lds_kernel; fp32 fma chain in both modes) - on the ENGINE's own last
+    # activation (it was covered end to end only): what is left is the summation order of 672 fp32 products in front of the tanh
+    wave = d.decode(codes.cuda()).cpu().reshape(B, 1, -1)
+    exp_wave = orc.final_stage(prev_act)
+    e_out = _rel(wave, exp_wave)
+    rows.append(f"out:{e_out:.1e}")
+    check(wave.shape == exp_wave.shape and e_out <= 1e-5, mode, fuse, "final conv + tanh", e_out)
+    check(float((wave - exp_wave).abs().max()) <= 1e-5, mode, fuse, "final conv + tanh max", float((wave - exp_wave).abs().max()))
+    log_parity(f"[dac stages {mode} fused={fuse}] {orc.n_stages()} stages + the final conv, {B} x {T} frames: worst raw-stream relative RMS {worst_raw:.2e}, "
                f"worst fraction of activation elements differing (<= 1 bf16 ulp each) {worst_flip:.2e}; per stage: {' '.join(rows)}"
                + (f"; FAILED: {fails[:6]}" if fails else ""), name="r04_parity_dac_stages.txt")
     d.close()

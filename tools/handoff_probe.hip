@@ -130,7 +130,7 @@ int main() {
       else {  // E: the product's LN1 + QKV node (LayerNorm prologue wave + 4 GEMV waves, 3 rows per wave) in the producer's place; F: + consumer
         GemvArgs ga = {};
         ga.W = Wl; ga.x = x; ga.x_ld = H; ga.gamma = gamma; ga.beta = beta; ga.out = q; ga.out_ld = NROWS; ga.N = NROWS; ga.K = H; ga.M = 1; ga.invK = 1.0f / H;
-        hipLaunchKernelGGL((gemv_kernel<bf16_t, 2, 3, GV_LN, GV_STORE, 1, 1, false>), dim3(256), dim3(320), H * 2, st, ga);
+        ptts_klaunch(gemv_kernel<bf16_t, 2, 3, GV_LN, GV_STORE, 1, 1, false>, dim3(256), dim3(320), H * 2, st, ga);
         if (variant == 5) hipLaunchKernelGGL(k_consumer, dim3(64), dim3(256), 0, st, KVl, q, out);
       }
       hipLaunchKernelGGL(k_rest, dim3(4), dim3(256), 0, st, out, x);
