@@ -1271,15 +1271,23 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   }
   const int nstrips = L.Cout / 16;
   // LDS-tiled kernel where it wins (rocprof per layer, profiles/r02_dac_layers.txt): every k7 conv (2x the direct kernel) and the
-  // transposed convs into >= 192 channels. The k1 convs and the last transposed conv are bound by their epilogue traffic
-  // (residual read + two writes per element) and run as fast or faster on the direct kernel's 4-5 waves per SIMD than on this one's 2.
+  // transposed convs into >= 192 channels. The last transposed conv is bound by its epilogue traffic (two writes per element) and runs as fast
+  // on the direct kernel's 4-5 waves per SIMD as on this one's 2 (round 2 said the same of the k1 convs; see lds_k1 below).
   static const bool no_lds = getenv("PTTS_DAC_NO_LDS") != nullptr;
   static const int lds_min_c = getenv("PTTS_DAC_LDS_MIN_C") ? atoi(getenv("PTTS_DAC_LDS_MIN_C")) : 96;
   static const bool lds_small_taps = getenv("PTTS_DAC_LDS_K1") != nullptr;
-  // the last transposed conv (-> 96 channels) stays on the direct kernel: the LDS-tiled one measured the same 5.19 ms per batch-32 launch
-  // (PTTS_DAC_LAST_UP_LDS=1 selects it; profiles/r04_experiments.txt call 7)
-  static const bool last_up_lds = getenv("PTTS_DAC_LAST_UP_LDS") && atoi(getenv("PTTS_DAC_LAST_UP_LDS"));
-  const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c : (lds_small_taps || (a.transposed && L.Cout >= (last_up_lds ? 96 : 192)));
+  // k1 convs (the un-fused units of the C = 768 block): on the LDS-tiled kernel from 32 K rows per launch (round 5) - with the whole-row epilogue
+  // through LDS it beats the direct kernel at batch 32 (63.1 -> 61.3 ms per decode) and loses 1 % on a single utterance's 6880 rows (2.69 vs 2.71 ms;
+  // profiles/r05_experiments.txt calls 13 / 15). PTTS_DAC_NO_LDS_K1=1: always direct; PTTS_DAC_LDS_K1=1: every k1 / transposed conv on the LDS kernel.
+  static const bool lds_k1_on = !(getenv("PTTS_DAC_NO_LDS_K1") && atoi(getenv("PTTS_DAC_NO_LDS_K1")));
+  const bool lds_k1 = lds_k1_on && (long long)B * Tin >= 32768;
+  // the last transposed conv (-> 96 channels): on the LDS-tiled kernel since round 5. Round 4 measured it equal to the direct kernel (5.19 ms per
+  // batch-32 launch) - with the 96-channel staging instance, which needs 324 VGPRs and ran one wave per SIMD; with 32-channel staging chunks
+  // (conv_lds_kernel<3, 2, 1, 2>, 228 VGPRs, two waves per SIMD) the batch-32 decode drops 61.3 -> 59.3 ms, 860 frames 2.71 -> 2.67 ms
+  // (profiles/r05_experiments.txt call 15). PTTS_DAC_LAST_UP_LDS=0: the direct kernel.
+  static const bool last_up_lds = !(getenv("PTTS_DAC_LAST_UP_LDS") && !atoi(getenv("PTTS_DAC_LAST_UP_LDS")));
+  const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c
+                                  : (lds_small_taps || (a.transposed && L.Cout >= (last_up_lds ? 96 : 192)) || (lds_k1 && !a.transposed && a.ntaps == 1));
   {
     const char* ced = getenv("PTTS_DAC_CONV_EPI_DIRECT");  // read per call (A/B inside one process)
     a.epi_direct = (ced && atoi(ced)) ? 1 : 0;
@@ -1293,8 +1301,12 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
       if (nw == 4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 1, 54>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((conv_lds_kernel<3, 2, 1, 54>), grid, dim3(128), 0, st, a);
     } else if (a.ntaps <= 2 && a.Cin % 96 == 0) {
+      // two-wave workgroups (Cout = 96: the last transposed conv): 32-channel staging chunks - the 96-channel instance stages 13 16-byte pieces per
+      // thread, needs 324 VGPRs and runs ONE wave per SIMD (hipcc: "fails its waves_per_eu(2,2) target"; tools/isa_audit.py)
+      static const bool ks3 = getenv("PTTS_DAC_UP2_KS3") && atoi(getenv("PTTS_DAC_UP2_KS3"));  // A/B: the 96-channel chunks
       if (nw == 4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 3, 2>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((conv_lds_kernel<3, 2, 3, 2>), grid, dim3(128), 0, st, a);
+      else if (ks3) hipLaunchKernelGGL((conv_lds_kernel<3, 2, 3, 2>), grid, dim3(128), 0, st, a);
+      else hipLaunchKernelGGL((conv_lds_kernel<3, 2, 1, 2>), grid, dim3(128), 0, st, a);
     } else {
       done = false;
     }
