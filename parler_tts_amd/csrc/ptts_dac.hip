@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "ptts_common.h"
 
@@ -312,8 +313,74 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     static_assert(EF0 >= 16, "one 16-frame pass of the output tile fits the slab memory");
     unsigned char* et = &slab[0][0];  // the last chunk's barrier has retired every slab read
     const int c0 = blockIdx.y * CW;
+    // Round 5 (as resunit_lds_kernel's epilogue): the Snake parameters of this workgroup's CW channels go through LDS, and a pass over EF whole
+    // rows is ONE straight-line block per (residual?, stream?, activation format) - no load from global memory and no branch between the stores,
+    // so no s_waitcnt vmcnt(0) (= "until my last stores are acknowledged") in front of every row piece.
+    constexpr int NPT = EF * VPR / NT;
+    static_assert(EF * VPR % NT == 0, "row pieces per thread and pass");
+    int tid_e = tid;  // an opaque copy for the epilogue's address arithmetic: computed from `tid` it is hoisted above the MFMA loop and spilled there
+    asm volatile("" : "+v"(tid_e));
+    static_assert(EF * RSE + 2 * CW * 4 <= SLB, "LDS: one pass of the output tile + the Snake parameters");
+    float* s_al = reinterpret_cast<float*>(et + EF * RSE);  // [2][CW]: alpha | 1 / (alpha + 1e-9)
+    if (a.out_act)
+      for (int i = tid; i < 2 * VPR; i += NT) {
+        const int hf = i / VPR, c4 = i - hf * VPR;
+        reinterpret_cast<float4*>(s_al)[i] = *reinterpret_cast<const float4*>(a.alpha + (size_t)hf * a.Cout + c0 + c4 * 4);
+      }
+    typedef std::integral_constant<int, 0> I0_;
+    typedef std::integral_constant<int, 1> I1_;
+    typedef std::integral_constant<int, 2> I2_;
+    auto pass = [&](auto skip_c, auto raw_c, auto act_c, const int r0, const int rows) __attribute__((always_inline)) {
+      constexpr bool SK = decltype(skip_c)::value != 0, RW = decltype(raw_c)::value != 0;
+      constexpr int AC = decltype(act_c)::value;  // 0: no activation output, 1: bf16, 2: fp32
+      auto offs = [&](const int i) { const int rr = i / VPR, cv = i - rr * VPR; return ((size_t)b * Tout + (size_t)(r0 + rr) * a.nphase + ph) * a.Cout + c0 + cv * 4; };
+      auto piece = [&](const int i, const size_t o, const float4 sk) __attribute__((always_inline)) {
+        const int rr = i / VPR, cv = i - rr * VPR;
+        float4 v = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
+        if constexpr (SK) { v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w; }
+        if constexpr (RW) *reinterpret_cast<float4*>(a.out_raw + o) = v;
+        if constexpr (AC != 0) {
+          const float4 al = *reinterpret_cast<const float4*>(s_al + cv * 4), ia = *reinterpret_cast<const float4*>(s_al + CW + cv * 4);
+          const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
+          if constexpr (AC == 1) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
+        }
+      };
+      if (rows == EF) {
+        constexpr int GP = NPT > 6 ? 6 : NPT;  // residual values in flight per group (registers: acc is still live for the next pass)
+        static_assert(NPT % GP == 0, "row pieces per group");
 #pragma unroll
-    for (int p0 = 0; p0 < FT; p0 += TPP) {
+        for (int k0 = 0; k0 < NPT; k0 += GP) {
+          float4 skp[SK ? GP : 1];
+          if constexpr (SK) {
+#pragma unroll
+            for (int k = 0; k < GP; ++k) skp[k] = *reinterpret_cast<const float4*>(a.skip + offs(tid_e + (k0 + k) * NT));
+          }
+#pragma unroll
+          for (int k = 0; k < GP; ++k) piece(tid_e + (k0 + k) * NT, offs(tid_e + (k0 + k) * NT), SK ? skp[SK ? k : 0] : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+      } else {
+#pragma unroll 2
+        for (int k = 0; k < NPT; ++k) {
+          const int i = tid_e + k * NT;
+          if (i / VPR < rows) {
+            const size_t o = offs(i);
+            float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (SK) sk = *reinterpret_cast<const float4*>(a.skip + o);
+            piece(i, o, sk);
+          }
+        }
+      }
+    };
+    auto by_act = [&](auto skip_c, auto raw_c, const int r0, const int rows) __attribute__((always_inline)) {
+      if (!a.out_act) pass(skip_c, raw_c, I0_(), r0, rows);
+      else if (a.act_f32) pass(skip_c, raw_c, I2_(), r0, rows);
+      else pass(skip_c, raw_c, I1_(), r0, rows);
+    };
+    // (explicitly instantiated per pass: inside a `#pragma unroll` loop the dispatch below stopped the unroller and `acc` went to scratch)
+    auto do_pass = [&](auto p0_c) __attribute__((always_inline)) {
+      constexpr int p0 = decltype(p0_c)::value;
+      if constexpr (p0 < FT) {
 #pragma unroll
       for (int s = 0; s < CSW; ++s) {
         const float4 bs = *reinterpret_cast<const float4*>(a.bias + (strip0 + s) * 16 + q * 4);
@@ -325,26 +392,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       }
       __syncthreads();
       const int r0 = t0 + p0 * 16, rows = min(EF, Tnv - r0);
-#pragma unroll 4
-      for (int i = tid; i < EF * VPR; i += NT) {
-        const int rr = i / VPR, cv = i - rr * VPR;
-        if (rr >= rows) break;
-        float4 v = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
-        const size_t o = ((size_t)b * Tout + (size_t)(r0 + rr) * a.nphase + ph) * a.Cout + c0 + cv * 4;
-        if (a.skip) {
-          const float4 sk = *reinterpret_cast<const float4*>(a.skip + o);
-          v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
-        }
-        if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + o) = v;
-        if (a.out_act) {
-          const float4 al = *reinterpret_cast<const float4*>(a.alpha + c0 + cv * 4), ia = ld_inv4(a.alpha, a.Cout, c0 + cv * 4);
-          const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
-          if (!a.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
-          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out_act) + o) = sv;
-        }
-      }
+      if (a.skip) { if (a.out_raw) by_act(I1_(), I1_(), r0, rows); else by_act(I1_(), I0_(), r0, rows); }
+      else { if (a.out_raw) by_act(I0_(), I1_(), r0, rows); else by_act(I0_(), I0_(), r0, rows); }
       if (p0 + TPP < FT) __syncthreads();  // the tile memory is rewritten by the next pass
-    }
+      }
+    };
+    do_pass(std::integral_constant<int, 0>()); do_pass(std::integral_constant<int, TPP>()); do_pass(std::integral_constant<int, 2 * TPP>());
+    do_pass(std::integral_constant<int, 3 * TPP>()); do_pass(std::integral_constant<int, 4 * TPP>()); do_pass(std::integral_constant<int, 5 * TPP>());
+    do_pass(std::integral_constant<int, 6 * TPP>()); do_pass(std::integral_constant<int, 7 * TPP>());
     return;
   }
   // direct epilogue: as conv_mfma_kernel (D[row = co_local = q*4 + r][col = frame j]); explicit (s, f) calls keep `acc` statically indexed
@@ -412,7 +467,9 @@ template <int NW, int KS = 1> struct ResunitLds {
 // = 384 cycles per wave, ~770 with the SIMD's second wave interleaved: one step ahead is ~0.3 us, less than an L2 round trip - and the
 // fragments DO come from the L2 every time (a wave re-streams its 3 strips x 7 taps x C channels = 129 KB at C = 192 per tile through a
 // 32 KB L1 shared by 8 waves), so every k-step waited for its weights: MFMA pipe 23-28 % busy (profiles/r03_pmc_dac_mfma.txt).
-template <int NW, int KS = 1, int WD = 3>
+// RAW / F32 (round 5): does the launch write the fp32 stream, and is the activation written as fp32 (the unit feeding the final conv)? Compile-time,
+// so that the epilogue's pass over a whole half tile is ONE straight-line block (see there).
+template <int NW, int KS = 1, int WD = 3, bool RAW = true, bool F32 = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) resunit_lds_kernel(ResArgs ra) {
   constexpr int CSW = 3, FT = 8, TF = FT * 16, MAXHALO = 54;
   constexpr int C = NW * CSW * 16;
@@ -595,7 +652,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   if (!ra.epi_direct) {
     constexpr int RSE = C * 4 + 16, VPR = C / 4;
     unsigned char* et = lds;
+    // The output Snake's [alpha | 1 / (alpha + 1e-9)] go through LDS (round 5): fetched from global memory inside the loop below, every iteration's
+    // s_waitcnt vmcnt() for them also waited for the STORES of the iteration before (loads and stores retire in order on one counter) - 24 store
+    // round trips in a row per workgroup, ~2/3 of the time the three fused units spent outside their MFMA loops (found in the ISA, not in a counter).
+    static_assert(ResunitLds<NW, KS>::bytes >= 64 * RSE + 2 * C * 4, "LDS: half output tile + the output Snake's parameters");
+    float* s_al = reinterpret_cast<float*>(lds + 64 * RSE);  // [2][C]
     __syncthreads();  // every wave has finished reading the y tile
+    for (int i = tid; i < 2 * C / 4; i += NT) reinterpret_cast<float4*>(s_al)[i] = reinterpret_cast<const float4*>(ra.alpha1)[i];
     // (requesting the residual rows before the transposition, and the second half's as the first half's registers free up, measured SLOWER:
     //  C = 96 unit 4228 -> 4735 us, profiles/r04_experiments.txt call 7; they are requested after the tile's barrier, 12 loads at once)
 #pragma unroll
@@ -614,24 +677,34 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
       const int r0 = t0 + hh * 64;
       const int rows = min(64, Tv - r0);
       const size_t base = ((size_t)b * a.Tn + r0) * C;
-      load_skip(hh);
-#pragma unroll
-      for (int k = 0; k < NPT; ++k) {
+      // A whole half tile (every tile but an utterance's last) is ONE straight-line block: 12 unconditional residual loads, then per row piece
+      // LDS reads -> add -> store(s) -> Snake -> store, no load from global memory and no branch in between. With the stream / activation format
+      // decided by branches inside the loop (and the Snake parameters loaded from global memory there), the compiler's wait-count bookkeeping
+      // put an s_waitcnt vmcnt(0) - "until my last STORES are acknowledged", loads and stores retire in order on one counter - in front of every
+      // row piece: 24 store round trips in a row per workgroup.
+      auto piece = [&](const int k, const float4 sk) __attribute__((always_inline)) {
         const int i = tid + k * NT;
         const int rr = i / VPR, cv = i - rr * VPR;
-        const float4 sk = skp[k];
-        if (rr < rows) {
-          const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
-          const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
-          const float4 v = make_float4(av.x + sk.x, av.y + sk.y, av.z + sk.z, av.w + sk.w);
-          if (ra.out_raw) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
-          if (ra.out_act) {
-            const float4 al = *reinterpret_cast<const float4*>(ra.alpha1 + cv * 4), ia = ld_inv4(ra.alpha1, C, cv * 4);
-            const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
-            if (!ra.act_f32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
-            else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
-          }
-        }
+        const float4 av = *reinterpret_cast<const float4*>(et + rr * RSE + cv * 16);
+        const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
+        const float4 v = make_float4(av.x + sk.x, av.y + sk.y, av.z + sk.z, av.w + sk.w);
+        if constexpr (RAW) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
+        const float4 al = *reinterpret_cast<const float4*>(s_al + cv * 4), ia = *reinterpret_cast<const float4*>(s_al + C + cv * 4);
+        const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
+        if constexpr (!F32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
+      };
+      if (rows == 64) {
+        const float* sb_ = ra.skip + base;
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) skp[k] = *reinterpret_cast<const float4*>(sb_ + (size_t)(tid + k * NT) * 4);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) piece(k, skp[k]);
+      } else {
+        load_skip(hh);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+          if ((tid + k * NT) / VPR < rows) piece(k, skp[k]);
       }
       if (hh == 0) __syncthreads();  // the tile is rewritten by the second half
     }
@@ -1373,26 +1446,31 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
     r.epi_direct = (ed && atoi(ed)) ? 1 : 0;
   }
   const dim3 grid((unsigned)(((T + 127) / 128) * B));
-  const char* wde = getenv("PTTS_DAC_WD1");  // A/B: weight fragments requested one k-step ahead (two register sets) instead of three
-  const bool wd3 = !(wde && atoi(wde));
+  // instances by (width, stream written?, fp32 activation?): compile-time in the kernel (its epilogue is straight-line code). The two-register-set
+  // weight prefetch (WD = 1, round 3) is no longer instantiated.
+  if (!out_act) return ptts_fail(PTTS_E_INVALID, "residual unit: no activation output");
+  const bool raw = out_raw != nullptr;
+  if (act_f32 && c7.Cout != 96) return ptts_fail(PTTS_E_UNSUPPORTED, "residual unit: fp32 activations only at the last block's width");
+#define PTTS_RU_LAUNCH(NWV, RAWV, F32V) \
+  hipLaunchKernelGGL((resunit_lds_kernel<NWV, 1, 3, RAWV, F32V>), grid, dim3(NWV * 64), (ResunitLds<NWV, 1>::bytes), st, r)
   if (c7.Cout == 384) {
     static PttsPerDeviceOnce attr_once;  // 100 KB of dynamic LDS needs the opt-in
     const int attr_dev = PttsPerDeviceOnce::device();
     if (attr_once.need(attr_dev)) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
-      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
+      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
       if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea));
       attr_once.done(attr_dev);
     }
-    if (wd3) hipLaunchKernelGGL((resunit_lds_kernel<8, 1, 3>), grid, dim3(512), (ResunitLds<8, 1>::bytes), st, r);
-    else hipLaunchKernelGGL((resunit_lds_kernel<8, 1, 1>), grid, dim3(512), (ResunitLds<8, 1>::bytes), st, r);
+    if (raw) PTTS_RU_LAUNCH(8, true, false); else PTTS_RU_LAUNCH(8, false, false);
   } else if (c7.Cout == 192) {
-    if (wd3) hipLaunchKernelGGL((resunit_lds_kernel<4, 1, 3>), grid, dim3(256), (ResunitLds<4, 1>::bytes), st, r);
-    else hipLaunchKernelGGL((resunit_lds_kernel<4, 1, 1>), grid, dim3(256), (ResunitLds<4, 1>::bytes), st, r);
+    if (raw) PTTS_RU_LAUNCH(4, true, false); else PTTS_RU_LAUNCH(4, false, false);
+  } else if (act_f32) {
+    if (raw) PTTS_RU_LAUNCH(2, true, true); else PTTS_RU_LAUNCH(2, false, true);
   } else {
-    if (wd3) hipLaunchKernelGGL((resunit_lds_kernel<2, 1, 3>), grid, dim3(128), (ResunitLds<2, 1>::bytes), st, r);
-    else hipLaunchKernelGGL((resunit_lds_kernel<2, 1, 1>), grid, dim3(128), (ResunitLds<2, 1>::bytes), st, r);
+    if (raw) PTTS_RU_LAUNCH(2, true, false); else PTTS_RU_LAUNCH(2, false, false);
   }
+#undef PTTS_RU_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "residual-unit launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;

@@ -853,6 +853,29 @@ __global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
       for (int mt = 0; mt < MT; ++mt) bf[mt] = bn[mt];
     }
   }
+  if constexpr (EPI == EPI_RESID) {
+    // every residual piece is requested BEFORE the first store: interleaved (load, add, store per piece) each load's s_waitcnt vmcnt() also
+    // waited for the store in front of it - loads and stores retire in order on one counter (found in the DAC epilogues, round 5)
+    float4 res[NS][MT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = min(m0 + mt * 16 + j, a.M - 1);
+        res[s][mt] = *reinterpret_cast<const float4*>(a.out + (size_t)m * a.out_ld + (strip0 + s) * 16 + q * 4);
+      }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + mt * 16 + j;
+        const f32x4 r = acc[s][mt];
+        if (m < a.M)
+          *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + (strip0 + s) * 16 + q * 4) =
+              make_float4(res[s][mt].x + r[0], res[s][mt].y + r[1], res[s][mt].z + r[2], res[s][mt].w + r[3]);
+      }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -966,6 +989,27 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
 #undef PTTS_TILE_FETCH
 #undef PTTS_TILE_COMMIT
 #undef PTTS_TILE_COMPUTE
+  if constexpr (EPI == EPI_RESID) {  // residual pieces requested before the first store (gemm_block_kernel)
+    float4 res[NS][MT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = min(m0 + (wm * MT + mt) * 16 + j, a.M - 1);
+        res[s][mt] = *reinterpret_cast<const float4*>(a.out + (size_t)m * a.out_ld + (strip0 + wn * NS + s) * 16 + q * 4);
+      }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (wm * MT + mt) * 16 + j;
+        const f32x4 r = acc[s][mt];
+        if (m < a.M)
+          *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + (strip0 + wn * NS + s) * 16 + q * 4) =
+              make_float4(res[s][mt].x + r[0], res[s][mt].y + r[1], res[s][mt].z + r[2], res[s][mt].w + r[3]);
+      }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s)
 #pragma unroll

@@ -274,9 +274,6 @@ def test_fused_residual_units_44khz(fuse384, monkeypatch):
     monkeypatch.setenv("PTTS_DAC_CONV_EPI_DIRECT", "1")  # conv_lds_kernel (k7 at C = 768, transposed convs): direct epilogue instead of whole rows through LDS
     assert torch.equal(d.decode(codes.cuda()).cpu(), fused)
     monkeypatch.delenv("PTTS_DAC_CONV_EPI_DIRECT")
-    monkeypatch.setenv("PTTS_DAC_WD1", "1")  # weight fragments requested one k-step ahead (two register sets) instead of three: same arithmetic
-    assert torch.equal(d.decode(codes.cuda()).cpu(), fused)
-    monkeypatch.delenv("PTTS_DAC_WD1")
     monkeypatch.setenv("PTTS_DAC_NO_FUSE_RES", "1")  # read per call: the two-launch path of the same engine
     plain = d.decode(codes.cuda()).cpu()
     monkeypatch.delenv("PTTS_DAC_NO_FUSE_RES")
