@@ -185,9 +185,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 //   * two LDS buffers: chunk c+1 is fetched into registers while chunk c computes and committed before the ONE barrier of
 //     the chunk; B fragments are read in two halves of 4 frame tiles, each half in flight under the other half's 12 MFMAs.
 // Per k-step and wave: 24 MFMAs 16x16x32 (384 cycles) against 8 ds_read_b128 + 3 global 16-B loads.
-template <int CSW, int NW, int KS, int MAXHALO>
+// FT (round 5): 16-frame tiles per workgroup - 8 (128 frames), or 4 where 128-frame tiles leave the launch with fewer than two workgroups per CU (the
+// first block of a single utterance: 56-224 workgroups on 256 CUs; the short windows of the streamer). Same k order per output: bit-identical.
+template <int CSW, int NW, int KS, int MAXHALO, int FT = 8>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_lds_kernel(ConvArgs a) {
-  constexpr int FT = 8, TF = FT * 16;
+  constexpr int TF = FT * 16, HF = FT / 2;
+  static_assert(FT == 8 || FT == 4, "frame tiles per workgroup");
   constexpr int KCH = 32 * KS;
   constexpr int RS = KS * 64 + 32;
   constexpr int SL = KS * 4;  // 16-byte slots per slab row
@@ -247,13 +250,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     const int tap_ = (S) / KS, kk_ = (S) - tap_ * KS;                                                                     \
     const int rel_ = a.transposed ? (a.ntaps - 1 - tap_) : tap_ * a.dil;                                                  \
     const unsigned char* sp_ = (SB) + (rel_ + (F0) * 16) * RS + kk_ * 64 + lrow;                                          \
-    _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) BV[f_] = *reinterpret_cast<const uint4*>(sp_ + f_ * 16 * RS);       \
+    _Pragma("unroll") for (int f_ = 0; f_ < HF; ++f_) BV[f_] = *reinterpret_cast<const uint4*>(sp_ + f_ * 16 * RS);       \
   } while (0)
 
   // One k-step: MFMAs of (chunk c, step st) with the weight fragments WC while WN receives those of the NEXT k-step (possibly the
   // first of chunk c + 1). The register sets rotate (never copied: a copy makes the compiler wait for the loads it has just issued). The last step of a chunk commits the staged slab and holds the chunk's barrier.
 #define PTTS_MFMA_HALF(WC, BV, F0)                                                                                      \
-  _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_)                      \
+  _Pragma("unroll") for (int f_ = 0; f_ < HF; ++f_) _Pragma("unroll") for (int s_ = 0; s_ < CSW; ++s_)                     \
     acc[s_][(F0) + f_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WC[s_]), __builtin_bit_cast(bf16x8, BV[f_]), acc[s_][(F0) + f_], 0, 0, 0);
 #define PTTS_STEP(WC, WN)                                                                                               \
   {                                                                                                                     \
@@ -263,10 +266,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     const int gc_ = gn_ / NS;               /* re-fetch at the very end): a branch here would merge into a conservative */ \
     if (st == 0 && more_) { PTTS_SLAB_FETCH(c + 1); } /* vmcnt on the MFMAs below */                                      \
     PTTS_W_FETCH(WN, gc_, gn_ - gc_ * NS);                                                                                \
-    PTTS_B_FETCH(bB, sb_, st, 4);                                                                                         \
+    PTTS_B_FETCH(bB, sb_, st, HF);                                                                                        \
     PTTS_MFMA_HALF(WC, bA, 0)                                                                                             \
     if (!lastst_) PTTS_B_FETCH(bA, sb_, st + 1, 0);                                                                       \
-    PTTS_MFMA_HALF(WC, bB, 4)                                                                                             \
+    PTTS_MFMA_HALF(WC, bB, HF)                                                                                            \
     if (lastst_) {                                                                                                        \
       if (more_) { PTTS_SLAB_COMMIT((c + 1) & 1); }                                                                       \
       __syncthreads();                                                                                                    \
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   }
   const int total = nchunk * NS;
   float4 w0[CSW], w1[CSW], w2[CSW], w3[CSW];  // four register sets: k-step g computes out of w[g % 4] while the fragments of k-step g + 3 land
-  uint4 bA[4], bB[4];
+  uint4 bA[HF], bB[HF];
   PTTS_W_FETCH(w0, 0, 0);
   { const int g1_ = min(1, total - 1), c1_ = g1_ / NS; PTTS_W_FETCH(w1, c1_, g1_ - c1_ * NS); }
   { const int g2_ = min(2, total - 1), c2_ = g2_ / NS; PTTS_W_FETCH(w2, c2_, g2_ - c2_ * NS); }
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   if (!a.epi_direct) {
     constexpr int CW = NW * CSW * 16, RSE = CW * 4 + 16, SLB = 2 * MAXROWS * RS, VPR = CW / 4;
     constexpr int EF0 = SLB / RSE;
-    constexpr int EF = EF0 >= 128 ? 128 : (EF0 >= 64 ? 64 : (EF0 >= 32 ? 32 : 16)), TPP = EF / 16;
+    constexpr int EF1 = EF0 >= 128 ? 128 : (EF0 >= 64 ? 64 : (EF0 >= 32 ? 32 : 16)), EF = EF1 > TF ? TF : EF1, TPP = EF / 16;
     static_assert(EF0 >= 16, "one 16-frame pass of the output tile fits the slab memory");
     unsigned char* et = &slab[0][0];  // the last chunk's barrier has retired every slab read
     const int c0 = blockIdx.y * CW;
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #define PTTS_EMIT_ROW(S)                                                                                                  \
   if (CSW > (S)) {                                                                                                        \
     emit(acc[(S) % CSW][0], S, 0); emit(acc[(S) % CSW][1], S, 1); emit(acc[(S) % CSW][2], S, 2); emit(acc[(S) % CSW][3], S, 3); \
-    emit(acc[(S) % CSW][4], S, 4); emit(acc[(S) % CSW][5], S, 5); emit(acc[(S) % CSW][6], S, 6); emit(acc[(S) % CSW][7], S, 7); \
+    if (FT > 4) { emit(acc[(S) % CSW][4 % FT], S, 4); emit(acc[(S) % CSW][5 % FT], S, 5); emit(acc[(S) % CSW][6 % FT], S, 6); emit(acc[(S) % CSW][7 % FT], S, 7); } \
   }
   PTTS_EMIT_ROW(0)
   PTTS_EMIT_ROW(1)
@@ -1368,11 +1371,21 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   if (L.bf16 && !no_lds && lds_ok && a.stride == 1 && nstrips % 6 == 0) {
     const int nw = nstrips % 12 == 0 ? 4 : 2;
     const int halo = a.transposed ? a.ntaps - 1 : (a.ntaps - 1) * a.dil;
-    const dim3 grid((unsigned)(((a.Tn + 127) / 128) * a.nphase * B), (unsigned)(nstrips / (3 * nw)));
+    // 64-frame tiles (FT = 4) where 128-frame tiles would leave the launch with about one workgroup per CU or fewer (round 5: the first block of a
+    // single utterance ran 56-224 workgroups on 256 CUs; the streamer's short windows even fewer): 860 frames 2.34 -> 2.27 ms, a 56-frame window
+    // 0.91 -> 0.82 ms; at 432-448 workgroups (two utterances) the smaller tiles LOSE 3.5 % (profiles/r05_experiments.txt call 18), hence the bound.
+    // Four-wave instances only; PTTS_DAC_NO_FT4=1: always 128 frames.
+    static const bool ft4_on = !(getenv("PTTS_DAC_NO_FT4") && atoi(getenv("PTTS_DAC_NO_FT4")));
+    const bool ft4 = ft4_on && nw == 4 && (long long)((a.Tn + 127) / 128) * a.nphase * B * (nstrips / (3 * nw)) < 320;
+    const int tfr = ft4 ? 64 : 128;
+    const dim3 grid((unsigned)(((a.Tn + tfr - 1) / tfr) * a.nphase * B), (unsigned)(nstrips / (3 * nw)));
     bool done = true;
     if (a.ntaps > 2 && halo <= 54 && a.Cin % 32 == 0) {
-      if (nw == 4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 1, 54>), grid, dim3(256), 0, st, a);
+      if (nw == 4 && ft4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 1, 54, 4>), grid, dim3(256), 0, st, a);
+      else if (nw == 4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 1, 54>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((conv_lds_kernel<3, 2, 1, 54>), grid, dim3(128), 0, st, a);
+    } else if (a.ntaps <= 2 && a.Cin % 96 == 0 && nw == 4 && ft4) {
+      hipLaunchKernelGGL((conv_lds_kernel<3, 4, 3, 2, 4>), grid, dim3(256), 0, st, a);
     } else if (a.ntaps <= 2 && a.Cin % 96 == 0) {
       // two-wave workgroups (Cout = 96: the last transposed conv): 32-channel staging chunks - the 96-channel instance stages 13 16-byte pieces per
       // thread, needs 324 VGPRs and runs ONE wave per SIMD (hipcc: "fails its waves_per_eu(2,2) target"; tools/isa_audit.py)
