@@ -401,12 +401,17 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // prefill attention on the tiled kernel (8 query rows per workgroup share the K / V tile; PTTS_PREFILL_ATTN=0: one workgroup per query row, attn_kernel)
   const bool prefill_attn = !(getenv("PTTS_PREFILL_ATTN") && !atoi(getenv("PTTS_PREFILL_ATTN")));
   bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
+  // prefill rows on the fused LN1 + QKV node, sinusoidal positions, engine-dtype cache: the node's epilogue writes the cache rows itself (no
+  // kv_append node: 24 launches of ~4 us + their boundaries off the time-to-first-token path; PTTS_KV_IN_QKV=0: the separate node)
+  static const bool kv_in_qkv_on = !(getenv("PTTS_KV_IN_QKV") && !atoi(getenv("PTTS_KV_IN_QKV")));
+  const bool kv_in_qkv = kv_in_qkv_on && prefill && lnproj_ok && !c.rope && !e->L[0].ks_self;
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
     if (lnproj_ok) {  // LN1 (+ fold of the previous fc2's partials) + fused QKV projection in one node
       LnProjArgs p = {};
       p.W = w.qkv; p.x = e->h; p.x_ld = H; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.K = H; p.out = e->qkv; p.out_ld = QKV; p.M = M; p.N = QKV;
       if (fc2_pending) { p.part = e->hpart; p.S = FC2_KSPLIT; fc2_pending = false; resid_fold = true; }
+      if (kv_in_qkv) { p.kcache = w.k_self; p.vcache = w.v_self; p.kv_Q = Q; p.kv_cap = c.max_ctx; p.kv_heads = nkv; p.kv_H = H; }
       PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st, lnproj_g)));
     } else {  // LN1 + fused QKV projection
       GemmArgs g = {}; g.decode = dec;
@@ -415,7 +420,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       if (fc2_pending) { g.part = e->hpart; g.S = FC2_KSPLIT; fc2_pending = false; }  // folded by the prep kernel (M > 8)
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
-    if (prefill) {
+    if (prefill && !kv_in_qkv) {
       bool done8 = false;
       if constexpr (sizeof(WT) == 2) {
         if (w.ks_self) {

@@ -1841,6 +1841,12 @@ struct LnProjArgs {
   int out_ld;
   int out_fo;           // EPI_GELU_WT: B-fragment order for the consumer GEMM
   int M, N;
+  // EPI_STORE at prefill (round 5): the QKV node also writes the K / V columns of its rows into the self-attention cache in the engine dtype
+  // (kv_append_kernel's store for sinusoidal positions and an engine-dtype cache: one node and one kernel boundary less per layer on the
+  // time-to-first-token path); null = no append
+  void* kcache;         // [B][kv_heads][kv_cap][64]
+  void* vcache;
+  int kv_Q, kv_cap, kv_heads, kv_H;  // rows per utterance (row m = utterance m / kv_Q, position m % kv_Q); columns [kv_H, kv_H + 64 kv_heads) = K, then V
 };
 
 // G = 16 (round 5): two rows per wave (rows w and w + 8, both in flight), all 16 columns of the MFMA tile in use - half the weight re-reads of
@@ -1994,8 +2000,18 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
     const f32x4 rr = *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave) * 64 + lane) * 4) +
                      *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave + 1) * 64 + lane) * 4);
     const int m = b0 + j, n = (blockIdx.x * 4 + wave) * 16 + q4 * 4;
-    if (EPI == EPI_STORE) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.out_ld + n) = make_float4(rr[0], rr[1], rr[2], rr[3]);
-    else act_store4<WT>(reinterpret_cast<WT*>(a.out), m, n, a.out_ld, a.out_fo, gelu_erf(rr[0]), gelu_erf(rr[1]), gelu_erf(rr[2]), gelu_erf(rr[3]));
+    if (EPI == EPI_STORE) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.out_ld + n) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+      if (a.kcache && n >= a.kv_H) {  // K / V columns: the cache row of (utterance, head, position), rounded as kv_append_kernel rounds it
+        const int Hkv = a.kv_heads * 64, nn = n - a.kv_H, isv = nn >= Hkv, n2 = isv ? nn - Hkv : nn;
+        const int head = n2 >> 6, d = n2 & 63, bu = m / a.kv_Q, pos = m - bu * a.kv_Q;
+        WT* dst = reinterpret_cast<WT*>(isv ? a.vcache : a.kcache) + (((size_t)bu * a.kv_heads + head) * a.kv_cap + pos) * 64 + d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_from_f32<WT>(dst + e, rr[e]);
+      }
+    } else {
+      act_store4<WT>(reinterpret_cast<WT*>(a.out), m, n, a.out_ld, a.out_fo, gelu_erf(rr[0]), gelu_erf(rr[1]), gelu_erf(rr[2]), gelu_erf(rr[3]));
+    }
   }
 }
 
