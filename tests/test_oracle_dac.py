@@ -96,8 +96,12 @@ def test_stage_by_stage_restatement_chains_to_decode_and_negative_controls(prec)
         keep[s] = (act, raw)
         raw, act, _ = o.stage(s, act, raw)
     n = len(spec.decoder_rates)
-    out = torch.tanh(F.conv1d(act, o.w[f"decoder.model.{n + 2}.weight"], o.w[f"decoder.model.{n + 2}.bias"], padding=3))
+    out = o.final_stage(act)  # the stage the GPU test pins conv_out_tanh_lds_kernel with (Conv1d(C -> 1, k7) + tanh on the last activation)
+    assert torch.equal(out, torch.tanh(F.conv1d(act, o.w[f"decoder.model.{n + 2}.weight"], o.w[f"decoder.model.{n + 2}.bias"], padding=3)))
     assert torch.equal(out, o.decode(codes))
+    # negative control for that stage's bar (relative RMS <= 1e-5, max |d| <= 1e-5 in tests/test_dac_stage_parity_gpu.py): an input slipped by one sample
+    slipped = o.final_stage(torch.roll(act, 1, dims=-1))
+    assert float((slipped - out).abs().max()) >= 1e-3
     if prec != "bf16":
         return
     rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())  # noqa: E731
