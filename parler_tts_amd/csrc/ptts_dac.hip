@@ -1387,11 +1387,9 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
     } else if (a.ntaps <= 2 && a.Cin % 96 == 0 && nw == 4 && ft4) {
       hipLaunchKernelGGL((conv_lds_kernel<3, 4, 3, 2, 4>), grid, dim3(256), 0, st, a);
     } else if (a.ntaps <= 2 && a.Cin % 96 == 0) {
-      // two-wave workgroups (Cout = 96: the last transposed conv): 32-channel staging chunks - the 96-channel instance stages 13 16-byte pieces per
-      // thread, needs 324 VGPRs and runs ONE wave per SIMD (hipcc: "fails its waves_per_eu(2,2) target"; tools/isa_audit.py)
-      static const bool ks3 = getenv("PTTS_DAC_UP2_KS3") && atoi(getenv("PTTS_DAC_UP2_KS3"));  // A/B: the 96-channel chunks
+      // two-wave workgroups (Cout = 96: the last transposed conv): 32-channel staging chunks - a 96-channel instance staged 13 16-byte pieces per
+      // thread, needed 324 VGPRs and ran ONE wave per SIMD (round 5: 5.59 vs 3.35 ms per batch-32 launch; the instance is gone since round 6)
       if (nw == 4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 3, 2>), grid, dim3(256), 0, st, a);
-      else if (ks3) hipLaunchKernelGGL((conv_lds_kernel<3, 2, 3, 2>), grid, dim3(128), 0, st, a);
       else hipLaunchKernelGGL((conv_lds_kernel<3, 2, 1, 2>), grid, dim3(128), 0, st, a);
     } else {
       done = false;

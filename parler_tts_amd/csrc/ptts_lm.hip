@@ -166,16 +166,31 @@ int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st, int g) {
   const size_t sh = (size_t)mg * (H * sizeof(WT) + 16) + 8 * 1024;
   const dim3 grid(p.N / 64, (p.M + g - 1) / g);
   const bool u16 = ((H / KT) / 2) % 16 == 0;
+  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation and device (the fp32 engine's 16-row instances ask for 72 KiB at
+  // H = 1024 and 104 KiB at H = 1536): same pattern as launch_gemm_inst
+#define PTTS_LNPROJ_ONE(UW, NF4, G)                                                                                   \
+  do {                                                                                                                \
+    static PttsPerDeviceOnce attr_once;                                                                               \
+    const int attr_dev = PttsPerDeviceOnce::device();                                                                 \
+    if (sh > 64 * 1024 && attr_once.need(attr_dev)) {                                                                 \
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&lnproj_fused_kernel<WT, UW, NF4, G, EPI>),  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea)); \
+      attr_once.done(attr_dev);                                                                                       \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, G, EPI>), grid, dim3(512), sh, st, p);                        \
+  } while (0)
 #define PTTS_LNPROJ_LAUNCH(UW, NF4)                                                                                   \
   do {                                                                                                                \
-    if (g == 16) hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 16, EPI>), grid, dim3(512), sh, st, p);            \
-    else if (g == 4) hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 4, EPI>), grid, dim3(512), sh, st, p);         \
-    else hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, 8, EPI>), grid, dim3(512), sh, st, p);                    \
+    if (g == 16) PTTS_LNPROJ_ONE(UW, NF4, 16);                                                                        \
+    else if (g == 4) PTTS_LNPROJ_ONE(UW, NF4, 4);                                                                     \
+    else PTTS_LNPROJ_ONE(UW, NF4, 8);                                                                                 \
   } while (0)
   if (H == 1024 && u16) PTTS_LNPROJ_LAUNCH(16, 4);
   else if (H == 1024) PTTS_LNPROJ_LAUNCH(8, 4);
   else PTTS_LNPROJ_LAUNCH(8, 6);
 #undef PTTS_LNPROJ_LAUNCH
+#undef PTTS_LNPROJ_ONE
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "lnproj launch failed: %s", hipGetErrorString(err));
   return PTTS_OK;

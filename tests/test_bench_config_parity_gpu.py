@@ -453,3 +453,62 @@ def test_several_steps_per_graph_launch_give_the_same_ids(bsz, dtype, monkeypatc
     monkeypatch.delenv("PTTS_GRAPH_STEPS", raising=False)
     assert runs[1].shape[0] == bsz * spec.num_codebooks
     assert torch.equal(runs[1], runs[8]) and torch.equal(runs[1], runs[16])
+
+
+def test_e4m3_kv_cache_full_depth_128_utterances_context_460():
+    """the `bs128_kv8` object of the bench line at ITS OWN shape - 24 layers at Mini-v1 widths, 128 utterances, the opt-in e4m3
+    self-attention cache (ptts_config::kv_fp8), teacher-forced from a 9-position prefill across every 64-position context bucket up to context 461
+    (the bench times the step at contexts ~300-700). All 128 utterances run on the engine (ragged description / prompt masks); the oracle - bf16
+    rounding model + the SAME e4m3 row quantiser (oracle/fp8_oracle.py) - evaluates three of them (first, middle, last: utterances are independent)
+    in ONE batched causal forward over the fed columns, which gives the logits of every pass. tests/test_lm_gpu.py::test_e4m3_kv_cache_mode covers
+    2 layers at contexts <= 64 with every utterance checked."""
+    from helpers import log_parity, make_engine
+    import cases as C
+
+    spec = DO.DecoderSpec(num_hidden_layers=24, max_position_embeddings=1024)
+    sd = DO.make_decoder_weights(spec, seed=606)
+    bsz, N, P, steps = 128, 64, 8, 452
+    K = spec.num_codebooks
+    g = torch.Generator().manual_seed(128)
+    enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
+    prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
+    enc_mask, prompt_mask = C.ragged_masks(bsz, N, P, enc_step=5)
+    enc = enc * enc_mask[..., None]
+    step_ids = torch.randint(0, 1024, (steps, bsz * K), generator=g)
+    pick = [0, 61, 127]  # utterances checked by the oracle (61 % 4 = 1 and 127 % 4 = 3: padded descriptions; 61 % 3 = 1: padded prompt)
+    rows = torch.cat([torch.arange(b * K, (b + 1) * K) for b in pick])
+
+    eng = make_engine(spec, sd, torch.bfloat16, max_batch=bsz, max_ctx=512, max_enc=N, max_prompt=P + 1, kv_fp8=True)
+    eng.set_gen_params(max_length=steps + 2)
+    eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
+    outs = [eng.logits()[rows.cuda()].cpu()]
+    for s in range(steps):
+        eng.push_tokens(step_ids[s])
+        eng.step_forward()
+        outs.append(eng.logits()[rows.cuda()].cpu())
+    eng.close()
+    out = torch.stack(outs, dim=1)  # [3 * K, steps + 1, V]
+
+    orc = DO.DecoderOracle(spec, sd, precision="bf16")
+    orc.kv_fp8 = True
+    fed = torch.cat([torch.full((len(pick) * K, 1), spec.bos_token_id), step_ids[:, rows].t()], dim=1)  # BOS column + the pushed columns
+    with torch.no_grad():
+        ref = orc.forward(fed, enc[pick], enc_mask[pick], prompt[pick], prompt_mask[pick])[:, P:]  # position P + s = pass s
+    assert ref.shape == out.shape, (ref.shape, out.shape)
+    d = (out - ref).abs()
+    per_bucket = [float(d[:, max(0, 64 * i - P - 1): 64 * (i + 1) - P - 1].max()) for i in range(8)]  # contexts [64 i, 64 i + 63]
+    err, rms = float(d.max()), float(d.pow(2).mean().sqrt())
+    top2 = torch.topk(ref, 2, dim=-1)[0]
+    margin = top2[..., 0] - top2[..., 1]
+    flips = out.argmax(-1) != ref.argmax(-1)
+    bad = int((flips & (margin > 2 * err)).sum())
+    log_parity(f"[e4m3 KV cache, full depth: 24 layers, 128 utterances (3 checked), prefill 9 + {steps} teacher-forced passes = context 461] "
+               f"max |dlogit| vs the quantised-cache bf16 oracle {err:.2e} (rms {rms:.2e}); per 64-position context bucket "
+               f"{' '.join(f'{x:.1e}' for x in per_bucket)}; arg-max agreement {1.0 - float(flips.float().mean()):.4f}, flips outside 2x the error: {bad}",
+               "r06_parity_kv8_full_depth.txt")
+    # tolerance from measurement, not by fiat: the rounding model evaluated in two summation orders (the oracle batched vs the oracle stepping, 24
+    # layers, 41 passes of 3 utterances, CPU) already differs by max 2.6e-2 / rms 4.2e-3 with the e4m3 cache (1.6e-2 / 2.9e-3 with the bf16 cache):
+    # an e4m3 code flips where an fp32 value sits on a rounding boundary (6 % of that element). Logits are O(0.6) rms.
+    assert err < 6e-2, err
+    assert rms < 8e-3, rms
+    assert bad == 0

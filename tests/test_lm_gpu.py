@@ -647,7 +647,7 @@ def test_fused_cross_block_with_fewer_utterances_per_workgroup(g, bsz, N, monkey
         assert err < 3e-2, (g, "large", err)
 
 
-@pytest.mark.parametrize("mode,g", [(1, 8), (2, 8), (3, 8), (3, 4)])
+@pytest.mark.parametrize("mode,g", [(1, 8), (2, 8), (3, 8), (3, 4), (3, 16)])
 @pytest.mark.parametrize("bsz", [9, 13, 32, 44, 128])
 def test_layernorm_plus_projection_as_one_node(mode, g, bsz, monkeypatch):
     """PTTS_LNPROJ (read at engine creation): above 8 utterances LN1 + QKV (mode >= 1) and LN3 + fc1 + GELU (mode 2: above 32 utterances, mode 3: always)
@@ -666,6 +666,22 @@ def test_layernorm_plus_projection_as_one_node(mode, g, bsz, monkeypatch):
         sd = DO.make_decoder_weights(spec, seed=77)
         err = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=10, P=5, steps=3, masks=True, seed=3)
         assert err < 3e-2, (mode, g, "large", err)
+
+
+@pytest.mark.parametrize("bsz", [44, 128])
+def test_default_policy_fp32_above_40_utterances(bsz):
+    """above 40 utterances the DEFAULT policy runs the 16-row LayerNorm + projection nodes, whose fp32 instances ask for more than
+    64 KiB of dynamic LDS (72 KiB at H = 1024, 104 KiB at H = 1536: launch_lnproj's hipFuncSetAttribute opt-in). No PTTS_* switch set: fp32 engine
+    at Mini widths (44 and 128 utterances) and at Large widths (44), teacher-forced against the fp32 oracle."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
+    sd = DO.make_decoder_weights(spec, seed=61)
+    err = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=bsz, N=17, P=5, steps=3, masks=True, seed=bsz)
+    assert err < 5e-5, (bsz, err)
+    if bsz == 44:
+        spec = DO.DecoderSpec(hidden_size=1536, num_attention_heads=24, ffn_dim=6144, num_hidden_layers=2, max_position_embeddings=256)
+        sd = DO.make_decoder_weights(spec, seed=77)
+        err = _teacher_forced_vs_oracle(spec, sd, torch.float32, "fp32", bsz=bsz, N=10, P=5, steps=3, masks=True, seed=3)
+        assert err < 6e-5, ("large", err)
 
 
 def test_large_v1_width_two_layers_bf16_and_fp32_batch():

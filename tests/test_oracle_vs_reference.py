@@ -397,3 +397,65 @@ def test_streamer_equals_reference_streamer_on_random_streams_live(ref, seed):
     assert len(want) >= 2 and [len(c) for c in got] == [len(c) for c in want], ([len(c) for c in got], [len(c) for c in want])
     for a, b in zip(got, want):  # window decode vs whole-cache decode on the CPU conv kernels: fp32 summation order differs at the 1e-6 level
         assert np.allclose(a, b, atol=2e-5), float(np.abs(a - b).max())
+
+
+def test_bf16_oracle_sits_between_reference_fp32_and_reference_bf16_live(ref):
+    """the timed dtype (bf16) pinned against the reference's OWN bf16 arithmetic. The reference's documented inference mode is
+    `model.to(device, dtype=torch.bfloat16)` (INFERENCE.md:24-32): bf16 weights, bf16 residual stream / LayerNorm outputs / probabilities
+    (modeling_parler_tts.py:983-1074). The engine (and DecoderOracle(precision="bf16"), which rounds where the engine rounds) keeps the residual
+    stream, LayerNorm and softmax in fp32 and rounds only the GEMM operands and the K/V cache. Mini-v1 widths at FULL depth (24 layers), prefill of 9
+    positions + 8 cached steps, the reference's ParlerTTSForCausalLM run three ways on the same weights:
+        ref_fp32 (the truth), ref_bf16 (the reference's own bf16 run), oracle_bf16 (the engine's rounding model)
+    asserted: the engine's rounding model is at least as close to the fp32 truth as the reference's own bf16 run is, and it stays within the
+    reference-bf16 noise of the reference's bf16 run (they are two roundings of the same function). The three numbers are printed (pytest -s) and
+    recorded in profiles/r06_parity_bf16_reference.txt."""
+    import copy
+
+    from transformers.cache_utils import DynamicCache, EncoderDecoderCache
+
+    import oracle.make_golden as mg
+    from oracle import decoder_oracle as DO
+
+    spec = DO.DecoderSpec(num_hidden_layers=24, max_position_embeddings=256)  # Mini-v1 widths: H = 1024, 16 heads, F = 4096
+    sd = DO.make_decoder_weights(spec, seed=2024)
+    bsz, N, P, steps = 1, 21, 8, 8
+    enc, enc_mask, prompt, prompt_mask = mg.synth_inputs(spec, bsz, N, P, seed=5, padded=False)
+    g = torch.Generator().manual_seed(17)
+    K = spec.num_codebooks
+    ids0 = torch.full((bsz * K, 1), spec.bos_token_id, dtype=torch.long)
+    step_ids = torch.randint(0, 1024, (steps, bsz * K, 1), generator=g)
+
+    def run_reference(dtype):
+        m = mg.build_reference_lm(ref, spec, sd)
+        if dtype != torch.float32:
+            m = m.to(dtype)
+        e, p = enc.to(dtype), prompt.to(dtype)
+        cache = EncoderDecoderCache(DynamicCache(), DynamicCache())
+        out = [mg.reference_forward(m, cache, ids0, e, enc_mask, p, prompt_mask, 0)[:, -1].float()]
+        past = P + 1
+        for s in range(steps):
+            out.append(mg.reference_forward(m, cache, step_ids[s], e, enc_mask, p, prompt_mask, past)[:, -1].float())
+            past += 1
+        del m
+        return torch.stack(out)
+
+    ref32 = run_reference(torch.float32)
+    ref16 = run_reference(torch.bfloat16)
+    orc = DO.DecoderOracle(spec, sd, precision="bf16")
+    o = [orc.forward(ids0, enc, enc_mask, prompt, prompt_mask)[:, -1]]
+    for s in range(steps):
+        o.append(orc.forward(step_ids[s])[:, -1])
+    o16 = torch.stack(o)
+    d_ref = float((ref16 - ref32).abs().max())      # the reference's own bf16 run vs its fp32 run
+    d_orc = float((o16 - ref32).abs().max())        # the engine's rounding model vs the reference in fp32
+    d_cross = float((o16 - ref16).abs().max())      # the engine's rounding model vs the reference in bf16
+    rms = lambda t: float(t.pow(2).mean().sqrt())
+    flips_ref = int((ref16.argmax(-1) != ref32.argmax(-1)).sum())
+    flips_orc = int((o16.argmax(-1) != ref32.argmax(-1)).sum())
+    print(f"\n[bf16 pin, Mini-v1 widths x 24 layers, prefill {P + 1} positions + {steps} cached steps, {ref32.shape[0] * ref32.shape[1]} logit rows] "
+          f"max|ref_bf16 - ref_fp32| = {d_ref:.3e} (rms {rms(ref16 - ref32):.3e}, argmax flips {flips_ref})  "
+          f"max|oracle_bf16 - ref_fp32| = {d_orc:.3e} (rms {rms(o16 - ref32):.3e}, argmax flips {flips_orc})  "
+          f"max|oracle_bf16 - ref_bf16| = {d_cross:.3e} (rms {rms(o16 - ref16):.3e})")
+    assert d_orc <= d_ref, (d_orc, d_ref)
+    assert rms(o16 - ref32) <= rms(ref16 - ref32)
+    assert d_cross <= 2.0 * d_ref, (d_cross, d_ref)

@@ -193,3 +193,30 @@ def test_generate_uses_native_encoder_and_matches_stock_module():
     log_parity(f"[t5 in generate()] native vs stock module, fp32: max |d| {err:.2e}", LOG)
     assert err <= 5e-5
     assert float(native[mask == 0].abs().max()) == 0.0
+
+
+def test_bench_ttft_shape_32_descriptions_24_blocks_bf16():
+    """the `ttft` object of the bench line at batch 32 at ITS OWN shape - flan-t5-large widths, all 24 blocks, 32 descriptions x
+    64 tokens = 2048 rows (the > 256-row GEMM path and the tiled attention), bf16 engine against the bf16-rounding oracle and against the fp32
+    oracle; ragged masks on two rows (right- and left-padded)."""
+    spec = TO.T5Spec(vocab_size=1024, d_model=1024, d_kv=64, d_ff=2816, num_layers=24, num_heads=16)
+    sd = TO.make_t5_weights(spec, seed=9)
+    g = torch.Generator().manual_seed(3264)
+    B, N = 32, 64
+    ids = torch.randint(0, spec.vocab_size, (B, N), generator=g)
+    mask = torch.ones(B, N, dtype=torch.long)
+    mask[1, 41:] = 0
+    mask[31, :9] = 0
+    out = make_t5(spec, sd, dtype=torch.bfloat16, max_batch=B, max_len=N).encode(ids.cuda(), mask.cuda()).cpu()
+    ref16 = TO.T5Oracle(spec, sd, precision="bf16", fold_norm=False).encode(ids, mask)  # > 256 rows: rows_prep nodes, no folded norms
+    ref32 = TO.T5Oracle(spec, sd).encode(ids, mask)
+    r16, r32, model = rel_rms(out, ref16), rel_rms(out, ref32), rel_rms(ref16, ref32)
+    err16 = float((out - ref16).abs().max())
+    log_parity(f"[t5 bf16 24 blocks, 32 x 64 tokens = 2048 rows] relative RMS vs bf16 oracle {r16:.2e} (max |d| {err16:.2e}), vs fp32 {r32:.2e} "
+               f"(bf16 oracle vs fp32 {model:.2e})", "r06_parity_t5.txt")
+    assert float(out[mask == 0].abs().max()) == 0.0
+    assert r16 <= 1e-2 and r32 <= 1.5 * model + 1e-4
+    out32 = make_t5(spec, sd, max_batch=B, max_len=N).encode(ids.cuda(), mask.cuda()).cpu()
+    e32, q32 = float((out32 - ref32).abs().max()), rel_rms(out32, ref32)
+    log_parity(f"[t5 fp32 24 blocks, 32 x 64 tokens] max |d| {e32:.2e}, relative RMS {q32:.2e}", "r06_parity_t5.txt")
+    assert q32 <= 2e-5
