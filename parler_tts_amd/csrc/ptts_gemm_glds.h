@@ -1,0 +1,149 @@
+// gemm_glds_kernel (round 6): the prefill-sized GEMM (> 256 activation rows: T5 on 32 descriptions x 64 tokens = 2048 rows, the prefill of 32
+// utterances x 33 positions = 1056 rows) as an LDS ring filled by LDS-DMA (`global_load_lds_dwordx4`: global -> LDS without destination registers),
+// NST stages deep, ONE raw s_barrier per stage and COUNTED vmcnt waits - loads stay in flight across the barriers. Round 5's gemm_tile_kernel staged
+// global -> registers -> LDS two stages ahead and ran at 6-15 % of the bf16 MFMA peak (144-364 TFLOP/s, profiles/r05_prefill_kernels_bs32.txt): with
+// K = 1024 a workgroup's whole MFMA work is shorter than one memory latency and the register ring cannot be deepened (VGPRs).
+//   out[m][n] = sum_k W[n][k] x[m][k]     (modeling_parler_tts.py:3048-3097 description encoder, :1437-1439 prefill rows, :877-878 cross K/V)
+// Operands (bf16 engine only; the fp32 parity engine keeps gemm_tile_kernel):
+//   A = weights, packed at load in MFMA A-fragment order [N/16 strips][K/32 fragments][64 lanes][16 B]: one fragment = one contiguous 1 KiB = ONE
+//       LDS-DMA wave-instruction, and the lane-linear LDS image (base + lane * 16) is exactly what the fragment's ds_read_b128 wants (conflict-free)
+//   B = activations, row-major bf16 [M][K]: one wave-instruction brings 8 rows x 128 B (full cache lines: lanes 8 r .. 8 r + 7 read one line) into an
+//       [8][8 x 16 B] image; the 16-byte piece a lane FETCHES is permuted within its line (piece = slot ^ row & 7: the swizzle sits on the SOURCE
+//       address, the LDS-DMA destination is always lane-linear) and the fragment read applies the same XOR: the 16 lanes of every ds_read_b128 lane
+//       group hit 16 different 16-byte slots of the 256-byte bank row (conflict-free; linear rows would be 4-way)
+// Tile: BNS strips (16 weight rows each) x BMT row tiles (16 activation rows each) per workgroup, WN x WM waves of (BNS / WN) x (BMT / WM) MFMA tiles,
+// BK = 64 per stage (2 fragments). Accumulation order over k is ascending whole fragments, no K split: bit-identical to gemm_tile_kernel /
+// gemm_block_kernel (tests compare them bitwise). Epilogues: gemm_store_tile (store / residual / GELU / gated GELU / cross K/V scatter).
+#pragma once
+#include "ptts_lm_kernels.h"
+
+namespace {
+
+template <int N> __device__ __forceinline__ void ptts_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, int BNS, int BMT, int WN, int WM, int NST>
+__global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
+  typedef bf16_t WT;
+  constexpr int KF = 2;                                   // 32-wide k fragments per stage
+  constexpr int NW = WN * WM, NS = BNS / WN, MT = BMT / WM;
+  constexpr int APC = BNS * KF, BPC = BMT * KF;           // 1 KiB pieces per stage: weights, activations
+  constexpr int PPW = (APC + BPC) / NW, APW = APC / NW;   // pieces per wave and stage (the first APW of them weight pieces)
+  static_assert(APC % NW == 0 && BPC % NW == 0 && BNS % WN == 0 && BMT % WM == 0, "tile / wave split");
+  static_assert((NST - 2) * PPW <= 63 && NST >= 2, "vmcnt is a 6-bit counter");
+  constexpr int STAGE_B = (APC + BPC) * 1024;
+  extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % WN, wm = wave / WN;
+  const int q = lane >> 4, j = lane & 15;
+  int bx, by;
+  xcd_tile_order(bx, by, a.xcd_swz);
+  const int strip0 = bx * BNS, m0 = by * BMT * 16;
+  const int nfrag = a.K >> 5, nstage = nfrag / KF;        // host guarantees K % 64 == 0
+  // this wave's pieces: piece p = wave + NW * i; p < APC: fragment p % KF of strip p / KF, else rows 8 (p - APC) .. + 7 of the row tile
+  const char* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave + NW * i;
+    if (i < APW) {
+      src[i] = reinterpret_cast<const char*>(a.W) + ((size_t)(strip0 + p / KF) * nfrag + p % KF) * 1024 + lane * 16;
+    } else {
+      const int row = min(m0 + (p - APC) * 8 + (lane >> 3), a.M - 1);  // clamped rows are computed and dropped
+      src[i] = reinterpret_cast<const char*>(a.x) + (size_t)(row * a.x_row_mul + a.x_row_off) * a.x_ld * sizeof(WT) + (((lane & 7) ^ (lane >> 3)) << 4);
+    }
+  }
+  auto issue = [&](int t, int buf) {
+    char* dst = smem_raw + buf * STAGE_B + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src[i] + (size_t)t * (i < APW ? KF * 1024 : KF * 64)),
+                                       (__attribute__((address_space(3))) void*)(dst + NW * i * 1024), 16, 0, 0);
+  };
+  f32x4 acc[NS][MT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-lane read offsets: weights lane-linear; activations row j of the tile, piece (f * 4 + q) ^ (j & 7)
+  const int a_off = wn * NS * KF * 1024 + lane * 16;
+  int b_off[KF];
+#pragma unroll
+  for (int f = 0; f < KF; ++f) b_off[f] = APC * 1024 + (wm * MT * 16 + j) * 128 + (((f * 4 + q) ^ (j & 7)) << 4);
+
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nstage) issue(t, t);
+  int buf = 0;
+  for (int t = 0; t < nstage; ++t) {
+    // stage t has landed for this wave: loads of at most min(NST - 2, nstage - 1 - t) later stages may still be in flight
+    const int later = nstage - 1 - t;
+    if (later >= NST - 2) ptts_wait_vmcnt<(NST - 2) * PPW>();
+    else if (NST > 3 && later == 1) ptts_wait_vmcnt<PPW>();
+    else if (NST > 4 && later == 2) ptts_wait_vmcnt<2 * PPW>();
+    else ptts_wait_vmcnt<0>();
+    // ... and for every wave, and every wave is done reading buffer (t - 1) % NST (its fragments were consumed by MFMAs issued before this point)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + NST - 1 < nstage) issue(t + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    const char* cur = smem_raw + buf * STAGE_B;
+#pragma unroll
+    for (int f = 0; f < KF; ++f) {
+      u32x4_t af[NS], bf[MT];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const u32x4_t*>(cur + a_off + (s * KF + f) * 1024);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = *reinterpret_cast<const u32x4_t*>(cur + b_off[f] + mt * 2048);
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mfma_step_v<WT>(af[s], bf[mt], acc[s][mt]);
+    }
+    buf = buf + 1 == NST ? 0 : buf + 1;
+  }
+  if constexpr (EPI == EPI_RESID) {  // residual pieces requested before the first store (loads and stores retire in order on one counter)
+    float4 res[NS][MT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = min(m0 + (wm * MT + mt) * 16 + j, a.M - 1);
+        res[s][mt] = *reinterpret_cast<const float4*>(a.out + (size_t)m * a.out_ld + (strip0 + wn * NS + s) * 16 + q * 4);
+      }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (wm * MT + mt) * 16 + j;
+        const f32x4 r = acc[s][mt];
+        if (m < a.M)
+          *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + (strip0 + wn * NS + s) * 16 + q * 4) =
+              make_float4(res[s][mt].x + r[0], res[s][mt].y + r[1], res[s][mt].z + r[2], res[s][mt].w + r[3]);
+      }
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + (wm * MT + mt) * 16 + j;
+      if (m < a.M) gemm_store_tile<WT, EPI>(a, m, (strip0 + wn * NS + s) * 16 + q * 4, acc[s][mt]);  // D[row = q*4 + r][col = j]
+    }
+}
+
+template <int EPI, int BNS, int BMT, int WN, int WM, int NST>
+int launch_gemm_glds_inst(const GemmArgs& a, hipStream_t st) {
+  constexpr size_t sh = (size_t)NST * (BNS + BMT) * 2 * 1024;
+  static PttsPerDeviceOnce attr_once;
+  const int attr_dev = PttsPerDeviceOnce::device();
+  if (sh > 64 * 1024 && attr_once.need(attr_dev)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
+    attr_once.done(attr_dev);
+  }
+  const dim3 grid(a.N / (16 * BNS), (a.M + BMT * 16 - 1) / (BMT * 16));
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST>), grid, dim3(WN * WM * 64), sh, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
+  return PTTS_OK;
+}
+
+}  // namespace

@@ -6,6 +6,7 @@
 
 #include "ptts_common.h"
 #include "ptts_lm_kernels.h"
+#include "ptts_gemm_glds.h"
 #include "ptts_strip_w8.h"
 
 namespace {

@@ -491,7 +491,11 @@ def test_e4m3_kv_cache_full_depth_128_utterances_context_460():
 
     orc = DO.DecoderOracle(spec, sd, precision="bf16")
     orc.kv_fp8 = True
-    fed = torch.cat([torch.full((len(pick) * K, 1), spec.bos_token_id), step_ids[:, rows].t()], dim=1)  # BOS column + the pushed columns
+    raw = torch.cat([torch.full((len(pick) * K, 1), spec.bos_token_id), step_ids[:, rows].t()], dim=1)  # BOS column + the pushed columns
+    # max_length >= 2 K - 1: the engine feeds every column through the delay pattern (BOS below the diagonal, PAD in the last K - 1 columns), as
+    # apply_delay_pattern_mask does before each forward of the reference (modeling_parler_tts.py:205-276, :2926)
+    _, pattern = DO.build_delay_pattern_mask(raw[:, :1], spec.bos_token_id, spec.pad_token_id, steps + 2, K)
+    fed = DO.apply_delay_pattern_mask(raw, pattern)
     with torch.no_grad():
         ref = orc.forward(fed, enc[pick], enc_mask[pick], prompt[pick], prompt_mask[pick])[:, P:]  # position P + s = pass s
     assert ref.shape == out.shape, (ref.shape, out.shape)
