@@ -21,10 +21,12 @@ namespace {
 
 template <int N> __device__ __forceinline__ void ptts_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int BNS, int BMT, int WN, int WM, int NST>
+// ABL (tools/gemm_probe only): 0 = the kernel; 1 = no fragment reads / MFMAs (load stream + barriers only); 2 = no LDS-DMA (compute on whatever the LDS holds)
+template <int EPI, int BNS, int BMT, int WN, int WM, int NST, int ABL = 0, int RP = 0, int KF = 2>
 __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
   typedef bf16_t WT;
-  constexpr int KF = 2;                                   // 32-wide k fragments per stage
+  static_assert(KF == 2 || KF == 4, "BK = 64 or 128 per stage");
+  constexpr int RB = KF * 64, SPR = RB / 16, RPP = 1024 / RB;  // activation image: bytes per row, 16-byte slots per row, rows per 1 KiB piece
   constexpr int NW = WN * WM, NS = BNS / WN, MT = BMT / WM;
   constexpr int APC = BNS * KF, BPC = BMT * KF;           // 1 KiB pieces per stage: weights, activations
   constexpr int PPW = (APC + BPC) / NW, APW = APC / NW;   // pieces per wave and stage (the first APW of them weight pieces)
@@ -46,11 +48,13 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
     if (i < APW) {
       src[i] = reinterpret_cast<const char*>(a.W) + ((size_t)(strip0 + p / KF) * nfrag + p % KF) * 1024 + lane * 16;
     } else {
-      const int row = min(m0 + (p - APC) * 8 + (lane >> 3), a.M - 1);  // clamped rows are computed and dropped
-      src[i] = reinterpret_cast<const char*>(a.x) + (size_t)(row * a.x_row_mul + a.x_row_off) * a.x_ld * sizeof(WT) + (((lane & 7) ^ (lane >> 3)) << 4);
+      const int rl = (p - APC) * RPP + lane / SPR;            // row of the tile; its image slot lane % SPR holds piece slot ^ (row & (SPR - 1))
+      const int row = min(m0 + rl, a.M - 1);                  // clamped rows are computed and dropped
+      src[i] = reinterpret_cast<const char*>(a.x) + (size_t)(row * a.x_row_mul + a.x_row_off) * a.x_ld * sizeof(WT) + (((lane % SPR) ^ (rl & (SPR - 1))) << 4);
     }
   }
   auto issue = [&](int t, int buf) {
+    if constexpr (ABL == 2) return;
     char* dst = smem_raw + buf * STAGE_B + wave * 1024;
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
@@ -66,7 +70,7 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
   const int a_off = wn * NS * KF * 1024 + lane * 16;
   int b_off[KF];
 #pragma unroll
-  for (int f = 0; f < KF; ++f) b_off[f] = APC * 1024 + (wm * MT * 16 + j) * 128 + (((f * 4 + q) ^ (j & 7)) << 4);
+  for (int f = 0; f < KF; ++f) b_off[f] = APC * 1024 + (wm * MT * 16 + j) * RB + (((f * 4 + q) ^ (j & (SPR - 1))) << 4);
 
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
@@ -85,17 +89,36 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (t + NST - 1 < nstage) issue(t + NST - 1, buf == 0 ? NST - 1 : buf - 1);
     const char* cur = smem_raw + buf * STAGE_B;
+    if constexpr (RP == 1 && ABL != 1) {
+      // every fragment read of the stage is issued before its first MFMA: one exposed LDS latency per stage instead of one per group of reads
+      u32x4_t af[KF][NS], bf[KF][MT];
 #pragma unroll
-    for (int f = 0; f < KF; ++f) {
+      for (int f = 0; f < KF; ++f) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) af[f][s] = *reinterpret_cast<const u32x4_t*>(cur + a_off + (s * KF + f) * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) bf[f][mt] = *reinterpret_cast<const u32x4_t*>(cur + b_off[f] + mt * 16 * RB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < KF; ++f)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mfma_step_v<WT>(af[f][s], bf[f][mt], acc[s][mt]);
+    } else {
+#pragma unroll
+    for (int f = 0; f < (ABL == 1 ? 0 : KF); ++f) {
       u32x4_t af[NS], bf[MT];
 #pragma unroll
       for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const u32x4_t*>(cur + a_off + (s * KF + f) * 1024);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) bf[mt] = *reinterpret_cast<const u32x4_t*>(cur + b_off[f] + mt * 2048);
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = *reinterpret_cast<const u32x4_t*>(cur + b_off[f] + mt * 16 * RB);
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mfma_step_v<WT>(af[s], bf[mt], acc[s][mt]);
+    }
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
   }
@@ -129,21 +152,40 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
     }
 }
 
-template <int EPI, int BNS, int BMT, int WN, int WM, int NST>
+template <int EPI, int BNS, int BMT, int WN, int WM, int NST, int ABL = 0, int RP = 0, int KF = 2>
 int launch_gemm_glds_inst(const GemmArgs& a, hipStream_t st) {
-  constexpr size_t sh = (size_t)NST * (BNS + BMT) * 2 * 1024;
+  constexpr size_t sh = (size_t)NST * (BNS + BMT) * KF * 1024;
   static PttsPerDeviceOnce attr_once;
   const int attr_dev = PttsPerDeviceOnce::device();
   if (sh > 64 * 1024 && attr_once.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST, ABL, RP, KF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
     attr_once.done(attr_dev);
   }
   const dim3 grid(a.N / (16 * BNS), (a.M + BMT * 16 - 1) / (BMT * 16));
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST>), grid, dim3(WN * WM * 64), sh, st, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST, ABL, RP, KF>), grid, dim3(WN * WM * 64), sh, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
+}
+
+// Tile policy, measured per shape on MI355X (tools/gemm_probe, profiles/r06_gemm_probe.txt; us per launch, fp32 outputs, weights from HBM):
+//   narrow projections (N <= 1024: o, cross q / o, wo, fc2): 64 x 64 tiles, 3-stage ring - 272..512 workgroups, two per CU
+//       2048 x 1024 x 1024 9.4 (r05 17.6)   2048 x 1024 x 2816 19.7 (41.0)   1056 x 1024 x 1024 8.3 (15.7)   1056 x 1024 x 4096 23.0 (53.0)
+//   wide projections with >= 400 tiles of 128 x 128 (T5 wi, Large fc1): 128 x 128, 8 waves, 2-stage ring (64 KiB: two workgroups per CU)
+//       2048 x 5632 x 1024 34.4 (73.0)   1056 x 6144 x 1536 28.7 (64.5)
+//   the rest (q|k|v, fc1, cross K|V): 128 weight rows x 64 activation rows, 4 waves, 2-stage ring (48 KiB: three workgroups per CU)
+//       2048 x 3072 x 1024 19.7 (41.6)   1056 x 3072 x 1024 14.5 (29.0)   1056 x 4096 x 1024 18.8 (34.5)   2048 x 2048 x 1024 15.2 (30.1)
+// Deeper rings lose above one stage in flight wherever they cost a resident workgroup: every variant is bound by what ONE workgroup's
+// dependent chain (barrier -> fragment reads -> MFMAs per stage) and its LDS-DMA issue rate sustain, so resident workgroups per CU beat
+// pipeline depth; BK = 128 stages (half the barriers) lose for the same reason (twice the LDS per stage). -1 = shape not served.
+template <int EPI>
+int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
+  if (a.K % 64 || a.N % 64 || a.x_ld % 8) return -1;
+  if (a.N <= 1024 || a.N % 128) return launch_gemm_glds_inst<EPI, 4, 4, 2, 2, 3>(a, st);
+  const int tiles128 = (a.N / 128) * ((a.M + 127) / 128);
+  if (tiles128 >= 400) return launch_gemm_glds_inst<EPI, 8, 8, 4, 2, 2, 0, 1>(a, st);
+  return launch_gemm_glds_inst<EPI, 8, 4, 2, 2, 2, 0, 1>(a, st);
 }
 
 }  // namespace

@@ -152,7 +152,14 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
     // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
     static const int xcd_swz = !(getenv("PTTS_GEMM_XCD") && !atoi(getenv("PTTS_GEMM_XCD")));
     a.xcd_swz = xcd_swz;
-    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part && !a.stats_out && !a.W8) {  // LDS-tiled kernel first (round 5)
+    if constexpr (sizeof(WT) == 2) {  // bf16 engine: the LDS-DMA ring (round 6, ptts_gemm_glds.h); PTTS_GEMM_GLDS=0: round 5's register-staged tiles
+      static const bool glds_on = !(getenv("PTTS_GEMM_GLDS") && !atoi(getenv("PTTS_GEMM_GLDS")));
+      if (glds_on && a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part && !a.stats_out && !a.W8 && !a.rs_part && !a.nx_out) {
+        const int rg = launch_gemm_glds<EPI>(a, st);
+        if (rg != -1) return rg;
+      }
+    }
+    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part && !a.stats_out && !a.W8) {  // LDS-tiled kernel (round 5)
       const int rt = launch_gemm_tile<WT, EPI>(a, st);
       if (rt != -1) return rt;
     }

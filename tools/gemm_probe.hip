@@ -28,7 +28,7 @@ static __global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float sca
 }
 
 struct Variant { const char* name; int (*fn)(const GemmArgs&, hipStream_t); int bn, bm; };
-template <int BNS, int BMT, int WN, int WM, int NST> int run_glds(const GemmArgs& a, hipStream_t st) { return launch_gemm_glds_inst<EPI_STORE, BNS, BMT, WN, WM, NST>(a, st); }
+template <int BNS, int BMT, int WN, int WM, int NST, int ABL = 0, int RP = 0, int KF = 2> int run_glds(const GemmArgs& a, hipStream_t st) { return launch_gemm_glds_inst<EPI_STORE, BNS, BMT, WN, WM, NST, ABL, RP, KF>(a, st); }
 static int run_tile44(const GemmArgs& a, hipStream_t st) { return launch_gemm_tile_inst<bf16_t, EPI_STORE, 4, 4>(a, st); }
 static int run_tile88(const GemmArgs& a, hipStream_t st) { return launch_gemm_tile_inst<bf16_t, EPI_STORE, 8, 8>(a, st); }
 
@@ -41,18 +41,19 @@ int main(int argc, char** argv) {
       {"prefill qkv   ", 1056, 3072, 1024}, {"prefill o / cq ", 1056, 1024, 1024}, {"prefill fc1   ", 1056, 4096, 1024}, {"prefill fc2   ", 1056, 1024, 4096},
       {"cross K|V     ", 2048, 2048, 1024}, {"Large fc1     ", 1056, 6144, 1536}, {"square 4096   ", 4096, 4096, 4096}};
   const Variant vars[] = {
-      {"tile 64x64 (r05)   ", run_tile44, 64, 64},
-      {"tile 128x128 (r05) ", run_tile88, 128, 128},
-      {"glds 128x128 4w s2 ", run_glds<8, 8, 2, 2, 2>, 128, 128},
-      {"glds 128x128 4w s3 ", run_glds<8, 8, 2, 2, 3>, 128, 128},
-      {"glds 128x128 4w s4 ", run_glds<8, 8, 2, 2, 4>, 128, 128},
-      {"glds 128x64  4w s3 ", run_glds<8, 4, 2, 2, 3>, 128, 64},
-      {"glds 128x64  4w s4 ", run_glds<8, 4, 2, 2, 4>, 128, 64},
-      {"glds 64x128  4w s4 ", run_glds<4, 8, 2, 2, 4>, 64, 128},
-      {"glds 64x64   4w s4 ", run_glds<4, 4, 2, 2, 4>, 64, 64},
-      {"glds 256x128 8w s3 ", run_glds<16, 8, 4, 2, 3>, 256, 128},
-      {"glds 128x256 8w s3 ", run_glds<8, 16, 2, 4, 3>, 128, 256},
-      {"glds 128x128 8w s4 ", run_glds<8, 8, 4, 2, 4>, 128, 128},
+      {"tile 64x64 (r05)      ", run_tile44, 64, 64},
+      {"glds 128x128 8w s2 rp ", run_glds<8, 8, 4, 2, 2, 0, 1>, 128, 128},
+      {"glds 128x64  4w s2 rp ", run_glds<8, 4, 2, 2, 2, 0, 1>, 128, 64},
+      {"glds 128x64  4w s3 rp ", run_glds<8, 4, 2, 2, 3, 0, 1>, 128, 64},
+      {"glds 64x64   4w s3    ", run_glds<4, 4, 2, 2, 3>, 64, 64},
+      {"glds 64x64   4w s2 k128", run_glds<4, 4, 2, 2, 2, 0, 1, 4>, 64, 64},
+      {"  .. compute only     ", run_glds<4, 4, 2, 2, 2, 2, 1, 4>, 64, 64},
+      {"glds 64x64   4w s3 k128", run_glds<4, 4, 2, 2, 3, 0, 1, 4>, 64, 64},
+      {"glds 64x64   8w s2 k128", run_glds<4, 4, 4, 2, 2, 0, 1, 4>, 64, 64},
+      {"glds 128x64  4w s2 k128", run_glds<8, 4, 2, 2, 2, 0, 1, 4>, 128, 64},
+      {"glds 128x64  8w s2 k128", run_glds<8, 4, 4, 2, 2, 0, 1, 4>, 128, 64},
+      {"glds 128x128 8w s2 k128", run_glds<8, 8, 4, 2, 2, 0, 1, 4>, 128, 128},
+      {"glds 128x128 4w s2 k128", run_glds<8, 8, 2, 2, 2, 0, 1, 4>, 128, 128},
   };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (const Shape& s : shapes) {
@@ -83,6 +84,7 @@ int main(int argc, char** argv) {
       const char* verdict = "reference";
       if (!have_ref) { href = hout; have_ref = true; }
       else verdict = memcmp(href.data(), hout.data(), obytes) == 0 ? "bit-identical" : "DIFFERENT";
+      if (strstr(v.name, "compute only")) verdict = "(ablation)";
       if (!strcmp(verdict, "DIFFERENT")) {
         double worst = 0; size_t nbad = 0;
         for (size_t i = 0; i < hout.size(); ++i) { const double d = fabs((double)hout[i] - href[i]); if (!(d == 0)) ++nbad; if (d > worst || d != d) worst = d; }
