@@ -258,8 +258,18 @@ int launch_attn(const AttnArgs& a, int B, hipStream_t st, int waves = 4) {
 }
 
 // prefill attention, tiled (prefill_attn_kernel): 8 query rows per workgroup; Q = a.Q rows per utterance, output in a.direct_out
+// mode (PTTS_PREFILL_ATTN): 1 = the VALU kernel, 2 = the f32-MFMA kernel (engine-dtype caches), anything else = by batch: the MFMA kernel's 16-query
+// waves fill the chip from 128 (utterance, head) pairs up
 template <typename WT>
-int launch_prefill_attn(const AttnArgs& a, int B, hipStream_t st) {
+int launch_prefill_attn(const AttnArgs& a, int B, hipStream_t st, int mode = 3) {
+  if (!a.kscale && (mode == 2 || (mode != 1 && B * a.nheads >= 128))) {
+    const int waves = std::min(4, (a.Q + 15) / 16);
+    const dim3 gm((a.Q + 16 * waves - 1) / (16 * waves), a.nheads, B);
+    hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT>), gm, dim3(64 * waves), 0, st, a);
+    hipError_t em = hipGetLastError();
+    if (em != hipSuccess) return ptts_fail(PTTS_E_HIP, "prefill attention launch failed: %s", hipGetErrorString(em));
+    return PTTS_OK;
+  }
   const dim3 grid((a.Q + 7) / 8, a.nheads, B);
   if (a.kscale) {
     if constexpr (sizeof(WT) == 2) hipLaunchKernelGGL((prefill_attn_kernel<WT, true>), grid, dim3(256), 0, st, a);

@@ -414,7 +414,8 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   static const bool lnproj_prefill = !(getenv("PTTS_LNPROJ_PREFILL") && !atoi(getenv("PTTS_LNPROJ_PREFILL")));
   const bool lnproj_ok = lnproj > 0 && (!prefill || (lnproj_prefill && M <= 40)) && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
   // prefill attention on the tiled kernel (8 query rows per workgroup share the K / V tile; PTTS_PREFILL_ATTN=0: one workgroup per query row, attn_kernel)
-  const bool prefill_attn = !(getenv("PTTS_PREFILL_ATTN") && !atoi(getenv("PTTS_PREFILL_ATTN")));
+  const int prefill_attn_mode = getenv("PTTS_PREFILL_ATTN") ? atoi(getenv("PTTS_PREFILL_ATTN")) : 3;  // 0: one workgroup per query row, 1: tiled VALU kernel, 2: f32-MFMA kernel, 3: by batch
+  const bool prefill_attn = prefill_attn_mode != 0;
   bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
   // prefill rows on the fused LN1 + QKV node, sinusoidal positions, engine-dtype cache: the node's epilogue writes the cache rows itself (no
   // kv_append node: 24 launches of ~4 us + their boundaries off the time-to-first-token path; PTTS_KV_IN_QKV=0: the separate node)
@@ -460,7 +461,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.kscale = w.ks_self; a.vscale = w.vs_self;
       a.direct_out = S_used == 1 ? e->xw : nullptr; a.out_fo = fo;
       a.exact_len = (!prefill && M > 8 && e->attn_exact) ? 1 : 0;
-      if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st)));
+      if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st, prefill_attn_mode)));
       else PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
     {  // [combine splits] + out_proj + residual
@@ -524,7 +525,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.kv_heads = nkc; a.n_rep = nh / nkc;
       a.fused_append = 0; a.scale = scale;
       a.direct_out = e->xw; a.out_fo = fo;  // the description is short: never split, softmax finished in the attention kernel
-      if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st)));
+      if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st, prefill_attn_mode)));
       else PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->cross_waves)));  // decode: as few waves as cover the description (no LDS combine at 1)
     }
     }

@@ -1590,6 +1590,155 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// prefill_attn_mfma_kernel (round 6): prefill_attn_kernel's attention on the f32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, an fmaf chain per
+// output - the same arithmetic in another summation order) for batches whose (utterance, head) pairs fill the chip: the VALU kernel took 21-22 us
+// per launch at 32 utterances x 33 positions, 48 launches = 1.0 of the 4.3 ms of that prefill (profiles/r06_prefill_kernels_bs32_v1.txt).
+// One workgroup = up to 64 consecutive query rows of one (utterance, head), one wave = 16 queries x all keys the workgroup can see; key blocks of
+// 64 with the K / V tiles in LDS as fp32 (the cache rows converted once per workgroup; 16-byte slots XOR-swizzled by row & 15: conflict-free b128
+// reads of K and b32 reads of V without padding). S^T = K Q^T (A = K rows, B = the wave's RoPE-rotated, pre-scaled Q fragments, held in registers):
+// lane (i = l & 15, g = l >> 4) holds the scores of query i against keys 16 kt + 4 g + r; base-2 softmax per query across the 4 lanes with the same
+// i, online across key blocks; O = P V takes the lane's own probability registers as the A operand (the MFMA sums over g) - no transpose.
+// Semantics of prefill_attn_kernel (masked keys carry no weight, a row without a visible key yields 0, q rotated also in the cross block).
+// ------------------------------------------------------------------------------------------------------
+template <typename WT>
+__global__ void __launch_bounds__(256) prefill_attn_mfma_kernel(AttnArgs a) {
+  constexpr int EPL = Elem<WT>::EPL;
+  __shared__ __attribute__((aligned(16))) float sK[64 * 64];
+  __shared__ __attribute__((aligned(16))) float sV[64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int nthreads = blockDim.x, qwg = (nthreads >> 6) * 16;  // 1..4 waves of 16 queries
+  const int h = blockIdx.y, b = blockIdx.z, i0w = blockIdx.x * qwg, i0 = i0w + w * 16;
+  const int kvh = h / a.n_rep;
+  const int P = a.dims->P;
+  const int Lmax = a.cross ? a.dims->N : min(i0w + qwg, a.Q);  // keys any query of this workgroup can see (self: causal, position = row index)
+  const int mask_len = a.cross ? Lmax : P;
+  const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2
+  const int iq = min(i0 + j, a.Q - 1);                     // clamped queries are computed and dropped
+  const int Lq = a.cross ? Lmax : iq + 1;
+  float4 qr[4];
+  {
+    const float* qrow = a.q + (size_t)(b * a.Q + iq) * a.q_ld + h * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int d0 = 16 * c + 4 * g;
+      float4 v = *reinterpret_cast<const float4*>(qrow + d0);
+      if (a.cos) {  // x * cos + rotate_half(x) * sin at the query's own position (modeling:409-436); a 4-element chunk never straddles the halves
+        const float4 t = *reinterpret_cast<const float4*>(qrow + (d0 < 32 ? d0 + 32 : d0 - 32));
+        const float sg = d0 < 32 ? -1.f : 1.f;
+        const float4 cs = *reinterpret_cast<const float4*>(a.cos + (size_t)iq * 64 + d0), sn = *reinterpret_cast<const float4*>(a.sin + (size_t)iq * 64 + d0);
+        v = make_float4(v.x * cs.x + sg * t.x * sn.x, v.y * cs.y + sg * t.y * sn.y, v.z * cs.z + sg * t.z * sn.z, v.w * cs.w + sg * t.w * sn.w);
+      }
+      qr[c] = make_float4(v.x * qscale, v.y * qscale, v.z * qscale, v.w * qscale);
+    }
+  }
+  const WT* Kc = reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
+  const WT* Vc = reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float4* sK4 = reinterpret_cast<const float4*>(sK);
+  for (int j0 = 0; j0 < Lmax; j0 += 64) {
+    if (j0) __syncthreads();  // the previous tiles are consumed
+    for (int e = tid; e < 64 * 8; e += nthreads) {  // 64 rows x 8 pieces of 8 elements per matrix
+      const int r = e >> 3, c8 = e & 7, key = j0 + r;
+      float kx[8], vx[8];
+      if (key < Lmax) {
+        const WT* kr = Kc + (size_t)key * 64 + c8 * 8;
+        const WT* vr = Vc + (size_t)key * 64 + c8 * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kx[i] = Elem<WT>::ld(kr + i); vx[i] = Elem<WT>::ld(vr + i); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kx[i] = 0.f; vx[i] = 0.f; }
+      }
+      const int s0 = (2 * c8) ^ (r & 15), s1 = (2 * c8 + 1) ^ (r & 15);
+      reinterpret_cast<float4*>(sK)[r * 16 + s0] = make_float4(kx[0], kx[1], kx[2], kx[3]);
+      reinterpret_cast<float4*>(sK)[r * 16 + s1] = make_float4(kx[4], kx[5], kx[6], kx[7]);
+      reinterpret_cast<float4*>(sV)[r * 16 + s0] = make_float4(vx[0], vx[1], vx[2], vx[3]);
+      reinterpret_cast<float4*>(sV)[r * 16 + s1] = make_float4(vx[4], vx[5], vx[6], vx[7]);
+    }
+    bool ok[4][4];  // key visible to this lane's query: inside its causal / description length and not padding
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + 16 * kt + 4 * g + r;
+        const int mk = (mrow && key < mask_len && key < a.mask_ld) ? mrow[key] : 1;
+        ok[kt][r] = key < Lq && (key >= mask_len || mk != 0);
+      }
+    __syncthreads();
+    f32x4 st[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 kr = sK4[(16 * kt + j) * 16 + ((4 * c + g) ^ j)];
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.x, qr[c].x, st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.y, qr[c].y, st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.z, qr[c].z, st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.w, qr[c].w, st[kt], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, ok[kt][r] ? st[kt][r] : -INFINITY);
+    const float m_new = fmaxf(m_run, across_groups_reduce<OpMax, 16>(mx));
+    const float alpha = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);  // m_run finite implies m_new finite
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = ok[kt][r] ? __builtin_amdgcn_exp2f(st[kt][r] - m_new) : 0.f;  // ok implies a finite score <= m_new
+        st[kt][r] = pv;
+        sum += pv;
+      }
+    l_run = l_run * alpha + across_groups_reduce<OpSum, 16>(sum);
+    m_run = m_new;
+    if (j0) {  // the accumulators hold queries 4 g + r; their factors live in the lanes whose l & 15 is that query
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, 4 * g + r);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt][r] *= ar;
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * kt + 4 * g + r;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const float vb = sV[row * 64 + (((4 * dt + (j >> 2)) ^ (row & 15)) << 2) + (j & 3)];
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb, o[dt], 0, 0, 0);
+        }
+      }
+  }
+  WT* dst0 = reinterpret_cast<WT*>(a.direct_out);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float lr = __shfl(l_run, 4 * g + r);
+    const int i = i0 + 4 * g + r;
+    if (i >= a.Q) continue;
+    const int row = b * a.Q + i;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int kcol = h * 64 + 16 * dt + j;
+      WT* dst = dst0;
+      if (a.out_fo) dst += fo_vec_index<WT>(row, kcol & ~(EPL - 1), a.H / Elem<WT>::KT) * EPL + (kcol & (EPL - 1));
+      else dst += (size_t)row * a.H + kcol;
+      store_from_f32<WT>(dst, lr > 0.f ? o[dt][r] / lr : 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // xattn_fused_kernel (decode, batch <= 8): encoder_attn_layer_norm + cross q projection + cross-attention for ONE head
 // per workgroup (modeling:1040-1052, :855-859, :872-875, :906-914). The description K/V is static and short, so the
 // whole chain is head-parallel: 8 waves = 4 weight strips (the head's 64 q rows) x 2 K halves for the projection,

@@ -156,6 +156,132 @@ __global__ void __launch_bounds__(256) t5_attn_kernel(T5AttnArgs a) {
   }
 }
 
+// t5_attn_mfma_kernel (round 6): the same attention on the f32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32, an fmaf chain per output - the
+// arithmetic of the kernel above in another summation order), for batches that fill the chip: t5_attn_kernel spends 34 us per block at 32 x 64 tokens
+// (16 TFLOP/s of VALU fmaf behind one LDS read per fmaf pair; profiles/r06_prefill_kernels_bs32_v1.txt). One workgroup = 64 queries of one
+// (utterance, head), one wave = 16 queries x ALL keys, key blocks of 64 with the K / V tiles in LDS (fp32, 16-byte slots XOR-swizzled by row & 15:
+// the b128 fragment reads of K and the b32 reads of V are both conflict-free without padding):
+//   S^T = K Q^T   A = K[key][d], B = Q[query][d] (Q fragments live in registers): lane (i = l & 15, g = l >> 4) ends up holding the scores of
+//                 query i against keys 16 kt + 4 g + r - 16 of the block's 64 keys, the other 48 in the three lanes with the same i
+//   softmax       per query across those 4 lanes (permlane swaps), online across key blocks
+//   O = P V       A = P: step (kt, r) takes the lane's OWN register P[i][16 kt + 4 g + r] (the MFMA sums over g: no transpose, no LDS round trip
+//                 for the probabilities), B = V[16 kt + 4 g + r][dv]
+// k order of the q.k sums: d = 16 c + e + 4 g over (c, e) then g (fixed, deterministic); of the p.v sums: keys 16 kt + r + 4 g over (kt, r) then g.
+template <typename WT>
+__global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs a) {
+  constexpr int EPL = Elem<WT>::EPL;
+  __shared__ __attribute__((aligned(16))) float sK[64 * 64];
+  __shared__ __attribute__((aligned(16))) float sV[64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * 64 + w * 16;
+  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const int iq = min(i0 + j, a.N - 1);  // clamped queries are computed and dropped
+  float4 qr[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qr[c] = *reinterpret_cast<const float4*>(base + (size_t)iq * a.ld + h * 64 + 16 * c + 4 * g);
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float4* sK4 = reinterpret_cast<const float4*>(sK);
+  for (int j0 = 0; j0 < a.N; j0 += 64) {
+    if (j0) __syncthreads();  // the previous tiles are consumed
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u, r = e >> 4, sl = e & 15, key = j0 + r;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (key < a.N) {
+        kv = *reinterpret_cast<const float4*>(base + (size_t)key * a.ld + a.inner + h * 64 + sl * 4);
+        vv = *reinterpret_cast<const float4*>(base + (size_t)key * a.ld + 2 * a.inner + h * 64 + sl * 4);
+      }
+      reinterpret_cast<float4*>(sK)[r * 16 + (sl ^ (r & 15))] = kv;
+      reinterpret_cast<float4*>(sV)[r * 16 + (sl ^ (r & 15))] = vv;
+    }
+    // bias and key flags of this lane's 16 (query, key) pairs: independent of the tiles, in flight across the barrier
+    float bias[4][4];
+    int flag[4][4];  // 0: no such key, 1: masked, 2: kept
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + 16 * kt + 4 * g + r, kc = min(key, a.N - 1);
+        bias[kt][r] = a.bias[(size_t)h * a.bias_ld + (kc - iq) + a.bias_zero];
+        flag[kt][r] = key >= a.N ? 0 : ((!a.mask || a.mask[(size_t)b * a.N + kc] != 0) ? 2 : 1);
+      }
+    __syncthreads();
+    f32x4 st[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 kr = sK4[(16 * kt + j) * 16 + ((4 * c + g) ^ j)];
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.x, qr[c].x, st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.y, qr[c].y, st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.z, qr[c].z, st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.w, qr[c].w, st[kt], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sc = flag[kt][r] == 0 ? -INFINITY : (flag[kt][r] == 2 ? st[kt][r] + bias[kt][r] : -3.402823466e38f);
+        st[kt][r] = sc;
+        mx = fmaxf(mx, sc);
+      }
+    const float m_new = fmaxf(m_run, across_groups_reduce<OpMax, 16>(mx));
+    const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = flag[kt][r] == 0 ? 0.f : expf(st[kt][r] - m_new);
+        st[kt][r] = pv;
+        sum += pv;
+      }
+    l_run = l_run * alpha + across_groups_reduce<OpSum, 16>(sum);
+    m_run = m_new;
+    if (j0) {  // the accumulators hold queries 4 g + r; their factors live in the lanes whose l & 15 is that query
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, 4 * g + r);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt][r] *= ar;
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * kt + 4 * g + r;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const float vb = sV[row * 64 + (((4 * dt + (j >> 2)) ^ (row & 15)) << 2) + (j & 3)];
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb, o[dt], 0, 0, 0);
+        }
+      }
+  }
+  WT* dst0 = reinterpret_cast<WT*>(a.out);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float lr = __shfl(l_run, 4 * g + r);
+    const int i = i0 + 4 * g + r;
+    if (i >= a.N) continue;
+    const int m = b * a.N + i;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int kcol = h * 64 + 16 * dt + j;
+      WT* dst = dst0;
+      if (a.out_fo) dst += fo_vec_index<WT>(m, kcol & ~(EPL - 1), a.inner / Elem<WT>::KT) * EPL + (kcol & (EPL - 1));
+      else dst += (size_t)m * a.inner + kcol;
+      store_from_f32<WT>(dst, o[dt][r] / lr);
+    }
+  }
+}
+
 template <typename DT>
 int t5_convert_into(DT* dst, const void* src, int src_dtype, size_t n, hipStream_t st) {
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
@@ -342,6 +468,7 @@ int t5_forward(ptts_t5* e, int B, int N, bool has_mask, hipStream_t st) {
   // the o / wo GEMMs' residual epilogues write the next GEMM's operand g o h and per-strip sums of h^2, the q|k|v and wi GEMMs scale their
   // accumulators by rstd (GemmArgs::rs_part / nx_out). 7 -> 5 nodes per block; block 0's first norm keeps its rows_prep node (PTTS_T5_NO_FOLD=1: all do)
   const bool fold = e->use_fold && M <= 256;
+  const int mfma_mode = getenv("PTTS_T5_ATTN_MFMA") ? atoi(getenv("PTTS_T5_ATTN_MFMA")) : 2;  // read per forward (a test switches it inside one process)
   auto consume = [&](GemmArgs& g) { g.rs_part = e->ss; g.rs_n = D / 16; g.rs_invD = 1.0f / (float)D; g.rms_eps = c.layer_norm_eps; };
   auto produce = [&](GemmArgs& g, const float* gamma) { g.nx_out = e->xw; g.nx_gamma = gamma; g.ss_out = e->ss; g.out_fo = fo; };
   for (int l = 0; l < c.num_layers; ++l) {
@@ -358,7 +485,11 @@ int t5_forward(ptts_t5* e, int B, int N, bool has_mask, hipStream_t st) {
       T5AttnArgs a = {};
       a.qkv = e->qkv; a.ld = 3 * I; a.inner = I; a.bias = e->bias; a.bias_ld = 2 * c.max_len - 1; a.bias_zero = c.max_len - 1;
       a.mask = has_mask ? e->mask : nullptr; a.out = e->ctx; a.out_fo = fo; a.B = B; a.N = N;
-      hipLaunchKernelGGL((t5_attn_kernel<WT>), dim3((N + 7) / 8, c.num_heads, B), dim3(256), 0, st, a);
+      // batches that fill the chip with 64-query workgroups: the f32-MFMA kernel (PTTS_T5_ATTN_MFMA=0: the VALU kernel everywhere; =1: the MFMA kernel everywhere)
+      if (mfma_mode == 1 || (mfma_mode == 2 && B * c.num_heads * ((N + 63) / 64) >= 128))
+        hipLaunchKernelGGL((t5_attn_mfma_kernel<WT>), dim3((N + 63) / 64, c.num_heads, B), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((t5_attn_kernel<WT>), dim3((N + 7) / 8, c.num_heads, B), dim3(256), 0, st, a);
     }
     {  // hidden = hidden + o(context)
       GemmArgs g = {};

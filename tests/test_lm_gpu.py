@@ -398,26 +398,30 @@ def test_fused_qkv_attention_default_bound_is_three_utterances():
 
 
 @pytest.mark.parametrize("rope", [False, True])
-def test_prefill_attention_tiled_kernel_vs_one_workgroup_per_row(rope, monkeypatch):
-    """prefill_attn_kernel (round 5: 8 query rows per workgroup share the K / V tile; default) against attn_kernel's one-workgroup-per-row
-    prefill (PTTS_PREFILL_ATTN=0) and both against the oracle: 70 prompt positions (two key tiles, causal boundary inside a tile), ragged
-    prompt / description masks incl. a fully padded prompt head, grouped-query attention, RoPE (q rotated in both blocks, cross keys not),
-    fp32 and bf16; 3 utterances (M = 213 rows) and 9 (M = 639: block GEMMs, row-major activations)."""
+@pytest.mark.parametrize("P", [70, 32])
+def test_prefill_attention_tiled_kernel_vs_one_workgroup_per_row(rope, P, monkeypatch):
+    """The three prefill attentions against the oracle and against each other: prefill_attn_mfma_kernel (round 6: exact-f32 MFMA, up to 64 query
+    rows per workgroup; PTTS_PREFILL_ATTN=2, the default from 128 (utterance, head) pairs up), prefill_attn_kernel (round 5: 8 query rows per
+    workgroup share the K / V tile; =1) and attn_kernel's one-workgroup-per-row prefill (=0). 70 prompt positions = 71 query rows (two 64-query
+    workgroups, two key blocks, causal boundary inside a block) and 32 = 33 rows (bench.py's prefill: three waves, the last with one query);
+    ragged prompt / description masks incl. a fully padded prompt head, grouped-query attention, RoPE (q rotated in both blocks, cross keys
+    not), fp32 and bf16; 3 utterances (strip GEMMs, fragment-order activations) and 9 (row-major activations, the > 256-row GEMMs)."""
     spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512, rope_embeddings=rope, num_key_value_heads=4, num_cross_attention_key_value_heads=2)
     sd = DO.make_decoder_weights(spec, seed=53)
     for bsz in (3, 9):
         for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
             runs = {}
-            for tiled in (True, False):
-                monkeypatch.setenv("PTTS_PREFILL_ATTN", "1" if tiled else "0")
-                runs[tiled], ref = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=70, P=70, steps=1, masks=True, seed=17, max_ctx=128, return_logits=True)
+            for mode in ("2", "1", "0"):
+                monkeypatch.setenv("PTTS_PREFILL_ATTN", mode)
+                runs[mode], ref = _teacher_forced_vs_oracle(spec, sd, dtype, prec, bsz=bsz, N=70, P=P, steps=1, masks=True, seed=17, max_ctx=128, return_logits=True)
             monkeypatch.delenv("PTTS_PREFILL_ATTN", raising=False)
-            for tiled in (True, False):
-                err = max(float((a - b).abs().max()) for a, b in zip(runs[tiled], ref))
-                assert err < tol, (bsz, prec, "tiled" if tiled else "per row", err)
+            for mode in ("2", "1", "0"):
+                err = max(float((a - b).abs().max()) for a, b in zip(runs[mode], ref))
+                assert err < tol, (bsz, prec, {"2": "f32 MFMA", "1": "tiled", "0": "per row"}[mode], err)
             if dtype == torch.float32:
-                ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
-                assert 0.0 < ab < 2e-5, (bsz, "tiled vs per-row prefill attention", ab)
+                for m in ("2", "1"):
+                    ab = max(float((a - b).abs().max()) for a, b in zip(runs[m], runs["0"]))
+                    assert 0.0 < ab < 2e-5, (bsz, m, "vs per-row prefill attention", ab)
 
 
 @pytest.mark.parametrize("bsz", [12, 40, 70])

@@ -220,3 +220,38 @@ def test_bench_ttft_shape_32_descriptions_24_blocks_bf16():
     e32, q32 = float((out32 - ref32).abs().max()), rel_rms(out32, ref32)
     log_parity(f"[t5 fp32 24 blocks, 32 x 64 tokens] max |d| {e32:.2e}, relative RMS {q32:.2e}", "r06_parity_t5.txt")
     assert q32 <= 2e-5
+
+
+@pytest.mark.parametrize("B,N", [(2, 64), (3, 40), (2, 140), (1, 17)])
+def test_f32_mfma_attention_kernel_vs_oracle_and_vs_valu_kernel(B, N, monkeypatch):
+    """t5_attn_mfma_kernel (round 6: exact-f32 MFMA, 64 queries per workgroup; the default from 128 workgroups up) forced on small shapes
+    (PTTS_T5_ATTN_MFMA=1) against the oracle and against the VALU kernel (=0; same arithmetic, another summation order): 64 tokens = one full key
+    block, 40 / 17 = a partial block (absent keys, clamped queries), 140 = three blocks (online softmax across blocks, saturated buckets); ragged
+    masks with left and right padding and one FULLY masked description (uniform attention, as the additive mask of the reference leaves it); fp32
+    engine (bit-level arithmetic visible) and bf16 engine (bf16 context rows written by the kernel). Graphs off: the switch is read per forward."""
+    monkeypatch.setenv("PTTS_T5_NO_GRAPH", "1")
+    spec = TO.T5Spec(vocab_size=300, d_model=1024, d_kv=64, d_ff=2816, num_layers=2, num_heads=16)
+    sd = TO.make_t5_weights(spec, seed=21)
+    g = torch.Generator().manual_seed(1000 * B + N)
+    ids = torch.randint(0, 300, (B, N), generator=g)
+    mask = torch.ones(B, N, dtype=torch.long)
+    if B > 1:
+        mask[1, N - N // 3:] = 0
+        mask[0, : N // 5] = 0
+    if B > 2:
+        mask[2, :] = 0  # fully masked row
+    ref = TO.T5Oracle(spec, sd).encode(ids, mask)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PTTS_T5_ATTN_MFMA", mode)
+        eng = make_t5(spec, sd, max_batch=B, max_len=N)
+        outs[mode] = eng.encode(ids.cuda(), mask.cuda()).cpu()
+    err, ab = float((outs["1"] - ref).abs().max()), float((outs["1"] - outs["0"]).abs().max())
+    log_parity(f"[t5 f32-MFMA attention fp32 B={B} N={N}] max |d| vs oracle {err:.2e}, vs the VALU kernel {ab:.2e}", "r06_parity_t5.txt")
+    assert err <= 5e-5 and ab <= 5e-5
+    monkeypatch.setenv("PTTS_T5_ATTN_MFMA", "1")
+    out16 = make_t5(spec, sd, dtype=torch.bfloat16, max_batch=B, max_len=N).encode(ids.cuda(), mask.cuda()).cpu()
+    ref16 = TO.T5Oracle(spec, sd, precision="bf16", fold_norm=B * N <= 256).encode(ids, mask)
+    r16 = rel_rms(out16, ref16)
+    log_parity(f"[t5 f32-MFMA attention bf16 B={B} N={N}] relative RMS vs bf16 oracle {r16:.2e}", "r06_parity_t5.txt")
+    assert r16 <= 3e-3

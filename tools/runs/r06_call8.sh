@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6, GPU call 8: f32-MFMA T5 attention kernel - parity (tests/test_t5_gpu.py) and the TTFT breakdown at 1 / 32 utterances
+cd "$GRAFT_REPO_ROOT" || exit 1
+timeout 900 python -m pytest tests/test_t5_gpu.py -x -q 2>&1 | tail -8
+timeout 300 python - <<'PY'
+import torch, bench, json
+dev = torch.device("cuda:0")
+model = bench.build_model_on_device(dev, torch.bfloat16, "mini")
+for bs in (1, 32):
+    print(bs, json.dumps({k: v for k, v in bench.measure_ttft_breakdown(model, bs, dev, reps=9).items() if k.endswith("_ms")}), flush=True)
+PY
