@@ -36,6 +36,9 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % WN, wm = wave / WN;
   const int q = lane >> 4, j = lane & 15;
+  if constexpr (EPI == EPI_KV) {  // the description's K/V of EVERY layer in one launch: blockIdx.z selects the layer's weights and caches
+    if (a.kv_layers) { const KvLayer kl = a.kv_layers[blockIdx.z]; a.W = kl.W; a.kcache = kl.k; a.vcache = kl.v; }
+  }
   int bx, by;
   xcd_tile_order(bx, by, a.xcd_swz);
   const int strip0 = bx * BNS, m0 = by * BMT * 16;
@@ -162,7 +165,7 @@ int launch_gemm_glds_inst(const GemmArgs& a, hipStream_t st) {
     if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
     attr_once.done(attr_dev);
   }
-  const dim3 grid(a.N / (16 * BNS), (a.M + BMT * 16 - 1) / (BMT * 16));
+  const dim3 grid(a.N / (16 * BNS), (a.M + BMT * 16 - 1) / (BMT * 16), (EPI == EPI_KV && a.kv_layers) ? a.kv_nlayers : 1);
   hipLaunchKernelGGL((gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST, ABL, RP, KF>), grid, dim3(WN * WM * 64), sh, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));

@@ -154,7 +154,7 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
     a.xcd_swz = xcd_swz;
     if constexpr (sizeof(WT) == 2) {  // bf16 engine: the LDS-DMA ring (round 6, ptts_gemm_glds.h); PTTS_GEMM_GLDS=0: round 5's register-staged tiles
       static const bool glds_on = !(getenv("PTTS_GEMM_GLDS") && !atoi(getenv("PTTS_GEMM_GLDS")));
-      if (glds_on && a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part && !a.stats_out && !a.W8 && !a.rs_part && !a.nx_out) {
+      if (glds_on && a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && (!a.kv_layers || EPI == EPI_KV) && !a.fold_part && !a.stats_out && !a.W8 && !a.rs_part && !a.nx_out) {
         const int rg = launch_gemm_glds<EPI>(a, st);
         if (rg != -1) return rg;
       }

@@ -232,7 +232,9 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     hipLaunchKernelGGL((convert_kernel<WT, float>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, e->qc,
                        reinterpret_cast<WT*>(e->xw2), n);
     static const bool kv_batched = !(getenv("PTTS_NO_KV_BATCHED") && atoi(getenv("PTTS_NO_KV_BATCHED")));
-    const bool one_launch = kv_batched && B * e->N <= 256;  // strip-kernel sized: every layer's K/V projection in ONE launch (blockIdx.z = layer)
+    // every layer's K/V projection in ONE launch (blockIdx.z = layer): the strip kernel up to 256 rows, the bf16 engine's LDS-DMA GEMM above (round 6:
+    // 24 launches of ~17 us at 32 descriptions x 64 tokens were one tenth of that prefill; a shape the GEMM declines falls back to the strips)
+    const bool one_launch = kv_batched && (B * e->N <= 256 || (sizeof(WT) == 2 && H % 64 == 0 && (2 * nkc * 64) % 64 == 0));
     for (int l = 0; l < (one_launch ? 1 : c.num_layers); ++l) {
       GemmArgs g = {};
       g.W = e->L[l].ckv; g.M = B * e->N; g.N = 2 * nkc * 64; g.K = H;

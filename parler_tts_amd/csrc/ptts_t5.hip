@@ -467,6 +467,9 @@ int t5_forward(ptts_t5* e, int B, int N, bool has_mask, hipStream_t st) {
   // <= 256 rows (the strip kernels): T5LayerNorm folded into the GEMMs around it - it has no mean and no bias, so W (g o x * rstd) = rstd * W (g o x):
   // the o / wo GEMMs' residual epilogues write the next GEMM's operand g o h and per-strip sums of h^2, the q|k|v and wi GEMMs scale their
   // accumulators by rstd (GemmArgs::rs_part / nx_out). 7 -> 5 nodes per block; block 0's first norm keeps its rows_prep node (PTTS_T5_NO_FOLD=1: all do)
+  // (round 6, measured and closed: the same producer / consumer epilogues on the LDS-DMA GEMM above 256 rows - T5 at 32 x 64 tokens 2.89 -> 2.97 ms:
+  //  the consumer's dependent round trip for its rows' partial sums at the end of every workgroup costs what the two removed 5 us nodes saved;
+  //  profiles/r06_experiments.txt call 11)
   const bool fold = e->use_fold && M <= 256;
   const int mfma_mode = getenv("PTTS_T5_ATTN_MFMA") ? atoi(getenv("PTTS_T5_ATTN_MFMA")) : 2;  // read per forward (a test switches it inside one process)
   auto consume = [&](GemmArgs& g) { g.rs_part = e->ss; g.rs_n = D / 16; g.rs_invD = 1.0f / (float)D; g.rms_eps = c.layer_norm_eps; };
