@@ -631,54 +631,7 @@ class ParlerTTSForConditionalGeneration(nn.Module):
             t5 = self.__dict__.pop("_t5_engine", None)  # the description encoder's packed weight copy goes with them
             if t5 is not None:
                 t5.close()
-            for e in self.__dict__.get("_split_engines") or []:  # the stream-split loop's engines hold packed copies of the same weights
-                e.close()
-            self.__dict__["_split_engines"], self.__dict__["_split_key"] = [], None
         self.__dict__["_engine_last"] = value
-
-    def _get_split_engines(self, n: int, Bsub: int, N: int, P: int, max_length: int, T: int = 0) -> List[DecoderEngine]:
-        """n engines of `Bsub` utterances each for the stream-split device loop (each holds its own packed weight copy)."""
-        d = self.config.decoder
-        dev, dt = self.device, self.dtype
-        fp8 = bool(getattr(self, "decoder_weights_fp8", False))
-        need = (dev, dt, fp8, n)
-        es = self.__dict__.get("_split_engines") or []
-        ok = len(es) == n and self.__dict__.get("_split_key") == need and all(
-            e.cfg.max_batch >= Bsub and e.cfg.max_enc >= N and e.cfg.max_prompt >= P + 1 + T and e.cfg.max_ctx >= P + max_length for e in es)
-        if not ok:
-            for e in es:
-                e.close()
-            es = []
-            for e in self.__dict__.get("_engines", {}).values():  # the single-engine cache holds another packed copy of the same weights (+ its KV arena)
-                e.close()
-            self.__dict__["_engines"] = {}
-            for _ in range(n):
-                e = DecoderEngine(hidden_size=d.hidden_size, num_layers=d.num_hidden_layers, num_heads=d.num_attention_heads, ffn_dim=d.ffn_dim,
-                                  num_codebooks=d.num_codebooks, vocab_size=d.vocab_size, max_positions=d.max_position_embeddings,
-                                  rope=d.rope_embeddings, rope_theta=d.rope_theta, pad_token_id=d.pad_token_id, eos_token_id=d.eos_token_id,
-                                  bos_token_id=d.bos_token_id, dtype=dt, max_batch=Bsub, max_ctx=max(P + max_length, 64), max_enc=max(N, 16),
-                                  max_prompt=max(P + 1 + T, 8), device=dev, num_kv_heads=d.num_key_value_heads,
-                                  num_cross_kv_heads=d.num_cross_attention_key_value_heads, weights_fp8=fp8)
-                e.load_state_dict(self.decoder.state_dict())
-                es.append(e)
-            self.__dict__["_split_engines"], self.__dict__["_split_key"] = es, need
-        return es
-
-    def _decode_streams(self, B: int) -> int:
-        """EXPERIMENTAL, off (model.decode_streams = n or PTTS_DECODE_STREAMS=n): run the batch as n independent sub-batches, each on its own
-        engine and HIP stream. Measured (profiles/r03_experiments.txt, r04_experiments.txt): batch 32 as 2 x 16 loses (a latency-bound chain does
-        not get shorter with fewer rows); 64 as 2 x 32 won 7.5 % while the strip GEMMs ran 64-row passes and is neutral since they run 2..3
-        lighter passes (call 26: 1690 vs 1698 ms per generate() at 64, 2137 vs 2126 at 96, 2541 vs 2534 at 128); four sub-batches are 2.7-3.3x
-        slower, and so are four or more single-utterance engines (call 20). No automatic split any more.
-        Greedy outputs equal the single-engine run (tests/test_generate_glue_cpu.py, tests/test_generate_gpu.py); with do_sample=True sub-batch i draws
-        from seed + i, so the samples differ from the single-engine run of the same torch seed (still deterministic for a given seed and split)."""
-        n = int(getattr(self, "decode_streams", 0) or os.environ.get("PTTS_DECODE_STREAMS", "0") or 0)
-        if n == 0:
-            n = 1
-        # smallest sub-batch that gets its own engine when a split is forced: 8 by default (decode_streams_min_sub / PTTS_DECODE_STREAMS_MIN_SUB lower
-        # it for probes: tools/streams_probe_small.py measured 2 x 1 at +6 %, everything else at 2..8 utterances slower than the one batched engine)
-        min_sub = int(getattr(self, "decode_streams_min_sub", 0) or os.environ.get("PTTS_DECODE_STREAMS_MIN_SUB", "8") or 8)
-        return n if n > 1 and B >= min_sub * n and B % n == 0 else 1
 
     # -- the pieces of generate() that stay on the torch side (once per call, off the per-token loop) ---------------
     def _encode_description_eager(self, input_ids, attention_mask):
@@ -882,30 +835,24 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         manual = manual or keep_scores or keep_logits
         self._step_records = ([] if keep_scores else None, [] if keep_logits else None)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if do_sample else 0  # follows torch.manual_seed()
-        n_split = self._decode_streams(B) if (not manual and streamer is None and not getattr(self, "overlap_codec", False)) else 1
         gen_kw = dict(max_length=max_length, min_new_tokens=min_new, do_sample=do_sample, temperature=float(gc.temperature or 1.0),
                       top_k=int(gc.top_k or 0) if do_sample else 0, top_p=float(gc.top_p if gc.top_p is not None else 1.0),
                       use_eos_gate=logits_processor is None)
-        if n_split > 1:
-            engines = self._get_split_engines(n_split, B // n_split, N, P, max_length, T0)
-            eng = None
-        else:
-            eng = self._get_engine(B, N, P, max_length, T0)
-            eng.set_gen_params(seed=seed, **gen_kw)
+        # (one engine per call: n independent sub-batches on n engines and streams - with or without disjoint CU masks - never beat it on one GPU:
+        #  profiles/r04_experiments.txt calls 20 / 26, profiles/r06_experiments.txt call 12; the split loop is gone since round 6)
+        eng = self._get_engine(B, N, P, max_length, T0)
+        eng.set_gen_params(seed=seed, **gen_kw)
         pad, eos = gc.pad_token_id if gc.pad_token_id is not None else d.pad_token_id, d.eos_token_id
         bos_col = torch.full((B * K, 1), bos, dtype=torch.long, device=dev)
         dec_ids = bos_col if prefix is None else torch.cat([bos_col, prefix], dim=-1)  # :3011-3018
         delayed, pattern = build_delay_pattern_mask(dec_ids, bos, pad, max_length, K)  # :3523-3530
         if streamer is not None:
             streamer.put(delayed.cpu())  # :3533-3534
-        if eng is not None:
-            eng.set_audio_prefix(prefix)
+        eng.set_audio_prefix(prefix)
         wav_pre = None
         # opt-in (model.overlap_codec = True): on ONE GPU the overlap does not pay (bs=32: 1513 -> 1575 ms per generate(), the codec's
         # MFMA kernels take CUs from the latency-bound token kernels; bs=1: the per-chunk polling costs what the 5.7 ms decode saves)
-        if n_split > 1:
-            output_ids = self._run_device_loop_split(engines, enc, enc_mask, prompt, prompt_mask, max_length, delayed.shape[1], prefix, gen_kw, seed, pad)
-        elif not manual and streamer is None and dev.type == "cuda" and getattr(self, "overlap_codec", False) and max_length - K >= 96:
+        if not manual and streamer is None and dev.type == "cuda" and getattr(self, "overlap_codec", False) and max_length - K >= 96:
             output_ids, wav_pre = self._run_device_loop_overlap(eng, enc, enc_mask, prompt, prompt_mask, max_length, delayed.shape[1])
         elif not manual:
             output_ids = self._run_device_loop(eng, enc, enc_mask, prompt, prompt_mask, max_length, streamer, delayed.shape[1], min_new)
@@ -1032,58 +979,6 @@ class ParlerTTSForConditionalGeneration(nn.Module):
                 streamer.put(cols[:, j])
         side.synchronize()
         return eng.ids()
-
-    def _run_device_loop_split(self, engines, enc, enc_mask, prompt, prompt_mask, max_length, given, prefix, gen_kw, seed, pad):
-        """The default loop over n independent sub-batches, each on its own engine and stream (see _decode_streams). Utterances never
-        interact, so the ids are those of the single-engine run (greedy; with sampling each sub-batch draws from its own seeded
-        stream); a sub-batch whose rows have all finished stops stepping and its columns are padded like finished rows are."""
-        import contextlib
-
-        n, B, K = len(engines), enc.shape[0], self.config.decoder.num_codebooks
-        per = B // n
-        cuda = self.device.type == "cuda"
-        if cuda:
-            main = torch.cuda.current_stream(self.device)
-            streams = self.__dict__.get("_split_streams") or []
-            if len(streams) != n or streams[0].device != self.device:
-                streams = self.__dict__["_split_streams"] = [torch.cuda.Stream(self.device, priority=-(i % 2)) for i in range(n)]
-            for st in streams:
-                st.wait_stream(main)
-            ctx = [torch.cuda.stream(st) for st in streams]
-        else:
-            ctx = [contextlib.nullcontext() for _ in range(n)]
-        sl = lambda t, i: None if t is None else t[i * per: (i + 1) * per]  # noqa: E731
-        for i, e in enumerate(engines):
-            with ctx[i]:
-                e.set_gen_params(seed=seed + i, **gen_kw)
-                e.set_audio_prefix(None if prefix is None else prefix[i * per * K: (i + 1) * per * K])
-                e.prefill(sl(enc, i), sl(enc_mask, i), sl(prompt, i), sl(prompt_mask, i), sample=True)
-        remaining = max_length - given - 1
-        done = [False] * n
-        made, min_new = 1, int(gen_kw.get("min_new_tokens", 0) or 0)
-        while remaining > 0 and not all(done):
-            k = min(64, remaining)
-            for i, e in enumerate(engines):
-                if not done[i]:
-                    with ctx[i]:
-                        e.decode_steps(k)
-            remaining -= k
-            made += k
-            if made > min_new or remaining == 0:  # like _run_device_loop: no host synchronisation while EOS is still blocked
-                for i, e in enumerate(engines):
-                    if not done[i]:
-                        with ctx[i]:
-                            _, done[i] = e.state()
-        parts = []
-        for i, e in enumerate(engines):
-            with ctx[i]:
-                parts.append(e.ids().clone())
-        if cuda:
-            for st in streams:
-                main.wait_stream(st)
-        width = max(p.shape[1] for p in parts)
-        parts = [p if p.shape[1] == width else torch.cat([p, p.new_full((p.shape[0], width - p.shape[1]), pad)], dim=1) for p in parts]
-        return torch.cat(parts, dim=0)
 
     def _codec_hop(self) -> int:
         return int(math.prod(getattr(self.audio_encoder, "decoder_rates", (8, 8, 4, 2))))

@@ -254,31 +254,3 @@ def test_device_loop_polls_the_device_only_once_eos_can_fire():
     c = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_new_tokens=150, min_new_tokens=0)
     assert len(polls) == 3
     assert torch.equal(a, b) and torch.equal(a, c)  # EOS never wins in this model (its logit rows are zeroed): the same utterance
-
-
-def test_stream_split_device_loop_equals_the_single_engine_run():
-    """model.decode_streams = 2 (experimental, off by default): the batch runs as two independent sub-batches on two engines; greedy
-    waveforms and lengths are those of the single-engine run, including sub-batches that finish at different columns (padding)."""
-    m, spec, sd, dac = _model(eos_gain=6.0)
-    g = torch.Generator().manual_seed(5)
-    B = 16
-    desc, prompt_ids = torch.randint(3, 128, (B, 6), generator=g), torch.randint(3, 128, (B, 3), generator=g)
-    kw = dict(input_ids=desc, prompt_input_ids=prompt_ids, do_sample=False, max_length=30, min_new_tokens=2, return_dict_in_generate=True)
-    one = m.generate(**kw)
-    made = []
-
-    def split_engines(n, Bsub, N, Pp, L, T=0):
-        assert (n, Bsub) == (2, 8)
-        made.extend(OracleEngine(spec, sd) for _ in range(n))
-        return made[-n:]
-
-    m._get_split_engines = split_engines
-    m.decode_streams = 2
-    two = m.generate(**kw)
-    assert len(made) == 2 and two["audios_length"] == one["audios_length"] and len(set(one["audios_length"])) > 1
-    assert two.sequences.shape == one.sequences.shape and torch.allclose(two.sequences, one.sequences, atol=1e-6)
-    widths = {e.ids().shape[1] for e in made}
-    m.decode_streams = 2
-    assert m._decode_streams(15) == 1 and m._decode_streams(8) == 1 and m._decode_streams(16) == 2  # small / indivisible batches: one engine
-    m.decode_streams = 0
-    assert m._decode_streams(32) == 1 and widths

@@ -411,26 +411,6 @@ def test_generate_sharded_over_rccl_world_size_1_equals_generate():
         dist.destroy_process_group()
 
 
-def test_stream_split_device_loop_equals_per_half_runs():
-    """model.decode_streams = 2 (opt-in; neutral since the strip GEMMs run 2..3 light M passes, profiles/r04_experiments.txt call 26): 16
-    utterances run as two sub-batches of 8 on two engines and two HIP streams. Utterances never interact and each sub-batch runs the batch-8
-    kernels, so the waveform must equal, bit for bit, the two halves generated one after the other on the ordinary single engine; nothing is
-    split automatically."""
-    m, spec, sd, dsd = _tiny_model(seed=2)
-    m = m.to("cuda")
-    g = torch.Generator().manual_seed(11)
-    desc, prompt_ids = torch.randint(3, 128, (16, 7), generator=g).cuda(), torch.randint(3, 128, (16, 4), generator=g).cuda()
-    kw = dict(do_sample=False, max_new_tokens=24, min_new_tokens=24)
-    assert all(m._decode_streams(b) == 1 for b in (16, 32, 64, 96, 128))
-    halves = [m.generate(input_ids=desc[i: i + 8], prompt_input_ids=prompt_ids[i: i + 8], **kw) for i in (0, 8)]
-    m.decode_streams = 2
-    assert m._decode_streams(16) == 2
-    both = m.generate(input_ids=desc, prompt_input_ids=prompt_ids, **kw)
-    m.decode_streams = 0
-    assert both.shape == (16, halves[0].shape[1]) and torch.equal(both, torch.cat(halves, dim=0))
-    assert len(m._split_engines) == 2 and float(both.abs().max()) > 0
-
-
 def test_generate_eos_terminated_batch_of_8_goes_through_one_ragged_codec_pass():
     """generate()'s per-sample tail (modeling_parler_tts.py:3615-3647) on an EOS-terminated batch of 8 with DISTINCT lengths: the ids the token
     loop produced (captured at the hand-over) are un-delayed, filtered and decoded utterance by utterance by the ORACLE, exactly as the
