@@ -87,7 +87,6 @@ struct ptts_engine {
   float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   float* lnstat = nullptr;             // strip statistics of the residual rows (EPI_RESID -> PRO_LNS), [max_batch][H/16][2]
   bool use_lns = true;                 // 8 < batch <= 32 decode: LayerNorm fused into the consumer GEMM (no rows_prep node)
-  bool attn_exact = true;              // batch > 8 decode self-attention fetches exactly the rows each utterance has (PTTS_NO_ATTN_EXACT=1: the kv_bound bucket)
   bool use_fo = true;                  // batch > 8 decode: engine-dtype activations in MFMA B-fragment order (PTTS_NO_FO=1: row-major, for A/B)
   int S_self = 4, S_cross = 1;
   int attn_waves = 4;  // waves per self-attention workgroup at decode
@@ -133,7 +132,7 @@ struct ptts_engine {
   bool in_capture = false;
   int* host_pinned = nullptr;
 #ifdef PTTS_TIMING
-  long long* dbg_stamps = nullptr;  // measurement build: [layers + 1][5 nodes][3 workgroups][16] s_memtime stamps of the single-utterance step (ptts_debug_stamps)
+  long long* dbg_stamps = nullptr;  // measurement build: [layers + 1][5 or 7 nodes][3 workgroups][16] wall-clock stamps of the decode step (ptts_debug_stamps)
 #endif
 
   template <typename T> int alloc(T** p, size_t n) {
@@ -423,10 +422,16 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // kv_append node: 24 launches of ~4 us + their boundaries off the time-to-first-token path; PTTS_KV_IN_QKV=0: the separate node)
   static const bool kv_in_qkv_on = !(getenv("PTTS_KV_IN_QKV") && !atoi(getenv("PTTS_KV_IN_QKV")));
   const bool kv_in_qkv = kv_in_qkv_on && prefill && lnproj_ok && !c.rope && !e->L[0].ks_self;
+#ifdef PTTS_TIMING
+#define PTTS_DBG_BIG(args, l_, k_) (args).dbg = (e->dbg_stamps && !prefill && M > 8) ? e->dbg_stamps + ((size_t)(l_) * 7 + (k_)) * 48 : nullptr
+#else
+#define PTTS_DBG_BIG(args, l_, k_) do { } while (0)
+#endif
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
     if (lnproj_ok) {  // LN1 (+ fold of the previous fc2's partials) + fused QKV projection in one node
       LnProjArgs p = {};
+      PTTS_DBG_BIG(p, l, 0);
       p.W = w.qkv; p.x = e->h; p.x_ld = H; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.K = H; p.out = e->qkv; p.out_ld = QKV; p.M = M; p.N = QKV;
       if (fc2_pending) { p.part = e->hpart; p.S = FC2_KSPLIT; fc2_pending = false; resid_fold = true; }
       if (kv_in_qkv) { p.kcache = w.k_self; p.vcache = w.v_self; p.kv_Q = Q; p.kv_cap = c.max_ctx; p.kv_heads = nkv; p.kv_H = H; }
@@ -462,7 +467,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
       a.kscale = w.ks_self; a.vscale = w.vs_self;
       a.direct_out = S_used == 1 ? e->xw : nullptr; a.out_fo = fo;
-      a.exact_len = (!prefill && M > 8 && e->attn_exact) ? 1 : 0;
+      PTTS_DBG_BIG(a, l, 1);
       if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st, prefill_attn_mode)));
       else PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->attn_waves)));
     }
@@ -472,6 +477,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
       if (resid_fold) { g.fold_part = e->hpart; g.fold_S = FC2_KSPLIT; resid_fold = false; }  // the LN1 node normalised h + partials without writing it back
       if (lns) g.stats_out = e->lnstat;  // strip statistics of the new residual rows for LN2 (PRO_LNS)
+      PTTS_DBG_BIG(g, l, 2);
       if (S_used == 1) {
         g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1;
         PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
@@ -487,6 +493,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       x.invK = 1.0f / (float)H; x.kcache = w.k_cross; x.vcache = w.v_cross; x.cap = c.max_enc; x.cur_len = e->cur_len; x.dims = e->dims;
       x.mask = e->enc_mask; x.mask_ld = c.max_enc; x.cos = c.rope ? e->rope_cos : nullptr; x.sin = c.rope ? e->rope_sin : nullptr;
       x.out = e->xw; x.B = M; x.nheads = nh; x.kv_heads = nkc; x.n_rep = nh / nkc; x.scale = scale; x.out_fo = fo;
+      PTTS_DBG_BIG(x, l, 3);
       // utterances per workgroup: 8 (one per wave) up to 8 utterances; above, e->xattn_g (8 / 4 / 2: heads x ceil(M / g) workgroups, the 8 / g
       // waves of an utterance split the description's row groups)
       // measured (profiles/r04_experiments.txt, us per step at mid context, g = 8 / 4 / 2): batch 32 1432 / 1381 / 1360, batch 128 2596 / 2682 / 2860
@@ -536,6 +543,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       g.W = w.co; g.W8 = w.co_p8; g.wscale = w.co_sc; g.x = reinterpret_cast<const float*>(e->xw); g.x_ld = H; g.x_row_mul = 1; g.x_fo = fo;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H;
       if (lns) g.stats_out = e->lnstat;  // for LN3
+      PTTS_DBG_BIG(g, l, 4);
       PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g, st)));
     }
     {  // LN3 + fc1 + GELU, then fc2 + residual. Above 8 rows the GELU output is written in the engine dtype so fc2
@@ -551,10 +559,12 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         if (lnproj_ok && (lnproj >= 3 || (lnproj == 2 && M > 32))) {  // LN3 + fc1 + GELU in one node
           LnProjArgs p = {};
           p.W = w.fc1; p.x = e->h; p.x_ld = H; p.gamma = w.ln3_g; p.beta = w.ln3_b; p.K = H; p.out = e->xw2; p.out_ld = F; p.out_fo = fo; p.M = M; p.N = F;
+          PTTS_DBG_BIG(p, l, 5);
           PTTS_TRY((launch_lnproj<WT, EPI_GELU_WT>(e, p, st, lnproj_g)));
         } else
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
         g2.x = reinterpret_cast<const float*>(e->xw2); g2.x_fo = fo;
+        PTTS_DBG_BIG(g2, l, 6);
         if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0) && !(lnproj_ok && lnproj_g == 16)) {  // (the 16-row LN1 node does not fold partials: fc2 runs un-split beside it)
           g2.out = e->hpart;  // h += sum of the partials happens in the next layer's LN1 prep kernel
           PTTS_TRY((launch_gemm_splitk<WT>(g2, st)));
@@ -864,7 +874,6 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc_bytes(&e->xw, (rows + 16) * H * es));  // + 16 rows: fragment order addresses whole 16-row tiles
   A(e->alloc_bytes(&e->xw2, std::max((rows + 16) * F, enc_rows * (size_t)H) * es));
   e->use_fo = !(getenv("PTTS_NO_FO") && atoi(getenv("PTTS_NO_FO")));
-  e->attn_exact = !(getenv("PTTS_NO_ATTN_EXACT") && atoi(getenv("PTTS_NO_ATTN_EXACT")));
   A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
@@ -886,7 +895,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   if (hipHostMalloc((void**)&e->host_pinned, ((size_t)c.max_batch * K + 16) * 4) != hipSuccess) return fail(ptts_fail(PTTS_E_HIP, "hipHostMalloc failed"));
 #ifdef PTTS_TIMING
   {
-    const size_t n = (size_t)(c.num_layers + 1) * 5 * 48;
+    const size_t n = (size_t)(c.num_layers + 1) * 7 * 48;  // 5 nodes per layer of the GEMV step, 7 of the batch > 8 step
     rc = e->alloc(&e->dbg_stamps, n);
     if (rc != PTTS_OK) return fail(rc);
     hipMemset(e->dbg_stamps, 0, n * sizeof(long long));

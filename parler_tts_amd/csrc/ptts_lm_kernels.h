@@ -193,10 +193,25 @@ static __global__ void pack_w8_kernel(const uint8_t* __restrict__ src, uint4* __
   dst[((size_t)(strip0 + s) * npair_total + p) * 64 + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
+// Measurement build only (-DPTTS_TIMING, tools/build_stamps.sh; never the product library): phase stamps of the device-wide 100 MHz counter
+// (wall_clock64 = s_memrealtime; s_memtime counts per XCD with unrelated offsets) by lane 0 of wave 0 of the first / middle / last workgroup of
+// a launch into dbg[3][16] - round 5 stamped the single-utterance GEMV step this way (ptts_gemv.h: GV_STAMP), round 6 the seven nodes per layer of
+// the batch > 8 step (lnproj_fused / attn / gemm_strip / xattn_fused): profiles/r06_node_stamps_bs32.txt
 #ifdef PTTS_TIMING
-#define PTTS_STAMP(ptr, i) do { if ((ptr) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) (ptr)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PTTS_DBG_FIELD long long* dbg;
+#define PTTS_STAMP(ptr, i)                                                                                                  \
+  do {                                                                                                                      \
+    if ((ptr) && threadIdx.x == 0) {                                                                                        \
+      const unsigned nb_ = gridDim.x * gridDim.y * gridDim.z, lb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+      const int slot_ = lb_ == 0 ? 0 : (lb_ == nb_ / 2 ? 1 : (lb_ == nb_ - 1 ? 2 : -1));                                    \
+      if (slot_ >= 0) (ptr)[slot_ * 16 + (i)] = (long long)wall_clock64();                                                  \
+    }                                                                                                                       \
+  } while (0)
+#define PTTS_WSTAMP(a, i) PTTS_STAMP((a).dbg, i)
 #else
+#define PTTS_DBG_FIELD
 #define PTTS_STAMP(ptr, i) do { } while (0)
+#define PTTS_WSTAMP(a, i) do { } while (0)
 #endif
 #ifdef PTTS_TIMING
 template <typename A> __device__ __forceinline__ long long* ptts_dbg_of(const A&) { return nullptr; }
@@ -1200,9 +1215,7 @@ struct AttnArgs {
   int out_fo;          // direct_out in MFMA B-fragment order (fo_vec_index) instead of row-major [rows][H]
   float* kscale;       // (KV8 instances) e4m3 self-attention cache: kcache / vcache hold 64 bytes per row and these one power-of-two scale per
   float* vscale;       // (utterance, K/V head, position): [B][kv_heads][cap] fp32, written at append like the rows; null = engine-dtype cache
-  int exact_len;       // decode self-attention at batch > 8: wait for the device-resident length (one scalar round trip) and fetch only the
-                       // rows this utterance has, instead of everything below kv_bound (the 64-position bucket: up to 63 unused rows per
-                       // (utterance, head), ~7-13 % of the K/V bytes at mid context; at batch 1..8 the extra round trip costs more than it saves)
+  PTTS_DBG_FIELD
 };
 
 // load EPL consecutive floats of a row chunk, optionally RoPE-rotated (x*cos + rotate_half(x)*sin, modeling:409-436)
@@ -1305,6 +1318,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   const int TW = a.S * NW, wv = s * NW + w;
   const int kvh = h / a.n_rep;
 
+  PTTS_WSTAMP(a, 0);
   // ---- t = 0: all loads ---------------------------------------------------------------------------------------------
   const int P = a.dims->P;
   const int Nenc = a.cross ? a.dims->N : 0;
@@ -1326,17 +1340,21 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   KVV kf[U], vf[U];
   float ksc[KV8 ? U : 1], vsc[KV8 ? U : 1];
   int mk[U];
-  // exact_len: self-attention decode, rows [0, P + cur_len - 1) are in the cache; the row of the new position comes from registers
-  const int fetch_bound = a.exact_len ? min(a.kv_bound, P + cl - 1) : a.kv_bound;
+  // The first batch is addressed from kernel arguments only (the host's bound kv_bound: rows below it exist in the arena whatever they hold; validity
+  // is applied from L below, and every later batch is clamped by L itself). Clamping it by the device-resident length instead (round 5's
+  // `exact_len`) measured no difference at 16 / 32 / 128 utterances (profiles/r06_experiments.txt call 14: 1248.4 vs 1248.7 us per step at 32) -
+  // the 2.9 us from entry to "first batch requested" in profiles/r06_node_stamps_bs32_bs128_raw.txt is the memory system taking the requests
+  // of every workgroup at once, not the two scalar round trips; the flag is gone.
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int t = (wv + u * TW) * RPI + r;
-    const int tc = t < fetch_bound ? t : 0;
+    const int tc = t < a.kv_bound ? t : 0;
     kf[u] = Kb[(size_t)tc * LPR + c];
     vf[u] = Vb[(size_t)tc * LPR + c];
     if constexpr (KV8) { ksc[u] = Ks[tc]; vsc[u] = Vs[tc]; }
     mk[u] = (mrow && t < a.mask_ld) ? mrow[t] : 1;
   }
+  PTTS_WSTAMP(a, 1);  // scalar state (dims, cur_len) read and the first batch of K / V rows + the q / k / v chunks requested
   // ---- lengths known from here on -------------------------------------------------------------------------------------
   const int pos = (a.cur_len ? P + cl - 1 : 0) + qi;
   const int L = a.cross ? Nenc : pos + 1;
@@ -1380,6 +1398,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f, o[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+  PTTS_WSTAMP(a, 2);  // the query chunk (the dependent operand: the previous node wrote it) is usable: rotated, scaled
 
   for (int g0 = wv; g0 < G; g0 += TW * U) {
     bool ok[U];
@@ -1434,6 +1453,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     }
     m_run = m_new;
   }
+  PTTS_WSTAMP(a, 3);  // K / V loop done
   // reduce over the RPI row slots of the wave (lanes sharing chunk c)
   l_run = across_groups_reduce<OpSum, LPR>(l_run);
 #pragma unroll
@@ -1461,6 +1481,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
       if (a.out_fo) dst += fo_vec_index<WT>(row, kcol & ~(EPL - 1), a.H / Elem<WT>::KT) * EPL + (kcol & (EPL - 1));
       else dst += (size_t)row * a.H + kcol;
       store_from_f32<WT>(dst, lv > 0.f ? ov / lv : 0.f);
+      PTTS_WSTAMP(a, 5);
       return;
     }
     a.part[((size_t)row * a.S + s) * a.H + h * 64 + tid] = ov;
@@ -1768,6 +1789,7 @@ struct XAttnArgs {
   int kv_heads, n_rep; // cross K/V heads (grouped-query attention)
   float scale;
   int out_fo;          // out in MFMA B-fragment order (fo_vec_index) for the out_proj GEMM at batch > 8
+  PTTS_DBG_FIELD
 };
 
 // G = utterances per workgroup (8: one per wave; 4 / 2: at batch > 8 the launch covers heads x ceil(B / G) workgroups - 128 / 256 at 32
@@ -1797,6 +1819,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   const int r = lane / LPR, c = lane % LPR;
   const int ul = wave / WPU, sub = wave % WPU;  // attention: utterance slot and row-group phase of this wave
   const int b = b0 + min(ul, nb - 1);
+  PTTS_WSTAMP(a, 0);
   const int N = a.dims->N;
 
   // ---- t = 0: every independent global load of the kernel goes in flight; the residual rows first (critical path:
@@ -1829,7 +1852,9 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
   };
   // ---- LayerNorm of the rows -> LDS, then the head's 64 q rows ------------------------------------------------------
   ln_stage<WT, NF4, true, XAttnArgs, false>(a, b0, nb, s_x, row_bytes, lane, wave, NWV, issue_bulk);  // K == NF4 * 256
+  PTTS_WSTAMP(a, 2);  // this wave's rows normalised
   __syncthreads();
+  PTTS_WSTAMP(a, 3);  // every row of the group is in LDS
   const char* brow = s_x + (size_t)min(j, nb - 1) * row_bytes + (size_t)q4 * 16;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int tb = t0; tb < t1; tb += UW) {
@@ -1849,6 +1874,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
       }
     }
   }
+  PTTS_WSTAMP(a, 4);  // last weight fragment consumed
   *reinterpret_cast<f32x4*>(s_red + ((size_t)wave * 64 + lane) * 4) = acc + acc2;
   __syncthreads();
   if (wave < 4) {  // wave s combines the two K halves of strip s: D[row = q4*4 + e][col = utterance j]
@@ -1860,6 +1886,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
     }
   }
   __syncthreads();
+  PTTS_WSTAMP(a, 5);  // the head's 64 q rows of every utterance of the group are in LDS
   if (WPU == 1 && ul >= nb) return;
   // ---- wave (b, sub): single-query attention of utterance b over its share of the N description positions ---------------
   const bool live = ul < nb;
@@ -1935,6 +1962,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
       for (int e = 0; e < EPL; ++e) s_o[wave * 64 + c * EPL + e] = o[e];
       if (c == 0) { s_ml[wave * 2] = m_run; s_ml[wave * 2 + 1] = l_run; }
     }
+    PTTS_WSTAMP(a, 6);  // this wave's share of the description attended
     __syncthreads();
     if (sub != 0 || !live) return;
     float M = -INFINITY;
@@ -1960,6 +1988,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
     if (a.out_fo) reinterpret_cast<uint4*>(a.out)[fo_vec_index<WT>(b, h * 64 + c * EPL, a.K / KT)] = pack16(res, WT());
     else reinterpret_cast<uint4*>(reinterpret_cast<WT*>(a.out) + (size_t)b * a.K + h * 64)[c] = pack16(res, WT());
   }
+  PTTS_WSTAMP(a, 7);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1996,6 +2025,7 @@ struct LnProjArgs {
   void* kcache;         // [B][kv_heads][kv_cap][64]
   void* vcache;
   int kv_Q, kv_cap, kv_heads, kv_H;  // rows per utterance (row m = utterance m / kv_Q, position m % kv_Q); columns [kv_H, kv_H + 64 kv_heads) = K, then V
+  PTTS_DBG_FIELD
 };
 
 // G = 16 (round 5): two rows per wave (rows w and w + 8, both in flight), all 16 columns of the MFMA tile in use - half the weight re-reads of
@@ -2018,6 +2048,7 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
   const uint4* Wp = reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
   const int q4 = lane >> 4, j = lane & 15;
   uint4 afr[UW];
+  PTTS_WSTAMP(a, 0);
   if constexpr (G > NWV) {  // two rows per wave, no pending partials
     if (wave < nb) {
       const bool two = wave + NWV < nb;
@@ -2054,8 +2085,10 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
           lds_store4<WT>(row, (lane + 64 * i) * 4, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
                          (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
       };
+      PTTS_WSTAMP(a, 1);  // rows + gamma / beta + the first weight fragments requested
       norm_row(v0, s_x + (size_t)wave * row_bytes);
       if (two) norm_row(v1, s_x + (size_t)(wave + NWV) * row_bytes);
+      PTTS_WSTAMP(a, 2);  // this wave's rows normalised (the dependent operand has arrived and been reduced)
     } else {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -2090,6 +2123,7 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
 #pragma unroll
     for (int uu = 0; uu < UW; ++uu) afr[uu] = ld_nt16(Wp + (size_t)(t0 + uu) * 64);
     __builtin_amdgcn_sched_barrier(0);
+    PTTS_WSTAMP(a, 1);  // row (+ partials) + gamma / beta + the first weight fragments requested
     if (a.part) {  // h + sum_s part[s] in fixed order: prep_ln_row_regs' arithmetic
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp)
@@ -2115,6 +2149,7 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
     for (int i = 0; i < NF4; ++i)
       lds_store4<WT>(row, (lane + 64 * i) * 4, (v[i].x - mean) * rstd * g[i].x + bt[i].x, (v[i].y - mean) * rstd * g[i].y + bt[i].y,
                      (v[i].z - mean) * rstd * g[i].z + bt[i].z, (v[i].w - mean) * rstd * g[i].w + bt[i].w);
+    PTTS_WSTAMP(a, 2);  // this wave's row normalised
   } else {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -2123,6 +2158,7 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
+  PTTS_WSTAMP(a, 3);  // every row of the group is in LDS
   // ---- the block's 64 projection rows for the group's utterances (columns j < nb of the MFMA tile)
   const char* brow = s_x + (size_t)min(j, nb - 1) * row_bytes + (size_t)q4 * 16;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2143,8 +2179,10 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
       }
     }
   }
+  PTTS_WSTAMP(a, 4);  // last weight fragment consumed
   *reinterpret_cast<f32x4*>(s_red + ((size_t)wave * 64 + lane) * 4) = acc + acc2;
   __syncthreads();
+  PTTS_WSTAMP(a, 5);  // cross-wave reduction buffer complete
   if (wave < 4 && j < nb) {  // wave s combines the two K halves of strip s: D[row = q4*4 + e][col = utterance j]
     const f32x4 rr = *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave) * 64 + lane) * 4) +
                      *reinterpret_cast<const f32x4*>(s_red + ((size_t)(2 * wave + 1) * 64 + lane) * 4);

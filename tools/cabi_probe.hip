@@ -114,7 +114,7 @@ struct Filler {
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #ifdef PTTS_STAMPS
-static int report_stamps(ptts_engine* e, hipStream_t st, double step_us);  // measurement build (tools/build_stamps.sh)
+static int report_stamps(ptts_engine* e, hipStream_t st, double step_us, int B);  // measurement build (tools/build_stamps.sh)
 #endif
 
 static const char* opt(int argc, char** argv, const char* key) {  // "key=value" -> value, bare "key" -> "", absent -> nullptr
@@ -280,10 +280,10 @@ static int run_lm(int argc, char** argv) {
          (t_loaded - t_create) * 1e3, cur);
   fflush(stdout);
 #ifdef PTTS_STAMPS
-  if (B == 1) {
+  if (B == 1 || B > 8) {  // the single-utterance GEMV step (5 nodes per layer) or the batch > 8 MFMA-path step (7 nodes per layer)
     PT(ptts_decode_steps(e, 4, st));
     HIPCHK(hipStreamSynchronize(st));
-    report_stamps(e, st, us[2]);
+    report_stamps(e, st, us[2], B);
   }
 #endif
   ptts_engine_destroy(e);
@@ -295,7 +295,8 @@ static int run_lm(int argc, char** argv) {
 // left in its last replay -> per node the phases inside the kernel, per edge the time from the producer's last store to the consumer's entry.
 extern "C" int ptts_debug_stamps(ptts_engine* e, long long** stamps_dev, int32_t* layers);
 __global__ void stamp_now_kernel(long long* p) { *p = (long long)wall_clock64(); }
-static int report_stamps(ptts_engine* e, hipStream_t st, double step_us) {
+static int report_stamps(ptts_engine* e, hipStream_t st, double step_us, int B) {
+  const int NN = B > 8 ? 7 : 5;  // nodes per layer
   long long* dev = nullptr;
   int32_t nl = 0;
   PT(ptts_debug_stamps(e, &dev, &nl));
@@ -313,11 +314,15 @@ static int report_stamps(ptts_engine* e, hipStream_t st, double step_us) {
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, a, b));
   const double tpu = (double)(t2[1] - t2[0]) / (ms * 1e3);  // ticks per microsecond
-  std::vector<long long> h((size_t)(nl + 1) * 5 * 48);
+  std::vector<long long> h((size_t)(nl + 1) * NN * 48);
   HIPCHK(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
-  auto S = [&](int l, int k, int slot, int idx) { return h[(((size_t)l * 5 + k) * 3 + slot) * 16 + idx]; };
-  const char* names[5] = {"qkv_attn (LN1 + q/k/v rows + self-attention + append)", "combine + out_proj + residual", "xfold_attn (LN2 + M rows + softmax + U columns)",
-                          "partial rows + LN3 + fc1 + GELU", "fc2 + residual"};
+  auto S = [&](int l, int k, int slot, int idx) { return h[(((size_t)l * NN + k) * 3 + slot) * 16 + idx]; };
+  const char* names5[5] = {"qkv_attn (LN1 + q/k/v rows + self-attention + append)", "combine + out_proj + residual", "xfold_attn (LN2 + M rows + softmax + U columns)",
+                           "partial rows + LN3 + fc1 + GELU", "fc2 + residual"};
+  const char* names7[7] = {"lnproj_fused (LN1 [+ fc2 partials] + q|k|v)", "attn_kernel (self-attention + append)", "gemm_strip (out_proj + residual)",
+                           "xattn_fused (LN2 + cross q + cross-attention)", "gemm_strip (cross out_proj + residual)", "lnproj_fused (LN3 + fc1 + GELU)",
+                           "gemm_strip (fc2: split-K partials or + residual)"};
+  const char** names = NN == 7 ? names7 : names5;
   int khz = 0;
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
   printf("[node stamps] wall_clock64 runs at %.2f ticks / us (calibrated over %.1f ms; hipDeviceAttributeWallClockRate %d kHz); step = %.1f us by HIP events; layers averaged: 2 .. %d\n",
@@ -327,17 +332,17 @@ static int report_stamps(ptts_engine* e, hipStream_t st, double step_us) {
   auto last_stamp = [&](int l, int k) { long long m = 0; for (int s = 0; s < 3; ++s) for (int i = 0; i < 16; ++i) m = std::max(m, S(l, k, s, i)); return m; };
   const int l0 = 2, l1 = nl - 2;
   double tot_in = 0, tot_gap = 0;
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < NN; ++k) {
     double in_kernel = 0, gap = 0, ph[16] = {0};
     int cnt[16] = {0}, n = 0;
     for (int l = l0; l <= l1; ++l) {
       const long long e0 = first_entry(l, k), e1 = last_stamp(l, k);
-      const int kn = (k + 1) % 5, ln = k == 4 ? l + 1 : l;
+      const int kn = (k + 1) % NN, ln = k == NN - 1 ? l + 1 : l;
       const long long en = first_entry(ln, kn);
       if (!e0 || !e1 || !en) continue;
       in_kernel += (double)(e1 - e0) / tpu; gap += (double)(en - e1) / tpu; ++n;
       for (int i = 1; i < 8; ++i) {  // phases of the FIRST sampled workgroup, relative to its own entry (weight wave: idx 2 when present)
-        const long long v = S(l, k, 0, i), base = (i >= 3 && S(l, k, 0, 2)) ? S(l, k, 0, 2) : S(l, k, 0, 0);
+        const long long v = S(l, k, 0, i), base = (NN == 5 && i >= 3 && S(l, k, 0, 2)) ? S(l, k, 0, 2) : S(l, k, 0, 0);
         if (v && base) { ph[i] += (double)(v - base) / tpu; ++cnt[i]; }
       }
     }
@@ -349,9 +354,15 @@ static int report_stamps(ptts_engine* e, hipStream_t st, double step_us) {
     printf("\n");
   }
   printf("[node stamps] per layer: in-kernel %.2f us + boundaries %.2f us = %.2f us (x %d layers = %.1f us of the %.1f us step); a boundary = %.2f us on average\n", tot_in,
-         tot_gap, tot_in + tot_gap, nl, (tot_in + tot_gap) * nl, step_us, tot_gap / 5);
-  printf("[node stamps] stamp legend - qkv_attn / xfold_attn (wave 0): s1 loads issued, s2 row normalised, s3 projection rows done, s4 attention loop done, s5 combine done; "
-         "GEMV nodes: s1 prologue wave done (row prepared), s3 weight wave: loads issued, s4 barrier passed, s5 dot products + reductions done, s6 store issued\n");
+         tot_gap, tot_in + tot_gap, nl, (tot_in + tot_gap) * nl, step_us, tot_gap / NN);
+  if (NN == 5)
+    printf("[node stamps] stamp legend - qkv_attn / xfold_attn (wave 0): s1 loads issued, s2 row normalised, s3 projection rows done, s4 attention loop done, s5 combine done; "
+           "GEMV nodes: s1 prologue wave done (row prepared), s3 weight wave: loads issued, s4 barrier passed, s5 dot products + reductions done, s6 store issued\n");
+  else
+    printf("[node stamps] stamp legend (wave 0 of the first workgroup, us from its entry) - lnproj_fused: s1 rows + first weight fragments requested, s2 its rows normalised, "
+           "s3 every row of the group in LDS, s4 last weight fragment consumed, s5 cross-wave reduction complete; attn_kernel: s1 scalar state read + first K/V batch "
+           "requested, s2 query chunk usable, s3 K/V loop done, s5 output stored; gemm_strip: s1 first weight fragments requested, s3 prologue done, s4 MFMA loop done, "
+           "s5 epilogue stored; xattn_fused: s2 rows normalised, s3 rows in LDS, s4 last q-weight fragment consumed, s5 q rows in LDS, s6 attention done, s7 stored\n");
   return 0;
 }
 #endif
