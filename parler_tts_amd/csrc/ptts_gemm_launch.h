@@ -154,16 +154,16 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
     a.xcd_swz = xcd_swz;
     if constexpr (sizeof(WT) == 2) {  // bf16 engine: the LDS-DMA ring (round 6, ptts_gemm_glds.h); PTTS_GEMM_GLDS=0: round 5's register-staged tiles
       static const bool glds_on = !(getenv("PTTS_GEMM_GLDS") && !atoi(getenv("PTTS_GEMM_GLDS")));
-      if (glds_on && a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && (!a.kv_layers || EPI == EPI_KV) && !a.fold_part && !a.stats_out && !a.W8 && !a.rs_part && !a.nx_out) {
+      if (glds_on && a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && (!a.kv_layers || EPI == EPI_KV) && !a.stats_out && !a.W8 && !a.rs_part && !a.nx_out) {
         const int rg = launch_gemm_glds<EPI>(a, st);
         if (rg != -1) return rg;
       }
     }
-    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part && !a.stats_out && !a.W8) {  // LDS-tiled kernel (round 5)
+    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.stats_out && !a.W8) {  // LDS-tiled kernel (round 5)
       const int rt = launch_gemm_tile<WT, EPI>(a, st);
       if (rt != -1) return rt;
     }
-    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers && !a.fold_part) {  // (pending split-K partials are folded by the strip kernel's EPI_RESID only)  // prefill-sized: register-blocked kernel, no K split
+    if (a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && !a.kv_layers) {  // prefill-sized: register-blocked kernel, no K split
       const int nstrips = a.N / 16;
       const int ns = (nstrips % 4 == 0 && nstrips >= 128) ? 4 : (nstrips % 2 == 0 ? 2 : 0);  // N = 1024: 2 strips per wave keeps > 500 waves in flight
       if (ns) {
@@ -187,46 +187,6 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
   if (mtp > 2) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm: %d activation rows per pass need the PRO_COPY path", rpp);
   if (full) rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, true>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, true>(a, grid, block, sh, st);
   else rc = mtp == 1 ? launch_gemm_inst<WT, PRO, EPI, 1, false>(a, grid, block, sh, st) : launch_gemm_inst<WT, PRO, EPI, 2, false>(a, grid, block, sh, st);
-  PTTS_TRY(rc);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
-  return PTTS_OK;
-}
-
-// fc2 at 8 < batch <= 32 (decode): 64 strips x 128 KB of weights on 64 CUs is bound by what ONE CU can pull (~50 GB/s:
-// 12.8 us for 8 MB). Split K over blockIdx.y -> 256 workgroups x 32 KB; the partial products go to part[split][M][N] and
-// the next LayerNorm prep kernel adds them (and the residual) in a fixed order: deterministic, no atomics.
-constexpr int FC2_KSPLIT = 4;
-template <typename WT>
-bool splitk_ok(int M, int N, int K, bool fo) {
-  const int nfrag = K / Elem<WT>::KT;
-  return M > 8 && M <= (fo ? 256 : 32) && N % 16 == 0 && nfrag % (FC2_KSPLIT * 16) == 0;
-}
-template <typename WT>
-int launch_gemm_splitk(GemmArgs a, hipStream_t st) {  // PRO_COPY, EPI_STORE of partials
-  const int per_split = a.K / Elem<WT>::KT / FC2_KSPLIT;
-  int W = 0;
-  for (int w = 8; w >= 2; --w)
-    if (per_split % (8 * w) == 0) { W = w; break; }
-  if (!W) return ptts_fail(PTTS_E_INVALID, "split-K gemm K=%d", a.K);
-  a.ksplit = per_split; a.frags_per_wave = per_split / W; a.invK = 1.0f / (float)a.K;
-  a.out_split_stride = (long long)a.M * a.out_ld;
-  const bool ms = a.M > msplit_rows(a.M, a.N, a.decode != 0) && a.x_fo;  // fragment-order activations only (above 32 rows splitk_ok() guarantees them)
-  a.rows_per_pass = ms ? msplit_rows(a.M, a.N, a.decode != 0) : a.M;     // passes of msplit_rows() rows over blockIdx.z
-  a.m_split = ms ? 1 : 0;
-  const int mtp = a.rows_per_pass > 32 ? 4 : (a.rows_per_pass > 16 ? 2 : 1);
-  const dim3 grid(a.N / 16, FC2_KSPLIT, (a.M + a.rows_per_pass - 1) / a.rows_per_pass), block(W * 64);
-  const size_t sh = (size_t)W * mtp * 1024;
-  if constexpr (sizeof(WT) == 2) {
-    if (a.W8) {
-      const int r8 = ptts_strip_w8_launch(PRO_COPY, EPI_STORE, mtp, a, grid, block, sh, st);
-      if (r8 == 0) return PTTS_OK;
-      if (r8 != -1) return PTTS_E_HIP;
-    }
-  }
-  int rc = mtp == 1 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 1, true>(a, grid, block, sh, st)
-           : (mtp == 2 ? launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 2, true>(a, grid, block, sh, st)
-                       : launch_gemm_inst<WT, PRO_COPY, EPI_STORE, 4, true>(a, grid, block, sh, st));
   PTTS_TRY(rc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));

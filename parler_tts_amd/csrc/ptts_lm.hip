@@ -84,7 +84,6 @@ struct ptts_engine {
   long long* prefix = nullptr;         // voice-prompt codes [max_batch*K][max_ctx], valid for the next prefill when pending_T > 0
   int pending_T = 0;
   int prefill_T = 0;                   // voice-prompt columns folded into the current prefill pass (batched multi-column prefill)
-  float* hpart = nullptr;              // split-K partials of fc2 at 8 < batch <= 32: [FC2_KSPLIT][max_batch][H]
   float* lnstat = nullptr;             // strip statistics of the residual rows (EPI_RESID -> PRO_LNS), [max_batch][H/16][2]
   bool use_lns = true;                 // 8 < batch <= 32 decode: LayerNorm fused into the consumer GEMM (no rows_prep node)
   bool use_fo = true;                  // batch > 8 decode: engine-dtype activations in MFMA B-fragment order (PTTS_NO_FO=1: row-major, for A/B)
@@ -159,7 +158,6 @@ template <typename WT, int EPI>
 int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st, int g) {
   constexpr int KT = Elem<WT>::KT;
   const int H = p.K;
-  if (g == 16 && p.part) return ptts_fail(PTTS_E_UNSUPPORTED, "lnproj: the 16-row instance does not fold split-K partials");
   p.invK = 1.0f / (float)H;
   const int mg = p.M < g ? p.M : g;
   const size_t sh = (size_t)mg * (H * sizeof(WT) + 16) + 8 * 1024;
@@ -393,7 +391,6 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     if (err != hipSuccess) return ptts_fail(PTTS_E_HIP, "forward launch failed: %s", hipGetErrorString(err));
     return PTTS_OK;
   }
-  bool fc2_pending = false;
   // KV splits of the self-attention: the engine's split factor at decode (long context, few rows); ONE at prefill - the context is the
   // prompt (tens of positions) and there is one workgroup per (head, position) anyway: splitting 4 ways + a combine kernel cost
   // 15 + 9 us per layer on the time-to-first-token path against ~7 us unsplit (profiles/r03_prefill_kernels.txt)
@@ -417,7 +414,6 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // prefill attention on the tiled kernel (8 query rows per workgroup share the K / V tile; PTTS_PREFILL_ATTN=0: one workgroup per query row, attn_kernel)
   const int prefill_attn_mode = getenv("PTTS_PREFILL_ATTN") ? atoi(getenv("PTTS_PREFILL_ATTN")) : 3;  // 0: one workgroup per query row, 1: tiled VALU kernel, 2: f32-MFMA kernel, 3: by batch
   const bool prefill_attn = prefill_attn_mode != 0;
-  bool resid_fold = false;  // fc2's split-K partials still to be added to the residual rows (by the next EPI_RESID GEMM)
   // prefill rows on the fused LN1 + QKV node, sinusoidal positions, engine-dtype cache: the node's epilogue writes the cache rows itself (no
   // kv_append node: 24 launches of ~4 us + their boundaries off the time-to-first-token path; PTTS_KV_IN_QKV=0: the separate node)
   static const bool kv_in_qkv_on = !(getenv("PTTS_KV_IN_QKV") && !atoi(getenv("PTTS_KV_IN_QKV")));
@@ -429,18 +425,16 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
 #endif
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->L[l];
-    if (lnproj_ok) {  // LN1 (+ fold of the previous fc2's partials) + fused QKV projection in one node
+    if (lnproj_ok) {  // LN1 + fused QKV projection in one node
       LnProjArgs p = {};
       PTTS_DBG_BIG(p, l, 0);
       p.W = w.qkv; p.x = e->h; p.x_ld = H; p.gamma = w.ln1_g; p.beta = w.ln1_b; p.K = H; p.out = e->qkv; p.out_ld = QKV; p.M = M; p.N = QKV;
-      if (fc2_pending) { p.part = e->hpart; p.S = FC2_KSPLIT; fc2_pending = false; resid_fold = true; }
       if (kv_in_qkv) { p.kcache = w.k_self; p.vcache = w.v_self; p.kv_Q = Q; p.kv_cap = c.max_ctx; p.kv_heads = nkv; p.kv_H = H; }
       PTTS_TRY((launch_lnproj<WT, EPI_STORE>(e, p, st, lnproj_g)));
     } else {  // LN1 + fused QKV projection
       GemmArgs g = {}; g.decode = dec;
       g.W = w.qkv; g.W8 = w.qkv_p8; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
       g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H; g.x_fo = fo;
-      if (fc2_pending) { g.part = e->hpart; g.S = FC2_KSPLIT; fc2_pending = false; }  // folded by the prep kernel (M > 8)
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
     if (prefill && !kv_in_qkv) {
@@ -475,7 +469,6 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       GemmArgs g = {}; g.decode = dec;
       g.W = w.o; g.W8 = w.o_p8; g.wscale = w.o_sc; g.part = e->part; g.stats = e->stats; g.S = S_used; g.nheads = nh;
       g.out = e->h; g.out_ld = H; g.M = M; g.N = H; g.K = H; g.x_fo = fo;
-      if (resid_fold) { g.fold_part = e->hpart; g.fold_S = FC2_KSPLIT; resid_fold = false; }  // the LN1 node normalised h + partials without writing it back
       if (lns) g.stats_out = e->lnstat;  // strip statistics of the new residual rows for LN2 (PRO_LNS)
       PTTS_DBG_BIG(g, l, 2);
       if (S_used == 1) {
@@ -565,13 +558,10 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
         PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_GELU_WT>(e, g, st)));
         g2.x = reinterpret_cast<const float*>(e->xw2); g2.x_fo = fo;
         PTTS_DBG_BIG(g2, l, 6);
-        if (!prefill && l + 1 < c.num_layers && splitk_ok<WT>(M, H, F, fo != 0) && !(lnproj_ok && lnproj_g == 16)) {  // (the 16-row LN1 node does not fold partials: fc2 runs un-split beside it)
-          g2.out = e->hpart;  // h += sum of the partials happens in the next layer's LN1 prep kernel
-          PTTS_TRY((launch_gemm_splitk<WT>(g2, st)));
-          fc2_pending = true;
-        } else {
-          PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g2, st)));
-        }
+        // fc2 runs un-split at every batch size (round 6, profiles/r06_experiments.txt calls 15-16: the split-K partials of round 2 cost the next LN1 node
+        // +1.0 us and the out_proj epilogue +1.2 us per layer - un-split: -2 % at 32, -3.3 % at 40, -7 % at Large-v1 x 32, equal at 12..16; only the
+        // e4m3-weight Mini engine loses 1.4-3 %; the split path and its folds are gone)
+        PTTS_TRY((launch_gemm<WT, PRO_COPY, EPI_RESID>(g2, st)));
       } else {
         g.out = e->ffn;
         PTTS_TRY((launch_gemm<WT, PRO_LN, EPI_GELU>(g, st)));
@@ -874,7 +864,6 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   A(e->alloc_bytes(&e->xw, (rows + 16) * H * es));  // + 16 rows: fragment order addresses whole 16-row tiles
   A(e->alloc_bytes(&e->xw2, std::max((rows + 16) * F, enc_rows * (size_t)H) * es));
   e->use_fo = !(getenv("PTTS_NO_FO") && atoi(getenv("PTTS_NO_FO")));
-  A(e->alloc(&e->hpart, (size_t)FC2_KSPLIT * c.max_batch * H));
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
   e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
   if (const char* ev = getenv("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));

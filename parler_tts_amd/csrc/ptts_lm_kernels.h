@@ -107,8 +107,6 @@ struct GemmArgs {
   float invK;          // 1 / K
   const float* lnstat; // PRO_LNS: [M][K/16][2] = (strip mean, strip M2) of x, written by the producer GEMM
   float* stats_out;    // EPI_RESID: [M][N/16][2] strip statistics of the updated residual rows, or null
-  int ksplit;          // split-K over blockIdx.y (PRO_COPY only): weight fragments per split, 0 = off
-  long long out_split_stride;  // elements between the partial outputs of two splits
   const void* W8;      // e4m3 strips [N/16][K/64 fragment pairs][64 lanes][16 B] (weights_fp8 engines), or null: bf16 / fp32 strips in W
   const float* wscale; // W8: one power-of-two scale per weight row [N], applied to the fp32 accumulators
   const KvLayer* kv_layers;  // PRO_COPY + EPI_KV: blockIdx.z selects the layer (W, kcache, vcache from this table): the description's K/V
@@ -130,8 +128,6 @@ struct GemmArgs {
   float* ss_out;         // producer: [M][N/16] sum of squares of the updated residual row over this strip's 16 columns
   float rms_eps;       // PRO_RMS / rs_part: T5Config.layer_norm_epsilon
   const int* row_keep; // PRO_RMS: [M] int32 or null; rows with 0 are written as zeros (masked description positions, modeling_parler_tts.py:3093-3097)
-  const float* fold_part;  // EPI_RESID: pending split-K partials [fold_S][M][N] of the previous fc2 that no prep kernel has added to the residual rows
-  int fold_S;              // (lnproj_fused_kernel normalised h + sum_s part[s] without writing it back): out = (out + sum_s part[s]) + acc, same order
 #ifdef PTTS_TIMING
   long long* dbg;      // phase timestamps (s_memtime) of workgroup 0 / wave 0
 #endif
@@ -559,12 +555,10 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
   const int nfrag = a.K / KT;
   const int per = FULL ? a.frags_per_wave : (nfrag + W - 1) / W;
   const int t0 = wave * per, t1 = FULL ? t0 + per : min(nfrag, t0 + per);
-  const int kb = PRO == PRO_COPY ? a.ksplit * (int)blockIdx.y : 0;  // split-K: this workgroup's first weight fragment
-  // W8: one uint4 per fragment PAIR (t0, kb and every 8-fragment group are even)
-  const uint4* Wp = W8 ? reinterpret_cast<const uint4*>(a.W8) + ((size_t)strip * (nfrag >> 1) + (kb >> 1)) * 64 + lane
-                       : reinterpret_cast<const uint4*>(a.W) + ((size_t)strip * nfrag + kb) * 64 + lane;
+  // W8: one uint4 per fragment PAIR (t0 and every 8-fragment group are even)
+  const uint4* Wp = W8 ? reinterpret_cast<const uint4*>(a.W8) + (size_t)strip * (nfrag >> 1) * 64 + lane
+                       : reinterpret_cast<const uint4*>(a.W) + (size_t)strip * nfrag * 64 + lane;
   const int q = lane >> 4, j = lane & 15;
-  if (PRO == PRO_COPY) a.out += (size_t)blockIdx.y * a.out_split_stride;
 
   const int m_first = (PRO == PRO_COPY && a.m_split) ? (int)blockIdx.z * a.rows_per_pass : 0;
   const int m_last = (PRO == PRO_COPY && a.m_split) ? min(a.M, m_first + a.rows_per_pass) : a.M;
@@ -633,10 +627,10 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     for (int mt = 0; mt < MTP; ++mt) {
       const int rloc = min(mt * 16 + j, nrows - 1);
       if (xfo)  // rows past M inside the last tile hold stale data: their output columns are never stored
-        brow[mt] = reinterpret_cast<const char*>(a.x) + (((size_t)((m0 >> 4) + min(mt, (nrows - 1) >> 4)) * nfrag + kb) * 64 + lane) * 16;
+        brow[mt] = reinterpret_cast<const char*>(a.x) + (((size_t)((m0 >> 4) + min(mt, (nrows - 1) >> 4)) * nfrag) * 64 + lane) * 16;
       else
         brow[mt] = PRO == PRO_COPY
-                       ? reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)((m0 + rloc) * a.x_row_mul + a.x_row_off) * a.x_ld + (size_t)kb * KT) + (size_t)q * 16
+                       ? reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.x) + (size_t)((m0 + rloc) * a.x_row_mul + a.x_row_off) * a.x_ld) + (size_t)q * 16
                        : s_x + (size_t)rloc * row_bytes + (size_t)q * 16;
     }
     const size_t bstep = xfo ? (size_t)1024 : (size_t)(KT * sizeof(WT));  // bytes between consecutive fragments of one row tile
@@ -713,12 +707,6 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
         } else if (EPI == EPI_RESID) {
           float4* p = reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n);
           float4 o = mt == wave ? resid_pre : *p;
-          if (a.fold_part) {
-            for (int sp = 0; sp < a.fold_S; ++sp) {
-              const float4 u = *reinterpret_cast<const float4*>(a.fold_part + ((size_t)sp * a.M + m) * a.N + n);
-              o.x += u.x; o.y += u.y; o.z += u.z; o.w += u.w;
-            }
-          }
           o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
           *p = o;
           r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = o.w;  // the updated residual values, for the strip statistics below
@@ -1039,11 +1027,11 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
 // (one wave per row) into an engine-dtype [M][K] buffer that the GEMM then stages with plain 16-byte copies
 // (PRO_COPY). At M <= 8 the fused prologues win (one graph node less: 1.58 us + a latency chain).
 // ------------------------------------------------------------------------------------------------------
-// one pass, row held in registers (K == NF4 * 256): every load of the row (+ pending split-K partials + gamma/beta) is in
+// one pass, row held in registers (K == NF4 * 256): every load of the row (+ gamma/beta) is in
 // flight at once - one dependent round trip instead of the three of the generic two-pass loop below
 template <typename WT, int NF4>
 __device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* dst, int lane) {
-  float* xr = const_cast<float*>(a.x) + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
+  const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
   float4 v[NF4], g[NF4], bt[NF4];
 #pragma unroll
   for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
@@ -1051,25 +1039,6 @@ __device__ __forceinline__ void prep_ln_row_regs(const GemmArgs& a, int m, WT* d
   for (int i = 0; i < NF4; ++i) {
     g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
     bt[i] = *reinterpret_cast<const float4*>(a.beta + (lane + 64 * i) * 4);
-  }
-  if (a.part) {  // pending split-K partials of the previous fc2: h += sum_s part[s] in fixed order, written back
-    constexpr int SB = 4;  // partial rows in flight per batch (the rolled loop was one cold round trip per split)
-    for (int s0 = 0; s0 < a.S; s0 += SB) {
-      float4 u[SB][NF4];
-#pragma unroll
-      for (int sp = 0; sp < SB; ++sp)
-#pragma unroll
-        for (int i = 0; i < NF4; ++i)
-          u[sp][i] = *reinterpret_cast<const float4*>(a.part + ((size_t)min(s0 + sp, a.S - 1) * a.M + m) * a.K + (lane + 64 * i) * 4);
-#pragma unroll
-      for (int sp = 0; sp < SB; ++sp)
-        if (s0 + sp < a.S) {
-#pragma unroll
-          for (int i = 0; i < NF4; ++i) { v[i].x += u[sp][i].x; v[i].y += u[sp][i].y; v[i].z += u[sp][i].z; v[i].w += u[sp][i].w; }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NF4; ++i) *reinterpret_cast<float4*>(xr + (lane + 64 * i) * 4) = v[i];
   }
   const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
   float s1 = 0.f, s2 = 0.f;
@@ -1141,17 +1110,6 @@ __global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restri
   if (PRO == PRO_LN && a.K == 1536) { prep_ln_row_regs<WT, 6>(a, m, dst, lane); return; }  // Large-v1
   if (PRO == PRO_LN) {
     const float* xr = a.x + (size_t)(m * a.x_row_mul + a.x_row_off) * a.x_ld;
-    if (a.part) {  // pending split-K partials of the previous fc2 (+ residual): h += sum_s part[s], in fixed order
-      float* xw = const_cast<float*>(xr);
-      for (int k = lane * 4; k < a.K; k += 256) {
-        float4 t = *reinterpret_cast<const float4*>(xr + k);
-        for (int sp = 0; sp < a.S; ++sp) {
-          const float4 u = *reinterpret_cast<const float4*>(a.part + ((size_t)sp * a.M + m) * a.K + k);
-          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-        }
-        *reinterpret_cast<float4*>(xw + k) = t;  // re-read below by the same lane only
-      }
-    }
     float s1 = 0.f, s2 = 0.f;
     const float c = xr[0];
     for (int k = lane * 4; k < a.K; k += 256) {
@@ -1992,7 +1950,7 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// lnproj_fused_kernel (decode, batch > 8): LayerNorm [+ fold of the previous fc2's split-K partials] + a 64-row block of a projection for a
+// lnproj_fused_kernel (decode, batch > 8): LayerNorm + a 64-row block of a projection for a
 // GROUP of G <= 8 utterances per workgroup - the front half of xattn_fused_kernel as a node of its own, for LN1 + QKV (:1020-1021, :848-850) and
 // LN3 + fc1 + GELU (:1059-1060). The strip GEMMs tile N only (16 weight rows x ALL M rows per workgroup): a LayerNorm prologue there would
 // normalise every row in every one of the N / 16 workgroups (88 % of the GEMM at M = 32, round 1), so LN1 / LN3 ran as a rows_prep node in
@@ -2002,15 +1960,11 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
 // (same fold order, same one-pass shifted statistics), so the normalised rows are bit-identical to the two-node path.
 // 8 waves = 4 weight strips x 2 K halves; wave w < nb normalises row b0 + w first.
 // EPI_STORE: fp32 [M][out_ld] (QKV); EPI_GELU_WT: gelu_erf in the engine dtype, row-major or MFMA B-fragment order (fc1 -> fc2).
-// The folded residual rows are NOT written back here (N / 64 workgroups read them concurrently): the next EPI_RESID GEMM on the stream
-// (out_proj) adds the same partials in the same order (GemmArgs::fold_part).
 // ------------------------------------------------------------------------------------------------------
 struct LnProjArgs {
   const void* W;        // packed strips [N/16][K/KT][64][16 B]
   const float* x;       // residual stream h [M][x_ld]
   int x_ld;
-  const float* part;    // pending split-K partials [S][M][K] fp32 of the previous fc2, or null
-  int S;
   const float* gamma;
   const float* beta;
   int K;                // hidden size (= NF4 * 256)
@@ -2029,8 +1983,7 @@ struct LnProjArgs {
 };
 
 // G = 16 (round 5): two rows per wave (rows w and w + 8, both in flight), all 16 columns of the MFMA tile in use - half the weight re-reads of
-// G = 8 per utterance (the L2 traffic of the strip GEMM it replaces at 64..128 utterances). No split-K fold in that instance (a.part must be
-// null: the host runs fc2 un-split beside it).
+// G = 8 per utterance (the L2 traffic of the strip GEMM it replaces at 64..128 utterances).
 template <typename WT, int UW, int NF4, int G, int EPI>
 __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
   constexpr int KT = Elem<WT>::KT, NWV = 8;
@@ -2049,7 +2002,7 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
   const int q4 = lane >> 4, j = lane & 15;
   uint4 afr[UW];
   PTTS_WSTAMP(a, 0);
-  if constexpr (G > NWV) {  // two rows per wave, no pending partials
+  if constexpr (G > NWV) {  // two rows per wave
     if (wave < nb) {
       const bool two = wave + NWV < nb;
       const float* xr0 = a.x + (size_t)(b0 + wave) * a.x_ld;
@@ -2097,7 +2050,7 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
   } else
-  // ---- t = 0: the residual row (+ its pending partials, + gamma / beta) of this wave first, then - behind a rendezvous, so that no wave's row
+  // ---- t = 0: the residual row (+ gamma / beta) of this wave first, then - behind a rendezvous, so that no wave's row
   // queues behind another wave's weights - the first UW weight fragments
   if (wave < nb) {
     const int m = b0 + wave;
@@ -2105,14 +2058,6 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
     float4 v[NF4], g[NF4], bt[NF4];
 #pragma unroll
     for (int i = 0; i < NF4; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
-    float4 u[4][NF4];  // S <= 4 partial rows (FC2_KSPLIT), all in flight with the row
-    if (a.part) {
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp)
-#pragma unroll
-        for (int i = 0; i < NF4; ++i)
-          u[sp][i] = *reinterpret_cast<const float4*>(a.part + ((size_t)min(sp, a.S - 1) * a.M + m) * a.K + (lane + 64 * i) * 4);
-    }
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
       g[i] = *reinterpret_cast<const float4*>(a.gamma + (lane + 64 * i) * 4);
@@ -2123,15 +2068,7 @@ __global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
 #pragma unroll
     for (int uu = 0; uu < UW; ++uu) afr[uu] = ld_nt16(Wp + (size_t)(t0 + uu) * 64);
     __builtin_amdgcn_sched_barrier(0);
-    PTTS_WSTAMP(a, 1);  // row (+ partials) + gamma / beta + the first weight fragments requested
-    if (a.part) {  // h + sum_s part[s] in fixed order: prep_ln_row_regs' arithmetic
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp)
-        if (sp < a.S) {
-#pragma unroll
-          for (int i = 0; i < NF4; ++i) { v[i].x += u[sp][i].x; v[i].y += u[sp][i].y; v[i].z += u[sp][i].z; v[i].w += u[sp][i].w; }
-        }
-    }
+    PTTS_WSTAMP(a, 1);  // row + gamma / beta + the first weight fragments requested
     const float c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[0].x)));
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll

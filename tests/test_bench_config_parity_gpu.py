@@ -366,8 +366,8 @@ def test_large_v1_full_depth_bf16_and_fp8_weights():
 @pytest.mark.parametrize("bsz", [33, 40, 64, 65, 128, 129, 256])
 def test_decode_batch_above_32(bsz):
     """More than 32 utterances per GPU (bench.py's `bs128` object; the whole-node throughput lever): prepared rows in fragment order,
-    64-row passes over blockIdx.z (ragged last pass at 33 / 40 / 65 / 129, four passes at 256), split-K fc2 folded by the next
-    LayerNorm prep, the fused cross block in up to 32 groups of 8 utterances. Mini width, 2 layers, ragged masks, 3 teacher-forced
+    64-row passes over blockIdx.z (ragged last pass at 33 / 40 / 65 / 129, four passes at 256), fc2 un-split with the residual in its own
+    epilogue (round 6), the fused cross block in up to 32 groups of 8 utterances. Mini width, 2 layers, ragged masks, 3 teacher-forced
     steps vs the oracle at the default tolerances, fp32 and bf16."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_lm_gpu import _teacher_forced_vs_oracle

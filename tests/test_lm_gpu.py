@@ -189,7 +189,7 @@ def test_prefill_block_gemm_path(dtype):
 @pytest.mark.parametrize("bsz", [3, 12])
 def test_grouped_query_attention_free_running(bsz):
     """Grouped-query attention (repeat_kv modeling:280-289; K/V projections with fewer heads :449-452): 4 query heads on 2 self /
-    1 cross K/V heads, RoPE, ragged masks. bsz 3: fused cross block + fused-prologue GEMMs; bsz 12: prep / split-K / plain
+    1 cross K/V heads, RoPE, ragged masks. bsz 3: fused cross block + fused-prologue GEMMs; bsz 12: prep / plain
     cross-attention path and the block-GEMM prefill. First-step logits and free-running greedy ids vs the oracle (itself pinned
     against the reference's GQA forward, tests/golden/decoder_gqa.npz)."""
     spec, sd, enc, enc_mask, prompt, prompt_mask, gp = C.gqa_case(bsz)
@@ -609,7 +609,7 @@ def test_mfma_strips_with_fused_prologues_on_a_wide_engine(bsz, fp8):
 @pytest.mark.parametrize("bsz", [12, 32])
 def test_mini_width_batch_12_and_32_producer_statistics_layernorm(bsz):
     """8 < batch <= 32 at Mini width: LN2 / LN3 take their row statistics from the producing out_proj GEMM (EPI_RESID strip
-    partials -> PRO_LNS prologue, no rows_prep node), LN1 folds the split-K fc2 partials in the prep kernel. Ragged masks."""
+    partials -> PRO_LNS prologue, no rows_prep node), fc2 un-split with the residual in its epilogue (round 6). Ragged masks."""
     spec = DO.DecoderSpec(num_hidden_layers=2, max_position_embeddings=512)
     sd = DO.make_decoder_weights(spec, seed=47)
     for dtype, prec, tol in ((torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)):
@@ -655,8 +655,8 @@ def test_fused_cross_block_with_fewer_utterances_per_workgroup(g, bsz, N, monkey
 @pytest.mark.parametrize("bsz", [9, 13, 32, 44, 128])
 def test_layernorm_plus_projection_as_one_node(mode, g, bsz, monkeypatch):
     """PTTS_LNPROJ (read at engine creation): above 8 utterances LN1 + QKV (mode >= 1) and LN3 + fc1 + GELU (mode 2: above 32 utterances, mode 3: always)
-    run as ONE node tiled over 64 weight rows x g utterances (lnproj_fused_kernel) instead of rows_prep + strip GEMM; the fc2 split-K partials of the
-    previous layer are folded by the LN1 node and by the following out_proj's residual epilogue. 3 layers (two fold hand-overs), ragged groups
+    run as ONE node tiled over 64 weight rows x g utterances (lnproj_fused_kernel) instead of rows_prep + strip GEMM (fc2 runs un-split with the
+    residual in its own epilogue since round 6: no partial rows are folded by these nodes any more). 3 layers, ragged groups
     (9, 13, 44), ragged masks; Mini widths in both dtypes, Large widths in bf16."""
     monkeypatch.setenv("PTTS_LNPROJ", str(mode))
     monkeypatch.setenv("PTTS_LNPROJ_G", str(g))

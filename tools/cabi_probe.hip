@@ -319,7 +319,7 @@ static int report_stamps(ptts_engine* e, hipStream_t st, double step_us, int B) 
   auto S = [&](int l, int k, int slot, int idx) { return h[(((size_t)l * NN + k) * 3 + slot) * 16 + idx]; };
   const char* names5[5] = {"qkv_attn (LN1 + q/k/v rows + self-attention + append)", "combine + out_proj + residual", "xfold_attn (LN2 + M rows + softmax + U columns)",
                            "partial rows + LN3 + fc1 + GELU", "fc2 + residual"};
-  const char* names7[7] = {"lnproj_fused (LN1 [+ fc2 partials] + q|k|v)", "attn_kernel (self-attention + append)", "gemm_strip (out_proj + residual)",
+  const char* names7[7] = {"lnproj_fused (LN1 + q|k|v)", "attn_kernel (self-attention + append)", "gemm_strip (out_proj + residual)",
                            "xattn_fused (LN2 + cross q + cross-attention)", "gemm_strip (cross out_proj + residual)", "lnproj_fused (LN3 + fc1 + GELU)",
                            "gemm_strip (fc2: split-K partials or + residual)"};
   const char** names = NN == 7 ? names7 : names5;
