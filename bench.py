@@ -342,13 +342,14 @@ def measure_ttft_breakdown(model, bs: int, device, reps: int = 20) -> dict:
             stages["first_tail_ms"].append(tail)
             stages["wall_ms"].append(wall)
     p50 = {k: sorted(v)[len(v) // 2] for k, v in stages.items()}
-    native = model.__dict__.get("_t5_engine") is not None
-    L = model.config.text_encoder.num_layers
+    t5e = model.__dict__.get("_t5_engine")
+    native = t5e is not None
+    t5_nodes = int(t5e.graph_nodes()) if (native and hasattr(t5e, "graph_nodes")) else 0  # the captured graph's own node count (ptts_t5_debug_graph_nodes)
     out = {k: round(p50[k], 3) for k in ("t5_ms", "prompt_embed_ms", "prefill_ms", "first_tail_ms")}
     out.update({"wall_p50_ms": round(p50["wall_ms"], 3), "bs": bs, "reps": reps,
                 "host_and_gaps_ms": round(p50["wall_ms"] - sum(p50[k] for k in ("t5_ms", "prompt_embed_ms", "prefill_ms", "first_tail_ms")), 3),
                 "t5_encoder": "native HIP (ptts_t5_encode)" if native else "stock transformers module (torch HIP graph replay)",
-                "launches": {"t5": f"2 copies + 1 hipGraph of {1 + 7 * L} kernel nodes + 1 final-norm launch" if native else "~50 per block (ATen / Tensile)",
+                "launches": {"t5": f"2 copies + 1 hipGraph of {t5_nodes} kernel nodes (counted at capture) + 1 final-norm launch" if native else "~50 per block (ATen / Tensile)",
                              "prompt_embed": 2, "first_tail": 1}})
     if native:  # before / after: the stock module on the same description
         try:

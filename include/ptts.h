@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTTS_ABI_VERSION 7
+#define PTTS_ABI_VERSION 8
 
 enum { PTTS_F32 = 0, PTTS_BF16 = 1 };
 
@@ -263,6 +263,9 @@ int ptts_t5_weights_ready(ptts_t5* e);
 int ptts_t5_encode(ptts_t5* e, const int64_t* ids_dev, const int32_t* mask_dev, int32_t B, int32_t N, float* out_dev, void* stream);
 /* Host-only (no device): T5Attention._relative_position_bucket for the bidirectional encoder, the function the bias table is built from. */
 int32_t ptts_t5_relative_bucket(int32_t relative_position, int32_t num_buckets, int32_t max_distance);
+/* (ABI v8) Kernel nodes of the encoder graph captured last by ptts_t5_encode (0 before the first capture, or with graphs off): what bench.py's
+ * `ttft.launches` reports instead of a formula. */
+int ptts_t5_debug_graph_nodes(ptts_t5* e, int32_t* nodes);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ class PttsDacConfig(C.Structure):
     ]
 
 
-ABI_VERSION = 7  # PTTS_ABI_VERSION in include/ptts.h
+ABI_VERSION = 8  # PTTS_ABI_VERSION in include/ptts.h
 
 # every symbol include/ptts.h declares: name -> (restype, argtypes)
 _VP, _I32, _I64P = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
@@ -93,6 +93,7 @@ SYMBOLS = {
     "ptts_t5_weights_ready": (C.c_int, [_VP]),
     "ptts_t5_encode": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _VP]),
     "ptts_t5_relative_bucket": (C.c_int32, [_I32, _I32, _I32]),
+    "ptts_t5_debug_graph_nodes": (C.c_int, [_VP, C.POINTER(_I32)]),
     "ptts_dac_debug_decode_upto": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_I32)]),
 }
 

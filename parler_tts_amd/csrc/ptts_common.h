@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <atomic>
 
@@ -57,6 +58,20 @@ struct PttsPerDeviceOnce {
   bool need(int dev) const { return !((mask.load(std::memory_order_acquire) >> dev) & 1ull); }
   void done(int dev) { mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
+
+// ---- environment switches ------------------------------------------------------------------------------------------------------
+// The product library reads FIFTEEN PTTS_* variables with getenv: each selects the un-fused / alternative side of a node that a parity test
+// compares with the default path (table in DESIGN.md section 6; tests/test_host_logic.py counts them). Every other switch that rounds 1-6 used
+// for an A/B measurement is a development knob: ptts_dev_env() answers nullptr in the product build, so the library takes the measured default
+// and the compiler folds the other side away; `tools/build_variant.sh <name> -DPTTS_DEV_KNOBS` builds a probe library that reads them.
+inline const char* ptts_dev_env(const char* name) {
+#ifdef PTTS_DEV_KNOBS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // ---- kernel-argument preload (gfx950) ---------------------------------------------------------------------------------------------
 // A wave's first instructions are s_load of its kernel arguments: one scalar round trip before the first global load can be addressed.

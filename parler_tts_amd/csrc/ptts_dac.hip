@@ -44,7 +44,7 @@ struct ConvArgs {
   int stride, Tn;      // input stride of a down-sampling conv (else 1); output frames per phase (Tin unless strided)
   const int* lens;     // ragged decode (ptts_dac_decode_ragged): latent frames per utterance [B] on the device, or null. Utterance b then has
   int len_mul;         // lens[b] * len_mul valid input rows (= output rows per phase): rows beyond read as the zero padding, tiles beyond exit
-  int epi_direct;      // conv_lds_kernel A/B (PTTS_DAC_CONV_EPI_DIRECT=1): the round-3 epilogue (a lane stores 4 channels of one frame)
+  int epi_direct;      // conv_lds_kernel A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane stores 4 channels of one frame)
 };
 
 // valid input rows of utterance b (buffers keep the full stride a.Tin)
@@ -1349,23 +1349,23 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   // LDS-tiled kernel where it wins (rocprof per layer, profiles/r02_dac_layers.txt): every k7 conv (2x the direct kernel) and the
   // transposed convs into >= 192 channels. The last transposed conv is bound by its epilogue traffic (two writes per element) and runs as fast
   // on the direct kernel's 4-5 waves per SIMD as on this one's 2 (round 2 said the same of the k1 convs; see lds_k1 below).
-  static const bool no_lds = getenv("PTTS_DAC_NO_LDS") != nullptr;
-  static const int lds_min_c = getenv("PTTS_DAC_LDS_MIN_C") ? atoi(getenv("PTTS_DAC_LDS_MIN_C")) : 96;
-  static const bool lds_small_taps = getenv("PTTS_DAC_LDS_K1") != nullptr;
+  static const bool no_lds = ptts_dev_env("PTTS_DAC_NO_LDS") != nullptr;
+  static const int lds_min_c = ptts_dev_env("PTTS_DAC_LDS_MIN_C") ? atoi(ptts_dev_env("PTTS_DAC_LDS_MIN_C")) : 96;
+  static const bool lds_small_taps = ptts_dev_env("PTTS_DAC_LDS_K1") != nullptr;
   // k1 convs (the un-fused units of the C = 768 block): on the LDS-tiled kernel from 32 K rows per launch (round 5) - with the whole-row epilogue
   // through LDS it beats the direct kernel at batch 32 (63.1 -> 61.3 ms per decode) and loses 1 % on a single utterance's 6880 rows (2.69 vs 2.71 ms;
   // profiles/r05_experiments.txt calls 13 / 15). PTTS_DAC_NO_LDS_K1=1: always direct; PTTS_DAC_LDS_K1=1: every k1 / transposed conv on the LDS kernel.
-  static const bool lds_k1_on = !(getenv("PTTS_DAC_NO_LDS_K1") && atoi(getenv("PTTS_DAC_NO_LDS_K1")));
+  static const bool lds_k1_on = !(ptts_dev_env("PTTS_DAC_NO_LDS_K1") && atoi(ptts_dev_env("PTTS_DAC_NO_LDS_K1")));
   const bool lds_k1 = lds_k1_on && (long long)B * Tin >= 32768;
   // the last transposed conv (-> 96 channels): on the LDS-tiled kernel since round 5. Round 4 measured it equal to the direct kernel (5.19 ms per
   // batch-32 launch) - with the 96-channel staging instance, which needs 324 VGPRs and ran one wave per SIMD; with 32-channel staging chunks
   // (conv_lds_kernel<3, 2, 1, 2>, 228 VGPRs, two waves per SIMD) the batch-32 decode drops 61.3 -> 59.3 ms, 860 frames 2.71 -> 2.67 ms
   // (profiles/r05_experiments.txt call 15). PTTS_DAC_LAST_UP_LDS=0: the direct kernel.
-  static const bool last_up_lds = !(getenv("PTTS_DAC_LAST_UP_LDS") && !atoi(getenv("PTTS_DAC_LAST_UP_LDS")));
+  static const bool last_up_lds = !(ptts_dev_env("PTTS_DAC_LAST_UP_LDS") && !atoi(ptts_dev_env("PTTS_DAC_LAST_UP_LDS")));
   const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c
                                   : (lds_small_taps || (a.transposed && L.Cout >= (last_up_lds ? 96 : 192)) || (lds_k1 && !a.transposed && a.ntaps == 1));
   {
-    const char* ced = getenv("PTTS_DAC_CONV_EPI_DIRECT");  // read per call (A/B inside one process)
+    const char* ced = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process): the same switch as the fused residual unit's epilogue
     a.epi_direct = (ced && atoi(ced)) ? 1 : 0;
   }
   if (L.bf16 && !no_lds && lds_ok && a.stride == 1 && nstrips % 6 == 0) {
@@ -1375,7 +1375,7 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
     // single utterance ran 56-224 workgroups on 256 CUs; the streamer's short windows even fewer): 860 frames 2.34 -> 2.27 ms, a 56-frame window
     // 0.91 -> 0.82 ms; at 432-448 workgroups (two utterances) the smaller tiles LOSE 3.5 % (profiles/r05_experiments.txt call 18), hence the bound.
     // Four-wave instances only; PTTS_DAC_NO_FT4=1: always 128 frames.
-    static const bool ft4_on = !(getenv("PTTS_DAC_NO_FT4") && atoi(getenv("PTTS_DAC_NO_FT4")));
+    static const bool ft4_on = !(ptts_dev_env("PTTS_DAC_NO_FT4") && atoi(ptts_dev_env("PTTS_DAC_NO_FT4")));
     const bool ft4 = ft4_on && nw == 4 && (long long)((a.Tn + 127) / 128) * a.nphase * B * (nstrips / (3 * nw)) < 320;
     const int tfr = ft4 ? 64 : 128;
     const dim3 grid((unsigned)(((a.Tn + tfr - 1) / tfr) * a.nphase * B), (unsigned)(nstrips / (3 * nw)));
@@ -1402,7 +1402,7 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   }
   // waves per workgroup: fewer (finer tiles) when the launch would otherwise put < ~6 workgroups on each CU, so the
   // 256 CUs finish together (324 four-wave workgroups on 256 CUs = 63 % balance; 1296 one-wave ones = 84 %+)
-  static int forced_nw = getenv("PTTS_DAC_WAVES") ? atoi(getenv("PTTS_DAC_WAVES")) : 0;
+  static int forced_nw = ptts_dev_env("PTTS_DAC_WAVES") ? atoi(ptts_dev_env("PTTS_DAC_WAVES")) : 0;
   int nwb = 4;
   {
     const int CS0 = nstrips % 8 == 0 ? 8 : (nstrips % 6 == 0 ? 6 : (nstrips % 4 == 0 ? 4 : (nstrips % 2 == 0 ? 2 : 1)));
@@ -1436,11 +1436,11 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
 // one residual unit (k7 dilated conv -> Snake -> k1 conv -> + skip -> Snake) in one launch; out_act must not be x's buffer
 static bool resunit_fusable(const ConvLayer& c7, const ConvLayer& c1) {
   const char* ev = getenv("PTTS_DAC_NO_FUSE_RES");  // read per call: a test can switch it inside one process
-  const bool on = !(ev && atoi(ev));
+  const int off = ev ? atoi(ev) : 0;  // 1: every unit as two launches; 2: only the C = 384 block's units (round 3's baseline)
+  const bool on = off != 1;
   // the C = 384 block's units too (8 waves, 100 KB of LDS, one workgroup per CU): batch 32 83.3 -> 77.9 ms, 860 frames 3.39 -> 3.28 ms
-  // (profiles/r03_pmc_dac_mfma.txt); PTTS_DAC_NO_FUSE_384=1 keeps them as two launches for A/B
-  const char* e384 = getenv("PTTS_DAC_NO_FUSE_384");
-  const bool fuse384 = !(e384 && atoi(e384));
+  // (profiles/r03_pmc_dac_mfma.txt)
+  const bool fuse384 = off != 2;
   return on && c7.bf16 && c1.bf16 && !c7.transposed && !c1.transposed && c7.stride == 1 && c1.stride == 1 && c7.ksize == 7 && c1.ksize == 1 &&
          c7.Cin == c7.Cout && c1.Cin == c7.Cout && c1.Cout == c7.Cout && (c7.Cout == 192 || c7.Cout == 96 || (c7.Cout == 384 && fuse384)) && 6 * c7.dil <= 54 &&
          c7.alpha && c1.alpha;
@@ -1546,7 +1546,7 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
     }
   }
   const int t_end = emit < 0 ? Tcur : std::min(Tcur, skip + emit);
-  static const bool out_direct = getenv("PTTS_DAC_OUT_DIRECT") && atoi(getenv("PTTS_DAC_OUT_DIRECT"));  // A/B: the per-thread kernel
+  static const bool out_direct = ptts_dev_env("PTTS_DAC_OUT_DIRECT") && atoi(ptts_dev_env("PTTS_DAC_OUT_DIRECT"));  // A/B: the per-thread kernel
   if (d->out_C == OUT_C && !out_direct && B <= 65535) {
     hipLaunchKernelGGL(conv_out_tanh_lds_kernel, dim3((unsigned)((Tcur + OUT_TILE - 1) / OUT_TILE), (unsigned)B), dim3(OUT_TILE), 0, st, (const float*)cur,
                        d->out_w, d->out_b, wave_dev, Tcur, skip, out_ld, t_end, lens, mul);

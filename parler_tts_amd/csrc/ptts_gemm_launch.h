@@ -20,7 +20,7 @@ namespace {
 // `decode` (GemmArgs::decode, set by the caller): the measured policy applies to decode steps; prefill-sized rows keep the 64-row passes
 inline int msplit_rows(int M, int N, bool decode) {
   static const int forced = [] {
-    const char* ev = getenv("PTTS_MSPLIT_ROWS");
+    const char* ev = ptts_dev_env("PTTS_MSPLIT_ROWS");
     const int x = ev ? atoi(ev) : 0;
     return (x == 16 || x == 32 || x == 64) ? x : 0;
   }();
@@ -31,7 +31,7 @@ inline int msplit_rows(int M, int N, bool decode) {
   //   Mini-v1 33 rows 1.89 | 1.57 | 1.63   66 rows 2.16 | 1.95 | 2.16   101 rows 2.34 | 2.13 | 2.31   132 rows 2.75 | 2.69 | 2.73   fp32 33 rows 3.47 | 2.32 | 2.32
   //   Large-v1 33 rows 3.17 | 3.36 | 3.17 (its 288- / 384-strip projections lose on light passes)
   // PTTS_MSPLIT_PREFILL = 0: never, 1: everywhere, 2 (default): by workgroup count
-  static const int prefill_mode = getenv("PTTS_MSPLIT_PREFILL") ? atoi(getenv("PTTS_MSPLIT_PREFILL")) : 2;
+  static const int prefill_mode = ptts_dev_env("PTTS_MSPLIT_PREFILL") ? atoi(ptts_dev_env("PTTS_MSPLIT_PREFILL")) : 2;
   if (!decode) {
     const bool lighter = prefill_mode == 1 || (prefill_mode == 2 && N > 0 && (N / 16) * ((M + 63) / 64) < 256);
     if (!lighter) return M > 32 ? 64 : 32;
@@ -49,12 +49,11 @@ int launch_gemm_inst(GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t 
   static PttsPerDeviceOnce attr_once;  // > 64 KiB of dynamic LDS needs an explicit opt-in, once per instantiation
   const int attr_dev = PttsPerDeviceOnce::device();
   if (attr_once.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(strip_entry<WT, PRO, EPI, MTP, FULL>(), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e));
     attr_once.done(attr_dev);
   }
-  hipLaunchKernelGGL((gemm_strip_kernel<WT, PRO, EPI, MTP, FULL>), grid, block, sh, st, a);
+  launch_strip<WT, PRO, EPI, MTP, FULL>(grid, block, sh, st, a);
   return PTTS_OK;
 }
 
@@ -78,7 +77,7 @@ int launch_gemm_tile_inst(const GemmArgs& a, hipStream_t st) {
 // -1 = shape not served (the caller keeps the register-blocked kernel)
 template <typename WT, int EPI>
 int launch_gemm_tile(const GemmArgs& a, hipStream_t st) {
-  static const int mode = getenv("PTTS_GEMM_TILE") ? atoi(getenv("PTTS_GEMM_TILE")) : 1;  // 0: off (gemm_block_kernel), 1: by workgroup count, 88 / 48 / 84 / 44: force a tile
+  static const int mode = ptts_dev_env("PTTS_GEMM_TILE") ? atoi(ptts_dev_env("PTTS_GEMM_TILE")) : 1;  // 0: off (gemm_block_kernel), 1: by workgroup count, 88 / 48 / 84 / 44: force a tile
   const int nstrips = a.N / 16, nfrag = a.K / Elem<WT>::KT;
   if (!mode || nstrips % 4 || nfrag % 2 || a.K % Elem<WT>::KT) return -1;
   auto wgs = [&](int bns, int bmt) { return (nstrips / bns) * ((a.M + bmt * 16 - 1) / (bmt * 16)); };
@@ -148,12 +147,12 @@ int launch_gemm(GemmArgs a, hipStream_t st) {
     }
   }
   if constexpr (PRO == PRO_COPY) {
-    static const int block_min_m = getenv("PTTS_BLOCK_MIN_M") ? atoi(getenv("PTTS_BLOCK_MIN_M")) : 256;
+    static const int block_min_m = ptts_dev_env("PTTS_BLOCK_MIN_M") ? atoi(ptts_dev_env("PTTS_BLOCK_MIN_M")) : 256;
     // measured (tools/ttft_bs32_probe.py, Mini-v1 prefill ms, strip / block): M=132 5.7 / 8.2, 264 8.3 / 8.1, 528 13.5 / 8.7, 1056 25.7 / 11.2
-    static const int xcd_swz = !(getenv("PTTS_GEMM_XCD") && !atoi(getenv("PTTS_GEMM_XCD")));
+    static const int xcd_swz = !(ptts_dev_env("PTTS_GEMM_XCD") && !atoi(ptts_dev_env("PTTS_GEMM_XCD")));
     a.xcd_swz = xcd_swz;
     if constexpr (sizeof(WT) == 2) {  // bf16 engine: the LDS-DMA ring (round 6, ptts_gemm_glds.h); PTTS_GEMM_GLDS=0: round 5's register-staged tiles
-      static const bool glds_on = !(getenv("PTTS_GEMM_GLDS") && !atoi(getenv("PTTS_GEMM_GLDS")));
+      static const bool glds_on = !(ptts_dev_env("PTTS_GEMM_GLDS") && !atoi(ptts_dev_env("PTTS_GEMM_GLDS")));
       if (glds_on && a.M > block_min_m && EPI != EPI_GELU && !a.x_fo && (!a.kv_layers || EPI == EPI_KV) && !a.stats_out && !a.W8 && !a.rs_part && !a.nx_out) {
         const int rg = launch_gemm_glds<EPI>(a, st);
         if (rg != -1) return rg;

@@ -108,7 +108,6 @@ struct ptts_engine {
                               // (PTTS_LNPROJ: 0 off, 1 = LN1 + QKV, 2 = + LN3 + fc1 above 32 utterances, 3 = + LN3 + fc1 at 9..32 too instead of the producer-statistics prologue)
   int fuse_qa_max = 3;        // largest batch that runs it (PTTS_FUSE_QA_MAX = 1..8)
   int last_graph_nodes = 0;   // kernel nodes of the step graph captured last (ptts_debug_graph_nodes)
-  bool fuse_qa_multi = true;  // the same node at 2..8 utterances, one grid slice per utterance (round 5; PTTS_FUSE_QA_MULTI=0: single utterance only)
   bool fuse_qa = true;        // single-utterance GEMV step: LN1 + QKV rows + self-attention + append as one node (qkv_attn_kernel), PTTS_NO_FUSE_QA=1 = two nodes
   int fuse_x = -1;            // single-utterance GEMV step, folded cross block: LN2 + scores + softmax + U p as one node of per-head partial rows (xfold_attn_kernel),
                               // summed by the LN3 + fc1 node's prologue (GV_LNP). -1 = by width: on up to hidden 1024 (Mini-v1 -1 %: 566 -> 561 us per step), off
@@ -118,7 +117,6 @@ struct ptts_engine {
   float* xpart = nullptr;     // [nheads][H] per-head partial rows of the fused cross block
   float* h2 = nullptr;        // [H] residual row after the cross block (x + partial rows), written by the LN3 + fc1 node
   bool fuse_xq = true;        // GEMV step, un-folded cross block: LN2 + cross-q rows + cross-attention as one node (xq_attn_kernel), PTTS_NO_FUSE_XQ=1 = two nodes
-  int graph_steps = 1;        // decode steps per hipGraphLaunch inside one context bucket (PTTS_GRAPH_STEPS = 1 / 2 / 4 / 8 / 16)
   int fuse_qa_s = 0;          // KV splits of that node: 0 = by context bucket (1 / 2 / 4 / 8 for <= 256 / 512 / 1024 / more positions), PTTS_FUSE_QA_S forces one
   int lnproj_g = 0;           // utterances per workgroup of that node: 0 = by batch size (8 up to 40 utterances, 16 above), PTTS_LNPROJ_G = 4 / 8 / 16 forces one
   int xattn_g = 0;            // utterances per workgroup of the fused cross block above 8 utterances: 0 = by batch size (2 up to 32, 4 up to 64, 8 above), PTTS_XATTN_G = 8 / 4 / 2 forces one
@@ -175,7 +173,7 @@ int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st, int g) {
       if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea)); \
       attr_once.done(attr_dev);                                                                                       \
     }                                                                                                                 \
-    hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, G, EPI>), grid, dim3(512), sh, st, p);                        \
+    hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, G, EPI>), grid, dim3(512), sh, st, PTTS_DBG0_ARG(p) p);                      \
   } while (0)
 #define PTTS_LNPROJ_LAUNCH(UW, NF4)                                                                                   \
   do {                                                                                                                \
@@ -228,7 +226,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const size_t n = (size_t)B * e->N * H;
     hipLaunchKernelGGL((convert_kernel<WT, float>), dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, e->qc,
                        reinterpret_cast<WT*>(e->xw2), n);
-    static const bool kv_batched = !(getenv("PTTS_NO_KV_BATCHED") && atoi(getenv("PTTS_NO_KV_BATCHED")));
+    static const bool kv_batched = !(ptts_dev_env("PTTS_NO_KV_BATCHED") && atoi(ptts_dev_env("PTTS_NO_KV_BATCHED")));
     // every layer's K/V projection in ONE launch (blockIdx.z = layer): the strip kernel up to 256 rows, the bf16 engine's LDS-DMA GEMM above (round 6:
     // 24 launches of ~17 us at 32 descriptions x 64 tokens were one tenth of that prefill; a shape the GEMM declines falls back to the strips)
     const bool one_launch = kv_batched && (B * e->N <= 256 || (sizeof(WT) == 2 && H % 64 == 0 && (2 * nkc * 64) % 64 == 0));
@@ -256,11 +254,11 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
     const float* rs = c.rope ? e->rope_sin : nullptr;
     const int mode = c.dtype == PTTS_F32 ? GV_F32 : (e->w8 ? GV_BF16_W8 : GV_BF16);
     // single utterance, sinusoidal positions: the two nodes of the self-attention block's first half as one (PTTS_NO_FUSE_QA=1: two nodes)
-    // (round 5: 2..8 utterances too - one grid slice per utterance, the slices of a head share its weight rows in the L2; PTTS_FUSE_QA_MULTI=0: one only)
+    // (round 5: 2..8 utterances too - one grid slice per utterance, the slices of a head share its weight rows in the L2; PTTS_FUSE_QA_MAX=1: one only)
     // measured, Mini-v1 us per step at contexts ~210 / ~460 / ~710, fused | two nodes (profiles/r05_experiments.txt call 2): 2 utterances 720 / 756 / 791 |
     // 769 / 777 / 791; 3: 741 / 788 / 862 | 780 / 796 / 821; 4: 777 / 864 / 923 | 803 / 832 / 862; 8: 966 / 1010 / 1068 | 907 / 965 / 1023 (the slices of
     // a head re-read its q / k / v rows from the L2 once per utterance and split): on up to fuse_qa_max utterances (3), PTTS_FUSE_QA_MAX forces a bound
-    const bool fuse_qa = e->fuse_qa && (M == 1 || (e->fuse_qa_multi && M <= e->fuse_qa_max && mode != GV_F32)) && !c.rope && ptts_qkvattn_ok(H, mode);
+    const bool fuse_qa = e->fuse_qa && (M == 1 || (M <= e->fuse_qa_max && mode != GV_F32)) && !c.rope && ptts_qkvattn_ok(H, mode);
     // KV splits of the fused node: the smallest count whose FIRST batch of row groups (8 waves x 4 groups x 8 bf16 / 4 fp32 rows per split,
     // requested before q exists) covers the context bucket this graph is captured for - fewer workgroups recompute the head's q rows, and no
     // split needs a second, dependent K/V batch (context ~210 / ~460 / ~710: 2 splits 554 / 562 / 586 us per step, 4 splits 575 / 577 / 579,
@@ -399,7 +397,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // decode at batch > 8: engine-dtype activations travel between kernels in MFMA B-fragment order (ptts_lm_kernels.h: fo_vec_index)
   // (and the prefill while its rows stay on the strip kernels, M <= 256: a single utterance's 33-position prefill is 240 latency-bound
   // launches on the time-to-first-token path; PTTS_NO_FO_PREFILL=1 keeps the row-major layout there for A/B)
-  static const bool fo_prefill = !(getenv("PTTS_NO_FO_PREFILL") && atoi(getenv("PTTS_NO_FO_PREFILL")));
+  static const bool fo_prefill = !(ptts_dev_env("PTTS_NO_FO_PREFILL") && atoi(ptts_dev_env("PTTS_NO_FO_PREFILL")));
   const int fo = (e->use_fo && M > 8 && (!prefill || (fo_prefill && M <= 256))) ? 1 : 0;
   // LayerNorm + projection as one node (lnproj_fused_kernel): decode, batch > 8, Mini / Large widths, weights in the engine dtype (e4m3 strips keep
   // streaming bytes through the strip GEMMs)
@@ -409,14 +407,14 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   const int lnproj_g = e->lnproj_g > 0 ? e->lnproj_g : (M <= 40 ? 8 : 16);
   // (round 5: the prefill rows of a short prompt, 8 < M <= 40, run the same fused nodes - three rows_prep nodes less per layer on the
   //  time-to-first-token path: prefill 1.41 -> 1.29 ms, first token 2.41 -> 2.28 ms at 33 rows, profiles/r05_experiments.txt call 2; PTTS_LNPROJ_PREFILL=0: off)
-  static const bool lnproj_prefill = !(getenv("PTTS_LNPROJ_PREFILL") && !atoi(getenv("PTTS_LNPROJ_PREFILL")));
+  static const bool lnproj_prefill = !(ptts_dev_env("PTTS_LNPROJ_PREFILL") && !atoi(ptts_dev_env("PTTS_LNPROJ_PREFILL")));
   const bool lnproj_ok = lnproj > 0 && (!prefill || (lnproj_prefill && M <= 40)) && M > 8 && !e->w8_strips && (H == 1024 || H == 1536) && ((H / KTf) / 2) % 8 == 0 && QKV % 64 == 0 && F % 64 == 0;
   // prefill attention on the tiled kernel (8 query rows per workgroup share the K / V tile; PTTS_PREFILL_ATTN=0: one workgroup per query row, attn_kernel)
   const int prefill_attn_mode = getenv("PTTS_PREFILL_ATTN") ? atoi(getenv("PTTS_PREFILL_ATTN")) : 3;  // 0: one workgroup per query row, 1: tiled VALU kernel, 2: f32-MFMA kernel, 3: by batch
   const bool prefill_attn = prefill_attn_mode != 0;
   // prefill rows on the fused LN1 + QKV node, sinusoidal positions, engine-dtype cache: the node's epilogue writes the cache rows itself (no
   // kv_append node: 24 launches of ~4 us + their boundaries off the time-to-first-token path; PTTS_KV_IN_QKV=0: the separate node)
-  static const bool kv_in_qkv_on = !(getenv("PTTS_KV_IN_QKV") && !atoi(getenv("PTTS_KV_IN_QKV")));
+  static const bool kv_in_qkv_on = !(ptts_dev_env("PTTS_KV_IN_QKV") && !atoi(ptts_dev_env("PTTS_KV_IN_QKV")));
   const bool kv_in_qkv = kv_in_qkv_on && prefill && lnproj_ok && !c.rope && !e->L[0].ks_self;
 #ifdef PTTS_TIMING
 #define PTTS_DBG_BIG(args, l_, k_) (args).dbg = (e->dbg_stamps && !prefill && M > 8) ? e->dbg_stamps + ((size_t)(l_) * 7 + (k_)) * 48 : nullptr
@@ -610,7 +608,7 @@ int fold_cross(ptts_engine* e, hipStream_t st) {
   const int H = c.hidden_size, nh = c.num_heads, NE = e->xfold_ne, n_rep = nh / e->nkc, L = c.num_layers;
   const float qscale = 1.44269504088896340736f / sqrtf((float)(H / nh));
   // tiled kernels (round 5; bit-identical to the row kernels, PTTS_FOLD_TILED=0 selects those for A/B)
-  static const bool tiled = !(getenv("PTTS_FOLD_TILED") && !atoi(getenv("PTTS_FOLD_TILED")));
+  static const bool tiled = !(ptts_dev_env("PTTS_FOLD_TILED") && !atoi(ptts_dev_env("PTTS_FOLD_TILED")));
   if (tiled && H % 64 == 0 && NE <= 64) {
     hipLaunchKernelGGL((xfold_tile_kernel<WT, W8, false>), dim3(H / 64, nh, L), dim3(256), 0, st, e->fold_layers, nh, H, NE, c.max_enc, n_rep, e->dims, qscale);
     hipLaunchKernelGGL((xfold_tile_kernel<WT, W8, true>), dim3(H / 64, nh, L), dim3(256), 0, st, e->fold_layers, nh, H, NE, c.max_enc, n_rep, e->dims, qscale);
@@ -629,7 +627,7 @@ int forward_dispatch(ptts_engine* e, bool prefill, hipStream_t st, bool with_emb
 }
 
 // every decode forward appends one self-KV position: advance the host's bound before launching it (eagerly or as a graph)
-static const bool g_no_kv_bound = getenv("PTTS_NO_KV_BOUND") && atoi(getenv("PTTS_NO_KV_BOUND"));
+static const bool g_no_kv_bound = ptts_dev_env("PTTS_NO_KV_BOUND") && atoi(ptts_dev_env("PTTS_NO_KV_BOUND"));
 static int advance_kv(ptts_engine* e) {
   e->kv_ub += 1;
   const int cap = e->cfg.max_ctx;
@@ -714,15 +712,15 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   // (an engine created for more than GV_MAX_ROWS utterances never takes the GEMV step: it does not hold the row-major copies either -
   // the model-level cache keeps one engine per batch-size class, each with the weight copies its own decode step streams)
   e->use_gemv = ptts_gemv_k_ok(H, gmode) && ptts_gemv_k_ok(F, gmode) && H <= 2048 && c.max_batch <= GV_MAX_ROWS &&
-                !(getenv("PTTS_NO_GEMV") && atoi(getenv("PTTS_NO_GEMV")));
+                !(ptts_dev_env("PTTS_NO_GEMV") && atoi(ptts_dev_env("PTTS_NO_GEMV")));
   e->gemv_rows = c.dtype == PTTS_F32 ? 1 : GV_MAX_ROWS;
-  if (const char* ev = getenv("PTTS_GEMV_ROWS")) e->gemv_rows = std::max(1, std::min(e->gemv_rows, atoi(ev)));  // A/B knob (tools/)
+  if (const char* ev = ptts_dev_env("PTTS_GEMV_ROWS")) e->gemv_rows = std::max(1, std::min(e->gemv_rows, atoi(ev)));  // A/B knob (tools/)
   e->w8 = c.weights_fp8 != 0;
   // static cross-attention folding: single utterance, sinusoidal positions (RoPE rotates the cross query by position), <= 64
   // description tokens, full cross K/V heads not required (n_rep handled), folded widths must be GEMV shapes
-  if (e->use_gemv && !c.rope && c.max_enc <= 64 && ptts_gemv_k_ok(nh * 64, gmode) && !(getenv("PTTS_NO_XFOLD") && atoi(getenv("PTTS_NO_XFOLD"))))
+  if (e->use_gemv && !c.rope && c.max_enc <= 64 && ptts_gemv_k_ok(nh * 64, gmode) && !(ptts_dev_env("PTTS_NO_XFOLD") && atoi(ptts_dev_env("PTTS_NO_XFOLD"))))
     e->xfold_ne = 64;
-  e->w8_strips = e->w8 && !e->use_gemv && !(getenv("PTTS_NO_W8_STRIPS") && atoi(getenv("PTTS_NO_W8_STRIPS")));
+  e->w8_strips = e->w8 && !e->use_gemv && !(ptts_dev_env("PTTS_NO_W8_STRIPS") && atoi(ptts_dev_env("PTTS_NO_W8_STRIPS")));
   if (c.kv_fp8 && (c.dtype != PTTS_BF16 || e->use_gemv)) {
     ptts_engine_destroy(e);
     return ptts_fail(PTTS_E_UNSUPPORTED, "kv_fp8 (e4m3 self-attention cache) needs the bf16 engine created for more than %d utterances (the MFMA strip step)", GV_MAX_ROWS);
@@ -829,13 +827,13 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
     while (s > 1 && (s - 1) * 4 * 8 * 8 >= c.max_ctx) --s;  // do not split below one 8-deep batch of row groups per wave
     e->S_self = s;
     e->S_cross = 1;
-    if (const char* ev = getenv("PTTS_ATTN_SPLITS")) e->S_self = std::max(1, std::min(8, atoi(ev)));  // tuning knobs (tools/)
-    if (const char* ev = getenv("PTTS_ATTN_WAVES")) e->attn_waves = atoi(ev) == 16 ? 16 : (atoi(ev) == 8 ? 8 : 4);
+    if (const char* ev = ptts_dev_env("PTTS_ATTN_SPLITS")) e->S_self = std::max(1, std::min(8, atoi(ev)));  // tuning knobs (tools/)
+    if (const char* ev = ptts_dev_env("PTTS_ATTN_WAVES")) e->attn_waves = atoi(ev) == 16 ? 16 : (atoi(ev) == 8 ? 8 : 4);
     {
       const int rows_per_wave = (c.dtype == PTTS_BF16 ? 8 : 4) * 8;  // RPI row groups x 8 loads in flight
       const int need = (c.max_enc + rows_per_wave - 1) / rows_per_wave;
       e->cross_waves = need <= 1 ? 1 : (need <= 2 ? 2 : 4);
-      if (const char* ev = getenv("PTTS_CROSS_WAVES")) e->cross_waves = atoi(ev) == 1 ? 1 : (atoi(ev) == 2 ? 2 : 4);
+      if (const char* ev = ptts_dev_env("PTTS_CROSS_WAVES")) e->cross_waves = atoi(ev) == 1 ? 1 : (atoi(ev) == 2 ? 2 : 4);
     }
     if (e->use_gemv) while (e->S_self & (e->S_self - 1)) --e->S_self;  // the GEMV combine prologue is instantiated for 2 / 4 / 8 splits
   }
@@ -853,20 +851,18 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   if (const char* ev = getenv("PTTS_FUSE_X")) e->fuse_x = atoi(ev) ? 1 : 0;
   if (const char* ev = getenv("PTTS_FUSE_X_NUR")) { const int v = atoi(ev); if (v == 2 || v == 4) e->fuse_x_nur = v; }
   e->fuse_qa = !(getenv("PTTS_NO_FUSE_QA") && atoi(getenv("PTTS_NO_FUSE_QA")));
-  e->fuse_qa_multi = !(getenv("PTTS_FUSE_QA_MULTI") && !atoi(getenv("PTTS_FUSE_QA_MULTI")));
   if (const char* ev = getenv("PTTS_FUSE_QA_MAX")) e->fuse_qa_max = std::max(1, std::min(GV_MAX_ROWS, atoi(ev)));
   e->fuse_xq = !(getenv("PTTS_NO_FUSE_XQ") && atoi(getenv("PTTS_NO_FUSE_XQ")));
-  if (const char* ev = getenv("PTTS_GRAPH_STEPS")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->graph_steps = v; }
-  if (const char* ev = getenv("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
+  if (const char* ev = ptts_dev_env("PTTS_FUSE_QA_S")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4 || v == 8) e->fuse_qa_s = v; }
   A(e->alloc(&e->ffn, std::max(rows * F, rows * (size_t)H)));
   A(e->alloc(&e->logits, (size_t)c.max_batch * K * V));
   A(e->alloc(&e->sort_buf, 16));
   A(e->alloc_bytes(&e->xw, (rows + 16) * H * es));  // + 16 rows: fragment order addresses whole 16-row tiles
   A(e->alloc_bytes(&e->xw2, std::max((rows + 16) * F, enc_rows * (size_t)H) * es));
-  e->use_fo = !(getenv("PTTS_NO_FO") && atoi(getenv("PTTS_NO_FO")));
+  e->use_fo = !(ptts_dev_env("PTTS_NO_FO") && atoi(ptts_dev_env("PTTS_NO_FO")));
   A(e->alloc(&e->lnstat, (size_t)c.max_batch * (H / 16) * 2 + 16));
-  e->use_lns = (H == 1024 || H == 1536) && !(getenv("PTTS_NO_LNS") && atoi(getenv("PTTS_NO_LNS")));
-  if (const char* ev = getenv("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));
+  e->use_lns = (H == 1024 || H == 1536) && !(ptts_dev_env("PTTS_NO_LNS") && atoi(ptts_dev_env("PTTS_NO_LNS")));
+  if (const char* ev = ptts_dev_env("PTTS_XATTN_GROUPS_MAX")) e->xattn_groups_max = std::max(8, atoi(ev));
   if (const char* ev = getenv("PTTS_LNPROJ")) e->lnproj = std::max(0, std::min(3, atoi(ev)));
   if (const char* ev = getenv("PTTS_LNPROJ_G")) e->lnproj_g = atoi(ev) == 4 ? 4 : (atoi(ev) == 16 ? 16 : (atoi(ev) == 8 ? 8 : 0));
   e->xattn_g_ok = (H == 1024 && ((H / (c.dtype == PTTS_BF16 ? 32 : 16)) / 2) % 16 == 0) || H == 1536;
@@ -1137,7 +1133,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   // causal attention over the same cache).
   const int T = e->pending_T;
   e->pending_T = 0;
-  const bool batched = T > 0 && P + 1 + T <= e->max_prompt && !(getenv("PTTS_NO_BATCHED_PREFIX") && atoi(getenv("PTTS_NO_BATCHED_PREFIX")));
+  const bool batched = T > 0 && P + 1 + T <= e->max_prompt && !(ptts_dev_env("PTTS_NO_BATCHED_PREFIX") && atoi(ptts_dev_env("PTTS_NO_BATCHED_PREFIX")));
   if (batched) {
     hipLaunchKernelGGL(push_prefix_all_kernel, dim3((B * K * T + 255) / 256), dim3(256), 0, st, e->ids, e->ids_ld, e->dims, T, B, K, c.bos_token_id);
     e->prefill_T = T;
@@ -1148,7 +1144,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
   // launch list is a pure function of the shape. Measured (profiles/r05_experiments.txt call 1): time to the first token 2.420 ms with the
   // graph, 2.401 ms with eager launches - behind the description encoder's 1 ms of GPU time the host is ahead of the GPU either way, and a
   // graph costs a capture + instantiate per new (batch, description, prompt) shape. OFF by default; PTTS_PREFILL_GRAPH=1 enables it (A/B).
-  static const bool prefill_graph = getenv("PTTS_PREFILL_GRAPH") && atoi(getenv("PTTS_PREFILL_GRAPH"));
+  static const bool prefill_graph = ptts_dev_env("PTTS_PREFILL_GRAPH") && atoi(ptts_dev_env("PTTS_PREFILL_GRAPH"));
   int rc_fwd = PTTS_OK;
   if (prefill_graph) {
     const long long key = (long long)B | ((long long)N << 12) | ((long long)P << 28) | ((long long)e->prefill_T << 44);
@@ -1199,7 +1195,7 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
     // matrices by stream order. (Round 2 ran 48 per-layer launches BEFORE the tail: +0.8 ms of time-to-first-token. Running it on a
     // second stream beside the prefill was measured and lost: 8.98 vs 8.44 ms to the first token, and the first streamed chunk 23 ms
     // later, the decode steps waiting on the second hardware queue; PTTS_FOLD_ASYNC=1 keeps that variant for A/B.)
-    static const bool sync_fold = !(getenv("PTTS_FOLD_ASYNC") && atoi(getenv("PTTS_FOLD_ASYNC")));
+    static const bool sync_fold = !(ptts_dev_env("PTTS_FOLD_ASYNC") && atoi(ptts_dev_env("PTTS_FOLD_ASYNC")));
     hipStream_t fs = sync_fold ? st : e->fold_stream;
     if (!sync_fold) PTTS_HIP(hipStreamWaitEvent(fs, e->ev_kv, 0));
     if (c.dtype == PTTS_F32) PTTS_TRY((fold_cross<float, false>(e, fs)));
@@ -1216,30 +1212,26 @@ extern "C" int ptts_prefill(ptts_engine* e, const float* enc_dev, const int32_t*
 
 // The decode step (170 kernel nodes for Mini-v1 at batch <= 8) is captured ONCE per batch size on the engine's private stream
 // (capture records, it does not execute; the legacy NULL stream cannot be captured) and replayed into the caller's.
-static int get_graph(ptts_engine* e, hipGraphExec_t* out, int nsteps = 1) {
+static int get_graph(ptts_engine* e, hipGraphExec_t* out) {
   // the node set of the step depends on the batch size and on the folded cross block; the attention fetch bound (a kernel argument)
-  // on the 64-position bucket of the context (forward<> reads it from e->kv_bound while capturing); nsteps consecutive steps of ONE
-  // bucket may share a graph (e->graph_steps: every length, position and token is device-resident, so a step is the same node list
-  // whatever its index; one hipGraphLaunch per nsteps frames instead of per frame)
-  const long long key = e->B * 2 + (e->xfold_valid ? 1 : 0) + 4096LL * (e->kv_bound / 64) + (1LL << 40) * (nsteps - 1);
+  // on the 64-position bucket of the context (forward<> reads it from e->kv_bound while capturing). (Several steps of one bucket per
+  // graph launch - round 4's PTTS_GRAPH_STEPS - measured 0.3-0.7 %, profiles/r04_experiments.txt call 19: removed in round 6.)
+  const long long key = e->B * 2 + (e->xfold_valid ? 1 : 0) + 4096LL * (e->kv_bound / 64);
   auto it = e->graphs.find(key);
   if (it != e->graphs.end()) { if (out) *out = it->second; return PTTS_OK; }
   hipGraph_t g = nullptr;
   hipStream_t st = e->own_stream;
   PTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   // decode step = layers + heads + tail; the tail embeds the column it just sampled for the NEXT replay (no embed node)
-  int rc = PTTS_OK;
-  for (int u = 0; u < nsteps && rc == PTTS_OK; ++u) {
-    rc = forward_dispatch(e, false, st, false);
-    if (rc == PTTS_OK) rc = launch_tail(e, st, true);
-  }
+  int rc = forward_dispatch(e, false, st, false);
+  if (rc == PTTS_OK) rc = launch_tail(e, st, true);
   hipError_t ce = hipStreamEndCapture(st, &g);
   if (rc != PTTS_OK) { if (g) hipGraphDestroy(g); return rc; }
   if (ce != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
   hipGraphExec_t ex = nullptr;
   {
     size_t nn = 0;
-    if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) e->last_graph_nodes = (int)(nn / (size_t)nsteps);
+    if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) e->last_graph_nodes = (int)nn;
   }
   hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
@@ -1257,7 +1249,7 @@ static int get_graph(ptts_engine* e, hipGraphExec_t* out, int nsteps = 1) {
 // the first decode_steps of the first call of every batch size. Graphs are cached for the engine's life, so only the first call of a
 // (batch, fold, bucket) pays. PTTS_NO_PRECAPTURE=1: capture lazily, at the launch that needs the graph (A/B).
 static int precapture_graphs(ptts_engine* e, int max_buckets) {
-  static const bool off = getenv("PTTS_NO_PRECAPTURE") && atoi(getenv("PTTS_NO_PRECAPTURE"));
+  static const bool off = ptts_dev_env("PTTS_NO_PRECAPTURE") && atoi(ptts_dev_env("PTTS_NO_PRECAPTURE"));
   if (off) return PTTS_OK;
   const int cap = e->cfg.max_ctx, saved_ub = e->kv_ub, saved_bound = e->kv_bound;
   const int last_ub = std::min(cap - 1, e->P + e->gp.max_length);  // positions the longest run of this call writes
@@ -1265,7 +1257,6 @@ static int precapture_graphs(ptts_engine* e, int max_buckets) {
   for (int ub = saved_ub + 1; ub <= last_ub && rc == PTTS_OK && done < max_buckets; ++done) {
     e->kv_bound = g_no_kv_bound ? cap : std::min(cap, (ub + 1 + 63) / 64 * 64);
     rc = get_graph(e, nullptr);
-    if (rc == PTTS_OK && e->graph_steps > 1 && !g_no_kv_bound) rc = get_graph(e, nullptr, e->graph_steps);
     ub = e->kv_bound;  // first upper bound of the next bucket: (ub + 1 + 63) / 64 * 64 > kv_bound
     if (g_no_kv_bound) break;
   }
@@ -1290,16 +1281,9 @@ extern "C" int ptts_decode_steps(ptts_engine* e, int32_t n_steps, void* stream) 
   for (int i = 0; i < n_steps;) {
     hipGraphExec_t ex = nullptr;
     advance_kv(e);
-    // steps that follow in the same 64-position bucket share the fetch bound: graph_steps of them go out as one graph launch
-    int run = 1;
-    if (e->graph_steps > 1 && !g_no_kv_bound) {
-      while (run < e->graph_steps && i + run < n_steps && std::min(cap, (e->kv_ub + run + 1 + 63) / 64 * 64) == e->kv_bound) ++run;
-      if (run < e->graph_steps) run = 1;  // only whole groups: two graphs per bucket, not one per remainder length
-    }
-    PTTS_TRY(get_graph(e, &ex, run));  // cached per (batch, fold, 64-position bucket, steps per launch)
+    PTTS_TRY(get_graph(e, &ex));  // cached per (batch, fold, 64-position bucket)
     PTTS_HIP(hipGraphLaunch(ex, st));
-    e->kv_ub += run - 1;
-    i += run;
+    ++i;
   }
   if (n_steps > 0) PTTS_TRY(precapture_graphs(e, 2));  // the current bucket and the next one, while the GPU works through what was just enqueued
   return PTTS_OK;

@@ -86,52 +86,71 @@ enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_KV = 3, EPI_GELU_WT = 4, 
 
 struct KvLayer { const void* W; void* k; void* v; };  // one layer's operands of the batched cross K/V projection (EPI_KV over blockIdx.z)
 
+// Field order: the first 56 bytes are what a strip-kernel wave needs to ADDRESS its first loads (weight fragments, B fragments of fragment-order
+// rows, the pass's rows): gemm_strip_kernel takes them as scalar parameters that the command processor preloads into SGPRs (ptts_common.h: kernel-
+// argument preload) and everything else as KTail<GemmArgs>. Round 6 measured what fetching this struct by s_load costs a strip node: 0.43 us from the
+// wave's first instruction until the struct is usable, three nodes per layer (profiles/r06_node_stamps_bs32_bs128.txt, slot 14); the other kernels
+// that take GemmArgs keep the by-value form.
 struct GemmArgs {
+  // ---- bytes 0..55: preloaded ----
   const void* W;       // packed strips
+  const void* W8;      // e4m3 strips [N/16][K/64 fragment pairs][64 lanes][16 B] (weights_fp8 engines), or null: bf16 / fp32 strips in W
   const float* x;      // PLAIN/LN input; x row index = m * x_row_mul + x_row_off
+  float* out;
+  int K, M;
+  int rows_per_pass;   // activation rows staged in LDS per pass (<= 16 * MTP)
+  int frags_per_wave;  // FULL variant: K/KT/W, a multiple of 8
+  int out_ld;
+  int kflags;          // set by ptts_klaunch: m_split | x_fo << 1 | waves per workgroup << 8 (blockDim would be a hidden argument behind an s_load)
+  // ---- tail: what the decode step's strip instances read first (one or two scalar cache lines behind the preloaded bytes: the s_load latency of
+  // this struct grew with the number of lines touched - 0.14 us for lnproj's 100 bytes, 0.43 us for five scattered lines of this one) ----
+  int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
+  int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
+  int N;
+  int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
+#ifdef PTTS_TIMING
+  long long* dbg;      // phase stamps (PTTS_STAMP)
+#endif
+  float* stats_out;    // EPI_RESID: [M][N/16][2] strip statistics of the updated residual rows, or null
+  const float* wscale; // W8: one power-of-two scale per weight row [N], applied to the fp32 accumulators
+  // T5 RMSNorm folded into the GEMMs around it (ptts_t5.hip, <= 256 rows; strip kernel only). T5LayerNorm has no mean and no bias, so it commutes with
+  // the projection: W (g o x * rstd) = rstd * (W (g o x)). The PRODUCER of the residual rows (EPI_RESID with nx_out) also writes the next GEMM's
+  // operand g o h in the engine dtype and the per-strip sums of h^2; the CONSUMER (EPI_STORE / EPI_GATE_WT with rs_part) sums a row's rs_n partials
+  // once per workgroup, in a fixed order, while its weights stream, and scales its accumulators by rstd[m]: no rows_prep node, no extra pass over h.
+  void* nx_out;          // producer (EPI_RESID): engine-dtype [M][N] (row-major or fragment order by out_fo) = updated residual row * nx_gamma, or null
+  const float* nx_gamma; // [N]
+  float* ss_out;         // producer: [M][N/16] sum of squares of the updated residual row over this strip's 16 columns
+  const float* rs_part;  // consumer: [M][rs_n] per-strip sums of squares of the un-normalised rows, or null
+  int rs_n;
+  float rs_invD;         // 1 / d_model
+  float rms_eps;       // PRO_RMS / rs_part: T5Config.layer_norm_epsilon
+  // ---- everything else ----
   int x_ld, x_row_mul, x_row_off;
   const float* gamma;
   const float* beta;
   const float* part;   // ATTN: [rows][S][K]
   const float* stats;  // ATTN: [rows][S][heads][2] = (max, sumexp)
   int S, nheads;
-  float* out;
-  int out_ld;
   void* kcache;        // EPI_KV
   void* vcache;
   int kv_rows_per_b;   // EPI_KV: N (rows of x per batch element)
   int kv_cap;          // EPI_KV: capacity (positions) of the cache
-  int M, N, K;
-  int rows_per_pass;   // activation rows staged in LDS per pass (<= 16 * MTP)
-  int frags_per_wave;  // FULL variant: K/KT/W, a multiple of 8
   float invK;          // 1 / K
   const float* lnstat; // PRO_LNS: [M][K/16][2] = (strip mean, strip M2) of x, written by the producer GEMM
-  float* stats_out;    // EPI_RESID: [M][N/16][2] strip statistics of the updated residual rows, or null
-  const void* W8;      // e4m3 strips [N/16][K/64 fragment pairs][64 lanes][16 B] (weights_fp8 engines), or null: bf16 / fp32 strips in W
-  const float* wscale; // W8: one power-of-two scale per weight row [N], applied to the fp32 accumulators
   const KvLayer* kv_layers;  // PRO_COPY + EPI_KV: blockIdx.z selects the layer (W, kcache, vcache from this table): the description's K/V
   int kv_nlayers;            // of EVERY layer in one launch (24 launches of ~8 us sat on the time-to-first-token path); null = W / kcache / vcache
-  int x_fo;            // PRO_COPY: x is in MFMA B-fragment order (fo_vec_index), written by a producer with out_fo set
-  int out_fo;          // EPI_GELU_WT / rows_prep: write the engine-dtype output in B-fragment order for the consumer GEMM
   int xcd_swz;         // gemm_block_kernel / gemm_tile_kernel: XCD-aware tile order (xcd_tile_order), set by launch_gemm (PTTS_GEMM_XCD=0: launch order)
   int decode;          // host-side launch policy only: 1 = a decode-step GEMM (light M passes, msplit_rows), 0 = prefill-sized rows
-  int m_split;         // PRO_COPY: blockIdx.z selects ONE pass of rows_per_pass rows (grid.z = passes) instead of looping over them
-  // T5 RMSNorm folded into the GEMMs around it (ptts_t5.hip, <= 256 rows; strip kernel only). T5LayerNorm has no mean and no bias, so it commutes with
-  // the projection: W (g o x * rstd) = rstd * (W (g o x)). The PRODUCER of the residual rows (EPI_RESID with nx_out) also writes the next GEMM's
-  // operand g o h in the engine dtype and the per-strip sums of h^2; the CONSUMER (EPI_STORE / EPI_GATE_WT with rs_part) sums a row's rs_n partials
-  // once per workgroup, in a fixed order, while its weights stream, and scales its accumulators by rstd[m]: no rows_prep node, no extra pass over h.
-  const float* rs_part;  // consumer: [M][rs_n] per-strip sums of squares of the un-normalised rows, or null
-  int rs_n;
-  float rs_invD;         // 1 / d_model
-  void* nx_out;          // producer (EPI_RESID): engine-dtype [M][N] (row-major or fragment order by out_fo) = updated residual row * nx_gamma, or null
-  const float* nx_gamma; // [N]
-  float* ss_out;         // producer: [M][N/16] sum of squares of the updated residual row over this strip's 16 columns
-  float rms_eps;       // PRO_RMS / rs_part: T5Config.layer_norm_epsilon
   const int* row_keep; // PRO_RMS: [M] int32 or null; rows with 0 are written as zeros (masked description positions, modeling_parler_tts.py:3093-3097)
-#ifdef PTTS_TIMING
-  long long* dbg;      // phase timestamps (s_memtime) of workgroup 0 / wave 0
-#endif
 };
+static_assert(sizeof(GemmArgs) % 8 == 0 && offsetof(GemmArgs, m_split) == 56, "GemmArgs: 56 preloaded bytes + tail");
+#define GemmArgs_KPARAMS                                                                                                                          \
+  const void *kW_, const void *kW8_, const float *kx_, float *kout_, int kK_, int kM_, int krpp_, int kfpw_, int kold_, int kfl_, KTail<GemmArgs> kt_
+#define GemmArgs_KJOIN(a)                                                                                          \
+  GemmArgs a;                                                                                                      \
+  PTTS_KTAIL_JOIN(GemmArgs, a);                                                                                    \
+  a.W = kW_; a.W8 = kW8_; a.x = kx_; a.out = kout_; a.K = kK_; a.M = kM_; a.rows_per_pass = krpp_; a.frags_per_wave = kfpw_; a.out_ld = kold_;  \
+  a.kflags = kfl_; a.m_split = kfl_ & 1; a.x_fo = (kfl_ >> 1) & 1;
 
 // ---- activations in MFMA B-fragment order ("FO") -----------------------------------------------------------------------------
 // Decode at batch > 8: the engine-dtype activation rows that a PRO_COPY GEMM consumes are written by their producers (rows_prep,
@@ -204,7 +223,16 @@ static __global__ void pack_w8_kernel(const uint8_t* __restrict__ src, uint4* __
     }                                                                                                                       \
   } while (0)
 #define PTTS_WSTAMP(a, i) PTTS_STAMP((a).dbg, i)
+// gemm_strip_kernel / lnproj_fused_kernel take the stamp buffer a second time as a leading SCALAR parameter: the command processor preloads it into
+// SGPRs (-amdgpu-kernarg-preload-count), so slot 14 is stamped at the wave's very first instructions - before the s_load of the by-value argument
+// struct has returned. s0 - s14 = what fetching the struct costs a node = the most a kernarg-preload conversion of these kernels could win.
+#define PTTS_DBG0_PARAM long long* dbg0_,
+#define PTTS_DBG0_ARG(a) (a).dbg,
+#define PTTS_STAMP0() PTTS_STAMP(dbg0_, 14)
 #else
+#define PTTS_DBG0_PARAM
+#define PTTS_DBG0_ARG(a)
+#define PTTS_STAMP0() do { } while (0)
 #define PTTS_DBG_FIELD
 #define PTTS_STAMP(ptr, i) do { } while (0)
 #define PTTS_WSTAMP(a, i) do { } while (0)
@@ -531,6 +559,13 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
   }
 }
 
+// host side of the split argument list of gemm_strip_kernel (GemmArgs_KPARAMS)
+template <typename Kn> inline void ptts_klaunch(Kn kern, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const GemmArgs& a) {
+  const int kflags = (a.m_split ? 1 : 0) | (a.x_fo ? 2 : 0) | ((int)(block.x >> 6) << 8);
+  hipLaunchKernelGGL(kern, grid, block, shmem, st, PTTS_DBG0_ARG(a) a.W, a.W8, a.x, a.out, a.K, a.M, a.rows_per_pass, a.frags_per_wave, a.out_ld, kflags,
+                     ptts_ktail(a));
+}
+
 // LN / ATTN prologues always reduce over K = hidden_size (<= 8 waves of >= 8 fragments); only the plain prologue
 // (fc2, K = ffn_dim) at batch <= 16 wants 16 waves, so only it pays the 128-VGPR cap of a 1024-thread workgroup.
 template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value = (PRO == PRO_PLAIN && MTP == 1) ? 1024 : 512; };
@@ -539,11 +574,11 @@ template <int PRO, int MTP> struct GemmMaxThreads { static constexpr int value =
 // FULL: every wave owns a whole number of 8-fragment groups and K % 256 == 0 -> straight-line code, no predicates.
 // W8 (bf16 engine, FULL only): the strip's weights are e4m3 fragment pairs (a.W8) + row scales (a.wscale) instead of a.W.
 template <typename WT, int PRO, int EPI, int MTP, bool FULL, bool W8 = false>
-__global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_strip_body(GemmArgs& a) {
   static_assert(!W8 || (FULL && sizeof(WT) == 2), "e4m3 strips: bf16 engine, FULL variant");
   constexpr int KT = Elem<WT>::KT, U = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = a.kflags >> 8;  // waves per workgroup, from the preloaded flags (not blockDim)
   const int row_bytes = a.K * (int)sizeof(WT) + 16;
   char* s_x = smem_raw;                                                                   // [rows_per_pass][row_bytes]
   float* s_red = reinterpret_cast<float*>(smem_raw + (PRO == PRO_COPY ? 0 : (size_t)a.rows_per_pass * row_bytes));  // [W][MTP][64][4]
@@ -746,6 +781,39 @@ __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_
     PTTS_STAMP(PTTS_DBG(a), 5);
     __syncthreads();
   }
+}
+
+// The two entry points of the strip GEMM. gemm_strip_kernel takes the first 56 bytes of GemmArgs as scalar parameters, which gfx950's command processor
+// preloads into SGPRs before the first wave starts (ptts_common.h), and the rest as KTail<GemmArgs>; gemm_strip_kernel_bv takes the struct by value
+// behind s_loads, as in rounds 1-5. Same body, same results. Measured on one box, preloaded | by value, us per step at mid context (profiles/
+// r06_experiments.txt call 23): 16 utterances 1100.9 | 1142.1, 32: 1200.1 | 1244.6, 64: 1540.2 | 1582.4, 128: 2384.6 | 2431.8, 32 x e4m3 weights
+// 1204.6 | 1263.5, Large-v1 x 32 2406.1 | 2457.4 (-1.9 .. -4.7 %). PTTS_STRIP_PRELOAD(PRO, EPI, FULL) picks the entry point per instance at compile
+// time: the FULL instances (every width of the released checkpoints) are preloaded; the non-FULL instances (other widths: the small golden specs of
+// the tests) keep the by-value form - see the note in launch_gemm_inst.
+#ifndef PTTS_STRIP_PRELOAD
+#define PTTS_STRIP_PRELOAD(PRO, EPI, FULL) (FULL)
+#endif
+template <typename WT, int PRO, int EPI, int MTP, bool FULL, bool W8 = false>
+__global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_kernel(PTTS_DBG0_PARAM GemmArgs_KPARAMS) {
+  PTTS_STAMP0();
+  GemmArgs_KJOIN(a)
+  gemm_strip_body<WT, PRO, EPI, MTP, FULL, W8>(a);
+}
+template <typename WT, int PRO, int EPI, int MTP, bool FULL, bool W8 = false>
+__global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_kernel_bv(PTTS_DBG0_PARAM GemmArgs a) {
+  PTTS_STAMP0();
+  a.kflags = (int)(blockDim.x >> 6) << 8;
+  gemm_strip_body<WT, PRO, EPI, MTP, FULL, W8>(a);
+}
+template <typename WT, int PRO, int EPI, int MTP, bool FULL, bool W8 = false>
+inline void launch_strip(dim3 grid, dim3 block, size_t shmem, hipStream_t st, const GemmArgs& a) {
+  if constexpr (PTTS_STRIP_PRELOAD(PRO, EPI, FULL)) ptts_klaunch(gemm_strip_kernel<WT, PRO, EPI, MTP, FULL, W8>, grid, block, shmem, st, a);
+  else hipLaunchKernelGGL((gemm_strip_kernel_bv<WT, PRO, EPI, MTP, FULL, W8>), grid, block, shmem, st, PTTS_DBG0_ARG(a) a);
+}
+template <typename WT, int PRO, int EPI, int MTP, bool FULL, bool W8 = false>
+inline const void* strip_entry() {
+  if constexpr (PTTS_STRIP_PRELOAD(PRO, EPI, FULL)) return reinterpret_cast<const void*>(&gemm_strip_kernel<WT, PRO, EPI, MTP, FULL, W8>);
+  else return reinterpret_cast<const void*>(&gemm_strip_kernel_bv<WT, PRO, EPI, MTP, FULL, W8>);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1301,7 +1369,7 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
   // The first batch is addressed from kernel arguments only (the host's bound kv_bound: rows below it exist in the arena whatever they hold; validity
   // is applied from L below, and every later batch is clamped by L itself). Clamping it by the device-resident length instead (round 5's
   // `exact_len`) measured no difference at 16 / 32 / 128 utterances (profiles/r06_experiments.txt call 14: 1248.4 vs 1248.7 us per step at 32) -
-  // the 2.9 us from entry to "first batch requested" in profiles/r06_node_stamps_bs32_bs128_raw.txt is the memory system taking the requests
+  // the 2.9 us from entry to "first batch requested" in profiles/r06_node_stamps_bs32_bs128.txt is the memory system taking the requests
   // of every workgroup at once, not the two scalar round trips; the flag is gone.
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -1985,7 +2053,8 @@ struct LnProjArgs {
 // G = 16 (round 5): two rows per wave (rows w and w + 8, both in flight), all 16 columns of the MFMA tile in use - half the weight re-reads of
 // G = 8 per utterance (the L2 traffic of the strip GEMM it replaces at 64..128 utterances).
 template <typename WT, int UW, int NF4, int G, int EPI>
-__global__ void __launch_bounds__(512) lnproj_fused_kernel(LnProjArgs a) {
+__global__ void __launch_bounds__(512) lnproj_fused_kernel(PTTS_DBG0_PARAM LnProjArgs a) {
+  PTTS_STAMP0();
   constexpr int KT = Elem<WT>::KT, NWV = 8;
   static_assert(G <= 2 * NWV, "at most two rows per wave");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

@@ -16,7 +16,7 @@ int launch(const GemmArgs& a, dim3 grid, dim3 block, size_t sh, hipStream_t st) 
     if (e != hipSuccess) { ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e)); return -2; }
     attr_once.done(attr_dev);
   }
-  hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO, EPI, MTP, true, true>), grid, block, sh, st, a);
+  ptts_klaunch(gemm_strip_kernel<bf16_t, PRO, EPI, MTP, true, true>, grid, block, sh, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { ptts_fail(PTTS_E_HIP, "e4m3 strip gemm launch failed: %s", hipGetErrorString(e)); return -2; }
   return 0;

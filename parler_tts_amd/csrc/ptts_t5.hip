@@ -316,6 +316,7 @@ struct ptts_t5 {
   bool use_fo = true, use_graph = true;
   std::set<std::string> loaded, required;
   std::map<long long, hipGraphExec_t> graphs;  // key: batch, length, masked?
+  int last_graph_nodes = 0;                    // kernel nodes of the graph captured last (ptts_t5_debug_graph_nodes)
 
   int alloc_bytes(void** p, size_t bytes) {
     void* v = nullptr;
@@ -409,7 +410,7 @@ extern "C" int ptts_t5_create(const ptts_t5_config* cfg, ptts_t5** out) {
   A(e->alloc(&e->ids, rows));
   A(e->alloc(&e->mask, rows));
 #undef A
-  e->use_fo = !(getenv("PTTS_T5_NO_FO") && atoi(getenv("PTTS_T5_NO_FO")));
+  e->use_fo = !(ptts_dev_env("PTTS_T5_NO_FO") && atoi(ptts_dev_env("PTTS_T5_NO_FO")));
   e->use_graph = !(getenv("PTTS_T5_NO_GRAPH") && atoi(getenv("PTTS_T5_NO_GRAPH")));
   e->use_fold = D % 64 == 0 && !(getenv("PTTS_T5_NO_FOLD") && atoi(getenv("PTTS_T5_NO_FOLD")));  // (a row's d_model / 16 partials are summed by 4 lanes)
   *out = e;
@@ -599,6 +600,12 @@ extern "C" int ptts_t5_load_weight(ptts_t5* e, const char* name_c, const void* d
   return ptts_fail(PTTS_E_INVALID, "unknown tensor name %s", name_c);
 }
 
+extern "C" int ptts_t5_debug_graph_nodes(ptts_t5* e, int32_t* nodes) {
+  PTTS_CHECK(e && nodes, PTTS_E_INVALID, "null argument");
+  *nodes = e->last_graph_nodes;
+  return PTTS_OK;
+}
+
 extern "C" int ptts_t5_weights_ready(ptts_t5* e) {
   PTTS_CHECK(e, PTTS_E_INVALID, "null engine");
   std::string missing;
@@ -636,10 +643,13 @@ extern "C" int ptts_t5_encode(ptts_t5* e, const int64_t* ids_dev, const int32_t*
       hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
       if (rc != PTTS_OK) { if (g) hipGraphDestroy(g); return rc; }
       if (ce != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+      size_t nn = 0;
+      if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) e->last_graph_nodes = (int)nn;
       hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
       hipGraphDestroy(g);
       if (ie != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
       if (e->graphs.size() > 64) {  // bounded: a server with many (batch, length) shapes re-captures instead of growing without limit
+        PTTS_HIP(hipStreamSynchronize(st));  // an evicted graph may still be in flight on the caller's stream
         for (auto& kv : e->graphs) hipGraphExecDestroy(kv.second);
         e->graphs.clear();
       }

@@ -312,6 +312,12 @@ class T5Engine:
             torch.cuda.current_stream(self.device).synchronize()  # the engine re-packs asynchronously; `t` must stay alive until then
         N.check(self.lib.ptts_t5_weights_ready(self._h), "ptts_t5_weights_ready")
 
+    def graph_nodes(self) -> int:
+        """Kernel nodes of the encoder graph captured last (``ptts_t5_debug_graph_nodes``; 0 before the first capture)."""
+        n = C.c_int32(0)
+        N.check(self.lib.ptts_t5_debug_graph_nodes(self._h, C.byref(n)), "ptts_t5_debug_graph_nodes")
+        return int(n.value)
+
     def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """input_ids int64 [B, N], attention_mask [B, N] or None -> float32 [B, N, d_model]: ``last_hidden_state`` with the masked
         positions zeroed (what generate() hands to the decoder, :3093-3097). Asynchronous on the current stream of the engine's device."""

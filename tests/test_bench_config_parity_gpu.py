@@ -426,35 +426,6 @@ def test_free_running_graph_path_batch_12_across_context_buckets():
     assert float((gap[free] == 0).float().mean()) >= 0.995
 
 
-@pytest.mark.parametrize("bsz,dtype", [(1, torch.float32), (3, torch.float32), (12, torch.bfloat16)])
-def test_several_steps_per_graph_launch_give_the_same_ids(bsz, dtype, monkeypatch):
-    """PTTS_GRAPH_STEPS = n: n consecutive decode steps of one 64-position context bucket are captured as ONE graph (one hipGraphLaunch
-    per n frames). Every length, position and token is device-resident, so the ids must be identical - bit for bit - to the one-step
-    graphs, across bucket boundaries (contexts 5 -> 205: three buckets, groups of 8 and the single-step remainders at the bucket
-    ends), for a call whose step count is not a multiple of n, and with early EOS rows (device-side `unfinished`)."""
-    import cases as C
-    from helpers import make_engine
-
-    spec = DO.TINY
-    sd = DO.make_decoder_weights(spec, seed=13)
-    g = torch.Generator().manual_seed(17)
-    N, P, L = 9, 4, 201
-    enc = torch.randn(bsz, N, spec.hidden_size, generator=g)
-    prompt = torch.randn(bsz, P, spec.hidden_size, generator=g) * 0.5
-    enc_mask, prompt_mask = C.ragged_masks(bsz, N, P)
-    enc = enc * enc_mask[..., None]
-    runs = {}
-    for n in (1, 8, 16):
-        monkeypatch.setenv("PTTS_GRAPH_STEPS", str(n))
-        eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=256, max_enc=16, max_prompt=8)
-        eng.set_gen_params(max_length=L, min_new_tokens=40)  # EOS allowed after 40 columns: rows finish at different steps
-        runs[n] = eng.generate_ids(enc, enc_mask, prompt, prompt_mask).cpu()
-        eng.close()
-    monkeypatch.delenv("PTTS_GRAPH_STEPS", raising=False)
-    assert runs[1].shape[0] == bsz * spec.num_codebooks
-    assert torch.equal(runs[1], runs[8]) and torch.equal(runs[1], runs[16])
-
-
 def test_e4m3_kv_cache_full_depth_128_utterances_context_460():
     """the `bs128_kv8` object of the bench line at ITS OWN shape - 24 layers at Mini-v1 widths, 128 utterances, the opt-in e4m3
     self-attention cache (ptts_config::kv_fp8), teacher-forced from a 9-position prefill across every 64-position context bucket up to context 461

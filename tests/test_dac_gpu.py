@@ -252,7 +252,7 @@ def test_errors():
 
 @pytest.mark.parametrize("fuse384", [True, False])
 def test_fused_residual_units_44khz(fuse384, monkeypatch):
-    """(fuse384 = False: PTTS_DAC_NO_FUSE_384=1 keeps the C = 384 block's units as two launches: the round-3 baseline, still a supported A/B path.)
+    """(fuse384 = False: PTTS_DAC_NO_FUSE_RES=2 keeps the C = 384 block's units as two launches: the round-3 baseline, still a supported A/B path.)
     Default bf16-operand path: the residual units of the three narrower blocks (C = 384, 192, 96) run as one launch each (k7 -> Snake -> bf16 tile in
     LDS -> k1 -> + skip -> Snake). Same arithmetic as the two-launch path up to the rounding of the intermediate to bf16 (both do it), so
     the two waveforms agree far inside the bf16 bar, and the fused one meets the bar against the fp32 oracle on its own. T = 150 frames
@@ -264,16 +264,15 @@ def test_fused_residual_units_44khz(fuse384, monkeypatch):
     codes = torch.randint(0, 1024, (2, 9, 150), generator=torch.Generator().manual_seed(8))
     ref = DA.DacOracle(spec, sd).decode(codes)
     if not fuse384:
-        monkeypatch.setenv("PTTS_DAC_NO_FUSE_384", "1")
+        monkeypatch.setenv("PTTS_DAC_NO_FUSE_RES", "2")
     d = DacEngine(max_batch=2, max_frames=160, compute_dtype=torch.bfloat16)
     d.load_state_dict(sd)
     fused = d.decode(codes.cuda()).cpu()
-    monkeypatch.setenv("PTTS_DAC_EPI_DIRECT", "1")  # read per call: the round-3 epilogue (64-byte pieces) instead of whole rows through LDS
+    # read per call: the round-3 epilogues (64-byte pieces) of the fused residual units AND of conv_lds_kernel (k7 at C = 768, transposed convs)
+    # instead of whole rows through LDS
+    monkeypatch.setenv("PTTS_DAC_EPI_DIRECT", "1")
     assert torch.equal(d.decode(codes.cuda()).cpu(), fused)  # same fp32 operations in the same order: bit-identical
     monkeypatch.delenv("PTTS_DAC_EPI_DIRECT")
-    monkeypatch.setenv("PTTS_DAC_CONV_EPI_DIRECT", "1")  # conv_lds_kernel (k7 at C = 768, transposed convs): direct epilogue instead of whole rows through LDS
-    assert torch.equal(d.decode(codes.cuda()).cpu(), fused)
-    monkeypatch.delenv("PTTS_DAC_CONV_EPI_DIRECT")
     monkeypatch.setenv("PTTS_DAC_NO_FUSE_RES", "1")  # read per call: the two-launch path of the same engine
     plain = d.decode(codes.cuda()).cpu()
     monkeypatch.delenv("PTTS_DAC_NO_FUSE_RES")

@@ -383,3 +383,34 @@ def test_dac_engine_capacities_grow_within_a_memory_bound(monkeypatch):
     assert d._get_engine(128, 2580) is big and len(made) == 4
     whole = d._get_engine(32, 100, whole_batch=True)  # chunked decode writes every utterance of the chunk in one pass
     assert whole.max_batch == 32 and whole.max_frames >= 100
+
+
+def test_library_reads_fifteen_switches():
+    """the product library reads at most 15 PTTS_* environment variables (56 in round 5), every one of them is a row of the table in
+    DESIGN.md section 6 (with the test that covers both sides) and is set by a test under tests/; everything else goes through ptts_dev_env(), which is
+    compiled out of the product build (-DPTTS_DEV_KNOBS builds only), and the built library carries no development-knob name at all."""
+    import glob
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = [f for pat in ("*.hip", "*.h", "*.inc") for f in glob.glob(os.path.join(root, "parler_tts_amd", "csrc", pat))]
+    read, dev = set(), set()
+    for f in srcs:
+        text = open(f).read()
+        read |= set(re.findall(r'(?<![a-z_])getenv\("(PTTS_[A-Z0-9_]+)"\)', text))
+        dev |= set(re.findall(r'ptts_dev_env\("(PTTS_[A-Z0-9_]+)"\)', text))
+    assert 0 < len(read) <= 15, sorted(read)
+    assert not (read & dev), sorted(read & dev)
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    rows = set(re.findall(r"^\| `(PTTS_[A-Z0-9_]+)` \|", design, flags=re.M))
+    assert rows == read, sorted(rows ^ read)
+    tests_text = "".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "test_*gpu*.py")))
+    for name in read:
+        assert f'"{name}"' in tests_text, f"{name}: no GPU test sets it"
+    from parler_tts_amd import _native as N
+
+    blob = open(N.LIB_PATH, "rb").read()
+    for name in read:
+        assert name.encode() in blob, f"{name} missing from the built library (stale build?)"
+    leaked = sorted(n for n in dev if n.encode() + b"\0" in blob)
+    assert not leaked, f"development knobs compiled into the product library: {leaked}"

@@ -347,7 +347,7 @@ def test_fused_qkv_attention_node_two_to_eight_utterances(bsz, gqa, monkeypatch)
     """qkv_attn_kernel with one grid slice per utterance (round 5): 2..8 utterances can run LN1 + q / k / v rows + split-KV self-attention +
     append as ONE node, combined per utterance by the out_proj node's GV_ATTN2 prologue (instances for 2..4 and 5..8 utterances). Default: up
     to 3 utterances (measured); PTTS_FUSE_QA_MAX=8 here so the 5..8 instances are covered too. bf16 (the fp32 engine serves one utterance on
-    this path): the fused step against the two-node step (PTTS_FUSE_QA_MULTI=0) AND both against the bf16 oracle, ragged description / prompt
+    this path): the fused step against the two-node step (PTTS_FUSE_QA_MAX=1: one utterance only) AND both against the bf16 oracle, ragged description / prompt
     masks, a short context (1 split) and a 600-position prompt (4 splits at <= 4 utterances, 2 above: second K/V batch of the attention
     loop), grouped-query attention (one writer per K/V group and utterance). That the fused node really is in the step is read off the
     captured graph: one kernel node less per layer (ptts_debug_graph_nodes) - in bf16 the two variants can agree to the last bit."""
@@ -356,11 +356,10 @@ def test_fused_qkv_attention_node_two_to_eight_utterances(bsz, gqa, monkeypatch)
         kw.update(num_key_value_heads=4, num_cross_attention_key_value_heads=2)
     spec = DO.DecoderSpec(**kw)
     sd = DO.make_decoder_weights(spec, seed=83)
-    monkeypatch.setenv("PTTS_FUSE_QA_MAX", "8")
     for P, max_ctx, steps in ((6, 200, 5), (600, 800, 3)):
         runs = {}
         for fuse in (True, False):
-            monkeypatch.setenv("PTTS_FUSE_QA_MULTI", "1" if fuse else "0")
+            monkeypatch.setenv("PTTS_FUSE_QA_MAX", "8" if fuse else "1")
             runs[fuse], ref = _teacher_forced_vs_oracle(spec, sd, torch.bfloat16, "bf16", bsz=bsz, N=21, P=P, steps=steps, masks=True, seed=11 + bsz, max_ctx=max_ctx,
                                                         return_logits=True)
         ab = max(float((a - b).abs().max()) for a, b in zip(runs[True], runs[False]))
@@ -373,7 +372,7 @@ def test_fused_qkv_attention_node_two_to_eight_utterances(bsz, gqa, monkeypatch)
     enc, prompt = torch.randn(bsz, 9, spec.hidden_size, generator=g), torch.randn(bsz, 4, spec.hidden_size, generator=g)
     nodes = {}
     for fuse in (True, False):
-        monkeypatch.setenv("PTTS_FUSE_QA_MULTI", "1" if fuse else "0")
+        monkeypatch.setenv("PTTS_FUSE_QA_MAX", "8" if fuse else "1")
         eng = make_engine(spec, sd, torch.bfloat16, max_batch=bsz, max_ctx=64, max_enc=16, max_prompt=5)
         eng.set_gen_params(max_length=12, min_new_tokens=11)
         eng.prefill(enc, None, prompt, None, sample=True)

@@ -27,7 +27,7 @@ def test_exports_every_declared_symbol():
     assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ptts_abi_version() == N.ABI_VERSION == 7
+    assert lib.ptts_abi_version() == N.ABI_VERSION == 8
 
 
 def test_invalid_config_is_value_error_not_crash():
@@ -157,10 +157,10 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
     subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", lib], capture_output=True, cwd=str(tmp_path), check=True)
     objs = [str(tmp_path / f) for f in os.listdir(tmp_path) if "amdgcn" in f]
     assert objs, "no embedded gfx950 code objects found"
-    seen, bad = 0, []
+    seen, bad, strips = 0, [], {}
     for obj in objs:
         syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--symbols", obj], capture_output=True, text=True).stdout
-        if "gemv_kernel" not in syms and "qkv_attn_kernel" not in syms:
+        if "gemv_kernel" not in syms and "qkv_attn_kernel" not in syms and "gemm_strip_kernel" not in syms:
             continue  # translation units without the step's nodes
         dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", obj], capture_output=True, text=True).stdout
         cur, head, flat = None, {}, {}
@@ -178,12 +178,23 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
             if t[0].startswith("flat_load") or t[0].startswith("flat_store"):
                 flat[cur] += 1
         for sym, ops in head.items():
-            if not re.search(r"11gemv_kernel|15qkv_attn_kernel|17xfold_attn_kernel", sym):
+            # round 6: the strip GEMM of the batch > 8 step has two entry points - the FULL instances (released checkpoint widths) on the preloaded
+            # one, everything else by value (ptts_lm_kernels.h: PTTS_STRIP_PRELOAD)
+            ms = re.match(r"_Z(17gemm_strip_kernel|20gemm_strip_kernel_bv)I[tf]Li\d+ELi\d+ELi\d+ELb([01])E", sym)
+            if ms:
+                strips[ms.group(1)] = strips.get(ms.group(1), 0) + 1
+                if (ms.group(1) == "17gemm_strip_kernel") != (ms.group(2) == "1"):
+                    bad.append((sym[:70], "strip instance on the wrong entry point", ms.groups()))
+                if ms.group(1) == "20gemm_strip_kernel_bv" and "s_branch" in ops:
+                    bad.append((sym[:70], "by-value entry point with a preload prologue", ops))
+            if not re.search(r"11gemv_kernel|15qkv_attn_kernel|17xfold_attn_kernel|_Z17gemm_strip_kernelI", sym):
                 continue
             seen += 1
             if "s_branch" not in ops or not ops[0].startswith("s_load"):
                 bad.append((sym[:60], "no preload prologue", ops))
-            if flat[sym]:
+            # (the batched cross K/V instances, PRO_COPY + EPI_KV, read their W / cache pointers from a device table: generic pointers by construction)
+            if flat[sym] and not re.match(r"_Z17gemm_strip_kernelI[tf]Li3ELi3E", sym):
                 bad.append((sym[:60], "flat memory instructions", flat[sym]))
     assert seen >= 20, seen
+    assert strips.get("17gemm_strip_kernel", 0) >= 20 and strips.get("20gemm_strip_kernel_bv", 0) >= 20, strips
     assert not bad, bad[:5]

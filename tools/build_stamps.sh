@@ -8,7 +8,7 @@ mkdir -p tools/stamps
 TORCH_LIB=$(python -c 'import torch, os; print(os.path.join(os.path.dirname(torch.__file__), "lib"))')
 pids=()
 for f in ptts_lm ptts_lm_w8 ptts_gemv_bf16 ptts_gemv_w8 ptts_gemv_f32; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DPTTS_TIMING -c parler_tts_amd/csrc/$f.hip -o tools/stamps/$f.o &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DPTTS_TIMING -mllvm -amdgpu-kernarg-preload-count=14 -c parler_tts_amd/csrc/$f.hip -o tools/stamps/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -346,11 +346,17 @@ static int report_stamps(ptts_engine* e, hipStream_t st, double step_us, int B) 
         if (v && base) { ph[i] += (double)(v - base) / tpu; ++cnt[i]; }
       }
     }
+    if (NN == 7) {  // slot 14: stamped from a PRELOADED scalar parameter before the argument struct's s_load has returned (strip / lnproj nodes)
+      double d = 0; int c14 = 0;
+      for (int l = l0; l <= l1; ++l) { const long long v14 = S(l, k, 0, 14), v0 = S(l, k, 0, 0); if (v14 && v0) { d += (double)(v0 - v14) / tpu; ++c14; } }
+      if (c14) { ph[15] = d; cnt[15] = c14; }
+    }
     if (!n) { printf("[node stamps] node %d: no stamps\n", k); continue; }
     tot_in += in_kernel / n; tot_gap += gap / n;
     printf("[node stamps] node %d %-58s first entry -> last sampled stamp %.2f us | last stamp -> next node's first entry %.2f us | workgroup 0 phases (us from its entry):", k,
            names[k], in_kernel / n, gap / n);
     for (int i = 1; i < 8; ++i) if (cnt[i]) printf(" s%d=%.2f", i, ph[i] / cnt[i]);
+    if (cnt[15]) printf(" | first instruction -> argument struct usable (s14 -> s0): %.2f us", ph[15] / cnt[15]);
     printf("\n");
   }
   printf("[node stamps] per layer: in-kernel %.2f us + boundaries %.2f us = %.2f us (x %d layers = %.1f us of the %.1f us step); a boundary = %.2f us on average\n", tot_in,

@@ -11,7 +11,7 @@ int ptts_fail(int code, const char*, ...) { return code; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <int PRO, int EPI> static void launch(const GemmArgs& a, int Wv, size_t sh, hipStream_t st) {
-  auto k = gemm_strip_kernel<bf16_t, PRO, EPI, 1, true>;
+  auto k = gemm_strip_kernel_bv<bf16_t, PRO, EPI, 1, true>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k, dim3(a.N / 16), dim3(Wv * 64), sh, st, a);
 }

@@ -89,14 +89,14 @@ int main() {
       const int mtp = rpp > 16 ? 2 : 1;
       const size_t sh = rpp * row_bytes + (size_t)Wv * mtp * 1024;
       auto launch = [&] {
-        if (cs.pro && mtp == 1) { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
-        else if (cs.pro) { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_LN, EPI_STORE, 2, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
-        else if (mtp == 1) { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
-        else { hipFuncSetAttribute((const void*)&gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          hipLaunchKernelGGL((gemm_strip_kernel<bf16_t, PRO_PLAIN, EPI_STORE, 2, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+        if (cs.pro && mtp == 1) { hipFuncSetAttribute((const void*)&gemm_strip_kernel_bv<bf16_t, PRO_LN, EPI_STORE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel_bv<bf16_t, PRO_LN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+        else if (cs.pro) { hipFuncSetAttribute((const void*)&gemm_strip_kernel_bv<bf16_t, PRO_LN, EPI_STORE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel_bv<bf16_t, PRO_LN, EPI_STORE, 2, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+        else if (mtp == 1) { hipFuncSetAttribute((const void*)&gemm_strip_kernel_bv<bf16_t, PRO_PLAIN, EPI_STORE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel_bv<bf16_t, PRO_PLAIN, EPI_STORE, 1, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
+        else { hipFuncSetAttribute((const void*)&gemm_strip_kernel_bv<bf16_t, PRO_PLAIN, EPI_STORE, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          hipLaunchKernelGGL((gemm_strip_kernel_bv<bf16_t, PRO_PLAIN, EPI_STORE, 2, true>), dim3(cs.N / 16), dim3(Wv * 64), sh, st, a); }
       };
       float us = time_launches(launch, 1000, st);
       long long t[8]; hipMemcpy(t, dbg, 64, hipMemcpyDeviceToHost);
