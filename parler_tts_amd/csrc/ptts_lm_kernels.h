@@ -1794,34 +1794,50 @@ __global__ void __launch_bounds__(256) prefill_attn_mfma_kernel(AttnArgs a) {
 // (PRO_COPY). RoPE quirk kept: q rotated, keys not (:858-859 vs :880).
 // ------------------------------------------------------------------------------------------------------
 struct XAttnArgs {
+  // ---- bytes 0..55: scalar kernel parameters, preloaded into SGPRs by the command processor (ptts_common.h; round 6) ----
   const void* W;       // packed cross q_proj [H/16][K/KT][64][16 B]
   const float* x;      // residual stream h [B][x_ld]
-  int x_ld, x_row_mul, x_row_off;
   const float* gamma;
-  const float* beta;
-  int K;               // hidden size
-  float invK;
   void* kcache;        // cross K/V [B][heads][cap][64]
   void* vcache;
+  int x_ld;
+  int K;               // hidden size
+  int B;
   int cap;
+  // ---- tail (KTail<XAttnArgs>) ----
+  int x_row_mul, x_row_off;
+  const float* beta;
+  float invK;
+  int mask_ld;
   const int* cur_len;
   const DevDims* dims;
   const int* mask;     // [B][mask_ld] or null
-  int mask_ld;
   const float* cos;
   const float* sin;
   void* out;           // [B][K] engine dtype
-  int B, nheads;
+  int nheads;
   int kv_heads, n_rep; // cross K/V heads (grouped-query attention)
   float scale;
   int out_fo;          // out in MFMA B-fragment order (fo_vec_index) for the out_proj GEMM at batch > 8
+  int xa_pad_;
   PTTS_DBG_FIELD
 };
+static_assert(sizeof(XAttnArgs) % 8 == 0 && offsetof(XAttnArgs, x_row_mul) == 56, "XAttnArgs: 56 preloaded bytes + tail");
+#define XAttnArgs_KPARAMS \
+  const void *kW_, const float *kx_, const float *kg_, void *kkc_, void *kvc_, int kxld_, int kK_, int kB_, int kcap_, KTail<XAttnArgs> kt_
+#define XAttnArgs_KJOIN(a)                                                                                   \
+  XAttnArgs a;                                                                                               \
+  PTTS_KTAIL_JOIN(XAttnArgs, a);                                                                             \
+  a.W = kW_; a.x = kx_; a.gamma = kg_; a.kcache = kkc_; a.vcache = kvc_; a.x_ld = kxld_; a.K = kK_; a.B = kB_; a.cap = kcap_;
+template <typename Kn> inline void ptts_klaunch(Kn kern, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const XAttnArgs& a) {
+  hipLaunchKernelGGL(kern, grid, block, shmem, st, a.W, a.x, a.gamma, a.kcache, a.vcache, a.x_ld, a.K, a.B, a.cap, ptts_ktail(a));
+}
 
 // G = utterances per workgroup (8: one per wave; 4 / 2: at batch > 8 the launch covers heads x ceil(B / G) workgroups - 128 / 256 at 32
 // utterances instead of 64 - and the 8 / G waves of an utterance split the description's row groups and merge through LDS).
 template <typename WT, int UW, int NF4, int G = 8>
-__global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
+__global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs_KPARAMS) {
+  XAttnArgs_KJOIN(a)
   constexpr int KT = Elem<WT>::KT, EPL = Elem<WT>::EPL, LPR = 64 / EPL, RPI = 64 / LPR, U = 8, NWV = 8;
   constexpr int WPU = NWV / G, UA = U / WPU;  // waves per utterance in the attention phase; row groups per wave and batch
   static_assert(G == 8 || G == 4 || G == 2, "utterances per workgroup");
@@ -2030,31 +2046,46 @@ __global__ void __launch_bounds__(512) xattn_fused_kernel(XAttnArgs a) {
 // EPI_STORE: fp32 [M][out_ld] (QKV); EPI_GELU_WT: gelu_erf in the engine dtype, row-major or MFMA B-fragment order (fc1 -> fc2).
 // ------------------------------------------------------------------------------------------------------
 struct LnProjArgs {
+  // ---- bytes 0..55: scalar kernel parameters, preloaded into SGPRs by the command processor (ptts_common.h; round 6: the node is on the path of every
+  // decode step above 8 utterances twice per layer and of a short prompt's prefill three times per layer) ----
   const void* W;        // packed strips [N/16][K/KT][64][16 B]
   const float* x;       // residual stream h [M][x_ld]
-  int x_ld;
   const float* gamma;
   const float* beta;
-  int K;                // hidden size (= NF4 * 256)
-  float invK;
   void* out;
+  int x_ld;
+  int K;                // hidden size (= NF4 * 256)
+  int M, N;
+  // ---- tail (KTail<LnProjArgs>) ----
+  float invK;
   int out_ld;
   int out_fo;           // EPI_GELU_WT: B-fragment order for the consumer GEMM
-  int M, N;
   // EPI_STORE at prefill (round 5): the QKV node also writes the K / V columns of its rows into the self-attention cache in the engine dtype
   // (kv_append_kernel's store for sinusoidal positions and an engine-dtype cache: one node and one kernel boundary less per layer on the
   // time-to-first-token path); null = no append
+  int kv_Q;             // rows per utterance (row m = utterance m / kv_Q, position m % kv_Q)
   void* kcache;         // [B][kv_heads][kv_cap][64]
   void* vcache;
-  int kv_Q, kv_cap, kv_heads, kv_H;  // rows per utterance (row m = utterance m / kv_Q, position m % kv_Q); columns [kv_H, kv_H + 64 kv_heads) = K, then V
+  int kv_cap, kv_heads, kv_H, kv_pad_;  // columns [kv_H, kv_H + 64 kv_heads) = K, then V
   PTTS_DBG_FIELD
 };
+static_assert(sizeof(LnProjArgs) % 8 == 0 && offsetof(LnProjArgs, invK) == 56, "LnProjArgs: 56 preloaded bytes + tail");
+#define LnProjArgs_KPARAMS \
+  const void *kW_, const float *kx_, const float *kg_, const float *kb_, void *kout_, int kxld_, int kK_, int kM_, int kN_, KTail<LnProjArgs> kt_
+#define LnProjArgs_KJOIN(a)                                                                                  \
+  LnProjArgs a;                                                                                              \
+  PTTS_KTAIL_JOIN(LnProjArgs, a);                                                                            \
+  a.W = kW_; a.x = kx_; a.gamma = kg_; a.beta = kb_; a.out = kout_; a.x_ld = kxld_; a.K = kK_; a.M = kM_; a.N = kN_;
+template <typename Kn> inline void ptts_klaunch(Kn kern, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const LnProjArgs& a) {
+  hipLaunchKernelGGL(kern, grid, block, shmem, st, PTTS_DBG0_ARG(a) a.W, a.x, a.gamma, a.beta, a.out, a.x_ld, a.K, a.M, a.N, ptts_ktail(a));
+}
 
 // G = 16 (round 5): two rows per wave (rows w and w + 8, both in flight), all 16 columns of the MFMA tile in use - half the weight re-reads of
 // G = 8 per utterance (the L2 traffic of the strip GEMM it replaces at 64..128 utterances).
 template <typename WT, int UW, int NF4, int G, int EPI>
-__global__ void __launch_bounds__(512) lnproj_fused_kernel(PTTS_DBG0_PARAM LnProjArgs a) {
+__global__ void __launch_bounds__(512) lnproj_fused_kernel(PTTS_DBG0_PARAM LnProjArgs_KPARAMS) {
   PTTS_STAMP0();
+  LnProjArgs_KJOIN(a)
   constexpr int KT = Elem<WT>::KT, NWV = 8;
   static_assert(G <= 2 * NWV, "at most two rows per wave");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

@@ -364,6 +364,20 @@ class ParlerTTSForConditionalGeneration(nn.Module):
         self.use_4dim_audio_codes = True  # model_type "dac_on_the_hub" (:2419-2422)
         self.generation_config = _default_generation_config(config)
         self._engine = None  # (property) drops every cached decoder engine
+        # the HIP engines hold PACKED COPIES of the decoder's and the text encoder's weights: loading a state dict into one of those sub-modules
+        # directly (model.text_encoder.load_state_dict(...), not through this class's load_state_dict) must drop the copies too
+        import weakref
+
+        me = weakref.ref(self)
+
+        def _drop_engines(module, incompatible_keys):
+            m = me()
+            if m is not None:
+                m._engine = None
+
+        for sub in (self.decoder, self.text_encoder):
+            if hasattr(sub, "register_load_state_dict_post_hook"):
+                sub.register_load_state_dict_post_hook(_drop_engines)
         for p in self.parameters():
             p.requires_grad_(False)
         self.eval()

@@ -181,3 +181,89 @@ def test_parity_tests_model_copy_equals_bench_build_model():
     assert got.dtype == torch.bfloat16 and got._engine is None and got is not T._MASTER[0]
     _, again, _ = T._bench_model(torch.float32, dev=torch.device("cpu"))
     assert len(T._MASTER) == 1 and again.dtype == torch.float32 and torch.equal(again.state_dict()["embed_prompts.weight"], T._MASTER[0].state_dict()["embed_prompts.weight"])
+
+
+@pytest.mark.parametrize("extra", [[], ["--model", "large", "--bs", "1"], ["--model", "large", "--dtype", "fp8w", "--bs", "4"]])
+def test_self_launch_builds_the_drivers_command_line(extra, monkeypatch):
+    """`python bench.py --gpus 8 [...]` must run unmodified when an 8-GPU node appears. Without WORLD_SIZE in the environment main()
+    re-launches itself with exactly the command the driver uses (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>), one rank per GPU, dmabuf IPC on - checked here by capturing the command instead of running it."""
+    import subprocess
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = list(cmd), dict(env)
+        return 0
+
+    argv = ["--gpus", "8", "--steps", "3", "--warmup", "1"] + extra
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:4] == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv  # the ranks see the caller's arguments, nothing added or dropped
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["PTTS_BENCH_LAUNCHED"] == "1"
+
+
+def test_gpus_flag_must_agree_with_the_process_group(monkeypatch):
+    """A launcher that starts 2 ranks while the command line says --gpus 4 is refused before any work (the line's n_gpus would otherwise lie)."""
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(ei.value.code)
+
+
+_RANK_SCRIPT = r'''
+import json, os, sys, types
+sys.path.insert(0, {root!r})
+import torch
+import bench
+import __graft_entry__ as ge
+
+class FakeModel:
+    def generate(self, **kw):
+        return torch.zeros(kw["input_ids"].shape[0], bench.FRAMES * 512)
+
+torch.cuda.is_available = lambda: True
+torch.cuda.device_count = lambda: 2
+torch.cuda.set_device = lambda i: None
+torch.cuda.synchronize = lambda *a: None
+ge.build = lambda: None
+bench.build_model = lambda rank, world, device, dtype, which="mini": FakeModel()
+bench.synthetic_batch = lambda bs, rank, device: (torch.zeros(bs, bench.N_DESC, dtype=torch.long), torch.zeros(bs, bench.N_PROMPT, dtype=torch.long))
+bench.measure_ttft = lambda model, bs, device, reps=20: 2.0 + int(os.environ["RANK"])
+bench.measure_decode_roofline = lambda model, bs, device, live_pmc=True: {{"bound": "hbm", "frac": 0.1, "live": live_pmc}}
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--bs", "3"]
+bench.main()
+'''
+
+
+def test_two_ranks_on_gloo_print_one_line_with_n_gpus_from_the_process_group(tmp_path):
+    """bench.main() as two real processes under torch.distributed.run (gloo, CPU; model and device calls stubbed): exactly ONE JSON line (rank 0's),
+    n_gpus = the process group's world size, value = the units of all ranks / the slowest rank's time, per-rank objects for both ranks, the
+    time-to-first-token of the line = the slowest rank's p50, and no profiler child passes on a multi-rank run."""
+    import socket
+    import subprocess
+
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, PTTS_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["world_size_reported_by_process_group"] == 2 and j["config"]["global_batch"] == 6 and j["config"]["backend"] == "gloo"
+    assert len(j["per_rank_ms_per_step"]) == 2 and len(j["per_rank_value"]) == 2
+    assert abs(j["value"] - 2 * 3 * 2 * bench.AUDIO_S / (max(j["per_rank_ms_per_step"]) * 2 / 1e3)) / j["value"] < 2e-3
+    assert j["per_rank_ttft_p50_ms"] == [2.0, 3.0] and j["ttft_p50_ms"] == 3.0 and j["roofline"]["live"] is False and j["scaling"] == "weak"

@@ -140,7 +140,8 @@ def test_torch_free_cxx_client_of_the_header_builds_and_links(tmp_path):
 
 
 def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
-    """The nodes of the single-utterance decode step (gemv_kernel / qkv_attn_kernel / xfold_attn_kernel) take the first 56 bytes of their argument
+    """The nodes of the single-utterance decode step (gemv_kernel / qkv_attn_kernel / xfold_attn_kernel) and, since round 6, the weight nodes of the batch > 8
+    step and of a short prompt's prefill (gemm_strip_kernel's FULL instances, lnproj_fused_kernel, xattn_fused_kernel) take the first 56 bytes of their argument
     struct as scalars and the library is built with -mllvm -amdgpu-kernarg-preload-count=14 (-3.3 % per step). What that looks like
     in the code object: a kernel with preloaded arguments starts with the 256-byte compatibility prologue for firmware without the feature -
     s_load of exactly those arguments, s_waitcnt, s_branch to the real entry - which a kernel without preload never has. Checked on the embedded
@@ -187,7 +188,7 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
                     bad.append((sym[:70], "strip instance on the wrong entry point", ms.groups()))
                 if ms.group(1) == "20gemm_strip_kernel_bv" and "s_branch" in ops:
                     bad.append((sym[:70], "by-value entry point with a preload prologue", ops))
-            if not re.search(r"11gemv_kernel|15qkv_attn_kernel|17xfold_attn_kernel|_Z17gemm_strip_kernelI", sym):
+            if not re.search(r"11gemv_kernel|15qkv_attn_kernel|17xfold_attn_kernel|_Z17gemm_strip_kernelI|_Z19lnproj_fused_kernelI|_Z18xattn_fused_kernelI", sym):
                 continue
             seen += 1
             if "s_branch" not in ops or not ops[0].startswith("s_load"):
