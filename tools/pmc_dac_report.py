@@ -8,7 +8,8 @@ fetch_db, write_db, trace_db, ndec = sys.argv[1], sys.argv[2], sys.argv[3], int(
 
 
 def short(nm):
-    return nm.split("(")[0].replace("void ", "")[:64]
+    nm = (nm or "").replace("void ", "").replace("(anonymous namespace)::", "")
+    return nm.split("(")[0][:64]
 
 
 def counters(path):
