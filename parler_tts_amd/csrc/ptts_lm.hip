@@ -416,6 +416,10 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
   // kv_append node: 24 launches of ~4 us + their boundaries off the time-to-first-token path; PTTS_KV_IN_QKV=0: the separate node)
   static const bool kv_in_qkv_on = !(ptts_dev_env("PTTS_KV_IN_QKV") && !atoi(ptts_dev_env("PTTS_KV_IN_QKV")));
   const bool kv_in_qkv = kv_in_qkv_on && prefill && lnproj_ok && !c.rope && !e->L[0].ks_self;
+  // ... and above 256 rows (a batch's prompts on the > 256-row GEMMs; round 6): the QKV projection's tile epilogue writes them (GemmArgs::kv_col0) -
+  // 24 kv_append launches of ~6 us + their boundaries off the time-to-first-token path of a batch. Between 41 and 256 rows the kv_append node stays
+  // (fragment-order rows_prep + strips: measured path of round 5).
+  const bool kv_in_gemm = kv_in_qkv_on && prefill && !kv_in_qkv && !lnproj_ok && M > 256 && !c.rope && !e->L[0].ks_self;
 #ifdef PTTS_TIMING
 #define PTTS_DBG_BIG(args, l_, k_) (args).dbg = (e->dbg_stamps && !prefill && M > 8) ? e->dbg_stamps + ((size_t)(l_) * 7 + (k_)) * 48 : nullptr
 #else
@@ -433,9 +437,10 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       GemmArgs g = {}; g.decode = dec;
       g.W = w.qkv; g.W8 = w.qkv_p8; g.wscale = w.qkv_sc; g.x = e->h; g.x_ld = H; g.x_row_mul = 1; g.gamma = w.ln1_g; g.beta = w.ln1_b;
       g.out = e->qkv; g.out_ld = QKV; g.M = M; g.N = QKV; g.K = H; g.x_fo = fo;
+      if (kv_in_gemm) { g.kcache = w.k_self; g.vcache = w.v_self; g.kv_rows_per_b = Q; g.kv_cap = c.max_ctx; g.nheads = nkv; g.kv_col0 = H; }
       PTTS_TRY((gemm_with_prologue<WT, PRO_LN, EPI_STORE>(e, g, st)));
     }
-    if (prefill && !kv_in_qkv) {
+    if (prefill && !kv_in_qkv && !kv_in_gemm) {
       bool done8 = false;
       if constexpr (sizeof(WT) == 2) {
         if (w.ks_self) {

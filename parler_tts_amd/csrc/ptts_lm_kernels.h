@@ -135,6 +135,10 @@ struct GemmArgs {
   void* vcache;
   int kv_rows_per_b;   // EPI_KV: N (rows of x per batch element)
   int kv_cap;          // EPI_KV: capacity (positions) of the cache
+  int kv_col0;         // EPI_STORE with kcache set (round 6: the prefill's QKV projection above 256 rows): output columns [kv_col0, kv_col0 + 64 nheads) are K,
+                       // the next 64 nheads V - also written into the self-attention cache rows (utterance m / kv_rows_per_b, position m % kv_rows_per_b) in
+                       // the engine dtype, as kv_append_kernel would: no kv_append node (sinusoidal positions, engine-dtype cache); 0 = off
+  int kv_pad_;
   float invK;          // 1 / K
   const float* lnstat; // PRO_LNS: [M][K/16][2] = (strip mean, strip M2) of x, written by the producer GEMM
   const KvLayer* kv_layers;  // PRO_COPY + EPI_KV: blockIdx.z selects the layer (W, kcache, vcache from this table): the description's K/V
@@ -559,6 +563,15 @@ __device__ __forceinline__ void stage_rows(const GemmArgs& a, int m0, int nrows,
   }
 }
 
+// EPI_STORE with GemmArgs::kv_col0: the K / V columns of a QKV projection row go straight into the self-attention cache (kv_append_kernel's store)
+template <typename WT>
+__device__ __forceinline__ void gemm_store_kv_cols(const GemmArgs& a, int m, int n, const f32x4& r) {
+  const int Hkv = a.nheads * 64, nn = n - a.kv_col0, isv = nn >= Hkv, n2 = isv ? nn - Hkv : nn;
+  const int head = n2 >> 6, d = n2 & 63, bu = m / a.kv_rows_per_b, pos = m - bu * a.kv_rows_per_b;
+  WT* dst = reinterpret_cast<WT*>(isv ? a.vcache : a.kcache) + (((size_t)bu * a.nheads + head) * a.kv_cap + pos) * 64 + d;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) store_from_f32<WT>(dst + e, r[e]);
+}
 // host side of the split argument list of gemm_strip_kernel (GemmArgs_KPARAMS)
 template <typename Kn> inline void ptts_klaunch(Kn kern, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const GemmArgs& a) {
   const int kflags = (a.m_split ? 1 : 0) | (a.x_fo ? 2 : 0) | ((int)(block.x >> 6) << 8);
@@ -732,6 +745,7 @@ __device__ __forceinline__ void gemm_strip_body(GemmArgs& a) {
       if (mloc < nrows) {
         if (EPI == EPI_STORE) {
           *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(r[0], r[1], r[2], r[3]);
+          if (a.kv_col0 && n >= a.kv_col0) gemm_store_kv_cols<WT>(a, m, n, r);  // (a shape the > 256-row kernels decline)
         } else if (EPI == EPI_GELU) {
           *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) =
               make_float4(gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
@@ -788,10 +802,14 @@ __device__ __forceinline__ void gemm_strip_body(GemmArgs& a) {
 // behind s_loads, as in rounds 1-5. Same body, same results. Measured on one box, preloaded | by value, us per step at mid context (profiles/
 // r06_experiments.txt call 23): 16 utterances 1100.9 | 1142.1, 32: 1200.1 | 1244.6, 64: 1540.2 | 1582.4, 128: 2384.6 | 2431.8, 32 x e4m3 weights
 // 1204.6 | 1263.5, Large-v1 x 32 2406.1 | 2457.4 (-1.9 .. -4.7 %). PTTS_STRIP_PRELOAD(PRO, EPI, FULL) picks the entry point per instance at compile
-// time: the FULL instances (every width of the released checkpoints) are preloaded; the non-FULL instances (other widths: the small golden specs of
-// the tests) keep the by-value form - see the note in launch_gemm_inst.
+// time: the FULL instances (every decoder width of the released checkpoints) are preloaded, and so are the non-FULL instances on prepared rows
+// (PRO_COPY: flan-t5-large's wo projection, K = 2816 = 88 fragments, is not a whole number of 8-fragment groups per wave for any wave count up to 8 - 24
+// nodes on the time-to-first-token path). The other non-FULL instances (fused LayerNorm / split-KV / plain prologues at widths no released checkpoint
+// has: the small golden specs of the tests) keep the by-value form: one of them - <bf16, PRO_LN, EPI_GELU, 1 tile>, 256 VGPRs and 186 spills - returns
+// NaN on the preloaded entry point and is correct by value (bisected over five builds, profiles/r06_strip_preload_bisect.txt: the PRO_COPY, PRO_PLAIN,
+// PRO_ATTN and PRO_LN + EPI_STORE families are correct on both; its prologue and s_loads read correct in the ISA; not root-caused).
 #ifndef PTTS_STRIP_PRELOAD
-#define PTTS_STRIP_PRELOAD(PRO, EPI, FULL) (FULL)
+#define PTTS_STRIP_PRELOAD(PRO, EPI, FULL) ((FULL) || (PRO) == PRO_COPY)
 #endif
 template <typename WT, int PRO, int EPI, int MTP, bool FULL, bool W8 = false>
 __global__ void __launch_bounds__((GemmMaxThreads<PRO, MTP>::value)) gemm_strip_kernel(PTTS_DBG0_PARAM GemmArgs_KPARAMS) {
@@ -829,6 +847,7 @@ template <typename WT, int EPI>
 __device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int m, int n, const f32x4& r) {
   if (EPI == EPI_STORE) {
     *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(r[0], r[1], r[2], r[3]);
+    if (a.kv_col0 && n >= a.kv_col0) gemm_store_kv_cols<WT>(a, m, n, r);
   } else if (EPI == EPI_GELU) {
     *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + n) = make_float4(gelu_erf(r[0]), gelu_erf(r[1]), gelu_erf(r[2]), gelu_erf(r[3]));
   } else if (EPI == EPI_GELU_WT) {

@@ -180,11 +180,12 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
                 flat[cur] += 1
         for sym, ops in head.items():
             # round 6: the strip GEMM of the batch > 8 step has two entry points - the FULL instances (released checkpoint widths) on the preloaded
-            # one, everything else by value (ptts_lm_kernels.h: PTTS_STRIP_PRELOAD)
-            ms = re.match(r"_Z(17gemm_strip_kernel|20gemm_strip_kernel_bv)I[tf]Li\d+ELi\d+ELi\d+ELb([01])E", sym)
+            # one (+ the non-FULL instances on prepared rows: T5's wo projection), everything else by value (ptts_lm_kernels.h: PTTS_STRIP_PRELOAD)
+            ms = re.match(r"_Z(17gemm_strip_kernel|20gemm_strip_kernel_bv)I[tf]Li(\d+)ELi\d+ELi\d+ELb([01])E", sym)
             if ms:
                 strips[ms.group(1)] = strips.get(ms.group(1), 0) + 1
-                if (ms.group(1) == "17gemm_strip_kernel") != (ms.group(2) == "1"):
+                preload_expected = ms.group(3) == "1" or ms.group(2) == "3"  # FULL, or prepared rows (PRO_COPY = 3)
+                if (ms.group(1) == "17gemm_strip_kernel") != preload_expected:
                     bad.append((sym[:70], "strip instance on the wrong entry point", ms.groups()))
                 if ms.group(1) == "20gemm_strip_kernel_bv" and "s_branch" in ops:
                     bad.append((sym[:70], "by-value entry point with a preload prologue", ops))
@@ -197,5 +198,5 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
             if flat[sym] and not re.match(r"_Z17gemm_strip_kernelI[tf]Li3ELi3E", sym):
                 bad.append((sym[:60], "flat memory instructions", flat[sym]))
     assert seen >= 20, seen
-    assert strips.get("17gemm_strip_kernel", 0) >= 20 and strips.get("20gemm_strip_kernel_bv", 0) >= 20, strips
+    assert strips.get("17gemm_strip_kernel", 0) >= 20 and strips.get("20gemm_strip_kernel_bv", 0) >= 10, strips
     assert not bad, bad[:5]
