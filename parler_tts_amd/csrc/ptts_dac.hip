@@ -45,6 +45,8 @@ struct ConvArgs {
   const int* lens;     // ragged decode (ptts_dac_decode_ragged): latent frames per utterance [B] on the device, or null. Utterance b then has
   int len_mul;         // lens[b] * len_mul valid input rows (= output rows per phase): rows beyond read as the zero padding, tiles beyond exit
   int epi_direct;      // conv_lds_kernel A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane stores 4 channels of one frame)
+  int order;           // conv_lds_kernel, transposed convs: blockIdx.x -> (utterance, phase, tile); 0: tile fastest, then phase, then utterance (rounds 2-5)
+                       // 1: phase slowest (one phase's weights at a time), 2: the phases of a tile on consecutive slots of ONE XCD (see the kernel)
 };
 
 // valid input rows of utterance b (buffers keep the full stride a.Tin)
@@ -201,7 +203,27 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & 15;
   const int ntile = (a.Tn + TF - 1) / TF;
-  const int tile = blockIdx.x % ntile, ph = (blockIdx.x / ntile) % a.nphase, b = blockIdx.x / (ntile * a.nphase);
+  // Which (utterance, phase, tile) a workgroup owns (round 6; the same work per workgroup in every order: outputs bit-identical). The phases of a
+  // transposed conv read the SAME input tile with DIFFERENT weights, and profiles/r06_pmc_dac_bs32.txt showed what the tile-fastest order costs: the
+  // 2-8 phases of a tile run ntile workgroups apart (other XCDs, other times), so the input is fetched once per phase (5.6 GB for 2.7 at the last
+  // transposed conv), and ~9 (utterance, phase) groups are in flight at once, so all 8 phases' weights (4.7-9.4 MB per column group at the two
+  // stride-8 layers) cycle through a 4 MB L2 (8.6 GB fetched for 0.3 GB of input).
+  //   order 2 (all phases' weights <= 2 MB): workgroups are dealt to the 8 XCDs round-robin by linear id, so slot s = id / 8 of XCD id % 8 takes phase
+  //           s % nphase of tile (s / nphase) * 8 + xcd: the phases of a tile are neighbours in ONE XCD's queue and share its L2 copy of the input.
+  //   order 1 (heavier weights): the phase is the slowest index - one phase's weights at a time stay L2-resident; the input is re-read per phase.
+  int tile, ph, b;
+  if (a.order == 2) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    ph = slot % a.nphase;
+    const int tl = (slot / a.nphase) * 8 + xcd;
+    if (tl >= ntile * a.B) return;
+    b = tl / ntile; tile = tl - b * ntile;
+  } else if (a.order == 1) {
+    const int per = ntile * a.B, r = blockIdx.x % per;
+    ph = blockIdx.x / per; b = r / ntile; tile = r - b * ntile;
+  } else {
+    tile = blockIdx.x % ntile; ph = (blockIdx.x / ntile) % a.nphase; b = blockIdx.x / (ntile * a.nphase);
+  }
   const int nstrips = a.Cout / 16;
   const int strip0 = (blockIdx.y * NW + wave) * CSW;
   const int cpt = a.Cin / 32, nk = a.ntaps * cpt;
@@ -444,6 +466,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 // HBM traffic drops from 16 to 12 bytes per element (no bf16 round trip of y) and one launch per unit goes away (per-layer table,
 // profiles/r02_dac_layers.txt: k7 + k1 = 339 us at C = 192, 260 us at C = 96, the k1 half bound by its epilogue traffic).
 // Phase A is conv_lds_kernel<3, NW, 1, 54>'s loop; the y tile overlays the two slab buffers once the last chunk's barrier has passed.
+// weight prefetch depth of the XIN instances per width (registers: an XIN unit stages twice the bytes per slab slot)
+template <int NW> struct ResunitXinWD { static constexpr int value = NW == 2 ? 1 : 3; };
 struct ResArgs {
   ConvArgs a;           // the k7 conv (x, Wp, bias, alpha = Snake between the two convs, dil, pad, B, Tin, Cin = Cout = C)
   const void* Wp1;      // k1 weights, packed [C/16][C/32][64][8 bf16]
@@ -454,6 +478,7 @@ struct ResArgs {
   void* out_act;        // activated output, bf16 (fp32 if act_f32): NOT the buffer x lives in (neighbouring tiles read x's halo rows)
   int act_f32;
   int epi_direct;       // A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane owns 4 channels of one frame: 64-byte pieces of the stream)
+  const float* alpha_in;  // XIN instances: [alpha | 1 / (alpha + 1e-9)] of the Snake that turns the fp32 stream `a.x` into this unit's input activation
 };
 
 // dynamic LDS of resunit_lds_kernel<NW>: the two slab buffers of phase A, overlaid by the y tile [128 frames][C bf16 + pad] of phase B
@@ -461,7 +486,8 @@ struct ResArgs {
 template <int NW, int KS = 1> struct ResunitLds {
   static constexpr int C = NW * 3 * 16, slabs = 2 * (128 + 54) * (KS * 64 + 32), ytile = 128 * (C * 2 + 32);
   static constexpr int etile = 64 * (C * 4 + 16);  // epilogue: half of the output tile as fp32 rows (16 bytes of padding: the 16 frames of one store hit 16 different bank groups)
-  static constexpr int bytes0 = slabs > ytile ? slabs : ytile;
+  static constexpr int ain = slabs + 2 * C * 4;  // XIN instances: the input Snake's [alpha | 1 / alpha] behind the two slabs
+  static constexpr int bytes0 = ain > ytile ? ain : ytile;
   static constexpr int bytes = bytes0 > etile ? bytes0 : etile;
 };
 // KS: 32-channel k-steps per staged chunk (1: 64-byte slab rows, the round-3 form; 2 for C >= 192: twice the bytes in flight per staging
@@ -472,7 +498,12 @@ template <int NW, int KS = 1> struct ResunitLds {
 // 32 KB L1 shared by 8 waves), so every k-step waited for its weights: MFMA pipe 23-28 % busy (profiles/r03_pmc_dac_mfma.txt).
 // RAW / F32 (round 5): does the launch write the fp32 stream, and is the activation written as fp32 (the unit feeding the final conv)? Compile-time,
 // so that the epilogue's pass over a whole half tile is ONE straight-line block (see there).
-template <int NW, int KS = 1, int WD = 3, bool RAW = true, bool F32 = false>
+// XIN / ACT (round 6): the codec is HBM-bound at batch 32 (profiles/r06_pmc_dac_bs32.txt: 195.7 GB per decode, the C = 96 units at 4.5-4.6 TB/s), so bytes
+// are what is left to cut. An XIN unit takes its input straight from the fp32 residual stream (`a.x` = `skip`): the Snake of the PREVIOUS layer's
+// output is evaluated on the way into the LDS slab (same function on the same fp32 values, rounded to bf16 once: bit-identical to reading the bf16
+// activation the producer would have written), and a producer whose consumer is an XIN unit does not write that activation at all (ACT = false):
+// per element and unit 12 C -> ~9.7 C bytes (halo rows of the stream are fp32 now, the bf16 copy is neither written nor read).
+template <int NW, int KS = 1, int WD = 3, bool RAW = true, bool F32 = false, bool XIN = false, bool ACT = true>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) resunit_lds_kernel(ResArgs ra) {
   constexpr int CSW = 3, FT = 8, TF = FT * 16, MAXHALO = 54;
   constexpr int C = NW * CSW * 16;
@@ -499,7 +530,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   const int o0 = -a.pad;
   const int halo = (a.ntaps - 1) * a.dil;
   const int nslot = (TF + halo) * SL;
-  const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)b * a.Tin * C * 2;
+  const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)b * a.Tin * C * (XIN ? 4 : 2);
+  float* s_ain = reinterpret_cast<float*>(lds + 2 * MAXROWS * RS);  // XIN: [2][C]
+  if constexpr (XIN) {
+    for (int i = tid; i < 2 * C / 4; i += NT) reinterpret_cast<float4*>(s_ain)[i] = reinterpret_cast<const float4*>(ra.alpha_in)[i];
+    __syncthreads();
+  }
   const float4* Wp = reinterpret_cast<const float4*>(a.Wp) + (size_t)strip0 * nk * 64 + lane;
   const int lrow = j * RS + q * 16;
   unsigned char* slab0 = lds;
@@ -511,18 +547,46 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
     for (int f = 0; f < FT; ++f) acc[s][f] = f32x4{0, 0, 0, 0};
 
-  uint4 stg[NST];
+  // a staged 16-byte slot = 8 bf16 channels of one frame: 16 bytes of the bf16 activation, or (XIN) 32 bytes of the fp32 stream that become those 16
+  // bytes at commit time (Snake, rounded once); rows outside the utterance read as zeros either way (Snake(0) = 0: the conv's zero padding)
+  uint4 stg[XIN ? 2 * NST : NST];
 #define RU_SLAB_FETCH(CC)                                                                                               \
   _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
     const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL, ti_ = t0 + o0 + r_;                              \
-    stg[i_] = make_uint4(0, 0, 0, 0);                                                                                    \
-    if (idx_ < nslot && ti_ >= 0 && ti_ < Tv)                                                                             \
-      stg[i_] = *reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * C + (size_t)(CC) * KCH) * 2 + sl_ * 16);               \
+    const bool ok_ = idx_ < nslot && ti_ >= 0 && ti_ < Tv;                                                                \
+    if constexpr (XIN) {                                                                                                  \
+      stg[2 * i_] = make_uint4(0, 0, 0, 0); stg[2 * i_ + 1] = make_uint4(0, 0, 0, 0);                                     \
+      if (ok_) {                                                                                                          \
+        const uint4* p_ = reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * C + (size_t)(CC) * KCH) * 4 + sl_ * 32);     \
+        stg[2 * i_] = p_[0]; stg[2 * i_ + 1] = p_[1];                                                                     \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      stg[i_] = make_uint4(0, 0, 0, 0);                                                                                   \
+      if (ok_) stg[i_] = *reinterpret_cast<const uint4*>(xb + ((size_t)ti_ * C + (size_t)(CC) * KCH) * 2 + sl_ * 16);     \
+    }                                                                                                                     \
   }
-#define RU_SLAB_COMMIT(BUFP)                                                                                            \
-  _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                    \
-    const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL;                                                  \
-    if (idx_ < nslot) *reinterpret_cast<uint4*>((BUFP) + r_ * RS + sl_ * 16) = stg[i_];                                    \
+#define RU_SLAB_COMMIT(BUFP, CC)                                                                                        \
+  {                                                                                                                     \
+    float4 al0_, al1_, ia0_, ia1_;                                                                                        \
+    if constexpr (XIN) {  /* the thread's slot column is the same for every i_ (NT % SL == 0): 8 channels of chunk CC */   \
+      const float* ap_ = s_ain + (CC) * KCH + (tid % SL) * 8;                                                             \
+      al0_ = *reinterpret_cast<const float4*>(ap_); al1_ = *reinterpret_cast<const float4*>(ap_ + 4);                      \
+      ia0_ = *reinterpret_cast<const float4*>(ap_ + C); ia1_ = *reinterpret_cast<const float4*>(ap_ + C + 4);              \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < NST; ++i_) {                                                                  \
+      const int idx_ = tid + i_ * NT, r_ = idx_ / SL, sl_ = idx_ - r_ * SL;                                                \
+      uint4 v_;                                                                                                           \
+      if constexpr (XIN) {                                                                                                \
+        const uint4 lo_ = stg[2 * i_], hi_ = stg[2 * i_ + 1];                                                             \
+        v_ = make_uint4(pack_bf16x2(snake_f<true>(__uint_as_float(lo_.x), al0_.x, ia0_.x), snake_f<true>(__uint_as_float(lo_.y), al0_.y, ia0_.y)), \
+                        pack_bf16x2(snake_f<true>(__uint_as_float(lo_.z), al0_.z, ia0_.z), snake_f<true>(__uint_as_float(lo_.w), al0_.w, ia0_.w)), \
+                        pack_bf16x2(snake_f<true>(__uint_as_float(hi_.x), al1_.x, ia1_.x), snake_f<true>(__uint_as_float(hi_.y), al1_.y, ia1_.y)), \
+                        pack_bf16x2(snake_f<true>(__uint_as_float(hi_.z), al1_.z, ia1_.z), snake_f<true>(__uint_as_float(hi_.w), al1_.w, ia1_.w))); \
+      } else {                                                                                                            \
+        v_ = stg[i_];                                                                                                     \
+      }                                                                                                                   \
+      if (idx_ < nslot) *reinterpret_cast<uint4*>((BUFP) + r_ * RS + sl_ * 16) = v_;                                       \
+    }                                                                                                                     \
   }
 #define RU_W_FETCH(WF, CC, S)                                                                                           \
   do {                                                                                                                  \
@@ -552,7 +616,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     if (!lastst_) RU_B_FETCH(bA, sb_, st + 1, 0);                                                                         \
     RU_MFMA_HALF(WC, bB, 4)                                                                                               \
     if (lastst_) {                                                                                                        \
-      if (more_) { RU_SLAB_COMMIT(nb_); }                                                                                 \
+      if (more_) { RU_SLAB_COMMIT(nb_, c + 1); }                                                                          \
       __syncthreads();                                                                                                    \
       if (more_) RU_B_FETCH(bA, nb_, 0, 0);                                                                               \
       ++c;                                                                                                                \
@@ -571,7 +635,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     RU_W_FETCH(w2, (2 < total ? 2 : 0) / NS, (2 < total ? 2 : 0) % NS);
   }
   RU_SLAB_FETCH(0);
-  RU_SLAB_COMMIT(slab0);
+  RU_SLAB_COMMIT(slab0, 0);
   __syncthreads();
   RU_B_FETCH(bA, slab0, 0, 0);
   int c = 0, st = 0, gi = 0;
@@ -661,7 +725,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
     static_assert(ResunitLds<NW, KS>::bytes >= 64 * RSE + 2 * C * 4, "LDS: half output tile + the output Snake's parameters");
     float* s_al = reinterpret_cast<float*>(lds + 64 * RSE);  // [2][C]
     __syncthreads();  // every wave has finished reading the y tile
-    for (int i = tid; i < 2 * C / 4; i += NT) reinterpret_cast<float4*>(s_al)[i] = reinterpret_cast<const float4*>(ra.alpha1)[i];
+    if constexpr (ACT)
+      for (int i = tid; i < 2 * C / 4; i += NT) reinterpret_cast<float4*>(s_al)[i] = reinterpret_cast<const float4*>(ra.alpha1)[i];
     // (requesting the residual rows before the transposition, and the second half's as the first half's registers free up, measured SLOWER:
     //  C = 96 unit 4228 -> 4735 us, profiles/r04_experiments.txt call 7; they are requested after the tile's barrier, 12 loads at once)
 #pragma unroll
@@ -692,10 +757,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
         const size_t o = base + (size_t)i * 4;  // the rows of a tile are contiguous in memory: i * 4 == rr * C + cv * 4
         const float4 v = make_float4(av.x + sk.x, av.y + sk.y, av.z + sk.z, av.w + sk.w);
         if constexpr (RAW) *reinterpret_cast<float4*>(ra.out_raw + o) = v;
-        const float4 al = *reinterpret_cast<const float4*>(s_al + cv * 4), ia = *reinterpret_cast<const float4*>(s_al + C + cv * 4);
-        const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
-        if constexpr (!F32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
-        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
+        if constexpr (ACT) {  // ACT = false: the consumer is an XIN unit and evaluates this Snake itself, out of the stream
+          const float4 al = *reinterpret_cast<const float4*>(s_al + cv * 4), ia = *reinterpret_cast<const float4*>(s_al + C + cv * 4);
+          const float4 sv = make_float4(snake_f<true>(v.x, al.x, ia.x), snake_f<true>(v.y, al.y, ia.y), snake_f<true>(v.z, al.z, ia.z), snake_f<true>(v.w, al.w, ia.w));
+          if constexpr (!F32) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(ra.out_act) + o) = make_uint2(pack_bf16x2(sv.x, sv.y), pack_bf16x2(sv.z, sv.w));
+          else *reinterpret_cast<float4*>(reinterpret_cast<float*>(ra.out_act) + o) = sv;
+        }
       };
       if (rows == 64) {
         const float* sb_ = ra.skip + base;
@@ -1378,7 +1445,11 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
     static const bool ft4_on = !(ptts_dev_env("PTTS_DAC_NO_FT4") && atoi(ptts_dev_env("PTTS_DAC_NO_FT4")));
     const bool ft4 = ft4_on && nw == 4 && (long long)((a.Tn + 127) / 128) * a.nphase * B * (nstrips / (3 * nw)) < 320;
     const int tfr = ft4 ? 64 : 128;
-    const dim3 grid((unsigned)(((a.Tn + tfr - 1) / tfr) * a.nphase * B), (unsigned)(nstrips / (3 * nw)));
+    // block order of the transposed convs (see conv_lds_kernel): by the weight bytes one column group's phases need together
+    static const int up_order = ptts_dev_env("PTTS_DAC_UP_ORDER") ? atoi(ptts_dev_env("PTTS_DAC_UP_ORDER")) : -1;
+    if (a.transposed && a.nphase > 1) a.order = up_order >= 0 ? up_order : ((size_t)a.nphase * a.ntaps * a.Cin * (3 * nw * 16) * 2 <= (2u << 20) ? 2 : 1);
+    const unsigned ntb = (unsigned)(((a.Tn + tfr - 1) / tfr) * B);
+    const dim3 grid(a.order == 2 ? (ntb + 7) / 8 * 8 * a.nphase : ntb * a.nphase, (unsigned)(nstrips / (3 * nw)));
     bool done = true;
     if (a.ntaps > 2 && halo <= 54 && a.Cin % 32 == 0) {
       if (nw == 4 && ft4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 1, 54, 4>), grid, dim3(256), 0, st, a);
@@ -1445,42 +1516,77 @@ static bool resunit_fusable(const ConvLayer& c7, const ConvLayer& c1) {
          c7.Cin == c7.Cout && c1.Cin == c7.Cout && c1.Cout == c7.Cout && (c7.Cout == 192 || c7.Cout == 96 || (c7.Cout == 384 && fuse384)) && 6 * c7.dil <= 54 &&
          c7.alpha && c1.alpha;
 }
+// Which widths run their residual units as XIN units (input = the fp32 stream, see resunit_lds_kernel): bit 0: C = 96, bit 1: C = 192, bit 2: C = 384.
+// Measured on MI355X (profiles/r06_dac_xin_ab.txt, ms per decode, mask 0 | 1 | 3 | 7): 32 x 860 frames 56.16 | 54.86 | 54.35 | 53.99, one utterance
+// 2.409 | 2.316 | 2.335 | 2.349 - the wider units gain only where the launch is bandwidth-bound, hence by the latent frames of the call.
+// PTTS_DAC_XIN=<mask> is read per call (a test switches it inside one process: every mask gives the same bits).
+static bool resunit_xin_width(int C, long long frames) {
+  const char* ev = getenv("PTTS_DAC_XIN");
+  const int m = ev ? atoi(ev) : (frames >= 8 * 860 ? 7 : 1);
+  return (C == 96 && (m & 1)) || (C == 192 && (m & 2)) || (C == 384 && (m & 4));
+}
+// `alpha_in` != null: an XIN unit - x is the fp32 stream (= skip) and alpha_in the [alpha | 1 / alpha] of the Snake in front of the unit; out_raw must
+// then be a DIFFERENT buffer (neighbouring workgroups read x's halo rows). out_act may be null for a unit whose consumer is an XIN unit.
 static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, const float* skip, float* out_raw, void* out_act, int B, int T,
-                       hipStream_t st, bool act_f32, const int* lens = nullptr, int len_mul = 1) {
+                       hipStream_t st, bool act_f32, const int* lens = nullptr, int len_mul = 1, const float* alpha_in = nullptr) {
   ResArgs r = {};
   r.a.lens = lens; r.a.len_mul = len_mul;
   r.a.x = x; r.a.Wp = c7.Wp; r.a.bias = c7.bias; r.a.alpha = c7.alpha; r.a.dil = c7.dil; r.a.pad = (c7.ksize - 1) * c7.dil / 2;
   r.a.B = B; r.a.Tin = T; r.a.Tn = T; r.a.Cin = c7.Cin; r.a.Cout = c7.Cout; r.a.ntaps = 7; r.a.nphase = 1; r.a.stride = 1;
   r.Wp1 = c1.Wp; r.bias1 = c1.bias; r.alpha1 = c1.alpha; r.skip = skip; r.out_raw = out_raw; r.out_act = out_act; r.act_f32 = act_f32 ? 1 : 0;
+  r.alpha_in = alpha_in;
   {
     const char* ed = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process, like PTTS_DAC_NO_FUSE_RES)
     r.epi_direct = (ed && atoi(ed)) ? 1 : 0;
   }
   const dim3 grid((unsigned)(((T + 127) / 128) * B));
-  // instances by (width, stream written?, fp32 activation?): compile-time in the kernel (its epilogue is straight-line code). The two-register-set
-  // weight prefetch (WD = 1, round 3) is no longer instantiated.
-  if (!out_act) return ptts_fail(PTTS_E_INVALID, "residual unit: no activation output");
-  const bool raw = out_raw != nullptr;
+  // instances by (width, stream written?, fp32 activation?, input from the stream?, activation written?): compile-time in the kernel (its epilogue is
+  // straight-line code). The two-register-set weight prefetch (WD = 1, round 3) serves the XIN instances at C = 96 (registers: see the kernel).
+  const bool raw = out_raw != nullptr, xin = alpha_in != nullptr, act = out_act != nullptr;
+  if (!act && !(xin && raw)) return ptts_fail(PTTS_E_INVALID, "residual unit: no activation output");
+  if (xin && ((const void*)skip != x || (const void*)out_raw == x || r.epi_direct))
+    return ptts_fail(PTTS_E_INVALID, "residual unit on the stream: x must be the skip buffer, out_raw another one, whole-row epilogue");
   if (act_f32 && c7.Cout != 96) return ptts_fail(PTTS_E_UNSUPPORTED, "residual unit: fp32 activations only at the last block's width");
 #define PTTS_RU_LAUNCH(NWV, RAWV, F32V) \
   hipLaunchKernelGGL((resunit_lds_kernel<NWV, 1, 3, RAWV, F32V>), grid, dim3(NWV * 64), (ResunitLds<NWV, 1>::bytes), st, r)
+#define PTTS_RU_LAUNCH_XIN(NWV, RAWV, F32V, ACTV) \
+  hipLaunchKernelGGL((resunit_lds_kernel<NWV, 1, ResunitXinWD<NWV>::value, RAWV, F32V, true, ACTV>), grid, dim3(NWV * 64), (ResunitLds<NWV, 1>::bytes), st, r)
+  // (stream written, activation written) of an XIN unit: (1, 0) units 1 and 2 of a block, (0, 1) unit 3, (1, 1) the parity probe's stop stage
+#define PTTS_RU_XIN_BY_OUT(NWV, F32V)                                   \
+  do {                                                                  \
+    if (raw && !act) PTTS_RU_LAUNCH_XIN(NWV, true, false, false);       \
+    else if (raw) PTTS_RU_LAUNCH_XIN(NWV, true, F32V, true);            \
+    else PTTS_RU_LAUNCH_XIN(NWV, false, F32V, true);                    \
+  } while (0)
   if (c7.Cout == 384) {
     static PttsPerDeviceOnce attr_once;  // 100 KB of dynamic LDS needs the opt-in
     const int attr_dev = PttsPerDeviceOnce::device();
     if (attr_once.need(attr_dev)) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
-      if (ea == hipSuccess) ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
-      if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea));
+      constexpr int WDX = ResunitXinWD<8>::value;
+      const void* fns[] = {reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3, true, false>), reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, 3, false, false>),
+                           reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, WDX, true, false, true, false>),
+                           reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, WDX, true, false, true, true>),
+                           reinterpret_cast<const void*>(&resunit_lds_kernel<8, 1, WDX, false, false, true, true>)};
+      for (const void* fn : fns) {
+        const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ResunitLds<8, 1>::bytes);
+        if (ea != hipSuccess) return ptts_fail(PTTS_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(ea));
+      }
       attr_once.done(attr_dev);
     }
-    if (raw) PTTS_RU_LAUNCH(8, true, false); else PTTS_RU_LAUNCH(8, false, false);
+    if (xin) PTTS_RU_XIN_BY_OUT(8, false);
+    else if (raw) PTTS_RU_LAUNCH(8, true, false); else PTTS_RU_LAUNCH(8, false, false);
   } else if (c7.Cout == 192) {
-    if (raw) PTTS_RU_LAUNCH(4, true, false); else PTTS_RU_LAUNCH(4, false, false);
+    if (xin) PTTS_RU_XIN_BY_OUT(4, false);
+    else if (raw) PTTS_RU_LAUNCH(4, true, false); else PTTS_RU_LAUNCH(4, false, false);
   } else if (act_f32) {
-    if (raw) PTTS_RU_LAUNCH(2, true, true); else PTTS_RU_LAUNCH(2, false, true);
+    if (xin) PTTS_RU_XIN_BY_OUT(2, true);
+    else if (raw) PTTS_RU_LAUNCH(2, true, true); else PTTS_RU_LAUNCH(2, false, true);
   } else {
-    if (raw) PTTS_RU_LAUNCH(2, true, false); else PTTS_RU_LAUNCH(2, false, false);
+    if (xin) PTTS_RU_XIN_BY_OUT(2, false);
+    else if (raw) PTTS_RU_LAUNCH(2, true, false); else PTTS_RU_LAUNCH(2, false, false);
   }
+#undef PTTS_RU_XIN_BY_OUT
+#undef PTTS_RU_LAUNCH_XIN
 #undef PTTS_RU_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "residual-unit launch failed: %s", hipGetErrorString(e));
@@ -1525,15 +1631,32 @@ static int dac_decode_window(ptts_dac* d, const int64_t* codes_dev, long long ld
   if (stop_here(nullptr, d->convs[0].Cout, false)) return PTTS_OK;
   for (int bi = 0; bi < c.num_rates; ++bi) {
     const ConvLayer& up = d->convs[li++];
-    PTTS_TRY(run_conv(d, up, cur, nullptr, d->bufY, other, B, Tcur, st, false, lens, mul));
+    // XIN block (round 6): all three units fused and this width enabled - the units read the fp32 stream (bufY / bufS in turns; bufS is otherwise only
+    // the un-fused units' y) and evaluate the Snake in front of them on the way into LDS; nobody writes a bf16 activation but the block's last unit
+    // (and the parity probe's stop stage, whose outputs the test reads). Same values, bit for bit.
+    bool xin = up.alpha != nullptr && resunit_xin_width(up.Cout, (long long)B * T);
+    for (int ri = 0; ri < 3 && xin; ++ri) xin = resunit_fusable(d->convs[li + 2 * ri], d->convs[li + 2 * ri + 1]);
+    const bool up_act = !xin || (dbg && stage == stop_stage);
+    PTTS_TRY(run_conv(d, up, cur, nullptr, d->bufY, up_act ? other : nullptr, B, Tcur, st, false, lens, mul));
     std::swap(cur, other);
     Tcur *= up.stride;
     mul *= up.stride;
     if (stop_here(d->bufY, up.Cout, false)) return PTTS_OK;
+    float *s_in = d->bufY, *s_out = d->bufS;  // XIN: the stream before / after the next unit
+    const float* alpha_in = up.alpha;
     for (int ri = 0; ri < 3; ++ri) {
       const ConvLayer& c7 = d->convs[li++];
       const ConvLayer& c1 = d->convs[li++];
       const bool last = bi + 1 == c.num_rates && ri == 2;  // feeds the final Conv1d(C -> 1): fp32 activations
+      if (xin) {
+        const bool want_raw = ri < 2 || dbg, want_act = ri == 2 || (dbg && stage == stop_stage);
+        PTTS_TRY(run_resunit(c7, c1, s_in, s_in, want_raw ? s_out : nullptr, want_act ? other : nullptr, B, Tcur, st, last, lens, mul, alpha_in));
+        if (want_act) std::swap(cur, other);
+        if (want_raw) std::swap(s_in, s_out);
+        alpha_in = c1.alpha;
+        if (stop_here(s_in, c1.Cout, last)) return PTTS_OK;
+        continue;
+      }
       float* raw_out = (c1.write_raw || dbg) ? d->bufY : nullptr;  // the parity probe also wants the stream after a block's last unit (same arithmetic, one more store)
       if (resunit_fusable(c7, c1)) {  // both convs in one launch; the output goes to the OTHER activation buffer
         PTTS_TRY(run_resunit(c7, c1, cur, d->bufY, raw_out, other, B, Tcur, st, last, lens, mul));

@@ -29,9 +29,14 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
   constexpr int RB = KF * 64, SPR = RB / 16, RPP = 1024 / RB;  // activation image: bytes per row, 16-byte slots per row, rows per 1 KiB piece
   constexpr int NW = WN * WM, NS = BNS / WN, MT = BMT / WM;
   constexpr int APC = BNS * KF, BPC = BMT * KF;           // 1 KiB pieces per stage: weights, activations
-  constexpr int PPW = (APC + BPC) / NW, APW = APC / NW;   // pieces per wave and stage (the first APW of them weight pieces)
-  static_assert(APC % NW == 0 && BPC % NW == 0 && BNS % WN == 0 && BMT % WM == 0, "tile / wave split");
+  // pieces per wave and stage (the first APW of them weight pieces). EVEN: every wave moves the same pieces per stage, weights first; otherwise
+  // (tiles such as 176 weight rows: 22 + 32 pieces on 8 waves) piece p = wave + NW * i is a weight piece iff p < APC, decided per wave at run time, and a
+  // wave without an i-th piece fetches its (i - 1)-th again (same source, same destination: the per-wave load count stays a compile-time constant)
+  constexpr bool EVEN = APC % NW == 0 && BPC % NW == 0;
+  constexpr int PPW = (APC + BPC + NW - 1) / NW, APW = APC / NW;
+  static_assert(BNS % WN == 0 && BMT % WM == 0, "tile / wave split");
   static_assert((NST - 2) * PPW <= 63 && NST >= 2, "vmcnt is a 6-bit counter");
+  static_assert(RP != 2 || NST >= 3, "the half-stage pipeline reads stage t + 1 while stage t computes");
   constexpr int STAGE_B = (APC + BPC) * 1024;
   extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave % WN, wm = wave / WN;
@@ -45,10 +50,15 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
   const int nfrag = a.K >> 5, nstage = nfrag / KF;        // host guarantees K % 64 == 0
   // this wave's pieces: piece p = wave + NW * i; p < APC: fragment p % KF of strip p / KF, else rows 8 (p - APC) .. + 7 of the row tile
   const char* src[PPW];
+  int adv[PPW], pdst[PPW];  // !EVEN: bytes per stage the piece's source advances by, and its LDS slot
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int p = wave + NW * i;
-    if (i < APW) {
+    int p = wave + NW * i;
+    if constexpr (!EVEN) { if (p >= APC + BPC) p -= NW; }
+    const bool wpiece = EVEN ? i < APW : p < APC;
+    adv[i] = wpiece ? KF * 1024 : KF * 64;
+    pdst[i] = p * 1024;
+    if (wpiece) {
       src[i] = reinterpret_cast<const char*>(a.W) + ((size_t)(strip0 + p / KF) * nfrag + p % KF) * 1024 + lane * 16;
     } else {
       const int rl = (p - APC) * RPP + lane / SPR;            // row of the tile; its image slot lane % SPR holds piece slot ^ (row & (SPR - 1))
@@ -60,9 +70,14 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
     if constexpr (ABL == 2) return;
     char* dst = smem_raw + buf * STAGE_B + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src[i] + (size_t)t * (i < APW ? KF * 1024 : KF * 64)),
-                                       (__attribute__((address_space(3))) void*)(dst + NW * i * 1024), 16, 0, 0);
+    for (int i = 0; i < PPW; ++i) {
+      if constexpr (EVEN)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src[i] + (size_t)t * (i < APW ? KF * 1024 : KF * 64)),
+                                         (__attribute__((address_space(3))) void*)(dst + NW * i * 1024), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src[i] + (size_t)t * adv[i]),
+                                         (__attribute__((address_space(3))) void*)(smem_raw + buf * STAGE_B + pdst[i]), 16, 0, 0);
+    }
   };
   f32x4 acc[NS][MT];
 #pragma unroll
@@ -79,6 +94,55 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
   for (int t = 0; t < NST - 1; ++t)
     if (t < nstage) issue(t, t);
   int buf = 0;
+  if constexpr (RP == 2 && ABL == 0) {
+    // Half-stage software pipeline for ONE resident workgroup per CU (tiles of ~1 / 256 of the output: nobody else fills the MFMA pipe while this
+    // workgroup's waves wait for their fragments): the reads of a stage's second half are issued before the MFMAs of its first half, and the reads of
+    // the NEXT stage's first half before the MFMAs of the second - so the top-of-iteration barrier is for stage t + 1 (landed for every wave), and at most
+    // NST - 3 later stages stay in flight across it. Same MFMA order per accumulator (fragments ascending): bit-identical to the other variants.
+    static_assert(KF == 2, "two halves per stage");
+    u32x4_t a0[NS], b0[MT], a1[NS], b1[MT];
+    auto reads = [&](const char* cur, const int f, u32x4_t (&af)[NS], u32x4_t (&bf)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const u32x4_t*>(cur + a_off + (s * KF + f) * 1024);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = *reinterpret_cast<const u32x4_t*>(cur + b_off[f] + mt * 16 * RB);
+    };
+    auto mfmas = [&](const u32x4_t (&af)[NS], const u32x4_t (&bf)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[s][mt] = mfma_step_v<WT>(af[s], bf[mt], acc[s][mt]);
+    };
+    // stage 0 landed (for every wave) before its first half is read
+    if (nstage - 1 >= NST - 2) ptts_wait_vmcnt<(NST - 2) * PPW>(); else ptts_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    reads(smem_raw, 0, a0, b0);
+    for (int t = 0; t < nstage; ++t) {
+      // stage t + 1 has landed for this wave: loads of at most min(NST - 3, nstage - 2 - t) later stages may still be in flight
+      const int later = nstage - 2 - t;
+      if (later >= NST - 3) ptts_wait_vmcnt<(NST - 3) * PPW>();
+      else if (NST > 4 && later == 1) ptts_wait_vmcnt<PPW>();
+      else if (NST > 5 && later == 2) ptts_wait_vmcnt<2 * PPW>();
+      else ptts_wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (t, first half) is in registers; every read of stage t - 1 retired long ago
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + NST - 1 < nstage) issue(t + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+      const char* cur = smem_raw + buf * STAGE_B;
+      const int nbuf = buf + 1 == NST ? 0 : buf + 1;
+      reads(cur, 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (t + 1 < nstage) reads(smem_raw + nbuf * STAGE_B, 0, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      buf = nbuf;
+    }
+  } else
   for (int t = 0; t < nstage; ++t) {
     // stage t has landed for this wave: loads of at most min(NST - 2, nstage - 1 - t) later stages may still be in flight
     const int later = nstage - 1 - t;

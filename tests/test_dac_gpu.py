@@ -273,6 +273,13 @@ def test_fused_residual_units_44khz(fuse384, monkeypatch):
     monkeypatch.setenv("PTTS_DAC_EPI_DIRECT", "1")
     assert torch.equal(d.decode(codes.cuda()).cpu(), fused)  # same fp32 operations in the same order: bit-identical
     monkeypatch.delenv("PTTS_DAC_EPI_DIRECT")
+    # round 6, read per call: residual units that take their input from the fp32 stream and evaluate the Snake in front of them on the way into LDS
+    # (no bf16 activation written between the units of a block; bit 0: C = 96, bit 1: C = 192, bit 2: C = 384) against units that read the bf16
+    # activation their producer wrote: the same function of the same fp32 values, rounded once - bit-identical, whatever the default mask is
+    for mask in ("0", "1", "2", "4", "7"):
+        monkeypatch.setenv("PTTS_DAC_XIN", mask)
+        assert torch.equal(d.decode(codes.cuda()).cpu(), fused), mask
+    monkeypatch.delenv("PTTS_DAC_XIN")
     monkeypatch.setenv("PTTS_DAC_NO_FUSE_RES", "1")  # read per call: the two-launch path of the same engine
     plain = d.decode(codes.cuda()).cpu()
     monkeypatch.delenv("PTTS_DAC_NO_FUSE_RES")

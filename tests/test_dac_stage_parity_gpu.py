@@ -27,14 +27,15 @@ def _rel(a, b):
     return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-20))
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp32"])
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("mode,fuse", [("bf16", True), ("bf16", False), ("bf16", "xin"), ("bf16", "no-xin"), ("fp32", True)])
 def test_every_stage_matches_the_oracle_on_identical_inputs(mode, fuse, monkeypatch):
+    """fuse = "xin" / "no-xin" (round 6): every fused block / no block on the units that read the fp32 stream (PTTS_DAC_XIN=7 / 0; `True` is the
+    default mask). The stop stage of an XIN block also writes its activation (the test reads it); its INPUT path is the production one."""
     from parler_tts_amd.engine import DacEngine
 
-    if not fuse:
-        if mode == "fp32":
-            pytest.skip("the fused residual units exist in the bf16-operand mode only")
+    if fuse in ("xin", "no-xin"):  # (the fused residual units exist in the bf16-operand mode only: fp32 runs once)
+        monkeypatch.setenv("PTTS_DAC_XIN", "7" if fuse == "xin" else "0")
+    elif not fuse:
         monkeypatch.setenv("PTTS_DAC_NO_FUSE_RES", "1")
     spec = DA.DAC_44KHZ
     sd = DA.make_dac_weights(spec, seed=4321)

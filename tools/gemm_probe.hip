@@ -46,14 +46,24 @@ int main(int argc, char** argv) {
       {"glds 128x64  4w s2 rp ", run_glds<8, 4, 2, 2, 2, 0, 1>, 128, 64},
       {"glds 128x64  4w s3 rp ", run_glds<8, 4, 2, 2, 3, 0, 1>, 128, 64},
       {"glds 64x64   4w s3    ", run_glds<4, 4, 2, 2, 3>, 64, 64},
-      {"glds 64x64   4w s2 k128", run_glds<4, 4, 2, 2, 2, 0, 1, 4>, 64, 64},
-      {"  .. compute only     ", run_glds<4, 4, 2, 2, 2, 2, 1, 4>, 64, 64},
-      {"glds 64x64   4w s3 k128", run_glds<4, 4, 2, 2, 3, 0, 1, 4>, 64, 64},
-      {"glds 64x64   8w s2 k128", run_glds<4, 4, 4, 2, 2, 0, 1, 4>, 64, 64},
-      {"glds 128x64  4w s2 k128", run_glds<8, 4, 2, 2, 2, 0, 1, 4>, 128, 64},
-      {"glds 128x64  8w s2 k128", run_glds<8, 4, 4, 2, 2, 0, 1, 4>, 128, 64},
-      {"glds 128x128 8w s2 k128", run_glds<8, 8, 4, 2, 2, 0, 1, 4>, 128, 128},
-      {"glds 128x128 4w s2 k128", run_glds<8, 8, 2, 2, 2, 0, 1, 4>, 128, 128},
+      // call 32: ONE workgroup per CU on ~1 / 256 of the output (the L2 -> LDS bytes per flop of a tile bound every variant above: 128 x 128 tiles reach
+      // 42 % even on 4096^3), deep rings, and the half-stage pipeline (p2: next half's fragment reads under this half's MFMAs)
+      {"glds 128x64  8w s3 p2 ", run_glds<8, 4, 4, 2, 3, 0, 2>, 128, 64},
+      {"glds 128x64  8w s4 p2 ", run_glds<8, 4, 4, 2, 4, 0, 2>, 128, 64},
+      {"glds 128x64  8w s6 p2 ", run_glds<8, 4, 4, 2, 6, 0, 2>, 128, 64},
+      {"glds 128x64  4w s4 p2 ", run_glds<8, 4, 2, 2, 4, 0, 2>, 128, 64},
+      {"glds 128x64  4w s6 rp ", run_glds<8, 4, 2, 2, 6, 0, 1>, 128, 64},
+      {"glds 64x64   4w s3 p2 ", run_glds<4, 4, 2, 2, 3, 0, 2>, 64, 64},
+      {"glds 128x128 8w s3 p2 ", run_glds<8, 8, 4, 2, 3, 0, 2>, 128, 128},
+      {"glds 128x128 8w s4 p2 ", run_glds<8, 8, 4, 2, 4, 0, 2>, 128, 128},
+      {"glds 192x128 8w s2 rp ", run_glds<12, 8, 4, 2, 2, 0, 1>, 192, 128},
+      {"glds 192x128 8w s3 rp ", run_glds<12, 8, 4, 2, 3, 0, 1>, 192, 128},
+      {"glds 192x128 8w s3 p2 ", run_glds<12, 8, 4, 2, 3, 0, 2>, 192, 128},
+      {"glds 192x128 8w s4 p2 ", run_glds<12, 8, 4, 2, 4, 0, 2>, 192, 128},
+      {"glds 256x128 8w s3 p2 ", run_glds<16, 8, 4, 2, 3, 0, 2>, 256, 128},
+      {"glds 352x128 8w s2 rp ", run_glds<22, 8, 2, 4, 2, 0, 1>, 352, 128},
+      {"glds 176x256 8w s2 rp ", run_glds<11, 16, 1, 8, 2, 0, 1>, 176, 256},
+      {"glds 256x256 8w s2 rp ", run_glds<16, 16, 4, 2, 2, 0, 1>, 256, 256},
   };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (const Shape& s : shapes) {
