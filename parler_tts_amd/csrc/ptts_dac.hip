@@ -45,8 +45,6 @@ struct ConvArgs {
   const int* lens;     // ragged decode (ptts_dac_decode_ragged): latent frames per utterance [B] on the device, or null. Utterance b then has
   int len_mul;         // lens[b] * len_mul valid input rows (= output rows per phase): rows beyond read as the zero padding, tiles beyond exit
   int epi_direct;      // conv_lds_kernel A/B (PTTS_DAC_EPI_DIRECT=1): the round-3 epilogue (a lane stores 4 channels of one frame)
-  int order;           // conv_lds_kernel, transposed convs: blockIdx.x -> (utterance, phase, tile); 0: tile fastest, then phase, then utterance (rounds 2-5)
-                       // 1: phase slowest (one phase's weights at a time), 2: the phases of a tile on consecutive slots of ONE XCD (see the kernel)
 };
 
 // valid input rows of utterance b (buffers keep the full stride a.Tin)
@@ -203,27 +201,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, j = lane & 15;
   const int ntile = (a.Tn + TF - 1) / TF;
-  // Which (utterance, phase, tile) a workgroup owns (round 6; the same work per workgroup in every order: outputs bit-identical). The phases of a
-  // transposed conv read the SAME input tile with DIFFERENT weights, and profiles/r06_pmc_dac_bs32.txt showed what the tile-fastest order costs: the
-  // 2-8 phases of a tile run ntile workgroups apart (other XCDs, other times), so the input is fetched once per phase (5.6 GB for 2.7 at the last
-  // transposed conv), and ~9 (utterance, phase) groups are in flight at once, so all 8 phases' weights (4.7-9.4 MB per column group at the two
-  // stride-8 layers) cycle through a 4 MB L2 (8.6 GB fetched for 0.3 GB of input).
-  //   order 2 (all phases' weights <= 2 MB): workgroups are dealt to the 8 XCDs round-robin by linear id, so slot s = id / 8 of XCD id % 8 takes phase
-  //           s % nphase of tile (s / nphase) * 8 + xcd: the phases of a tile are neighbours in ONE XCD's queue and share its L2 copy of the input.
-  //   order 1 (heavier weights): the phase is the slowest index - one phase's weights at a time stay L2-resident; the input is re-read per phase.
-  int tile, ph, b;
-  if (a.order == 2) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    ph = slot % a.nphase;
-    const int tl = (slot / a.nphase) * 8 + xcd;
-    if (tl >= ntile * a.B) return;
-    b = tl / ntile; tile = tl - b * ntile;
-  } else if (a.order == 1) {
-    const int per = ntile * a.B, r = blockIdx.x % per;
-    ph = blockIdx.x / per; b = r / ntile; tile = r - b * ntile;
-  } else {
-    tile = blockIdx.x % ntile; ph = (blockIdx.x / ntile) % a.nphase; b = blockIdx.x / (ntile * a.nphase);
-  }
+  // (round 6, profiles/r06_dac_up_order_ab.txt: the phases of a transposed conv as neighbours in ONE XCD's queue - sharing its L2 copy of the input tile -
+  //  or the phase as the slowest index - one phase's weights L2-resident at a time - measured equal to this order, 54.2-54.7 vs 53.8-54.2 ms per batch-32
+  //  decode, bit-identical: the re-fetched bytes the PMC table shows for these layers do not cost time. Not kept.)
+  const int tile = blockIdx.x % ntile, ph = (blockIdx.x / ntile) % a.nphase, b = blockIdx.x / (ntile * a.nphase);
   const int nstrips = a.Cout / 16;
   const int strip0 = (blockIdx.y * NW + wave) * CSW;
   const int cpt = a.Cin / 32, nk = a.ntaps * cpt;
@@ -1432,7 +1413,7 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
   const bool lds_ok = a.ntaps > 2 ? L.Cout >= lds_min_c
                                   : (lds_small_taps || (a.transposed && L.Cout >= (last_up_lds ? 96 : 192)) || (lds_k1 && !a.transposed && a.ntaps == 1));
   {
-    const char* ced = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process): the same switch as the fused residual unit's epilogue
+    const char* ced = ptts_dev_env("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process): the same switch as the fused residual unit's epilogue
     a.epi_direct = (ced && atoi(ced)) ? 1 : 0;
   }
   if (L.bf16 && !no_lds && lds_ok && a.stride == 1 && nstrips % 6 == 0) {
@@ -1445,11 +1426,7 @@ static int run_conv(ptts_dac* d, const ConvLayer& L, const void* x, const float*
     static const bool ft4_on = !(ptts_dev_env("PTTS_DAC_NO_FT4") && atoi(ptts_dev_env("PTTS_DAC_NO_FT4")));
     const bool ft4 = ft4_on && nw == 4 && (long long)((a.Tn + 127) / 128) * a.nphase * B * (nstrips / (3 * nw)) < 320;
     const int tfr = ft4 ? 64 : 128;
-    // block order of the transposed convs (see conv_lds_kernel): by the weight bytes one column group's phases need together
-    static const int up_order = ptts_dev_env("PTTS_DAC_UP_ORDER") ? atoi(ptts_dev_env("PTTS_DAC_UP_ORDER")) : -1;
-    if (a.transposed && a.nphase > 1) a.order = up_order >= 0 ? up_order : ((size_t)a.nphase * a.ntaps * a.Cin * (3 * nw * 16) * 2 <= (2u << 20) ? 2 : 1);
-    const unsigned ntb = (unsigned)(((a.Tn + tfr - 1) / tfr) * B);
-    const dim3 grid(a.order == 2 ? (ntb + 7) / 8 * 8 * a.nphase : ntb * a.nphase, (unsigned)(nstrips / (3 * nw)));
+    const dim3 grid((unsigned)(((a.Tn + tfr - 1) / tfr) * a.nphase * B), (unsigned)(nstrips / (3 * nw)));
     bool done = true;
     if (a.ntaps > 2 && halo <= 54 && a.Cin % 32 == 0) {
       if (nw == 4 && ft4) hipLaunchKernelGGL((conv_lds_kernel<3, 4, 1, 54, 4>), grid, dim3(256), 0, st, a);
@@ -1517,12 +1494,15 @@ static bool resunit_fusable(const ConvLayer& c7, const ConvLayer& c1) {
          c7.alpha && c1.alpha;
 }
 // Which widths run their residual units as XIN units (input = the fp32 stream, see resunit_lds_kernel): bit 0: C = 96, bit 1: C = 192, bit 2: C = 384.
-// Measured on MI355X (profiles/r06_dac_xin_ab.txt, ms per decode, mask 0 | 1 | 3 | 7): 32 x 860 frames 56.16 | 54.86 | 54.35 | 53.99, one utterance
-// 2.409 | 2.316 | 2.335 | 2.349 - the wider units gain only where the launch is bandwidth-bound, hence by the latent frames of the call.
-// PTTS_DAC_XIN=<mask> is read per call (a test switches it inside one process: every mask gives the same bits).
+// Measured on MI355X (profiles/r06_dac_xin_ab.txt, r06_dac_up_order_ab.txt; ms per decode of 860 frames, mask 0 | 1 | 3 | 7): 32 utterances 56.16 | 54.86 |
+// 54.35 | 53.99, 8: - | 14.30 | - | 14.13, 4: - | 7.69 | - | 7.55, one utterance 2.409 | 2.316 | 2.335 | 2.349 - the wider units gain only where the launch
+// is bandwidth-bound, hence by the latent frames of the call. PTTS_DAC_XIN=<mask> is read per call (a test switches it inside one process: every mask
+// gives the same bits); the round-3 epilogue (PTTS_DAC_EPI_DIRECT=1, an A/B path) exists for the units on the bf16 activation only.
 static bool resunit_xin_width(int C, long long frames) {
+  const char* ed = ptts_dev_env("PTTS_DAC_EPI_DIRECT");
+  if (ed && atoi(ed)) return false;
   const char* ev = getenv("PTTS_DAC_XIN");
-  const int m = ev ? atoi(ev) : (frames >= 8 * 860 ? 7 : 1);
+  const int m = ev ? atoi(ev) : (frames >= 2 * 860 ? 7 : 1);
   return (C == 96 && (m & 1)) || (C == 192 && (m & 2)) || (C == 384 && (m & 4));
 }
 // `alpha_in` != null: an XIN unit - x is the fp32 stream (= skip) and alpha_in the [alpha | 1 / alpha] of the Snake in front of the unit; out_raw must
@@ -1536,7 +1516,7 @@ static int run_resunit(const ConvLayer& c7, const ConvLayer& c1, const void* x, 
   r.Wp1 = c1.Wp; r.bias1 = c1.bias; r.alpha1 = c1.alpha; r.skip = skip; r.out_raw = out_raw; r.out_act = out_act; r.act_f32 = act_f32 ? 1 : 0;
   r.alpha_in = alpha_in;
   {
-    const char* ed = getenv("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process, like PTTS_DAC_NO_FUSE_RES)
+    const char* ed = ptts_dev_env("PTTS_DAC_EPI_DIRECT");  // read per call (A/B inside one process, like PTTS_DAC_NO_FUSE_RES)
     r.epi_direct = (ed && atoi(ed)) ? 1 : 0;
   }
   const dim3 grid((unsigned)(((T + 127) / 128) * B));

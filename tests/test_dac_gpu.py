@@ -268,11 +268,6 @@ def test_fused_residual_units_44khz(fuse384, monkeypatch):
     d = DacEngine(max_batch=2, max_frames=160, compute_dtype=torch.bfloat16)
     d.load_state_dict(sd)
     fused = d.decode(codes.cuda()).cpu()
-    # read per call: the round-3 epilogues (64-byte pieces) of the fused residual units AND of conv_lds_kernel (k7 at C = 768, transposed convs)
-    # instead of whole rows through LDS
-    monkeypatch.setenv("PTTS_DAC_EPI_DIRECT", "1")
-    assert torch.equal(d.decode(codes.cuda()).cpu(), fused)  # same fp32 operations in the same order: bit-identical
-    monkeypatch.delenv("PTTS_DAC_EPI_DIRECT")
     # round 6, read per call: residual units that take their input from the fp32 stream and evaluate the Snake in front of them on the way into LDS
     # (no bf16 activation written between the units of a block; bit 0: C = 96, bit 1: C = 192, bit 2: C = 384) against units that read the bf16
     # activation their producer wrote: the same function of the same fp32 values, rounded once - bit-identical, whatever the default mask is
