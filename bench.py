@@ -540,12 +540,13 @@ def measure_dac(device, bs_list=(1, 32), with_f32: bool = True) -> dict:
             out[f"{mode}_bs{bs}"] = {"ms_per_launch": round(sec * 1e3, 3), "flops_per_launch": fl * FRAMES * bs, "achieved": round(ach, 1), "peak": peak,
                                      "frac": round(ach / peak, 4), "audio_seconds_per_sec": round(bs * AUDIO_S / sec, 1)}
             if mode == "bf16" and bs == 32:
-                # round 6 (profiles/r06_pmc_dac_bs32.txt: rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE, separate passes over this very decode): with one
-                # launch per layer the codec moves 195.70 GB per 32 x 860 frames - by bytes its floor at 8 TB/s (24.5 ms) is ABOVE its floor by flops
-                # (17.7 ms at 2.5 PF): at this batch the dominant bound is HBM. Traffic from the committed pass, time from this run.
-                tb = 195.70e9
+                # round 6 (profiles/r06_pmc_dac_bs32_xin.txt: rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE, separate passes over this very decode, on the
+                # tree with the residual units on the fp32 stream): with one launch per layer the codec moves 197.29 GB per 32 x 860 frames - by bytes its
+                # floor at 8 TB/s (24.7 ms) is ABOVE its floor by flops (17.7 ms at 2.5 PF): at this batch the dominant bound is HBM. Traffic from the
+                # committed pass, time from this run.
+                tb = 197.29e9
                 out["bf16_bs32"]["hbm"] = {"traffic_bytes_per_launch_pmc": tb, "achieved_GBps": round(tb / sec / 1e9, 1), "peak_GBps": 8000.0,
-                                           "frac": round(tb / sec / 8e12, 4), "source": "profiles/r06_pmc_dac_bs32.txt (committed PMC pass) / this run's time"}
+                                           "frac": round(tb / sec / 8e12, 4), "source": "profiles/r06_pmc_dac_bs32_xin.txt (committed PMC pass) / this run's time"}
         eng.close()
     return out
 

@@ -246,21 +246,25 @@ int launch_gemm_glds_inst(const GemmArgs& a, hipStream_t st) {
 // Deeper rings lose above one stage in flight wherever they cost a resident workgroup: every variant is bound by what ONE workgroup's
 // dependent chain (barrier -> fragment reads -> MFMAs per stage) and its LDS-DMA issue rate sustain, so resident workgroups per CU beat
 // pipeline depth; BK = 128 stages (half the barriers) lose for the same reason (twice the LDS per stage). -1 = shape not served.
-// Round 6, call 32 (profiles/r06_gemm_probe_call32.txt): where a tile of ~1 / 256 of the output exists, ONE workgroup per CU on it beats two or three smaller
-// resident ones - fewer L2 -> LDS bytes per flop: 2048 x 3072 x 1024 on 192 x 128 tiles (256 of them, 3-stage ring) 18.7 us against 21.0, 2048 x 5632 x 1024
-// on 176 x 256 tiles (256 of them; 22 + 32 pieces per stage on 8 waves: the uneven split) 30.5 against 34.2 (the vendor library, graph-captured
-// torch.matmul: 16.9 / 32.6, profiles/r06_vendor_gemm.txt). Deeper rings and the half-stage pipeline (RP = 2) lose on every shape and stay probe-only.
+// Round 6, calls 32-34 (profiles/r06_gemm_probe_call32.txt, _call34.txt): where tiles of ~1 / 256 of the output (or whole rounds of them) exist, fewer and
+// larger workgroups beat two or three smaller resident ones - fewer L2 -> LDS bytes per flop: 2048 | 4096 | 8192 x 3072 x 1024 on 192 x 128 tiles (2-stage
+// ring: two workgroups per CU) 19.2 | 31.3 | 61.0 us against 21.4 | 34.8 | 65.5, x 5632 on 176 x 256 tiles (one workgroup per CU; 22 + 32 pieces per stage
+// on 8 waves: the uneven split) 29.5 | 60.9 | 111.2 against 34.8 | 62.5 | 118.9 (the vendor library at 2048 rows, graph-captured torch.matmul: 16.9 / 32.6,
+// profiles/r06_vendor_gemm.txt). Only where the tile count fills whole rounds (>= 85 %): 1056 x 3072 on 192 x 128 tiles (144 of them) loses, 17.0 against 14.2.
+// Deeper rings and the half-stage pipeline (RP = 2) lose on every shape and stay probe-only.
+static inline bool glds_fills_rounds(int tiles, int slots) {
+  const int rounds = (tiles + slots - 1) / slots;
+  return tiles > 224 && (tiles <= 256 || tiles * 100 >= rounds * slots * 85);
+}
 template <int EPI>
 int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
   if (a.K % 64 || a.N % 64 || a.x_ld % 8) return -1;
   static const bool big_tiles = !(ptts_dev_env("PTTS_GLDS_BIG_TILES") && !atoi(ptts_dev_env("PTTS_GLDS_BIG_TILES")));  // A/B (dev-knob build): 0 = calls 2-6 policy
   if constexpr (EPI == EPI_STORE) {
-    const int t = a.N % 192 || !big_tiles ? 0 : (a.N / 192) * ((a.M + 127) / 128);
-    if (t > 224 && t <= 256) return launch_gemm_glds_inst<EPI, 12, 8, 4, 2, 3, 0, 1>(a, st);
+    if (big_tiles && a.N % 192 == 0 && glds_fills_rounds((a.N / 192) * ((a.M + 127) / 128), 512)) return launch_gemm_glds_inst<EPI, 12, 8, 4, 2, 2, 0, 1>(a, st);
   }
   if constexpr (EPI == EPI_GATE_WT) {
-    const int t = a.N % 176 || !big_tiles ? 0 : (a.N / 176) * ((a.M + 255) / 256);
-    if (t > 224 && t <= 256) return launch_gemm_glds_inst<EPI, 11, 16, 1, 8, 2, 0, 1>(a, st);
+    if (big_tiles && a.N % 176 == 0 && glds_fills_rounds((a.N / 176) * ((a.M + 255) / 256), 256)) return launch_gemm_glds_inst<EPI, 11, 16, 1, 8, 2, 0, 1>(a, st);
   }
   if (a.N <= 1024 || a.N % 128) return launch_gemm_glds_inst<EPI, 4, 4, 2, 2, 3>(a, st);
   const int tiles128 = (a.N / 128) * ((a.M + 127) / 128);

@@ -39,7 +39,9 @@ int main(int argc, char** argv) {
   const Shape shapes[] = {
       {"T5 q|k|v      ", 2048, 3072, 1024}, {"T5 o          ", 2048, 1024, 1024}, {"T5 wi (gated) ", 2048, 5632, 1024}, {"T5 wo         ", 2048, 1024, 2816},
       {"prefill qkv   ", 1056, 3072, 1024}, {"prefill o / cq ", 1056, 1024, 1024}, {"prefill fc1   ", 1056, 4096, 1024}, {"prefill fc2   ", 1056, 1024, 4096},
-      {"cross K|V     ", 2048, 2048, 1024}, {"Large fc1     ", 1056, 6144, 1536}, {"square 4096   ", 4096, 4096, 4096}};
+      {"cross K|V     ", 2048, 2048, 1024}, {"Large fc1     ", 1056, 6144, 1536}, {"square 4096   ", 4096, 4096, 4096},
+      {"T5 q|k|v x64  ", 4096, 3072, 1024}, {"T5 wi x64     ", 4096, 5632, 1024}, {"T5 q|k|v x128 ", 8192, 3072, 1024}, {"T5 wi x128    ", 8192, 5632, 1024}};
+  const char* only = argc > 2 ? argv[2] : nullptr;  // run only the shapes whose name contains this text
   const Variant vars[] = {
       {"tile 64x64 (r05)      ", run_tile44, 64, 64},
       {"glds 128x128 8w s2 rp ", run_glds<8, 8, 4, 2, 2, 0, 1>, 128, 128},
@@ -64,9 +66,19 @@ int main(int argc, char** argv) {
       {"glds 352x128 8w s2 rp ", run_glds<22, 8, 2, 4, 2, 0, 1>, 352, 128},
       {"glds 176x256 8w s2 rp ", run_glds<11, 16, 1, 8, 2, 0, 1>, 176, 256},
       {"glds 256x256 8w s2 rp ", run_glds<16, 16, 4, 2, 2, 0, 1>, 256, 256},
+      // call 35: 1056 rows = 66 row tiles of 16 = 2 x 3 x 11: 48-row tiles give an EVEN number of row tiles (22), which xcd_tile_order can split 2 x 4
+      // (17 or 11 row tiles: every XCD streams the whole activation matrix)
+      {"glds 64x48   4w s3    ", run_glds<4, 3, 4, 1, 3>, 64, 48},
+      {"glds 64x48   4w s4    ", run_glds<4, 3, 4, 1, 4>, 64, 48},
+      {"glds 128x48  4w s3    ", run_glds<8, 3, 4, 1, 3>, 128, 48},
+      {"glds 128x48  8w s3    ", run_glds<8, 3, 8, 1, 3>, 128, 48},
+      {"glds 64x96   4w s3 rp ", run_glds<4, 6, 2, 2, 3, 0, 1>, 64, 96},
+      {"glds 128x96  4w s2 rp ", run_glds<8, 6, 2, 2, 2, 0, 1>, 128, 96},
+      {"glds 128x96  8w s3 rp ", run_glds<8, 6, 4, 2, 3, 0, 1>, 128, 96},
   };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (const Shape& s : shapes) {
+    if (only && !strstr(s.what, only)) continue;
     const size_t wbytes = (size_t)s.N * s.K * 2, xbytes = (size_t)s.M * s.K * 2, obytes = (size_t)s.M * s.N * 4;
     const int ncopy = (int)std::min<size_t>(24, (300u << 20) / wbytes + 1);
     uint16_t *Wsrc, *W, *X; float *O, *Oref;
