@@ -267,7 +267,9 @@ int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
     if (big_tiles && a.N % 176 == 0 && glds_fills_rounds((a.N / 176) * ((a.M + 255) / 256), 256)) return launch_gemm_glds_inst<EPI, 11, 16, 1, 8, 2, 0, 1>(a, st);
   }
   if (a.N <= 1024 || a.N % 128) return launch_gemm_glds_inst<EPI, 4, 4, 2, 2, 3>(a, st);
-  const int tiles128 = (a.N / 128) * ((a.M + 127) / 128);
+  // (the description's K / V of every layer in ONE launch is kv_nlayers problems' worth of tiles: it fills the chip for many rounds like a large GEMM)
+  static const bool kv_all = !(ptts_dev_env("PTTS_GLDS_KV_TILES") && !atoi(ptts_dev_env("PTTS_GLDS_KV_TILES")));  // A/B (dev-knob build): 0 = per-layer tile count
+  const int tiles128 = (a.N / 128) * ((a.M + 127) / 128) * ((EPI == EPI_KV && a.kv_layers && kv_all) ? a.kv_nlayers : 1);
   if (tiles128 >= 400) return launch_gemm_glds_inst<EPI, 8, 8, 4, 2, 2, 0, 1>(a, st);
   return launch_gemm_glds_inst<EPI, 8, 4, 2, 2, 2, 0, 1>(a, st);
 }
