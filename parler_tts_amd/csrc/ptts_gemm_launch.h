@@ -224,7 +224,10 @@ int launch_prefill_attn(const AttnArgs& a, int B, hipStream_t st, int mode = 3) 
   if (!a.kscale && (mode == 2 || (mode != 1 && B * a.nheads >= 128))) {
     const int waves = std::min(4, (a.Q + 15) / 16);
     const dim3 gm((a.Q + 16 * waves - 1) / (16 * waves), a.nheads, B);
-    hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT>), gm, dim3(64 * waves), 0, st, a);
+    if (waves == 4) hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 4>), gm, dim3(256), 0, st, a);
+    else if (waves == 3) hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 3>), gm, dim3(192), 0, st, a);
+    else if (waves == 2) hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 2>), gm, dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 1>), gm, dim3(64), 0, st, a);
     hipError_t em = hipGetLastError();
     if (em != hipSuccess) return ptts_fail(PTTS_E_HIP, "prefill attention launch failed: %s", hipGetErrorString(em));
     return PTTS_OK;

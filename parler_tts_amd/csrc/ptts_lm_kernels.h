@@ -1666,13 +1666,16 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(AttnArgs a) {
 // i, online across key blocks; O = P V takes the lane's own probability registers as the A operand (the MFMA sums over g) - no transpose.
 // Semantics of prefill_attn_kernel (masked keys carry no weight, a row without a visible key yields 0, q rotated also in the cross block).
 // ------------------------------------------------------------------------------------------------------
-template <typename WT>
-__global__ void __launch_bounds__(256) prefill_attn_mfma_kernel(AttnArgs a) {
+// NW (round 6, call 38): waves per workgroup at compile time - with blockDim read at run time the K / V staging loop stayed rolled: three rounds of
+// load -> wait -> LDS store in a row in front of every key block (profiles/r06_prefill_kernels_bs32_v4.txt: 15.4 us per launch for 33 x 33 / 33 x 64 scores
+// per head). Unrolled, all of a thread's K / V pieces are requested before the first is stored. Same arithmetic: bit-identical.
+template <typename WT, int NW>
+__global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) {
   constexpr int EPL = Elem<WT>::EPL;
   __shared__ __attribute__((aligned(16))) float sK[64 * 64];
   __shared__ __attribute__((aligned(16))) float sV[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
-  const int nthreads = blockDim.x, qwg = (nthreads >> 6) * 16;  // 1..4 waves of 16 queries
+  constexpr int nthreads = NW * 64, qwg = NW * 16;  // 1..4 waves of 16 queries
   const int h = blockIdx.y, b = blockIdx.z, i0w = blockIdx.x * qwg, i0 = i0w + w * 16;
   const int kvh = h / a.n_rep;
   const int P = a.dims->P;
@@ -1682,21 +1685,33 @@ __global__ void __launch_bounds__(256) prefill_attn_mfma_kernel(AttnArgs a) {
   const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2
   const int iq = min(i0 + j, a.Q - 1);                     // clamped queries are computed and dropped
   const int Lq = a.cross ? Lmax : iq + 1;
+  // Every global load below is UNCONDITIONAL on a clamped address and selected afterwards (call 38): with the loads inside per-lane conditions the compiler
+  // wrapped each one in a branch with its own s_waitcnt vmcnt(0) - 4 + 6 + 16 dependent round trips per workgroup (q chunks, K / V pieces, mask flags) in
+  // front of 128 MFMAs; a wave-uniform branch (rope?, mask?) around a whole group of loads keeps them in flight together.
   float4 qr[4];
   {
     const float* qrow = a.q + (size_t)(b * a.Q + iq) * a.q_ld + h * 64;
+    float4 qv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int d0 = 16 * c + 4 * g;
-      float4 v = *reinterpret_cast<const float4*>(qrow + d0);
-      if (a.cos) {  // x * cos + rotate_half(x) * sin at the query's own position (modeling:409-436); a 4-element chunk never straddles the halves
-        const float4 t = *reinterpret_cast<const float4*>(qrow + (d0 < 32 ? d0 + 32 : d0 - 32));
-        const float sg = d0 < 32 ? -1.f : 1.f;
-        const float4 cs = *reinterpret_cast<const float4*>(a.cos + (size_t)iq * 64 + d0), sn = *reinterpret_cast<const float4*>(a.sin + (size_t)iq * 64 + d0);
-        v = make_float4(v.x * cs.x + sg * t.x * sn.x, v.y * cs.y + sg * t.y * sn.y, v.z * cs.z + sg * t.z * sn.z, v.w * cs.w + sg * t.w * sn.w);
+    for (int c = 0; c < 4; ++c) qv[c] = *reinterpret_cast<const float4*>(qrow + 16 * c + 4 * g);
+    if (a.cos) {  // x * cos + rotate_half(x) * sin at the query's own position (modeling:409-436); a 4-element chunk never straddles the halves
+      float4 qt[4], cs[4], sn[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d0 = 16 * c + 4 * g;
+        qt[c] = *reinterpret_cast<const float4*>(qrow + (d0 < 32 ? d0 + 32 : d0 - 32));
+        cs[c] = *reinterpret_cast<const float4*>(a.cos + (size_t)iq * 64 + d0);
+        sn[c] = *reinterpret_cast<const float4*>(a.sin + (size_t)iq * 64 + d0);
       }
-      qr[c] = make_float4(v.x * qscale, v.y * qscale, v.z * qscale, v.w * qscale);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float sg = 16 * c + 4 * g < 32 ? -1.f : 1.f;
+        const float4 v = qv[c], t = qt[c];
+        qv[c] = make_float4(v.x * cs[c].x + sg * t.x * sn[c].x, v.y * cs[c].y + sg * t.y * sn[c].y, v.z * cs[c].z + sg * t.z * sn[c].z, v.w * cs[c].w + sg * t.w * sn[c].w);
+      }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qr[c] = make_float4(qv[c].x * qscale, qv[c].y * qscale, qv[c].z * qscale, qv[c].w * qscale);
   }
   const WT* Kc = reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
   const WT* Vc = reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
@@ -1707,23 +1722,44 @@ __global__ void __launch_bounds__(256) prefill_attn_mfma_kernel(AttnArgs a) {
   const float4* sK4 = reinterpret_cast<const float4*>(sK);
   for (int j0 = 0; j0 < Lmax; j0 += 64) {
     if (j0) __syncthreads();  // the previous tiles are consumed
-    for (int e = tid; e < 64 * 8; e += nthreads) {  // 64 rows x 8 pieces of 8 elements per matrix
-      const int r = e >> 3, c8 = e & 7, key = j0 + r;
-      float kx[8], vx[8];
-      if (key < Lmax) {
-        const WT* kr = Kc + (size_t)key * 64 + c8 * 8;
-        const WT* vr = Vc + (size_t)key * 64 + c8 * 8;
+    constexpr int NIT = (64 * 8 + nthreads - 1) / nthreads;  // 64 rows x 8 pieces of 8 elements per matrix
+    float kx[NIT][8], vx[NIT][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { kx[i] = Elem<WT>::ld(kr + i); vx[i] = Elem<WT>::ld(vr + i); }
-      } else {
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * nthreads, r = e >> 3, c8 = e & 7, key = min(j0 + r, Lmax - 1);  // j0 < Lmax: the clamped row exists
+      const WT* kr = Kc + (size_t)key * 64 + c8 * 8;
+      const WT* vr = Vc + (size_t)key * 64 + c8 * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { kx[i] = 0.f; vx[i] = 0.f; }
+      for (int i = 0; i < 8; ++i) { kx[it][i] = Elem<WT>::ld(kr + i); vx[it][i] = Elem<WT>::ld(vr + i); }
+    }
+    int mk[4][4];  // mask flags of this lane's 16 keys (1 where there is no mask entry): requested before the tiles are stored
+    if (mrow) {
+      const int lim = min(mask_len, a.mask_ld);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk[kt][r] = mrow[max(min(j0 + 16 * kt + 4 * g + r, lim - 1), 0)];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk[kt][r] = j0 + 16 * kt + 4 * g + r < lim ? mk[kt][r] : 1;
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk[kt][r] = 1;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * nthreads, r = e >> 3, c8 = e & 7;
+      const bool live = j0 + r < Lmax;  // rows beyond the visible keys are zeros
+      if (e < 64 * 8) {
+        const int s0 = (2 * c8) ^ (r & 15), s1 = (2 * c8 + 1) ^ (r & 15);
+        reinterpret_cast<float4*>(sK)[r * 16 + s0] = live ? make_float4(kx[it][0], kx[it][1], kx[it][2], kx[it][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(sK)[r * 16 + s1] = live ? make_float4(kx[it][4], kx[it][5], kx[it][6], kx[it][7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(sV)[r * 16 + s0] = live ? make_float4(vx[it][0], vx[it][1], vx[it][2], vx[it][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(sV)[r * 16 + s1] = live ? make_float4(vx[it][4], vx[it][5], vx[it][6], vx[it][7]) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      const int s0 = (2 * c8) ^ (r & 15), s1 = (2 * c8 + 1) ^ (r & 15);
-      reinterpret_cast<float4*>(sK)[r * 16 + s0] = make_float4(kx[0], kx[1], kx[2], kx[3]);
-      reinterpret_cast<float4*>(sK)[r * 16 + s1] = make_float4(kx[4], kx[5], kx[6], kx[7]);
-      reinterpret_cast<float4*>(sV)[r * 16 + s0] = make_float4(vx[0], vx[1], vx[2], vx[3]);
-      reinterpret_cast<float4*>(sV)[r * 16 + s1] = make_float4(vx[4], vx[5], vx[6], vx[7]);
     }
     bool ok[4][4];  // key visible to this lane's query: inside its causal / description length and not padding
 #pragma unroll
@@ -1731,8 +1767,7 @@ __global__ void __launch_bounds__(256) prefill_attn_mfma_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = j0 + 16 * kt + 4 * g + r;
-        const int mk = (mrow && key < mask_len && key < a.mask_ld) ? mrow[key] : 1;
-        ok[kt][r] = key < Lq && (key >= mask_len || mk != 0);
+        ok[kt][r] = key < Lq && (key >= mask_len || mk[kt][r] != 0);
       }
     __syncthreads();
     f32x4 st[4];

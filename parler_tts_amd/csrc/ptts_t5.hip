@@ -186,16 +186,14 @@ __global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs a) {
   const float4* sK4 = reinterpret_cast<const float4*>(sK);
   for (int j0 = 0; j0 < a.N; j0 += 64) {
     if (j0) __syncthreads();  // the previous tiles are consumed
+    // (call 38) every global load is unconditional on a clamped address and selected afterwards: inside per-lane conditions each one had been compiled into
+    // its own branch + s_waitcnt vmcnt(0) - 8 + 32 dependent round trips per key block (tools/isa_load_chains.py)
+    float4 kq[4], vq[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = tid + 256 * u, r = e >> 4, sl = e & 15, key = j0 + r;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (key < a.N) {
-        kv = *reinterpret_cast<const float4*>(base + (size_t)key * a.ld + a.inner + h * 64 + sl * 4);
-        vv = *reinterpret_cast<const float4*>(base + (size_t)key * a.ld + 2 * a.inner + h * 64 + sl * 4);
-      }
-      reinterpret_cast<float4*>(sK)[r * 16 + (sl ^ (r & 15))] = kv;
-      reinterpret_cast<float4*>(sV)[r * 16 + (sl ^ (r & 15))] = vv;
+      const int e = tid + 256 * u, r = e >> 4, sl = e & 15, key = min(j0 + r, a.N - 1);
+      kq[u] = *reinterpret_cast<const float4*>(base + (size_t)key * a.ld + a.inner + h * 64 + sl * 4);
+      vq[u] = *reinterpret_cast<const float4*>(base + (size_t)key * a.ld + 2 * a.inner + h * 64 + sl * 4);
     }
     // bias and key flags of this lane's 16 (query, key) pairs: independent of the tiles, in flight across the barrier
     float bias[4][4];
@@ -204,10 +202,33 @@ __global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs a) {
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = j0 + 16 * kt + 4 * g + r, kc = min(key, a.N - 1);
+        const int kc = min(j0 + 16 * kt + 4 * g + r, a.N - 1);
         bias[kt][r] = a.bias[(size_t)h * a.bias_ld + (kc - iq) + a.bias_zero];
-        flag[kt][r] = key >= a.N ? 0 : ((!a.mask || a.mask[(size_t)b * a.N + kc] != 0) ? 2 : 1);
+        flag[kt][r] = 2;
       }
+    if (a.mask) {  // wave-uniform
+      int mv[4][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mv[kt][r] = a.mask[(size_t)b * a.N + min(j0 + 16 * kt + 4 * g + r, a.N - 1)];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) flag[kt][r] = mv[kt][r] != 0 ? 2 : 1;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (j0 + 16 * kt + 4 * g + r >= a.N) flag[kt][r] = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u, r = e >> 4, sl = e & 15;
+      const bool live = j0 + r < a.N;
+      reinterpret_cast<float4*>(sK)[r * 16 + (sl ^ (r & 15))] = live ? kq[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(sV)[r * 16 + (sl ^ (r & 15))] = live ? vq[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
     f32x4 st[4];
 #pragma unroll
