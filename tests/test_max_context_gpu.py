@@ -1,0 +1,123 @@
+"""Maximum sizes of the released checkpoints on the GPU path: generation to `generation_config.max_length` = 30 s x 86 frames/s = 2580
+columns (helpers/model_init_scripts/init_model_600M.py:29,62) behind a 33-position prompt, i.e. a self-attention context of 2612
+positions - every context bucket the engine pre-captures, every KV-split count of the attention nodes, the last rows of the KV arena -
+and the codec on the 2571 frames such a run returns.
+
+The oracle side stays cheap: the engine's OWN free run (prefill + 2579 hipGraph replays) is judged column by column against ONE batched
+causal forward of the oracle teacher-forced on those ids (same arithmetic as the cached passes up to summation order), so an early
+near-tie cannot cascade: a choice may differ from the oracle's arg-max only inside the stated error band. The logits of the LAST pass
+(context = the maximum) are compared directly. Mini-v1 widths, 2 layers (depth does not change the indexing; the 24-layer pins at
+context ~460 are tests/test_bench_config_parity_gpu.py).
+
+Tolerances: fp32 |dlogit| <= 5e-5 (summation order), bf16 <= 2e-2 against DecoderOracle(precision="bf16") (activation re-rounding, as in
+tests/test_lm_gpu.py); codec exact-f32 waveform |d| <= 1e-4 absolute on the compared windows (north_star: RMS 1e-4)."""
+import os
+
+import pytest
+import torch
+
+import cases as C
+from helpers import log_parity, make_dac, make_engine
+from oracle import dac_oracle as DA
+from oracle import decoder_oracle as DO
+
+pytestmark = pytest.mark.gpu
+
+MAX_LENGTH = 2580  # int(30 * frame_rate), init_model_600M.py:62
+N_DESC, N_PROMPT = 64, 33
+LOG = "r06_parity_max_context.txt"
+
+
+def _run(dtype, prec, bsz, tol, masks, seed, kv_fp8=False):
+    spec = DO.DecoderSpec(num_hidden_layers=2)  # Mini-v1 widths, max_position_embeddings 4096
+    K, L = spec.num_codebooks, MAX_LENGTH
+    sd = DO.make_decoder_weights(spec, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    enc = torch.randn(bsz, N_DESC, spec.hidden_size, generator=g)
+    prompt = torch.randn(bsz, N_PROMPT, spec.hidden_size, generator=g) * 0.5
+    enc_mask = prompt_mask = None
+    if masks:
+        enc_mask, prompt_mask = C.ragged_masks(bsz, N_DESC, N_PROMPT, enc_step=2)
+        enc = enc * enc_mask[..., None]
+    eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=N_PROMPT + L, max_enc=N_DESC, max_prompt=N_PROMPT + 1, kv_fp8=kv_fp8)
+    eng.set_gen_params(max_length=L, min_new_tokens=L - 1)
+    ids = eng.generate_ids(enc, enc_mask, prompt, prompt_mask).cpu()
+    last = eng.logits().cpu()  # the logits of pass L - 2: the one that chose the last column, at the largest context of the run
+    eng.close()
+    assert ids.shape == (bsz * K, L)
+    assert bool((ids[:, 0] == spec.bos_token_id).all())
+    _, pattern = DO.build_delay_pattern_mask(ids[:, :1], spec.bos_token_id, spec.pad_token_id, L, K)
+    fed = DO.apply_delay_pattern_mask(ids, pattern)[:, : L - 1]
+    torch.set_num_threads(min(os.cpu_count() or 8, 16))
+    orc = DO.DecoderOracle(spec, sd, precision=prec)
+    orc.kv_fp8 = kv_fp8
+    lgs = []
+    with torch.no_grad():
+        for b in range(bsz):  # one utterance at a time: the [heads, 2612, 2612] score tensors of a whole batch would not fit a small host
+            orc.reset()
+            sl = slice(b, b + 1)
+            lgs.append(orc.forward(fed[b * K:(b + 1) * K], enc[sl], None if enc_mask is None else enc_mask[sl], prompt[sl],
+                                   None if prompt_mask is None else prompt_mask[sl])[:, -(L - 1):].float())
+    lg = torch.cat(lgs, dim=0)  # [rows, pass, V]: pass s chooses column s + 1
+    err_last = float((last - lg[:, -1]).abs().max())
+    m = lg.clone()
+    m[..., spec.eos_token_id] = -float("inf")  # min_new_tokens blocks EOS on every pass of this run
+    top2, idx = torch.topk(m, 2, dim=-1)
+    margin = top2[..., 0] - top2[..., 1]
+    diff = idx[..., 0] != ids[:, 1:]
+    # a differing choice is legitimate only if the engine's pick scores within the error band of the oracle's best
+    gap = top2[..., 0] - m.gather(-1, ids[:, 1:, None])[..., 0]
+    outside = int((diff & (gap > 2 * tol)).sum())
+    late = diff[:, L // 2:]
+    log_parity(f"[max context {prec} bs={bsz}{' e4m3-kv' if kv_fp8 else ''}] {L - 1} free-running passes x {bsz * K} rows, context up to {N_PROMPT + L - 2}: "
+               f"{int(diff.sum())} of {diff.numel()} choices differ from the oracle's arg-max at the same history ({int(late.sum())} in the second half), "
+               f"{outside} outside 2 x {tol:g}; max |dlogit| of the last pass {err_last:.2e}; min oracle top-2 margin {float(margin.min()):.2e}", LOG)
+    assert err_last <= tol, err_last
+    assert outside == 0, outside
+    assert float(diff.float().mean()) <= 0.02
+    return ids
+
+
+def test_fp32_single_utterance_to_max_length():
+    """GEMV step: 2579 graph replays, contexts 33..2611 (every bucket, every split count)."""
+    _run(torch.float32, "fp32", 1, 5e-5, masks=False, seed=101)
+
+
+def test_bf16_single_utterance_to_max_length():
+    _run(torch.bfloat16, "bf16", 1, 2e-2, masks=False, seed=102)
+
+
+def test_bf16_ragged_batch_of_12_to_max_length():
+    """MFMA-strip step (> 8 utterances) with ragged description / prompt masks."""
+    _run(torch.bfloat16, "bf16", 12, 2e-2, masks=True, seed=103)
+
+
+def test_bf16_e4m3_kv_cache_batch_of_12_to_max_length():
+    """Opt-in e4m3 KV cache (own oracle leg): the scale arena and the byte rows at the far end of the context."""
+    _run(torch.bfloat16, "bf16", 12, 2e-2, masks=True, seed=104, kv_fp8=True)
+
+
+def test_codec_on_the_frames_of_a_max_length_run():
+    """44 kHz decoder, exact-f32 engine, 2571 frames (= 2580 - 9 columns after the un-delay) x 2 utterances in one call: three windows of the
+    waveform (first, middle, last frames) against the oracle run on 64-frame windows of the same codes - away from a window's inner edges
+    (one-sided receptive field 13 latent frames) the decoder sees identical inputs, and the utterance's own edges are the window's edges."""
+    from parler_tts_amd.streamer import receptive_halo_frames
+
+    spec = DA.DAC_44KHZ
+    sd = DA.make_dac_weights(spec, seed=77)
+    T = MAX_LENGTH - spec.num_codebooks
+    codes = torch.randint(0, 1024, (2, 9, T), generator=torch.Generator().manual_seed(9))
+    wav = make_dac(spec, sd, max_batch=2, max_frames=T).decode(codes.cuda()).cpu()
+    hop = spec.hop_length
+    assert wav.shape == (2, 1, hop * T)
+    halo = receptive_halo_frames(spec.decoder_rates)
+    orc = DA.DacOracle(spec, sd)
+    worst = 0.0
+    for a, b in ((0, 64), (T // 2 - 32, T // 2 + 32), (T - 64, T)):
+        ref = orc.decode(codes[:, :, a:b])
+        lo = a if a == 0 else a + halo
+        hi = b if b == T else b - halo
+        d = float((wav[..., lo * hop: hi * hop] - ref[..., (lo - a) * hop: (hi - a) * hop]).abs().max())
+        worst = max(worst, d)
+    log_parity(f"[codec, 2 x {T} frames, exact-f32] three 64-frame windows vs the oracle: max |d| {worst:.2e}", LOG)
+    assert worst <= 1e-4, worst
