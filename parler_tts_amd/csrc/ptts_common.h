@@ -207,3 +207,56 @@ template <typename Op> __device__ __forceinline__ float wave_reduce(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce<OpSum>(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce<OpMax>(v); }
+
+// ---- 64-key block of the f32-MFMA attention kernels (prefill_attn_mfma_kernel, t5_attn_mfma_kernel) ----------------------------------
+// K / V tiles in LDS as fp32 [64 keys][16 slots of 16 B], slot XOR-swizzled by key & 15; lane (j = l & 15, g = l >> 4).
+// Round 6, call 46: the compiler had scheduled each fragment read directly in front of its MFMAs - ds_read -> s_waitcnt lgkmcnt(0) -> MFMA, 16 + 64 LDS
+// round trips in a row per key block (~5 us of a 14 us launch for 1.7 us of MFMA issue). Now every fragment of a phase is requested before the first
+// MFMA of that phase (a scheduling barrier keeps the order; the waits become counted), and V is read as ONE b128 per (key, lane) instead of four b32:
+// output tile dt of lane j is column d = 4 j + dt (was 16 dt + j) - which lane holds which column changes, the sum of each output does not.
+// S^T = K Q^T: lane ends up with the scores of query j against keys 16 kt + 4 g + r; k order d = 16 c + e + 4 g over (c, e) then g.
+__device__ __forceinline__ void attn_block_scores(const float4* sK4, int j, int g, const float4 (&qr)[4], f32x4 (&st)[4]) {
+  float4 kr[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) kr[c][kt] = sK4[(16 * kt + j) * 16 + ((4 * c + g) ^ j)];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // four independent accumulator chains interleaved; each chain's own order is (c, e) as before
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[c][kt].x, qr[c].x, st[kt], 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[c][kt].y, qr[c].y, st[kt], 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[c][kt].z, qr[c].z, st[kt], 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[c][kt].w, qr[c].w, st[kt], 0, 0, 0);
+  }
+}
+// V rows of this lane's 16 keys, columns 4 j .. 4 j + 3: requested behind the score MFMAs, in flight under the softmax
+__device__ __forceinline__ void attn_block_v_request(const float4* sV4, int j, int g, float4 (&vb)[4][4]) {
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * kt + 4 * g + r;
+      vb[kt][r] = sV4[row * 16 + (j ^ (row & 15))];
+    }
+  __builtin_amdgcn_sched_barrier(0);
+}
+// O += P V with the lane's own probabilities as the A operand (the MFMA sums over g): o[dt][r] = query 4 g + r, column 4 j + dt;
+// k order keys 16 kt + r + 4 g over (kt, r) then g
+__device__ __forceinline__ void attn_block_pv(const f32x4 (&p)[4], const float4 (&vb)[4][4], f32x4 (&o)[4]) {
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[kt][r], vb[kt][r].x, o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[kt][r], vb[kt][r].y, o[1], 0, 0, 0);
+      o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[kt][r], vb[kt][r].z, o[2], 0, 0, 0);
+      o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[kt][r], vb[kt][r].w, o[3], 0, 0, 0);
+    }
+}

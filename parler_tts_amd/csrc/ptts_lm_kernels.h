@@ -1666,12 +1666,23 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(AttnArgs a) {
 // i, online across key blocks; O = P V takes the lane's own probability registers as the A operand (the MFMA sums over g) - no transpose.
 // Semantics of prefill_attn_kernel (masked keys carry no weight, a row without a visible key yields 0, q rotated also in the cross block).
 // ------------------------------------------------------------------------------------------------------
+// eight consecutive cache elements of a row as they are loaded (16 or 32 bytes), converted to fp32 when they are used
+template <typename WT> struct Row8;
+template <> struct Row8<bf16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float (&o)[8]) const { unpack16(v, o, bf16_t()); }
+};
+template <> struct Row8<float> {
+  float4 lo, hi;
+  __device__ __forceinline__ void load(const float* p) { lo = *reinterpret_cast<const float4*>(p); hi = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void get(float (&o)[8]) const { o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w; }
+};
 // NW (round 6, call 38): waves per workgroup at compile time - with blockDim read at run time the K / V staging loop stayed rolled: three rounds of
 // load -> wait -> LDS store in a row in front of every key block (profiles/r06_prefill_kernels_bs32_v4.txt: 15.4 us per launch for 33 x 33 / 33 x 64 scores
 // per head). Unrolled, all of a thread's K / V pieces are requested before the first is stored. Same arithmetic: bit-identical.
 template <typename WT, int NW>
 __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) {
-  constexpr int EPL = Elem<WT>::EPL;
   __shared__ __attribute__((aligned(16))) float sK[64 * 64];
   __shared__ __attribute__((aligned(16))) float sV[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -1682,12 +1693,36 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
   const int Lmax = a.cross ? a.dims->N : min(i0w + qwg, a.Q);  // keys any query of this workgroup can see (self: causal, position = row index)
   const int mask_len = a.cross ? Lmax : P;
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
+  const int mlim = mrow ? min(mask_len, a.mask_ld) : 0;  // keys below it have a mask entry
   const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2
   const int iq = min(i0 + j, a.Q - 1);                     // clamped queries are computed and dropped
   const int Lq = a.cross ? Lmax : iq + 1;
+  const WT* Kc = reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
+  const WT* Vc = reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
+  const int* msrc = mrow ? mrow : reinterpret_cast<const int*>(Kc);
   // Every global load below is UNCONDITIONAL on a clamped address and selected afterwards (call 38): with the loads inside per-lane conditions the compiler
   // wrapped each one in a branch with its own s_waitcnt vmcnt(0) - 4 + 6 + 16 dependent round trips per workgroup (q chunks, K / V pieces, mask flags) in
   // front of 128 MFMAs; a wave-uniform branch (rope?, mask?) around a whole group of loads keeps them in flight together.
+  // Call 46: the first key block's K / V pieces and mask flags are requested BEFORE the query rows (whose RoPE arithmetic waits for them): one memory
+  // round trip in front of the first MFMA instead of two.
+  constexpr int NIT = (64 * 8 + nthreads - 1) / nthreads;  // 64 rows x 8 pieces of 8 elements per matrix
+  Row8<WT> kraw[NIT], vraw[NIT];  // as loaded: converted on the way into LDS, so that nothing waits for them before the query rows are requested
+  int mk[4][4];  // mask flags of this lane's 16 keys, raw (selected against the mask length where they are used)
+  auto request = [&](int j0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * nthreads, r = e >> 3, c8 = e & 7, key = max(min(j0 + r, Lmax - 1), 0);  // a row of the block that exists
+      kraw[it].load(Kc + (size_t)key * 64 + c8 * 8);
+      vraw[it].load(Vc + (size_t)key * 64 + c8 * 8);
+    }
+    // no branch around these (inside `if (mask)` the compiler compared the flags in the branch: 16 waits in front of the query loads): without a mask
+    // the same 16 loads read the first bytes of the K row block - a valid address, values ignored
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mk[kt][r] = msrc[max(min(j0 + 16 * kt + 4 * g + r, mlim - 1), 0)];
+  };
+  request(0);  // unconditional (row 0 exists even for an empty key range): a branch here pulls the flag compares - and their waits - in front of the query loads
   float4 qr[4];
   {
     const float* qrow = a.q + (size_t)(b * a.Q + iq) * a.q_ld + h * 64;
@@ -1713,41 +1748,15 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
 #pragma unroll
     for (int c = 0; c < 4; ++c) qr[c] = make_float4(qv[c].x * qscale, qv[c].y * qscale, qv[c].z * qscale, qv[c].w * qscale);
   }
-  const WT* Kc = reinterpret_cast<const WT*>(a.kcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
-  const WT* Vc = reinterpret_cast<const WT*>(a.vcache) + ((size_t)b * a.kv_heads + kvh) * a.cap * 64;
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float4* sK4 = reinterpret_cast<const float4*>(sK);
   for (int j0 = 0; j0 < Lmax; j0 += 64) {
-    if (j0) __syncthreads();  // the previous tiles are consumed
-    constexpr int NIT = (64 * 8 + nthreads - 1) / nthreads;  // 64 rows x 8 pieces of 8 elements per matrix
-    float kx[NIT][8], vx[NIT][8];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int e = tid + it * nthreads, r = e >> 3, c8 = e & 7, key = min(j0 + r, Lmax - 1);  // j0 < Lmax: the clamped row exists
-      const WT* kr = Kc + (size_t)key * 64 + c8 * 8;
-      const WT* vr = Vc + (size_t)key * 64 + c8 * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { kx[it][i] = Elem<WT>::ld(kr + i); vx[it][i] = Elem<WT>::ld(vr + i); }
-    }
-    int mk[4][4];  // mask flags of this lane's 16 keys (1 where there is no mask entry): requested before the tiles are stored
-    if (mrow) {
-      const int lim = min(mask_len, a.mask_ld);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mk[kt][r] = mrow[max(min(j0 + 16 * kt + 4 * g + r, lim - 1), 0)];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mk[kt][r] = j0 + 16 * kt + 4 * g + r < lim ? mk[kt][r] : 1;
-    } else {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mk[kt][r] = 1;
+    if (j0) {
+      __syncthreads();  // the previous tiles are consumed
+      request(j0);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1755,34 +1764,28 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
       const bool live = j0 + r < Lmax;  // rows beyond the visible keys are zeros
       if (e < 64 * 8) {
         const int s0 = (2 * c8) ^ (r & 15), s1 = (2 * c8 + 1) ^ (r & 15);
-        reinterpret_cast<float4*>(sK)[r * 16 + s0] = live ? make_float4(kx[it][0], kx[it][1], kx[it][2], kx[it][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4*>(sK)[r * 16 + s1] = live ? make_float4(kx[it][4], kx[it][5], kx[it][6], kx[it][7]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4*>(sV)[r * 16 + s0] = live ? make_float4(vx[it][0], vx[it][1], vx[it][2], vx[it][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4*>(sV)[r * 16 + s1] = live ? make_float4(vx[it][4], vx[it][5], vx[it][6], vx[it][7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float kx[8], vx[8];
+        kraw[it].get(kx);
+        vraw[it].get(vx);
+        reinterpret_cast<float4*>(sK)[r * 16 + s0] = live ? make_float4(kx[0], kx[1], kx[2], kx[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(sK)[r * 16 + s1] = live ? make_float4(kx[4], kx[5], kx[6], kx[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(sV)[r * 16 + s0] = live ? make_float4(vx[0], vx[1], vx[2], vx[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(sV)[r * 16 + s1] = live ? make_float4(vx[4], vx[5], vx[6], vx[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    bool ok[4][4];  // key visible to this lane's query: inside its causal / description length and not padding
+    bool ok[4][4];  // key visible to this lane's query: inside its causal / description length and not padding (no mask entry: kept)
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = j0 + 16 * kt + 4 * g + r;
-        ok[kt][r] = key < Lq && (key >= mask_len || mk[kt][r] != 0);
+        ok[kt][r] = (key < Lq) & ((key >= mlim) | (mk[kt][r] != 0));  // bitwise: && / || became 16 branches with a wait each; beyond mlim there is no mask entry
       }
     __syncthreads();
     f32x4 st[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 kr = sK4[(16 * kt + j) * 16 + ((4 * c + g) ^ j)];
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.x, qr[c].x, st[kt], 0, 0, 0);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.y, qr[c].y, st[kt], 0, 0, 0);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.z, qr[c].z, st[kt], 0, 0, 0);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.w, qr[c].w, st[kt], 0, 0, 0);
-      }
-    }
+    attn_block_scores(sK4, j, g, qr, st);
+    float4 vb[4][4];
+    attn_block_v_request(reinterpret_cast<const float4*>(sV), j, g, vb);
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
@@ -1809,33 +1812,17 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
         for (int dt = 0; dt < 4; ++dt) o[dt][r] *= ar;
       }
     }
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * kt + 4 * g + r;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const float vb = sV[row * 64 + (((4 * dt + (j >> 2)) ^ (row & 15)) << 2) + (j & 3)];
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb, o[dt], 0, 0, 0);
-        }
-      }
+    attn_block_pv(st, vb, o);
   }
   WT* dst0 = reinterpret_cast<WT*>(a.direct_out);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < 4; ++r) {  // o[dt][r]: query 4 g + r, column 4 j + dt of the head - four consecutive elements per lane
     const float lr = __shfl(l_run, 4 * g + r);
     const int i = i0 + 4 * g + r;
     if (i >= a.Q) continue;
-    const int row = b * a.Q + i;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int kcol = h * 64 + 16 * dt + j;
-      WT* dst = dst0;
-      if (a.out_fo) dst += fo_vec_index<WT>(row, kcol & ~(EPL - 1), a.H / Elem<WT>::KT) * EPL + (kcol & (EPL - 1));
-      else dst += (size_t)row * a.H + kcol;
-      store_from_f32<WT>(dst, lr > 0.f ? o[dt][r] / lr : 0.f);
-    }
+    const bool any = lr > 0.f;  // a row without a visible key yields 0
+    act_store4<WT>(dst0, b * a.Q + i, h * 64 + 4 * j, a.H, a.out_fo, any ? o[0][r] / lr : 0.f, any ? o[1][r] / lr : 0.f, any ? o[2][r] / lr : 0.f,
+                   any ? o[3][r] / lr : 0.f);
   }
 }
 

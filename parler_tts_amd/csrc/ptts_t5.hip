@@ -165,11 +165,10 @@ __global__ void __launch_bounds__(256) t5_attn_kernel(T5AttnArgs a) {
 //                 query i against keys 16 kt + 4 g + r - 16 of the block's 64 keys, the other 48 in the three lanes with the same i
 //   softmax       per query across those 4 lanes (permlane swaps), online across key blocks
 //   O = P V       A = P: step (kt, r) takes the lane's OWN register P[i][16 kt + 4 g + r] (the MFMA sums over g: no transpose, no LDS round trip
-//                 for the probabilities), B = V[16 kt + 4 g + r][dv]
+//                 for the probabilities), B = V[16 kt + 4 g + r][4 j + dt] (one b128 read per key: ptts_common.h, attn_block_*)
 // k order of the q.k sums: d = 16 c + e + 4 g over (c, e) then g (fixed, deterministic); of the p.v sums: keys 16 kt + r + 4 g over (kt, r) then g.
 template <typename WT>
 __global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs a) {
-  constexpr int EPL = Elem<WT>::EPL;
   __shared__ __attribute__((aligned(16))) float sK[64 * 64];
   __shared__ __attribute__((aligned(16))) float sV[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -231,18 +230,9 @@ __global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs a) {
     }
     __syncthreads();
     f32x4 st[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 kr = sK4[(16 * kt + j) * 16 + ((4 * c + g) ^ j)];
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.x, qr[c].x, st[kt], 0, 0, 0);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.y, qr[c].y, st[kt], 0, 0, 0);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.z, qr[c].z, st[kt], 0, 0, 0);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr.w, qr[c].w, st[kt], 0, 0, 0);
-      }
-    }
+    attn_block_scores(sK4, j, g, qr, st);
+    float4 vb[4][4];
+    attn_block_v_request(reinterpret_cast<const float4*>(sV), j, g, vb);
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
@@ -273,33 +263,15 @@ __global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs a) {
         for (int dt = 0; dt < 4; ++dt) o[dt][r] *= ar;
       }
     }
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * kt + 4 * g + r;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const float vb = sV[row * 64 + (((4 * dt + (j >> 2)) ^ (row & 15)) << 2) + (j & 3)];
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb, o[dt], 0, 0, 0);
-        }
-      }
+    attn_block_pv(st, vb, o);
   }
   WT* dst0 = reinterpret_cast<WT*>(a.out);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < 4; ++r) {  // o[dt][r]: query 4 g + r, column 4 j + dt of the head - four consecutive elements per lane
     const float lr = __shfl(l_run, 4 * g + r);
     const int i = i0 + 4 * g + r;
     if (i >= a.N) continue;
-    const int m = b * a.N + i;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int kcol = h * 64 + 16 * dt + j;
-      WT* dst = dst0;
-      if (a.out_fo) dst += fo_vec_index<WT>(m, kcol & ~(EPL - 1), a.inner / Elem<WT>::KT) * EPL + (kcol & (EPL - 1));
-      else dst += (size_t)m * a.inner + kcol;
-      store_from_f32<WT>(dst, o[dt][r] / lr);
-    }
+    act_store4<WT>(dst0, b * a.N + i, h * 64 + 4 * j, a.inner, a.out_fo, o[0][r] / lr, o[1][r] / lr, o[2][r] / lr, o[3][r] / lr);
   }
 }
 
