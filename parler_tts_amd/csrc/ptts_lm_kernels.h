@@ -1672,17 +1672,22 @@ template <> struct Row8<bf16_t> {
   uint4 v;
   __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ void get(float (&o)[8]) const { unpack16(v, o, bf16_t()); }
+  __device__ __forceinline__ void fill(int x) { v = make_uint4(0x3c003c00u + x, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); }  // probe only
 };
 template <> struct Row8<float> {
   float4 lo, hi;
   __device__ __forceinline__ void load(const float* p) { lo = *reinterpret_cast<const float4*>(p); hi = *reinterpret_cast<const float4*>(p + 4); }
   __device__ __forceinline__ void get(float (&o)[8]) const { o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w; }
+  __device__ __forceinline__ void fill(int x) { lo = make_float4(0.01f * x, 0.02f, 0.03f, 0.04f); hi = lo; }  // probe only
 };
 // NW (round 6, call 38): waves per workgroup at compile time - with blockDim read at run time the K / V staging loop stayed rolled: three rounds of
 // load -> wait -> LDS store in a row in front of every key block (profiles/r06_prefill_kernels_bs32_v4.txt: 15.4 us per launch for 33 x 33 / 33 x 64 scores
 // per head). Unrolled, all of a thread's K / V pieces are requested before the first is stored. Same arithmetic: bit-identical.
-template <typename WT, int NW>
+// ABL (tools/attn_probe.hip only; 0 on the product path): ablation bits - 1: no MFMAs, 2: no K / V / mask loads, 4: no LDS staging, 8: no store, 16: exit at
+// entry, 32: no query loads
+template <typename WT, int NW, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) {
+  if (ABL & 16) return;
   __shared__ __attribute__((aligned(16))) float sK[64 * 64];
   __shared__ __attribute__((aligned(16))) float sV[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -1709,6 +1714,15 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
   Row8<WT> kraw[NIT], vraw[NIT];  // as loaded: converted on the way into LDS, so that nothing waits for them before the query rows are requested
   int mk[4][4];  // mask flags of this lane's 16 keys, raw (selected against the mask length where they are used)
   auto request = [&](int j0) {
+    if (ABL & 2) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) { kraw[it].fill(tid + it); vraw[it].fill(tid - it); }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mk[kt][r] = 1;
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + it * nthreads, r = e >> 3, c8 = e & 7, key = max(min(j0 + r, Lmax - 1), 0);  // a row of the block that exists
@@ -1728,8 +1742,8 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
     const float* qrow = a.q + (size_t)(b * a.Q + iq) * a.q_ld + h * 64;
     float4 qv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) qv[c] = *reinterpret_cast<const float4*>(qrow + 16 * c + 4 * g);
-    if (a.cos) {  // x * cos + rotate_half(x) * sin at the query's own position (modeling:409-436); a 4-element chunk never straddles the halves
+    for (int c = 0; c < 4; ++c) qv[c] = (ABL & 32) ? make_float4(0.01f * lane, 0.02f, 0.03f * c, 0.04f) : *reinterpret_cast<const float4*>(qrow + 16 * c + 4 * g);
+    if (a.cos && !(ABL & 32)) {  // x * cos + rotate_half(x) * sin at the query's own position (modeling:409-436); a 4-element chunk never straddles the halves
       float4 qt[4], cs[4], sn[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -1762,7 +1776,7 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + it * nthreads, r = e >> 3, c8 = e & 7;
       const bool live = j0 + r < Lmax;  // rows beyond the visible keys are zeros
-      if (e < 64 * 8) {
+      if (e < 64 * 8 && !((ABL & 4) && c8 != 7)) {
         const int s0 = (2 * c8) ^ (r & 15), s1 = (2 * c8 + 1) ^ (r & 15);
         float kx[8], vx[8];
         kraw[it].get(kx);
@@ -1781,10 +1795,18 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
         const int key = j0 + 16 * kt + 4 * g + r;
         ok[kt][r] = (key < Lq) & ((key >= mlim) | (mk[kt][r] != 0));  // bitwise: && / || became 16 branches with a wait each; beyond mlim there is no mask entry
       }
-    __syncthreads();
+    if (!(ABL & 4)) __syncthreads();
     f32x4 st[4];
-    attn_block_scores(sK4, j, g, qr, st);
     float4 vb[4][4];
+    if (ABL & 1) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const float4 kr = sK4[(16 * kt + j) * 16 + (g ^ j)];
+        st[kt] = f32x4{kr.x * qr[0].x, kr.y * qr[1].y, kr.z * qr[2].z, kr.w * qr[3].w};
+      }
+    } else {
+      attn_block_scores(sK4, j, g, qr, st);
+    }
     attn_block_v_request(reinterpret_cast<const float4*>(sV), j, g, vb);
     float mx = -INFINITY;
 #pragma unroll
@@ -1812,7 +1834,14 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
         for (int dt = 0; dt < 4; ++dt) o[dt][r] *= ar;
       }
     }
-    attn_block_pv(st, vb, o);
+    if (ABL & 1) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[0][r] += st[kt][r] * vb[kt][r].x; o[1][r] += st[kt][r] * vb[kt][r].y; o[2][r] += st[kt][r] * vb[kt][r].z; o[3][r] += st[kt][r] * vb[kt][r].w; }
+    } else {
+      attn_block_pv(st, vb, o);
+    }
   }
   WT* dst0 = reinterpret_cast<WT*>(a.direct_out);
 #pragma unroll
@@ -1820,6 +1849,7 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
     const float lr = __shfl(l_run, 4 * g + r);
     const int i = i0 + 4 * g + r;
     if (i >= a.Q) continue;
+    if ((ABL & 8) && o[0][r] != 12345.f) continue;
     const bool any = lr > 0.f;  // a row without a visible key yields 0
     act_store4<WT>(dst0, b * a.Q + i, h * 64 + 4 * j, a.H, a.out_fo, any ? o[0][r] / lr : 0.f, any ? o[1][r] / lr : 0.f, any ? o[2][r] / lr : 0.f,
                    any ? o[3][r] / lr : 0.f);
