@@ -121,3 +121,36 @@ def test_codec_on_the_frames_of_a_max_length_run():
         worst = max(worst, d)
     log_parity(f"[codec, 2 x {T} frames, exact-f32] three 64-frame windows vs the oracle: max |d| {worst:.2e}", LOG)
     assert worst <= 1e-4, worst
+
+
+@pytest.mark.parametrize("dtype,prec,tol", [(torch.float32, "fp32", 5e-5), (torch.bfloat16, "bf16", 2e-2)])
+def test_five_second_voice_prompts_prefilled_in_one_pass(dtype, prec, tol):
+    """decoder_input_ids of 430 frames (5 s of a reference voice, modeling:3136-3194) for 9 utterances with ragged masks: the prompt, the BOS column and the
+    430 delayed code columns run as ONE prefill pass of 9 x 464 rows - the > 256-row GEMMs with the K / V rows written by the QKV epilogue, the f32-MFMA prefill
+    attention with eight 64-query blocks x up to eight key blocks per (utterance, head) - and the logits of the continuation's first position are compared
+    with the oracle's single multi-column forward (what the reference runs)."""
+    spec = DO.DecoderSpec(num_hidden_layers=2)
+    K, T, bsz = spec.num_codebooks, 430, 9
+    sd = DO.make_decoder_weights(spec, seed=211)
+    g = torch.Generator().manual_seed(212)
+    enc = torch.randn(bsz, N_DESC, spec.hidden_size, generator=g)
+    prompt = torch.randn(bsz, N_PROMPT, spec.hidden_size, generator=g) * 0.5
+    enc_mask, prompt_mask = C.ragged_masks(bsz, N_DESC, N_PROMPT, enc_step=2)
+    enc = enc * enc_mask[..., None]
+    pre = torch.randint(0, 1024, (bsz, K, T), generator=g)
+    L = T + 40
+    eng = make_engine(spec, sd, dtype, max_batch=bsz, max_ctx=N_PROMPT + L + 8, max_enc=N_DESC, max_prompt=N_PROMPT + 1 + T)
+    eng.set_gen_params(max_length=L)
+    eng.set_audio_prefix(pre)
+    eng.prefill(enc, enc_mask, prompt, prompt_mask, sample=False)
+    got = eng.logits().cpu()
+    eng.close()
+    seq0 = torch.cat([torch.full((bsz * K, 1), spec.bos_token_id), pre.reshape(bsz * K, T)], 1)
+    delayed, pattern = DO.build_delay_pattern_mask(seq0, spec.bos_token_id, spec.pad_token_id, L, K)
+    fed = DO.apply_delay_pattern_mask(delayed, pattern)
+    torch.set_num_threads(min(os.cpu_count() or 8, 16))
+    with torch.no_grad():
+        ref = DO.DecoderOracle(spec, sd, precision=prec).forward(fed, enc, enc_mask, prompt, prompt_mask)[:, -1].float()
+    err = float((got - ref).abs().max())
+    log_parity(f"[voice prompt of {T} frames x {bsz} utterances, {prec}] one prefill pass of {bsz} x {N_PROMPT + 1 + T} rows: max |dlogit| at the continuation's first position {err:.2e}", LOG)
+    assert err <= tol, err
