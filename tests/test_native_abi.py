@@ -200,3 +200,61 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
     assert seen >= 20, seen
     assert strips.get("17gemm_strip_kernel", 0) >= 20 and strips.get("20gemm_strip_kernel_bv", 0) >= 10, strips
     assert not bad, bad[:5]
+
+
+def test_mfma_attention_kernels_request_their_lds_fragments_ahead_of_the_mfmas(tmp_path):
+    """prefill_attn_mfma_kernel / t5_attn_mfma_kernel (the attention nodes of the time-to-first-token path above 128 (utterance, head) pairs): every K / V
+    fragment of a key block is requested from LDS before the MFMAs that consume it (ptts_common.h: attn_block_scores / _v_request / _pv; DESIGN.md §4.4 (h):
+    the compiler had scheduled ds_read -> s_waitcnt lgkmcnt(0) -> MFMA 16 + 64 times in a row, 14.3 -> 11.7 us per launch once removed). What that looks like
+    in the shipped gfx950 code objects: at most a handful of `s_waitcnt lgkmcnt(0)` that follow one or two ds_reads ("short groups": one dependent LDS round trip
+    each; tools/isa_lds_chains.py counts the same thing on the assembly), V read with b128 (no ds_read_b32 feeding the P V MFMAs), 128 MFMAs per key block."""
+    import shutil
+    import subprocess
+
+    N, _ = _lib()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(N.LIB_PATH, lib)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", lib], capture_output=True, cwd=str(tmp_path), check=True)
+    objs = [str(tmp_path / f) for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert objs, "no embedded gfx950 code objects found"
+    seen, bad = 0, []
+    for obj in objs:
+        syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--symbols", obj], capture_output=True, text=True).stdout
+        if "attn_mfma_kernel" not in syms:
+            continue
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", obj], capture_output=True, text=True).stdout
+        cur, stat = None, {}
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1) if "attn_mfma_kernel" in m.group(1) else None
+                if cur:
+                    stat[cur] = dict(reads=0, b32=0, short=0, since=0, mfma=0)
+                continue
+            t = line.split()
+            if cur is None or not t:
+                continue
+            s = stat[cur]
+            if t[0].startswith("ds_read"):
+                s["reads"] += 1
+                s["since"] += 1
+                s["b32"] += t[0] in ("ds_read_b32", "ds_read2_b32", "ds_read2st64_b32")
+            elif t[0].startswith("v_mfma"):
+                s["mfma"] += 1
+            elif t[0] == "s_waitcnt" and "lgkmcnt(" in line:
+                if 0 < s["since"] <= 2 and "lgkmcnt(0)" in line:
+                    s["short"] += 1
+                s["since"] = 0
+        for sym, s in stat.items():
+            seen += 1
+            if s["mfma"] < 128 or s["mfma"] % 128:
+                bad.append((sym[:60], "MFMAs per key block", s))
+            if s["short"] > 6:
+                bad.append((sym[:60], "LDS reads waited for one at a time", s))
+            if s["b32"]:
+                bad.append((sym[:60], "V read element by element", s))
+    assert seen >= 10, seen  # prefill: 1..4 waves x {bf16, fp32}; T5: {bf16, fp32}
+    assert not bad, bad[:5]
