@@ -28,8 +28,8 @@ N_DESC, N_PROMPT = 64, 33
 LOG = "r06_parity_max_context.txt"
 
 
-def _run(dtype, prec, bsz, tol, masks, seed, kv_fp8=False):
-    spec = DO.DecoderSpec(num_hidden_layers=2)  # Mini-v1 widths, max_position_embeddings 4096
+def _run(dtype, prec, bsz, tol, masks, seed, kv_fp8=False, spec=None, tag=""):
+    spec = spec or DO.DecoderSpec(num_hidden_layers=2)  # Mini-v1 widths, max_position_embeddings 4096
     K, L = spec.num_codebooks, MAX_LENGTH
     sd = DO.make_decoder_weights(spec, seed=seed)
     g = torch.Generator().manual_seed(seed + 1)
@@ -69,7 +69,7 @@ def _run(dtype, prec, bsz, tol, masks, seed, kv_fp8=False):
     gap = top2[..., 0] - m.gather(-1, ids[:, 1:, None])[..., 0]
     outside = int((diff & (gap > 2 * tol)).sum())
     late = diff[:, L // 2:]
-    log_parity(f"[max context {prec} bs={bsz}{' e4m3-kv' if kv_fp8 else ''}] {L - 1} free-running passes x {bsz * K} rows, context up to {N_PROMPT + L - 2}: "
+    log_parity(f"[max context {prec} bs={bsz}{' e4m3-kv' if kv_fp8 else ''}{tag}] {L - 1} free-running passes x {bsz * K} rows, context up to {N_PROMPT + L - 2}: "
                f"{int(diff.sum())} of {diff.numel()} choices differ from the oracle's arg-max at the same history ({int(late.sum())} in the second half), "
                f"{outside} outside 2 x {tol:g}; max |dlogit| of the last pass {err_last:.2e}; min oracle top-2 margin {float(margin.min()):.2e}", LOG)
     assert err_last <= tol, err_last
@@ -95,6 +95,22 @@ def test_bf16_ragged_batch_of_12_to_max_length():
 def test_bf16_e4m3_kv_cache_batch_of_12_to_max_length():
     """Opt-in e4m3 KV cache (own oracle leg): the scale arena and the byte rows at the far end of the context."""
     _run(torch.bfloat16, "bf16", 12, 2e-2, masks=True, seed=104, kv_fp8=True)
+
+
+@pytest.mark.parametrize("bsz", [1, 9])
+def test_large_v1_widths_to_max_length(bsz):
+    """Large-v1 widths (H = 1536, 24 heads, F = 6144; helpers/model_init_scripts/init_large_model.py:25-43), 2 layers, bf16: the single-utterance GEMV step without
+    the folded cross block (that width runs LN2 + cross-q + attention and the output projection as two nodes) and 9 ragged utterances on the MFMA strips."""
+    spec = DO.DecoderSpec(hidden_size=1536, num_hidden_layers=2, num_attention_heads=24, ffn_dim=6144)
+    _run(torch.bfloat16, "bf16", bsz, 2e-2, masks=bsz > 1, seed=105 + bsz, spec=spec, tag=" Large-v1 widths")
+
+
+@pytest.mark.parametrize("bsz", [1, 9])
+def test_rope_and_grouped_query_attention_to_max_length(bsz):
+    """`rope_embeddings` (positions up to 2611 through the cos / sin tables, the q-only rotation quirk of the cross block) with grouped-query attention
+    (4 self / 2 cross K/V heads) - the configuration axes of the released Mini-v1 / Large-v1 checkpoints' siblings - fp32."""
+    spec = DO.DecoderSpec(num_hidden_layers=2, rope_embeddings=True, num_key_value_heads=4, num_cross_attention_key_value_heads=2)
+    _run(torch.float32, "fp32", bsz, 5e-5, masks=bsz > 1, seed=120 + bsz, spec=spec, tag=" RoPE + GQA")
 
 
 def test_codec_on_the_frames_of_a_max_length_run():
