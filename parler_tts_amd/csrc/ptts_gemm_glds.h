@@ -23,7 +23,12 @@ template <int N> __device__ __forceinline__ void ptts_wait_vmcnt() { asm volatil
 
 // ABL (tools/gemm_probe only): 0 = the kernel; 1 = no fragment reads / MFMAs (load stream + barriers only); 2 = no LDS-DMA (compute on whatever the LDS holds)
 template <int EPI, int BNS, int BMT, int WN, int WM, int NST, int ABL = 0, int RP = 0, int KF = 2>
-__global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
+__global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs_KPARAMS) {
+  // Kernel-argument preload (ptts_common.h; call 52): everything that addresses the wave's first LDS-DMA pieces - W, x, K, M and, in the two preloaded slots
+  // the strip kernel's pass geometry occupies, the activation row stride and the tile-order flag + grid extents (launch_gemm_glds_inst; gridDim is a hidden argument behind an s_load) - arrives in SGPRs written by the
+  // command processor; the tail (epilogue operands) comes by s_load in the shadow of the first stage.
+  GemmArgs_KJOIN(a)
+  const int x_ld = a.rows_per_pass, xcd_swz = a.frags_per_wave & 1, grid_n = (a.frags_per_wave >> 1) & 0x7ff, grid_m = (int)((unsigned)a.frags_per_wave >> 12);
   typedef bf16_t WT;
   static_assert(KF == 2 || KF == 4, "BK = 64 or 128 per stage");
   constexpr int RB = KF * 64, SPR = RB / 16, RPP = 1024 / RB;  // activation image: bytes per row, 16-byte slots per row, rows per 1 KiB piece
@@ -45,7 +50,7 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
     if (a.kv_layers) { const KvLayer kl = a.kv_layers[blockIdx.z]; a.W = kl.W; a.kcache = kl.k; a.vcache = kl.v; }
   }
   int bx, by;
-  xcd_tile_order(bx, by, a.xcd_swz);
+  xcd_tile_order(bx, by, xcd_swz, grid_n, grid_m);
   const int strip0 = bx * BNS, m0 = by * BMT * 16;
   const int nfrag = a.K >> 5, nstage = nfrag / KF;        // host guarantees K % 64 == 0
   // this wave's pieces: piece p = wave + NW * i; p < APC: fragment p % KF of strip p / KF, else rows 8 (p - APC) .. + 7 of the row tile
@@ -63,7 +68,7 @@ __global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs a) {
     } else {
       const int rl = (p - APC) * RPP + lane / SPR;            // row of the tile; its image slot lane % SPR holds piece slot ^ (row & (SPR - 1))
       const int row = min(m0 + rl, a.M - 1);                  // clamped rows are computed and dropped
-      src[i] = reinterpret_cast<const char*>(a.x) + (size_t)(row * a.x_row_mul + a.x_row_off) * a.x_ld * sizeof(WT) + (((lane % SPR) ^ (rl & (SPR - 1))) << 4);
+      src[i] = reinterpret_cast<const char*>(a.x) + (size_t)row * x_ld * sizeof(WT) + (((lane % SPR) ^ (rl & (SPR - 1))) << 4);  // x_row_mul 1, x_row_off 0 (launcher)
     }
   }
   auto issue = [&](int t, int buf) {
@@ -230,7 +235,11 @@ int launch_gemm_glds_inst(const GemmArgs& a, hipStream_t st) {
     attr_once.done(attr_dev);
   }
   const dim3 grid(a.N / (16 * BNS), (a.M + BMT * 16 - 1) / (BMT * 16), (EPI == EPI_KV && a.kv_layers) ? a.kv_nlayers : 1);
-  hipLaunchKernelGGL((gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST, ABL, RP, KF>), grid, dim3(WN * WM * 64), sh, st, a);
+  if (a.x_row_mul != 1 || a.x_row_off != 0) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm_glds: activation rows must be consecutive (x_row_mul %d, x_row_off %d)", a.x_row_mul, a.x_row_off);
+  GemmArgs b = a;  // the two preloaded slots of the strip kernel's pass geometry carry what this kernel needs to address its first loads
+  if (grid.x > 0x7ffu || grid.y > 0xfffffu) return ptts_fail(PTTS_E_UNSUPPORTED, "gemm_glds: %u x %u tiles do not fit the packed grid extents", grid.x, grid.y);
+  b.rows_per_pass = a.x_ld; b.frags_per_wave = (int)((a.xcd_swz ? 1u : 0u) | (grid.x << 1) | (grid.y << 12));  // tile-order flag | tiles along N | tiles along M
+  ptts_klaunch(gemm_glds_kernel<EPI, BNS, BMT, WN, WM, NST, ABL, RP, KF>, grid, dim3(WN * WM * 64), sh, st, b);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "gemm launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
@@ -258,7 +267,7 @@ static inline bool glds_fills_rounds(int tiles, int slots) {
 }
 template <int EPI>
 int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
-  if (a.K % 64 || a.N % 64 || a.x_ld % 8) return -1;
+  if (a.K % 64 || a.N % 64 || a.x_ld % 8 || a.x_row_mul != 1 || a.x_row_off != 0) return -1;
   static const bool big_tiles = !(ptts_dev_env("PTTS_GLDS_BIG_TILES") && !atoi(ptts_dev_env("PTTS_GLDS_BIG_TILES")));  // A/B (dev-knob build): 0 = calls 2-6 policy
   if constexpr (EPI == EPI_STORE) {
     if (big_tiles && a.N % 192 == 0 && glds_fills_rounds((a.N / 192) * ((a.M + 127) / 128), 512)) return launch_gemm_glds_inst<EPI, 12, 8, 4, 2, 2, 0, 1>(a, st);

@@ -878,8 +878,9 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs& a, int m, int n,
 // of both operands (measured: the batch-32 T5 GEMMs moved ~200 MB per launch at ~3 TB/s - L2-miss bound). Remapped, XCD x owns one contiguous
 // (RN x RM) region of the tile grid (RN * RM = 8), so a panel is fetched by ONE XCD. Bijective; grids it cannot split evenly keep launch order
 // (a speed choice only: the placement itself is not guaranteed by the runtime).
-__device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int swz) {
-  const int NB = gridDim.x, MB = gridDim.y, total = NB * MB;
+// (NB, MB given: the caller has the grid extents in preloaded SGPRs - gridDim itself is a hidden argument behind an s_load)
+__device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int swz, int NB, int MB) {
+  const int total = NB * MB;
   bx = blockIdx.x; by = blockIdx.y;
   if (!swz || total % 8) return;
   int RM = 2, RN = 4;
@@ -895,6 +896,7 @@ __device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int swz) {
   by = (xcd / RN) * mbr + slot / nbr;
   (void)mbr;
 }
+__device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int swz) { xcd_tile_order(bx, by, swz, (int)gridDim.x, (int)gridDim.y); }
 
 template <typename WT, int EPI, int NS>
 __global__ void __launch_bounds__(256) gemm_block_kernel(GemmArgs a) {
