@@ -23,7 +23,7 @@ template <int N> __device__ __forceinline__ void ptts_wait_vmcnt() { asm volatil
 
 // ABL (tools/gemm_probe only): 0 = the kernel; 1 = no fragment reads / MFMAs (load stream + barriers only); 2 = no LDS-DMA (compute on whatever the LDS holds)
 template <int EPI, int BNS, int BMT, int WN, int WM, int NST, int ABL = 0, int RP = 0, int KF = 2>
-__global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(GemmArgs_KPARAMS) {
+__global__ void __launch_bounds__(WN * WM * 64) gemm_glds_kernel(PTTS_DBG0_PARAM GemmArgs_KPARAMS) {
   // Kernel-argument preload (ptts_common.h; call 52): everything that addresses the wave's first LDS-DMA pieces - W, x, K, M and, in the two preloaded slots
   // the strip kernel's pass geometry occupies, the activation row stride and the tile-order flag + grid extents (launch_gemm_glds_inst; gridDim is a hidden argument behind an s_load) - arrives in SGPRs written by the
   // command processor; the tail (epilogue operands) comes by s_load in the shadow of the first stage.

@@ -224,21 +224,25 @@ int launch_prefill_attn(const AttnArgs& a, int B, hipStream_t st, int mode = 3) 
   if (!a.kscale && (mode == 2 || (mode != 1 && B * a.nheads >= 128))) {
     const int waves = std::min(4, (a.Q + 15) / 16);
     const dim3 gm((a.Q + 16 * waves - 1) / (16 * waves), a.nheads, B);
-    if (waves == 4) hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 4>), gm, dim3(256), 0, st, a);
-    else if (waves == 3) hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 3>), gm, dim3(192), 0, st, a);
-    else if (waves == 2) hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 2>), gm, dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((prefill_attn_mfma_kernel<WT, 1>), gm, dim3(64), 0, st, a);
+    int rcm;
+    if (waves == 4) rcm = ptts_launch_prefill_attn_kernel(prefill_attn_mfma_kernel<WT, 4>, gm, dim3(256), st, a);
+    else if (waves == 3) rcm = ptts_launch_prefill_attn_kernel(prefill_attn_mfma_kernel<WT, 3>, gm, dim3(192), st, a);
+    else if (waves == 2) rcm = ptts_launch_prefill_attn_kernel(prefill_attn_mfma_kernel<WT, 2>, gm, dim3(128), st, a);
+    else rcm = ptts_launch_prefill_attn_kernel(prefill_attn_mfma_kernel<WT, 1>, gm, dim3(64), st, a);
+    if (rcm != PTTS_OK) return rcm;
     hipError_t em = hipGetLastError();
     if (em != hipSuccess) return ptts_fail(PTTS_E_HIP, "prefill attention launch failed: %s", hipGetErrorString(em));
     return PTTS_OK;
   }
   const dim3 grid((a.Q + 7) / 8, a.nheads, B);
+  int rcv;
   if (a.kscale) {
-    if constexpr (sizeof(WT) == 2) hipLaunchKernelGGL((prefill_attn_kernel<WT, true>), grid, dim3(256), 0, st, a);
+    if constexpr (sizeof(WT) == 2) rcv = ptts_launch_prefill_attn_kernel(prefill_attn_kernel<WT, true>, grid, dim3(256), st, a);
     else return ptts_fail(PTTS_E_UNSUPPORTED, "kv_fp8 needs the bf16 engine");
   } else {
-    hipLaunchKernelGGL((prefill_attn_kernel<WT, false>), grid, dim3(256), 0, st, a);
+    rcv = ptts_launch_prefill_attn_kernel(prefill_attn_kernel<WT, false>, grid, dim3(256), st, a);
   }
+  if (rcv != PTTS_OK) return rcv;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ptts_fail(PTTS_E_HIP, "prefill attention launch failed: %s", hipGetErrorString(e));
   return PTTS_OK;
@@ -247,7 +251,11 @@ int launch_prefill_attn(const AttnArgs& a, int B, hipStream_t st, int mode = 3) 
 template <typename WT, int PRO>
 int launch_prep(GemmArgs a, void* dst, hipStream_t st) {
   a.invK = 1.0f / (float)a.K;
-  hipLaunchKernelGGL((rows_prep_kernel<WT, PRO>), dim3((a.M + 3) / 4), dim3(256), 0, st, a, reinterpret_cast<WT*>(dst));
+  if ((unsigned)a.x_row_mul > 0xffffu || (unsigned)a.x_row_off > 0xffffu) return ptts_fail(PTTS_E_UNSUPPORTED, "rows_prep: row selection %d * m + %d does not fit the packed slot", a.x_row_mul, a.x_row_off);
+  // the preloaded slots this node does not use carry what addresses its first loads (rows_prep_kernel)
+  a.W = a.gamma; a.W8 = a.beta; a.out = reinterpret_cast<float*>(dst); a.rows_per_pass = a.x_ld; a.frags_per_wave = (int)((unsigned)a.x_row_mul | ((unsigned)a.x_row_off << 16));
+  a.out_ld = a.out_fo;
+  ptts_klaunch(rows_prep_kernel<WT, PRO>, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
   return PTTS_OK;
 }
 

@@ -462,7 +462,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;
       a.part = e->part; a.stats = e->stats; a.S = S_used; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 0;
       a.fused_append = prefill ? 0 : 1; a.scale = scale;
-      a.kscale = w.ks_self; a.vscale = w.vs_self;
+      a.kscale = w.ks_self; a.vscale = w.vs_self; a.hostP = e->P; a.hostN = e->N;
       a.direct_out = S_used == 1 ? e->xw : nullptr; a.out_fo = fo;
       PTTS_DBG_BIG(a, l, 1);
       if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st, prefill_attn_mode)));
@@ -528,7 +528,7 @@ int forward(ptts_engine* e, bool prefill, hipStream_t st, bool with_embed = true
       a.cos = c.rope ? e->rope_cos : nullptr; a.sin = c.rope ? e->rope_sin : nullptr;  // quirk: q rotated, keys not (:858 vs :880)
       a.part = e->part; a.stats = e->stats; a.S = 1; a.Q = Q; a.nheads = nh; a.H = H; a.cross = 1;
       a.kv_heads = nkc; a.n_rep = nh / nkc;
-      a.fused_append = 0; a.scale = scale;
+      a.fused_append = 0; a.scale = scale; a.hostP = e->P; a.hostN = e->N;
       a.direct_out = e->xw; a.out_fo = fo;  // the description is short: never split, softmax finished in the attention kernel
       if (prefill && prefill_attn) PTTS_TRY((launch_prefill_attn<WT>(a, B, st, prefill_attn_mode)));
       else PTTS_TRY((launch_attn<WT>(a, B, st, prefill ? 4 : e->cross_waves)));  // decode: as few waves as cover the description (no LDS combine at 1)

@@ -1183,8 +1183,16 @@ __device__ __forceinline__ void prep_rms_row(const GemmArgs& a, int m, WT* dst, 
   }
 }
 
+// Kernel-argument preload (ptts_common.h; call 54): the node takes the first 56 bytes of GemmArgs as scalars like the GEMMs it feeds. It has no weights, so
+// launch_prep puts what addresses a wave's first loads into the preloaded slots it does not use - gamma / beta in W / W8, the destination in `out`, the row
+// stride in rows_per_pass, x_row_mul | x_row_off << 16 in frags_per_wave, out_fo in out_ld - and the kernel writes them back into the re-assembled struct (in
+// registers: the tail's own copies of those fields are never loaded).
 template <typename WT, int PRO>
-__global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restrict__ dst) {
+__global__ void __launch_bounds__(256) rows_prep_kernel(PTTS_DBG0_PARAM GemmArgs_KPARAMS) {
+  GemmArgs_KJOIN(a)
+  a.gamma = reinterpret_cast<const float*>(a.W); a.beta = reinterpret_cast<const float*>(a.W8);
+  a.x_ld = a.rows_per_pass; a.x_row_mul = a.frags_per_wave & 0xffff; a.x_row_off = (int)((unsigned)a.frags_per_wave >> 16); a.out_fo = a.out_ld;
+  WT* __restrict__ dst = reinterpret_cast<WT*>(a.out);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= a.M) return;
@@ -1236,13 +1244,17 @@ __global__ void __launch_bounds__(256) rows_prep_kernel(GemmArgs a, WT* __restri
 //   cross        : static K/V (:872-875), additive padding mask (:1553-1562) as -inf, q rotated if RoPE (quirk)
 // ------------------------------------------------------------------------------------------------------
 struct AttnArgs {
+  // ---- bytes 0..55: what the PREFILL attention kernels take as scalar kernel parameters (preloaded into SGPRs by the command processor; call 54) ----
   const float* q;      // [rows][q_ld], head h at column h*64
   int q_ld;
-  const float* knew;   // fused append sources (same row indexing), or null
-  const float* vnew;
-  int kv_ld;
+  int pre0;            // prefill kernels: P | mask_ld << 16 (launch_prefill_attn)
+  const float* knew;   // fused append sources (same row indexing), or null            | prefill kernels: the mask pointer
+  const float* vnew;   //                                                              | prefill kernels: Q | kv_heads << 32 | n_rep << 48
+  int kv_ld;           //                                                              | prefill kernels: cap
+  int pre1;            // prefill kernels: the description length N (cross block) or -1 (self block)
   void* kcache;
   void* vcache;
+  // ---- tail ----
   int cap;             // cache capacity in positions
   int kv_bound;        // host-known upper bound of the valid length (<= cap): first-batch rows at or beyond it are not fetched
   const int* cur_len;  // decode: per-batch column count (position = P + cur_len[b] - 1); null in prefill
@@ -1262,8 +1274,39 @@ struct AttnArgs {
   int out_fo;          // direct_out in MFMA B-fragment order (fo_vec_index) instead of row-major [rows][H]
   float* kscale;       // (KV8 instances) e4m3 self-attention cache: kcache / vcache hold 64 bytes per row and these one power-of-two scale per
   float* vscale;       // (utterance, K/V head, position): [B][kv_heads][cap] fp32, written at append like the rows; null = engine-dtype cache
+  int hostP, hostN;    // prefill: the prompt / description lengths of this call as the HOST knows them (dims holds the same numbers on the device)
   PTTS_DBG_FIELD
 };
+static_assert(sizeof(AttnArgs) % 8 == 0 && offsetof(AttnArgs, cap) == 56, "AttnArgs: 56 preloaded bytes + tail");
+// The prefill attention kernels (prefill_attn_kernel, prefill_attn_mfma_kernel) take the first 56 bytes as scalars; they never use knew / vnew / kv_ld, so
+// launch_prefill_attn carries in those slots what addresses a wave's first loads - and what the kernels used to fetch through `dims` on the device (a
+// second, dependent scalar round trip): P, N, Q, the cache capacity, the mask pointer / row stride and the K/V head geometry. PREFILL_ATTN_JOIN writes them
+// back into the re-assembled struct (in registers: the tail's own copies are never loaded) and defines P and NK (N of the cross block, -1 for self).
+#define AttnArgs_KPARAMS \
+  const float *kq_, int kqld_, int kpre0_, const float *kknew_, const float *kvnew_, int kkvld_, int kpre1_, void *kkc_, void *kvc_, KTail<AttnArgs> kt_
+#define PREFILL_ATTN_JOIN(a)                                                                                                          \
+  AttnArgs a;                                                                                                                         \
+  PTTS_KTAIL_JOIN(AttnArgs, a);                                                                                                       \
+  a.q = kq_; a.q_ld = kqld_; a.kcache = kkc_; a.vcache = kvc_; a.cap = kkvld_;                                                        \
+  a.mask = reinterpret_cast<const int*>(kknew_); a.mask_ld = (int)((unsigned)kpre0_ >> 16);                                          \
+  const int P = kpre0_ & 0xffff, NK = kpre1_;                                                                                         \
+  a.cross = NK >= 0;                                                                                                                  \
+  {                                                                                                                                   \
+    const unsigned long long u_ = reinterpret_cast<unsigned long long>(kvnew_);                                                       \
+    a.Q = (int)(u_ & 0xffffffffull); a.kv_heads = (int)((u_ >> 32) & 0xffff); a.n_rep = (int)(u_ >> 48);                              \
+  }
+template <typename Kn> inline int ptts_launch_prefill_attn_kernel(Kn kern, dim3 grid, dim3 block, hipStream_t st, const AttnArgs& a) {
+  if ((unsigned)a.hostP > 0xffffu || (unsigned)a.mask_ld > 0xffffu || (unsigned)a.kv_heads > 0xffffu || (unsigned)a.n_rep > 0xffffu || a.Q < 0)
+    return ptts_fail(PTTS_E_UNSUPPORTED, "prefill attention: P %d / mask_ld %d / heads %d x %d do not fit the packed slots", a.hostP, a.mask_ld, a.kv_heads, a.n_rep);
+  AttnArgs b = a;
+  b.pre0 = (int)((unsigned)a.hostP | ((unsigned)a.mask_ld << 16));
+  b.pre1 = a.cross ? a.hostN : -1;
+  b.knew = reinterpret_cast<const float*>(a.mask);
+  b.vnew = reinterpret_cast<const float*>((unsigned long long)(unsigned)a.Q | ((unsigned long long)a.kv_heads << 32) | ((unsigned long long)a.n_rep << 48));
+  b.kv_ld = a.cap;
+  hipLaunchKernelGGL(kern, grid, block, 0, st, b.q, b.q_ld, b.pre0, b.knew, b.vnew, b.kv_ld, b.pre1, b.kcache, b.vcache, ptts_ktail(b));
+  return PTTS_OK;
+}
 
 // load EPL consecutive floats of a row chunk, optionally RoPE-rotated (x*cos + rotate_half(x)*sin, modeling:409-436)
 template <int EPL>
@@ -1552,7 +1595,8 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
 // Reference: modeling_parler_tts.py:906-914 (SDPA), :1474-1501 / :1553-1562 (masks).
 // ------------------------------------------------------------------------------------------------------
 template <typename WT, bool KV8 = false>
-__global__ void __launch_bounds__(256) prefill_attn_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256) prefill_attn_kernel(AttnArgs_KPARAMS) {
+  PREFILL_ATTN_JOIN(a)
   static_assert(!KV8 || sizeof(WT) == 2, "e4m3 cache: bf16 engine");
   constexpr int QW = 2, QB = 4 * QW, EPL = Elem<WT>::EPL;
   __shared__ float sK[64 * 65];
@@ -1562,8 +1606,7 @@ __global__ void __launch_bounds__(256) prefill_attn_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * QB;
   const int kvh = h / a.n_rep;
-  const int P = a.dims->P;
-  const int Lmax = a.cross ? a.dims->N : min(i0 + QB, a.Q);  // keys any query of this workgroup can see (self: causal, position = row index)
+  const int Lmax = a.cross ? NK : min(i0 + QB, a.Q);  // keys any query of this workgroup can see (self: causal, position = row index)
   const int mask_len = a.cross ? Lmax : P;
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
   const float qscale = a.scale * 1.44269504088896340736f;  // softmax in base 2 (attn_kernel)
@@ -1688,7 +1731,8 @@ template <> struct Row8<float> {
 // ABL (tools/attn_probe.hip only; 0 on the product path): ablation bits - 1: no MFMAs, 2: no K / V / mask loads, 4: no LDS staging, 8: no store, 16: exit at
 // entry, 32: no query loads
 template <typename WT, int NW, int ABL = 0>
-__global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs_KPARAMS) {
+  PREFILL_ATTN_JOIN(a)
   if (ABL & 16) return;
   __shared__ __attribute__((aligned(16))) float sK[64 * 64];
   __shared__ __attribute__((aligned(16))) float sV[64 * 64];
@@ -1696,8 +1740,7 @@ __global__ void __launch_bounds__(NW * 64) prefill_attn_mfma_kernel(AttnArgs a) 
   constexpr int nthreads = NW * 64, qwg = NW * 16;  // 1..4 waves of 16 queries
   const int h = blockIdx.y, b = blockIdx.z, i0w = blockIdx.x * qwg, i0 = i0w + w * 16;
   const int kvh = h / a.n_rep;
-  const int P = a.dims->P;
-  const int Lmax = a.cross ? a.dims->N : min(i0w + qwg, a.Q);  // keys any query of this workgroup can see (self: causal, position = row index)
+  const int Lmax = a.cross ? NK : min(i0w + qwg, a.Q);  // keys any query of this workgroup can see (self: causal, position = row index)
   const int mask_len = a.cross ? Lmax : P;
   const int* mrow = a.mask ? a.mask + (size_t)b * a.mask_ld : nullptr;
   const int mlim = mrow ? min(mask_len, a.mask_ld) : 0;  // keys below it have a mask entry

@@ -74,16 +74,27 @@ struct T5AttnArgs {
   int bias_ld, bias_zero;
   const int* mask;    // [B][N] int32 (1 = keep) or null
   void* out;          // [B*N][inner] engine dtype, row-major or MFMA B-fragment order
+  int N;
   int out_fo;
-  int B, N;
 };
+// The attention kernels take the struct's fields as SCALAR parameters (14 dwords = exactly what the command processor preloads into SGPRs before the first wave
+// starts, -mllvm -amdgpu-kernarg-preload-count=14, ptts_common.h): no s_load in front of the wave's first loads (call 54).
+static_assert(sizeof(T5AttnArgs) == 56, "T5AttnArgs: the 14 preloaded dwords");
+#define T5AttnArgs_KPARAMS const float *kqkv_, int kld_, int kinner_, const float *kbias_, int kbld_, int kbz_, const int *kmask_, void *kout_, int kN_, int kfo_
+#define T5AttnArgs_KJOIN(a) \
+  T5AttnArgs a;             \
+  a.qkv = kqkv_; a.ld = kld_; a.inner = kinner_; a.bias = kbias_; a.bias_ld = kbld_; a.bias_zero = kbz_; a.mask = kmask_; a.out = kout_; a.N = kN_; a.out_fo = kfo_;
+template <typename Kn> inline void t5_attn_launch(Kn kern, dim3 grid, dim3 block, hipStream_t st, const T5AttnArgs& a) {
+  hipLaunchKernelGGL(kern, grid, block, 0, st, a.qkv, a.ld, a.inner, a.bias, a.bias_ld, a.bias_zero, a.mask, a.out, a.N, a.out_fo);
+}
 
 // T5Attention.forward, encoder self-attention: scores = q k^T (NO 1/sqrt(d) scale) + position_bias (+ (1 - mask) * finfo.min), softmax in fp32,
 // context = p v. One workgroup = 8 queries of one (utterance, head): 4 waves x 2 queries; keys in tiles of 64 (lane = key), K / V tiles staged in
 // LDS once per workgroup, online softmax across tiles. A masked key keeps the score -FLT_MAX exactly as the additive mask leaves it (a fully
 // masked row is therefore uniform over all N keys, like the reference); keys beyond N do not exist.
 template <typename WT>
-__global__ void __launch_bounds__(256) t5_attn_kernel(T5AttnArgs a) {
+__global__ void __launch_bounds__(256) t5_attn_kernel(T5AttnArgs_KPARAMS) {
+  T5AttnArgs_KJOIN(a)
   constexpr int QW = 2, QB = 4 * QW, EPL = Elem<WT>::EPL;
   __shared__ float sK[64 * 65];
   __shared__ __attribute__((aligned(16))) float sV[64 * 64];
@@ -168,7 +179,8 @@ __global__ void __launch_bounds__(256) t5_attn_kernel(T5AttnArgs a) {
 //                 for the probabilities), B = V[16 kt + 4 g + r][4 j + dt] (one b128 read per key: ptts_common.h, attn_block_*)
 // k order of the q.k sums: d = 16 c + e + 4 g over (c, e) then g (fixed, deterministic); of the p.v sums: keys 16 kt + r + 4 g over (kt, r) then g.
 template <typename WT>
-__global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs a) {
+__global__ void __launch_bounds__(256) t5_attn_mfma_kernel(T5AttnArgs_KPARAMS) {
+  T5AttnArgs_KJOIN(a)
   __shared__ __attribute__((aligned(16))) float sK[64 * 64];
   __shared__ __attribute__((aligned(16))) float sV[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 15, g = lane >> 4;
@@ -481,12 +493,12 @@ int t5_forward(ptts_t5* e, int B, int N, bool has_mask, hipStream_t st) {
     {
       T5AttnArgs a = {};
       a.qkv = e->qkv; a.ld = 3 * I; a.inner = I; a.bias = e->bias; a.bias_ld = 2 * c.max_len - 1; a.bias_zero = c.max_len - 1;
-      a.mask = has_mask ? e->mask : nullptr; a.out = e->ctx; a.out_fo = fo; a.B = B; a.N = N;
+      a.mask = has_mask ? e->mask : nullptr; a.out = e->ctx; a.out_fo = fo; a.N = N;
       // batches that fill the chip with 64-query workgroups: the f32-MFMA kernel (PTTS_T5_ATTN_MFMA=0: the VALU kernel everywhere; =1: the MFMA kernel everywhere)
       if (mfma_mode == 1 || (mfma_mode == 2 && B * c.num_heads * ((N + 63) / 64) >= 128))
-        hipLaunchKernelGGL((t5_attn_mfma_kernel<WT>), dim3((N + 63) / 64, c.num_heads, B), dim3(256), 0, st, a);
+        t5_attn_launch(t5_attn_mfma_kernel<WT>, dim3((N + 63) / 64, c.num_heads, B), dim3(256), st, a);
       else
-        hipLaunchKernelGGL((t5_attn_kernel<WT>), dim3((N + 7) / 8, c.num_heads, B), dim3(256), 0, st, a);
+        t5_attn_launch(t5_attn_kernel<WT>, dim3((N + 7) / 8, c.num_heads, B), dim3(256), st, a);
     }
     {  // hidden = hidden + o(context)
       GemmArgs g = {};

@@ -6,14 +6,15 @@
 #include "../parler_tts_amd/csrc/ptts_common.h"
 #include "../parler_tts_amd/csrc/ptts_lm_kernels.h"
 #include <vector>
+int ptts_fail(int code, const char* fmt, ...) { fprintf(stderr, "ptts_fail(%d): %s\n", code, fmt); return code; }  // the library's error sink, stubbed
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int ABL> float run(const AttnArgs& a, dim3 grid, hipStream_t st, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((prefill_attn_mfma_kernel<bf16_t, 3, ABL>), grid, dim3(192), 0, st, a);
+  for (int i = 0; i < 20; ++i) ptts_launch_prefill_attn_kernel(prefill_attn_mfma_kernel<bf16_t, 3, ABL>, grid, dim3(192), st, a);
   hipEventRecord(e0, st);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((prefill_attn_mfma_kernel<bf16_t, 3, ABL>), grid, dim3(192), 0, st, a);
+  for (int i = 0; i < reps; ++i) ptts_launch_prefill_attn_kernel(prefill_attn_mfma_kernel<bf16_t, 3, ABL>, grid, dim3(192), st, a);
   hipEventRecord(e1, st); hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   return ms * 1e3f / reps;
@@ -36,7 +37,7 @@ int main() {
   for (int cross = 0; cross < 2; ++cross) {
     AttnArgs a = {};
     a.q = q; a.q_ld = QKV; a.kcache = kc; a.vcache = vc; a.cap = cross ? N : cap; a.kv_bound = a.cap; a.dims = dims; a.mask = nullptr; a.mask_ld = 40;
-    a.S = 1; a.Q = Q; a.nheads = nh; a.H = H; a.kv_heads = nh; a.n_rep = 1; a.cross = cross; a.scale = 0.125f; a.direct_out = out; a.out_fo = 1;
+    a.hostP = hd.P; a.hostN = hd.N; a.S = 1; a.Q = Q; a.nheads = nh; a.H = H; a.kv_heads = nh; a.n_rep = 1; a.cross = cross; a.scale = 0.125f; a.direct_out = out; a.out_fo = 1;
     const dim3 grid((Q + 47) / 48, nh, B);
     const int reps = 400;
     printf("[attn_probe %s] full %.2f | no MFMA %.2f | no K/V/mask loads %.2f | no q loads %.2f | no loads at all %.2f | no LDS staging %.2f | no store %.2f | "
