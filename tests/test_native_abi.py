@@ -158,7 +158,7 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
     subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", lib], capture_output=True, cwd=str(tmp_path), check=True)
     objs = [str(tmp_path / f) for f in os.listdir(tmp_path) if "amdgcn" in f]
     assert objs, "no embedded gfx950 code objects found"
-    seen, bad, strips, glds = 0, [], {}, 0
+    seen, bad, strips, glds, ttft = 0, [], {}, 0, 0
     for obj in objs:
         syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--symbols", obj], capture_output=True, text=True).stdout
         if "gemv_kernel" not in syms and "qkv_attn_kernel" not in syms and "gemm_strip_kernel" not in syms:
@@ -189,9 +189,10 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
                     bad.append((sym[:70], "strip instance on the wrong entry point", ms.groups()))
                 if ms.group(1) == "20gemm_strip_kernel_bv" and "s_branch" in ops:
                     bad.append((sym[:70], "by-value entry point with a preload prologue", ops))
-            if not re.search(r"11gemv_kernel|15qkv_attn_kernel|17xfold_attn_kernel|_Z17gemm_strip_kernelI|_Z19lnproj_fused_kernelI|_Z18xattn_fused_kernelI|16gemm_glds_kernelI", sym):
+            if not re.search(r"11gemv_kernel|15qkv_attn_kernel|17xfold_attn_kernel|_Z17gemm_strip_kernelI|_Z19lnproj_fused_kernelI|_Z18xattn_fused_kernelI|16gemm_glds_kernelI|_Z16rows_prep_kernelI|_Z19prefill_attn_kernelI|_Z24prefill_attn_mfma_kernelI|14t5_attn_kernelI|19t5_attn_mfma_kernelI", sym):
                 continue
             seen += 1
+            ttft += bool(re.search(r"rows_prep_kernelI|prefill_attn_kernelI|prefill_attn_mfma_kernelI|t5_attn_kernelI|t5_attn_mfma_kernelI", sym))  # call 54: the rest of the TTFT path
             glds += "16gemm_glds_kernelI" in sym  # round 6, call 52: the > 256-row LDS-DMA GEMM (time-to-first-token path) takes its first 56 bytes preloaded too
             if "s_branch" not in ops or not ops[0].startswith("s_load"):
                 bad.append((sym[:60], "no preload prologue", ops))
@@ -200,6 +201,7 @@ def test_step_nodes_are_built_for_kernarg_preload(tmp_path):
                 bad.append((sym[:60], "flat memory instructions", flat[sym]))
     assert seen >= 20, seen
     assert glds >= 10, glds
+    assert ttft >= 20, ttft
     assert strips.get("17gemm_strip_kernel", 0) >= 20 and strips.get("20gemm_strip_kernel_bv", 0) >= 10, strips
     assert not bad, bad[:5]
 
