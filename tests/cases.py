@@ -89,19 +89,19 @@ GEN_FIXED_SEEDS = {False: (2, 101), True: (2, 100)}  # rope -> (model seed, inpu
 GEN_VOICE_SEEDS = (0, 4)  # 7.9e-4
 
 
-def tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False, init_weights=True):
+def tiny_model(seed=0, eos_gain=None, rope=False, prompt_cross_attention=False, init_weights=True, max_positions=256):
     import parler_tts_amd as P
     from oracle import dac_oracle as DA
     from transformers import T5Config
 
     torch.manual_seed(seed)
     t5 = T5Config(vocab_size=128, d_model=128, d_kv=32, d_ff=256, num_layers=2, num_heads=4, feed_forward_proj="gated-gelu")
-    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=256, num_hidden_layers=2, ffn_dim=256, num_attention_heads=2,
+    dec = P.ParlerTTSDecoderConfig(vocab_size=1088, max_position_embeddings=max_positions, num_hidden_layers=2, ffn_dim=256, num_attention_heads=2,
                                    hidden_size=128, num_codebooks=9, pad_token_id=1024, eos_token_id=1024, bos_token_id=1025, rope_embeddings=rope)
     dac = P.DACConfig(latent_dim=64, decoder_dim=256, decoder_rates=[4, 2, 2, 2], encoder_dim=16)
     cfg = P.ParlerTTSConfig.from_sub_models_config(t5, dac, dec, vocab_size=128, prompt_cross_attention=prompt_cross_attention)
     m = P.ParlerTTSForConditionalGeneration(cfg, init_weights=init_weights)
-    spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "rope_embeddings": rope})
+    spec = DO.DecoderSpec(**{**DO.TINY.__dict__, "rope_embeddings": rope, "max_position_embeddings": max_positions})
     sd = DO.make_decoder_weights(spec, seed=1234 + seed)
     if eos_gain:
         for k in range(9):

@@ -170,3 +170,52 @@ def test_five_second_voice_prompts_prefilled_in_one_pass(dtype, prec, tol):
     err = float((got - ref).abs().max())
     log_parity(f"[voice prompt of {T} frames x {bsz} utterances, {prec}] one prefill pass of {bsz} x {N_PROMPT + 1 + T} rows: max |dlogit| at the continuation's first position {err:.2e}", LOG)
     assert err <= tol, err
+
+
+def test_generate_end_to_end_at_the_default_max_length():
+    """`ParlerTTSForConditionalGeneration.generate()` itself at the released checkpoints' `generation_config.max_length` = 2580 (tiny T5 + tiny decoder + tiny
+    codec, 2 ragged utterances, EOS allowed from column 2000 on): the chunked decode loop without host synchronisation while MinNewTokens blocks EOS, every context
+    bucket, the un-delay of a 2580-column run, the per-sample special-id filter and ONE ragged codec pass over ~2570 frames per utterance. A free run of 2 x 9 x 2579
+    choices cannot be margin-safe, so the engine's own ids (read back from the engine generate() used) are judged against the oracle's batched forward at the same
+    history, and everything behind the ids - un-delay, filter, codec, zero padding, `audios_length` - against the oracle pipeline on those ids."""
+    m, spec, sd, dsd = C.tiny_model(seed=3, eos_gain=6.0, max_positions=4096)
+    m = m.to("cuda")
+    L, K = MAX_LENGTH, spec.num_codebooks
+    desc, desc_mask, prompt_ids, prompt_mask, _ = C.gen_eos_inputs(111)
+    m.generation_config.max_length = L
+    out = m.generate(input_ids=desc.cuda(), attention_mask=desc_mask.cuda(), prompt_input_ids=prompt_ids.cuda(), prompt_attention_mask=prompt_mask.cuda(),
+                     do_sample=False, min_new_tokens=2000, return_dict_in_generate=True)
+    wav, lens = out.sequences.cpu(), [int(x) for x in out["audios_length"]]
+    ids = m._engine.ids().cpu()
+    Lout = ids.shape[1]
+    assert ids.shape[0] == 2 * K and 2001 <= Lout <= L
+    # (a) the ids against the oracle at the same history
+    enc = m._encode_description(desc.cuda(), desc_mask.cuda()).float().cpu()
+    prompt = m.embed_prompts(prompt_ids.cuda()).float().cpu()
+    _, pattern = DO.build_delay_pattern_mask(ids[:, :1], spec.bos_token_id, spec.pad_token_id, L, K)
+    fed = DO.apply_delay_pattern_mask(ids, pattern)[:, : Lout - 1]
+    with torch.no_grad():
+        lg = DO.DecoderOracle(spec, sd).forward(fed, enc, desc_mask, prompt, prompt_mask)[:, -(Lout - 1):].float()
+    # judged on the 1999 passes in which MinNewTokens blocks EOS (every row alive, plain arg-max); the EOS gate, finished-row padding and the stop test
+    # behind them are pinned bit-exactly by the short margin-safe runs of tests/test_generate_gpu.py and tests/test_lm_gpu.py
+    n_judged = 2000 - 1
+    m_ = lg[:, :n_judged].clone()
+    m_[..., spec.eos_token_id] = -float("inf")
+    top2, idx = torch.topk(m_, 2, dim=-1)
+    chosen = ids[:, 1: 1 + n_judged]
+    gap = top2[..., 0] - m_.gather(-1, chosen[..., None])[..., 0]
+    bad = int(((idx[..., 0] != chosen) & (gap > 1e-4)).sum())
+    # (b) everything behind the ids against the oracle pipeline on those ids
+    codes = DO.undelay(ids, spec, L)
+    worst = 0.0
+    for b in range(2):
+        c = DO.valid_frames(codes[b])
+        ref = DA.DacOracle(DA.DAC_TINY, dsd).decode(c[None])[0, 0]
+        assert lens[b] == ref.shape[0], (b, lens, ref.shape)
+        worst = max(worst, float((wav[b, : lens[b]] - ref).pow(2).mean().sqrt()))
+        assert float(wav[b, lens[b]:].abs().sum()) == 0.0
+    log_parity(f"[generate() end to end, max_length {L}] {Lout} columns generated, kept frames {[l // DA.DAC_TINY.hop_length for l in lens]}; choices of the first {n_judged} passes outside 1e-4 of the "
+               f"oracle's best at the same history: {bad}; waveform rms vs the oracle pipeline on the engine's ids {worst:.2e}", LOG)
+    assert bad == 0
+    assert worst <= 1e-4, worst
+    assert min(lens) // DA.DAC_TINY.hop_length >= 1000  # (random heads emit the 64 special ids now and then: those frames are filtered, :3627-3636)
